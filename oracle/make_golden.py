@@ -1,0 +1,288 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference with the
+run-time stand-ins of oracle/ref_import.py) and, in the same run, checks the oracle restatement
+(oracle/vpu_oracle.py) against it.  Build-container only; the fixtures it writes are data (inputs +
+expected outputs), never reference source.
+
+    python oracle/make_golden.py            # writes tests/golden/{pue,disk,tiny,vitb}.npz
+
+Weights are NOT stored: they are regenerated bit-identically from ``vpu_oracle.synth_state_dict``
+(integer hash), so fixtures stay small.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+import vpu_oracle as vo  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def build_reference(cfg, ref_vpu):
+    from isegm.model.modeling.common import FFNBlock
+    D = cfg["embed_dim"]
+    bp = dict(img_size=(cfg["img"],) * 2, patch_size=(cfg["patch"],) * 2, in_chans=3, embed_dim=D,
+              depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True)
+    npar = dict(in_dim=D, out_dims=list(cfg["out_dims"]), img_size=(cfg["img"],) * 2)
+    hp = dict(in_channels=list(cfg["out_dims"]), in_index=[0, 1, 2, 3], dropout_ratio=0.1, num_classes=1,
+              loss_decode=None, align_corners=False, upsample='x1', ed_loss=True,
+              channels=cfg["head_channels"])
+    m = ref_vpu.VitMultiGaussianVector_ed_Model(
+        use_disks=True, norm_radius=5, with_prev_mask=True, backbone_params=bp, neck_params=npar,
+        head_params=hp, random_split=False, residual=True, with_aux_output=True)
+    if D != 768:  # reference hard-codes d_model=768 in the head (swin_transformer.py:668)
+        m.head.d_model = D
+        m.head.ffn_layer = FFNBlock(embedding_dim=D, mlp_dim=2 * D, out_dim=cfg["head_channels"])
+    shapes = vo.param_shapes(cfg)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(shapes.keys()), "state-dict key order differs from reference"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    sd = vo.synth_state_dict(shapes, seed=0)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m, sd
+
+
+def patch_box_rasteriser(model):
+    """cv2 is absent: route the reference's draw_box through the oracle's rasteriser so that every
+    DOWNSTREAM tensor of the box path is still produced by the reference."""
+    def draw_box(image_, box_, points, gt_mask=None):
+        n = points.shape[1] // 2
+        arr = vo.box_outline(image_.cpu().numpy().copy(), box_.cpu().numpy(), n)
+        image_[:] = torch.from_numpy(arr)
+        return image_
+    model.draw_box = draw_box
+
+
+def sub(t, step=7):
+    return t[..., ::step, ::step].contiguous().numpy()
+
+
+def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_full_small=True):
+    t0 = time.time()
+    model, sd = build_reference(cfg, ref_vpu)
+    patch_box_rasteriser(model)
+    batch = vo.synth_batch(B, cfg["img"], seed=3)
+    img4 = torch.cat([batch["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1)
+    # a non-trivial previous mask for sample 0 (as in click iteration > 0)
+    img4[0, 3] = torch.sigmoid(4 * (batch["instances"][0, 0] - 0.5))
+    pts, boxes, gt = batch["points"], batch["boxes"], batch["instances"]
+    fx = {"cfg_" + k: np.asarray(v) for k, v in cfg.items()}
+    fx["B"] = np.asarray(B)
+
+    for mode, ptype in (("click", 0), ("box", 1)):
+        taps_ref = {}
+        hooks = []
+        hooks.append(model.backbone.register_forward_hook(lambda m_, i, o: None))
+        feats = {}
+        def bb_hook(m_, i, o):
+            feats["bb"] = o
+        orig_fb = model.backbone.forward_backbone
+        def fb(*a, **k):
+            o = orig_fb(*a, **k)
+            feats["bb"] = o
+            return o
+        model.backbone.forward_backbone = fb
+        orig_neck = model.neck.forward
+        def nk(*a, **k):
+            o = orig_neck(*a, **k)
+            feats["neck"] = o
+            return o
+        model.neck.forward = nk
+        orig_head = model.head.forward_feat
+        def hd(*a, **k):
+            o = orig_head(*a, **k)
+            feats["head"] = o
+            return o
+        model.head.forward_feat = hd
+
+        params = [p for p in model.parameters()]
+        for p in params:
+            p.grad = None
+        prompts = [pts, boxes, [None, None]] if ptype else None
+        out = model(img4.clone(), pts.clone(), prompts, ptype, True, False)
+        model.backbone.forward_backbone, model.neck.forward, model.head.forward_feat = orig_fb, orig_neck, orig_head
+        for h in hooks:
+            h.remove()
+
+        # ---- oracle vs reference (this is the pin) ----
+        taps = {}
+        with torch.no_grad():
+            o_or = vo.vpu_forward(sd, cfg, img4, pts, boxes, ptype, taps=taps)
+        for k in ("instances", "instances_aux"):
+            err = (o_or[k] - out[k]).abs().max().item()
+            ref_mag = out[k].abs().max().item()
+            print(f"[{name}/{mode}] oracle vs reference {k}: max abs err {err:.3e} (max |ref| {ref_mag:.3f})")
+            assert err <= 2e-5 * max(1.0, ref_mag), "oracle restatement diverges from the reference"
+        assert (taps["backbone"] - feats["bb"]).abs().max().item() < 2e-4
+        assert (taps["q_out"] - feats["neck"][1]).abs().max().item() < 2e-4
+
+        fx[f"{mode}_backbone_sub"] = feats["bb"].detach()[:, ::37, ::5].contiguous().numpy()
+        fx[f"{mode}_backbone_abs_mean"] = np.asarray(feats["bb"].detach().abs().mean().item())
+        fx[f"{mode}_q_out"] = feats["neck"][1].detach().numpy()
+        for i, f in enumerate(feats["neck"][0]):
+            fx[f"{mode}_fpn{i}_abs_mean"] = np.asarray(f.detach().abs().mean().item())
+            fx[f"{mode}_fpn{i}_sub"] = f.detach()[:, ::9, ::3, ::3].contiguous().numpy()
+        fx[f"{mode}_seg_lowres"] = feats["head"][0].detach().numpy()
+        fx[f"{mode}_sim_lowres_sub"] = feats["head"][1].detach()[:, ::6, ::2, ::2].contiguous().numpy()
+        fx[f"{mode}_sim_lowres_slot_mean"] = feats["head"][1].detach().mean(dim=(2, 3)).numpy()
+        fx[f"{mode}_instances_sub"] = sub(out["instances"].detach())
+        fx[f"{mode}_instances_aux_sub"] = sub(out["instances_aux"].detach()[:, ::6])
+        fx[f"{mode}_instances_mean"] = np.asarray(out["instances"].detach().mean().item())
+        fx[f"{mode}_instances_aux_mean"] = np.asarray(out["instances_aux"].detach().mean().item())
+
+        if with_grads:
+            ed = vo.ed_mask_label(gt, cfg["num_max_points"])
+            nfl = ref_losses.NormalizedFocalLossSigmoid(alpha=0.5, gamma=2, penalty_loss=False)
+            dice = ref_losses.DiceLoss(use_sigmoid=True, activate=True, naive_dice=True, loss_weight=1.0)
+            bce = ref_losses.SigmoidBinaryCrossEntropyLoss(from_sigmoid=True)
+            l_nfl = torch.mean(nfl(out["instances"], gt))
+            l_dice = torch.mean(dice(out["instances"], gt))
+            l_pcl = torch.mean(bce(out["instances_aux"], ed))
+            loss = 1.0 * l_nfl + 1.0 * l_dice + 2.0 * l_pcl
+            loss.backward()
+            tot_or, parts = vo.step_loss({k: v for k, v in out.items()}, gt, ed)
+            assert abs(tot_or.item() - loss.item()) < 1e-5 * max(1, abs(loss.item())), (tot_or.item(), loss.item())
+            fx[f"{mode}_loss"] = np.asarray([loss.item(), l_nfl.item(), l_dice.item(), l_pcl.item()])
+            names = [n for n, _ in model.named_parameters()]
+            gnorm = {}
+            for n, p in model.named_parameters():
+                gnorm[n] = float(p.grad.norm().item()) if p.grad is not None else -1.0
+            fx[f"{mode}_grad_names"] = np.asarray(names)
+            fx[f"{mode}_grad_norms"] = np.asarray([gnorm[n] for n in names])
+            no_grad = sorted(n for n in names if gnorm[n] < 0)
+            assert no_grad == sorted(vo.unused_param_names(cfg)), no_grad
+            # oracle backward vs reference backward
+            sd_g = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+            o2 = vo.vpu_forward(sd_g, cfg, img4, pts, boxes, ptype)
+            t2, _ = vo.step_loss(o2, gt, ed)
+            t2.backward()
+            worst = 0.0
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                g2 = sd_g[n].grad
+                # k_proj.bias gradients are analytically zero (softmax is invariant to a key bias):
+                # only rounding noise ~1e-10 lives there, hence the absolute floor.
+                rel = max(0.0, (g2 - p.grad).norm().item() - 5e-9) / (p.grad.norm().item() + 1e-12)
+                worst = max(worst, rel)
+            print(f"[{name}/{mode}] oracle vs reference grads: worst rel-L2 err {worst:.3e}")
+            assert worst < 1e-3
+            # a few full gradients (small tensors) and slices of big ones
+            keep = ["backbone.blocks.0.norm1.weight", "backbone.blocks.0.attn.qkv.bias",
+                    f"backbone.blocks.{cfg['depth'] - 1}.mlp.fc2.bias", "backbone.patch_embed.proj.bias",
+                    "patch_embed_coords.proj.bias", "neck.att.layers.0.norm1.weight",
+                    "neck.att.layers.2.cross_attn_image_to_token.out_proj.bias",
+                    "neck.att.norm_final_attn.bias", "neck.down_4.6.weight", "neck.down_32.3.bias",
+                    "head.conv_seg.weight", "head.fusion_conv.conv.bias", "head.ffn_layer.lin2.bias",
+                    "neck.ffn_layer.lin2.bias"]
+            for n, p in model.named_parameters():
+                if n in keep:
+                    fx[f"{mode}_grad::{n}"] = p.grad.detach().numpy().copy()
+            fx[f"{mode}_grad_slice::backbone.blocks.0.attn.qkv.weight"] = \
+                dict(model.named_parameters())["backbone.blocks.0.attn.qkv.weight"].grad[::17, ::13].numpy().copy()
+            fx[f"{mode}_grad_slice::neck.ffn_layer.lin1.weight"] = \
+                dict(model.named_parameters())["neck.ffn_layer.lin1.weight"].grad[::64, ::29].numpy().copy()
+
+    fx["images_seed"] = np.asarray(3)
+    fx["points"] = pts.numpy()
+    fx["boxes"] = boxes.numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fx)
+    print(f"[{name}] written in {time.time() - t0:.1f}s")
+
+
+def prompt_fixtures(ref_vpu):
+    """Known-answer vectors for the integer bookkeeping: PuE click/box rows and disk maps on
+    crafted edge cases (corner-drop quirk, truncation, invalid rows, tiny boxes, fewer than 24 slots)."""
+    from isegm.model.ops import DistMaps
+    cfg = vo.make_cfg(embed_dim=64, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+    model, _ = build_reference(cfg, ref_vpu)
+    P = -np.ones((6, 48, 3), np.float32)
+    # sample 0: interior, fractional, borders
+    P[0, 0] = (200, 150, 0); P[0, 1] = (123.7, 200.2, 1); P[0, 2] = (0, 0, 2); P[0, 3] = (447, 447, 3)
+    P[0, 24] = (5, 5, 4); P[0, 25] = (438, 5, 5)
+    # sample 1: corner-drop quirk cases
+    P[1, 0] = (445, 5, 0); P[1, 1] = (5, 445, 1); P[1, 2] = (439, 5, 2); P[1, 3] = (445, 445, 3)
+    P[1, 24] = (9, 438, 4); P[1, 25] = (10, 439, 5); P[1, 26] = (8.99, 438.5, 6)
+    # sample 2: valid order but coordinates -1 / order -1 with valid coordinates / half-integer
+    P[2, 0] = (100.5, 200.5, 0); P[2, 1] = (-1, -1, 1); P[2, 2] = (50, 60, -1); P[2, 24] = (300.25, 10.75, 2)
+    # sample 3: all 24 positive slots used
+    for i in range(24):
+        P[3, i] = (10 + 17 * i, 430 - 16 * i, i)
+    P[3, 47] = (222, 111, 24)
+    # sample 4: nothing valid;  sample 5: near-border sweep
+    for i, v in enumerate((0, 1, 8, 9, 10, 437, 438, 439, 440, 446, 447)):
+        P[5, i] = (v, 224, i); P[5, 24 + i] = (224, v, 11 + i)
+    pts = torch.from_numpy(P)
+    fx = {"points": P}
+    with torch.no_grad():
+        ref_click = model._guassinvector_click(pts).numpy()
+    assert ref_click.dtype == np.float64
+    mine = vo.pue_click(P)
+    assert np.array_equal(mine, ref_click), "PuE click restatement is not bit-exact"
+    fx["pue_click"] = ref_click
+    # fewer than 24 slots per polarity (predictor path, base.py:195-213)
+    P6 = -np.ones((2, 6, 3), np.float32)
+    P6[0, 0] = (200, 150, 0); P6[0, 3] = (20, 30, 1); P6[1, 1] = (444, 3, 0); P6[1, 5] = (100.9, 100.1, 1)
+    with torch.no_grad():
+        ref6 = model._guassinvector_click(torch.from_numpy(P6)).numpy()
+    assert np.array_equal(vo.pue_click(P6), ref6)
+    fx["points_n3"] = P6
+    fx["pue_click_n3"] = ref6
+    # boxes: (xc, yc, w, h, slot)
+    BX = np.array([[224, 224, 100, 60, 1], [224, 224, 7, 60, 0], [30, 420, 100, 100, 2], [100, 100, 8, 8, 30],
+                   [0, 0, 0, 0, 0], [440, 10, 40, 30, 47]], np.int32)
+    with torch.no_grad():
+        ref_box = model._guassinvector_box(pts, torch.from_numpy(BX)).numpy()
+    mine_b = vo.pue_box(P, BX)
+    err = np.abs(mine_b - ref_box).max()
+    print("PuE box: max abs err", err, " nonzero pattern equal:", np.array_equal(mine_b != 0, ref_box != 0))
+    assert err <= 1e-7 and np.array_equal(mine_b != 0, ref_box != 0)
+    fx["boxes"] = BX
+    fx["pue_box"] = ref_box
+    fx["click_lut"] = vo.click_lut()
+    np.savez_compressed(os.path.join(OUT, "pue.npz"), **fx)
+
+    dm = DistMaps(norm_radius=5, spatial_scale=1.0, cpu_mode=False, use_disks=True)
+    with torch.no_grad():
+        ref_d = dm(torch.zeros(6, 3, 448, 448), pts).numpy()
+    mine_d = vo.disk_maps(P, 448, 448)
+    assert np.array_equal(mine_d, ref_d), "disk-map restatement is not bit-exact"
+    # non-square / small canvas, random fractional clicks
+    rs = np.random.RandomState(5)
+    Pr = -np.ones((3, 10, 3), np.float32)
+    for b in range(3):
+        for i in (0, 1, 2, 5, 6):
+            Pr[b, i] = (rs.rand() * 95, rs.rand() * 130, i)
+    with torch.no_grad():
+        ref_r = dm(torch.zeros(3, 3, 96, 131), torch.from_numpy(Pr)).numpy()
+    assert np.array_equal(vo.disk_maps(Pr, 96, 131), ref_r)
+    np.savez_compressed(os.path.join(OUT, "disk.npz"), points=P, disks_packed=np.packbits(ref_d.astype(np.uint8)),
+                        disks_shape=np.asarray(ref_d.shape), disk_counts=ref_d.sum(axis=(2, 3)),
+                        points_small=Pr, disks_small=ref_r.astype(np.uint8))
+    print("disk counts sample0:", ref_d[0].sum(axis=(1, 2)), " half-integer click:", ref_d[2, 0].sum())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref_vpu, ref_losses = ref_import.import_reference()
+    which = sys.argv[1:] or ["pue", "tiny", "vitb"]
+    if "pue" in which:
+        prompt_fixtures(ref_vpu)
+    if "tiny" in which:
+        cfg = vo.make_cfg(embed_dim=64, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+        run_model_fixture("tiny", cfg, 2, ref_vpu, ref_losses)
+    if "vitb" in which:
+        run_model_fixture("vitb", vo.make_cfg(), 2, ref_vpu, ref_losses)
+
+
+if __name__ == "__main__":
+    main()

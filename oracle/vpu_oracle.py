@@ -1,0 +1,683 @@
+"""CPU oracle for the VPUFormer forward/backward hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module, and only as the checker / the CPU
+baseline.  The product path (``pvpuformer_amd``) never imports it and has no CPU fallback.
+
+It is a from-scratch restatement (numpy for the integer / byte bookkeeping, functional
+torch-CPU fp32 for the floating-point path) of the reference algorithm; every function cites the
+reference lines it follows (paths relative to /root/reference).  The reference publishes no tests
+or golden vectors, so the oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF,
+generated in the build container by ``oracle/make_golden.py`` (which imports the reference) and
+committed under ``tests/golden/``;  ``tests/test_oracle_golden.py`` checks it against them.
+
+Parity status: PINNED for a1,a2,a4-a8,a10-a15.  UNPINNED for the OpenCV
+rasterisers (a3: cv2.rectangle / cv2.polylines, thickness 3) -- cv2 is not installable here.
+
+State-dict keys are the reference's (``backbone.blocks.0.attn.qkv.weight`` ...).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic, platform-independent pseudo-random numbers (shared by fixtures, tests, bench)
+# ----------------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def hash_uniform(n, seed):
+    """n floats in [-1, 1): splitmix64 of (index, seed); exact integer arithmetic, so the same on
+    every machine.  float32."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x632BE59BD9B4E019)
+             + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)  # 24 bits -> exact in fp32
+    return (u * 2.0 - 1.0).astype(np.float32)
+
+
+def _name_seed(name):
+    h = 1469598103934665603
+    for ch in name.encode():
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h & 0x7FFFFFFF
+
+
+def synth_state_dict(shapes, seed=0):
+    """Deterministic weights for a {name: shape} table (same values on every machine).
+    Matrices: uniform(+-sqrt(6/(fan_in+fan_out))) as the reference's xavier init
+    (isegm/model/modeling/models_vit.py:168-188); norm weights 1+-0.1; biases / vectors +-0.05;
+    pos_embed +-0.04."""
+    sd = {}
+    for name, shape in shapes.items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        u = hash_uniform(n, _name_seed(name) + 7919 * seed)
+        leaf = name.split(".")[-1]
+        if len(shape) >= 2 and "pos_embed" not in name and "cls_token" not in name:
+            fan_out = shape[0]
+            fan_in = int(np.prod(shape[1:]))
+            if "down_" in name and len(shape) == 4 and _is_convT(name):
+                fan_in, fan_out = shape[0] * shape[2] * shape[3], shape[1]
+            a = math.sqrt(6.0 / (fan_in + fan_out))
+            v = u * np.float32(a)
+        elif leaf == "weight" and len(shape) == 1:
+            v = np.float32(1.0) + u * np.float32(0.1)
+        elif "pos_embed" in name:
+            v = u * np.float32(0.04)
+        elif len(shape) == 0:
+            v = np.float32(2.6593) + u * np.float32(0.0)
+        else:
+            v = u * np.float32(0.05)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(v.reshape(shape)))
+    return sd
+
+
+def _is_convT(name):
+    return name.startswith("neck.down_4.0.") or name.startswith("neck.down_4.3.") \
+        or name.startswith("neck.down_8.0.") or ".up_conv" in name and name.split(".")[-2] == "0"
+
+
+# ----------------------------------------------------------------------------------------------
+# model configuration + parameter table
+# ----------------------------------------------------------------------------------------------
+def make_cfg(embed_dim=768, depth=12, num_heads=12, img=448, patch=16, mlp_ratio=4,
+             out_dims=(128, 256, 512, 1024), head_channels=256, num_max_points=24,
+             head_d_model=None):
+    """ViT-B/448 defaults = models/iSegNet/vpu_base448_cocolvis.py:13-56.  ``head_d_model`` is the
+    reference's hard-coded 768 (swin_transformer.py:668); for embed_dim != 768 the golden script
+    patches the reference head to ``embed_dim``."""
+    return dict(embed_dim=embed_dim, depth=depth, num_heads=num_heads, img=img, patch=patch,
+                mlp_ratio=mlp_ratio, out_dims=tuple(out_dims), head_channels=head_channels,
+                num_max_points=num_max_points,
+                head_d_model=head_d_model if head_d_model is not None else embed_dim)
+
+
+def param_shapes(cfg):
+    """All state-dict entries of VitMultiGaussianVector_ed_Model (is_vpu_model.py:140-186)
+    including the never-used ones, in the reference's registration order."""
+    D, P, img = cfg["embed_dim"], cfg["patch"], cfg["img"]
+    n_tok = (img // P) ** 2
+    hid = D * cfg["mlp_ratio"]
+    o = cfg["out_dims"]
+    C = cfg["head_channels"]
+    s = {}
+    s["patch_embed_coords.proj.weight"] = (D, 3, P, P)
+    s["patch_embed_coords.proj.bias"] = (D,)
+    s["backbone.cls_token"] = (1, 1, D)
+    s["backbone.pos_embed"] = (1, n_tok + 1, D)
+    s["backbone.patch_embed.proj.weight"] = (D, 3, P, P)
+    s["backbone.patch_embed.proj.bias"] = (D,)
+    for i in range(cfg["depth"]):
+        p = f"backbone.blocks.{i}."
+        s[p + "norm1.weight"] = (D,); s[p + "norm1.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,); s[p + "norm2.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D); s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D); s[p + "attn.proj.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (hid, D); s[p + "mlp.fc1.bias"] = (hid,)
+        s[p + "mlp.fc2.weight"] = (D, hid); s[p + "mlp.fc2.bias"] = (D,)
+    s["backbone.fc_norm.weight"] = (D,); s["backbone.fc_norm.bias"] = (D,)
+    s["backbone.head.weight"] = (1000, D); s["backbone.head.bias"] = (1000,)
+    # neck (is_vpu_model.py:18-91): hide_dim = 1024 hard-coded
+    s["neck.ffn_layer.lin1.weight"] = (2048, 2 * img + 3); s["neck.ffn_layer.lin1.bias"] = (2048,)
+    s["neck.ffn_layer.lin2.weight"] = (D, 2048); s["neck.ffn_layer.lin2.bias"] = (D,)
+
+    def attn(prefix, internal):
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            s[f"{prefix}.{nm}.weight"] = (internal, D); s[f"{prefix}.{nm}.bias"] = (internal,)
+        s[f"{prefix}.out_proj.weight"] = (D, internal); s[f"{prefix}.out_proj.bias"] = (D,)
+    for l in range(3):
+        p = f"neck.att.layers.{l}"
+        attn(p + ".self_attn", D)
+        s[p + ".norm1.weight"] = (D,); s[p + ".norm1.bias"] = (D,)
+        attn(p + ".cross_attn_token_to_image", D // 2)
+        s[p + ".norm2.weight"] = (D,); s[p + ".norm2.bias"] = (D,)
+        s[p + ".mlp.lin1.weight"] = (1024, D); s[p + ".mlp.lin1.bias"] = (1024,)
+        s[p + ".mlp.lin2.weight"] = (D, 1024); s[p + ".mlp.lin2.bias"] = (D,)
+        s[p + ".norm3.weight"] = (D,); s[p + ".norm3.bias"] = (D,)
+        s[p + ".norm4.weight"] = (D,); s[p + ".norm4.bias"] = (D,)
+        attn(p + ".cross_attn_image_to_token", D // 2)
+    attn("neck.att.final_attn_token_to_image", D // 2)
+    s["neck.att.norm_final_attn.weight"] = (D,); s["neck.att.norm_final_attn.bias"] = (D,)
+    c4 = max(o[0] * 2, D // 2)
+    s["neck.down_4.0.weight"] = (D, c4, 2, 2); s["neck.down_4.0.bias"] = (c4,)
+    s["neck.down_4.1.weight"] = (c4,); s["neck.down_4.1.bias"] = (c4,)
+    s["neck.down_4.3.weight"] = (c4, c4 // 2, 2, 2); s["neck.down_4.3.bias"] = (c4 // 2,)
+    s["neck.down_4.4.weight"] = (c4 // 2,); s["neck.down_4.4.bias"] = (c4 // 2,)
+    s["neck.down_4.5.weight"] = (o[0], c4 // 2, 1, 1); s["neck.down_4.5.bias"] = (o[0],)
+    s["neck.down_4.6.weight"] = (o[0],); s["neck.down_4.6.bias"] = (o[0],)
+    c8 = max(o[1], D // 2)
+    s["neck.down_8.0.weight"] = (D, c8, 2, 2); s["neck.down_8.0.bias"] = (c8,)
+    s["neck.down_8.1.weight"] = (c8,); s["neck.down_8.1.bias"] = (c8,)
+    s["neck.down_8.2.weight"] = (o[1], c8, 1, 1); s["neck.down_8.2.bias"] = (o[1],)
+    s["neck.down_8.3.weight"] = (o[1],); s["neck.down_8.3.bias"] = (o[1],)
+    s["neck.down_16.0.weight"] = (o[2], D, 1, 1); s["neck.down_16.0.bias"] = (o[2],)
+    s["neck.down_16.1.weight"] = (o[2],); s["neck.down_16.1.bias"] = (o[2],)
+    c32 = max(o[3], D * 2)
+    s["neck.down_32.0.weight"] = (c32, D, 2, 2); s["neck.down_32.0.bias"] = (c32,)
+    s["neck.down_32.1.weight"] = (c32,); s["neck.down_32.1.bias"] = (c32,)
+    s["neck.down_32.2.weight"] = (o[3], c32, 1, 1); s["neck.down_32.2.bias"] = (o[3],)
+    s["neck.down_32.3.weight"] = (o[3],); s["neck.down_32.3.bias"] = (o[3],)
+    # head (swin_transformer.py:666-721, decode_head.py:82)
+    s["head.logit_scale"] = ()
+    s["head.conv_seg.weight"] = (1, C, 1, 1); s["head.conv_seg.bias"] = (1,)
+    for i in range(4):
+        s[f"head.convs.{i}.conv.weight"] = (C, o[i], 1, 1); s[f"head.convs.{i}.conv.bias"] = (C,)
+    s["head.fusion_conv.conv.weight"] = (C, 4 * C, 1, 1); s["head.fusion_conv.conv.bias"] = (C,)
+    s["head.up_conv1.0.weight"] = (C, C // 2, 2, 2); s["head.up_conv1.0.bias"] = (C // 2,)
+    s["head.up_conv1.1.weight"] = (C // 2,); s["head.up_conv1.1.bias"] = (C // 2,)
+    s["head.up_conv1.2.weight"] = (C // 2, C // 2, 1, 1); s["head.up_conv1.2.bias"] = (C // 2,)
+    s["head.up_conv1.3.weight"] = (C // 2,); s["head.up_conv1.3.bias"] = (C // 2,)
+    s["head.up_conv2.0.weight"] = (C // 2, C // 4, 2, 2); s["head.up_conv2.0.bias"] = (C // 4,)
+    s["head.up_conv2.1.weight"] = (C // 4,); s["head.up_conv2.1.bias"] = (C // 4,)
+    s["head.up_conv2.2.weight"] = (C // 4, C // 4, 1, 1); s["head.up_conv2.2.bias"] = (C // 4,)
+    s["head.up_conv2.3.weight"] = (C // 4,); s["head.up_conv2.3.bias"] = (C // 4,)
+    dm = cfg["head_d_model"]
+    s["head.ffn_layer.lin1.weight"] = (2 * dm, dm); s["head.ffn_layer.lin1.bias"] = (2 * dm,)
+    s["head.ffn_layer.lin2.weight"] = (C, 2 * dm); s["head.ffn_layer.lin2.bias"] = (C,)
+    s["pe_layer.positional_encoding_gaussian_matrix"] = (2, D // 2)
+    for i in range(4):
+        s[f"point_embeddings.{i}.weight"] = (1, D)
+    s["not_a_point_embed.weight"] = (1, D)
+    s["head_aux.weight"] = (1, 128, 1, 1); s["head_aux.bias"] = (1,)
+    return s
+
+
+# Tensors that never receive a gradient on the VPU path.
+def unused_param_names(cfg):
+    names = ["backbone.cls_token", "backbone.fc_norm.weight", "backbone.fc_norm.bias",
+             "backbone.head.weight", "backbone.head.bias", "head.logit_scale",
+             "not_a_point_embed.weight", "head_aux.weight", "head_aux.bias"]
+    for u in ("up_conv1", "up_conv2"):
+        for i in range(4):
+            names += [f"head.{u}.{i}.weight", f"head.{u}.{i}.bias"]
+    names += [f"point_embeddings.{i}.weight" for i in range(4)]
+    return names
+
+
+# ----------------------------------------------------------------------------------------------
+# a7/a8: Prompt-unified Encoder (PuE) Gaussian vectors -- integer bookkeeping, numpy
+# ----------------------------------------------------------------------------------------------
+def click_lut(sigma=3):
+    """19-tap clip exp(-(d^2)/(2 sigma^2)) in float32 with the peak raised by 1
+    (isegm/model/ops.py:51-61)."""
+    r = int(sigma * 3)
+    t = np.arange(0, 2 * r + 1, 1, np.float32)
+    lut = np.exp(-((t - (2 * r + 1) // 2) ** 2) / (2 * sigma ** 2))
+    lut[r] += 1
+    return lut  # float32
+
+
+def _in_img(x, y, w, h):
+    return not (x < 0 or x > w or y < 0 or y > h)  # ops.py:63-67 (inclusive upper bound)
+
+
+def _gauss_pair(x, y, rx, ry, lut_x, lut_y, size):
+    """Two 1-D vectors with the reference's clipping rule (ops.py:80-104 / 170-201)."""
+    vx = np.zeros(size, np.float64)
+    vy = np.zeros(size, np.float64)
+    ulx, uly, brx, bry = x - rx, y - ry, x + rx + 1, y + ry + 1
+    if (not _in_img(ulx, uly, size, size)) and (not _in_img(brx, bry, size, size)):
+        return vx, vy  # "corner-drop" quirk: both corners outside in EITHER coordinate
+    for j in range(max(0, ulx), min(size, brx)):
+        vx[j] = lut_x[j - ulx]
+    for j in range(max(0, uly), min(size, bry)):
+        vy[j] = lut_y[j - uly]
+    return vx, vy
+
+
+def pue_click(points, num_max_points=24, img=448):
+    """_guassinvector_click (is_vpu_model.py:189-230).  points [B,2n,3] (row, col, order).
+    Returns float64 [B, 2*num_max_points, 2*img+3].  Note the reference feeds (row, col) as
+    (x, y): the first img entries encode points[...,0]."""
+    pts = np.asarray(points, dtype=np.float32)
+    B, N, _ = pts.shape
+    n = N // 2
+    E = 2 * img + 3
+    lut = click_lut()
+    rows = np.zeros((B, N, E), np.float64)
+    for b in range(B):
+        for i in range(N):
+            if pts[b, i, 2] == -1:
+                rows[b, i, E - 1] = 1.0
+                continue
+            xy = (pts[b, i, :2] * 4 / 4).astype("int32")  # truncation toward zero (ops.py:81)
+            vx, vy = _gauss_pair(int(xy[0]), int(xy[1]), 9, 9, lut, lut, img)
+            rows[b, i, :img] = vx
+            rows[b, i, img:2 * img] = vy
+            rows[b, i, 2 * img + (0 if i < n else 1)] = 1.0
+    return _pad_slots(rows, n, num_max_points, E)
+
+
+def _pad_slots(rows, n, num_max_points, E):
+    if n == num_max_points:
+        return rows
+    B = rows.shape[0]
+    nap = np.zeros((B, num_max_points - n, E), np.float64)
+    nap[:, :, E - 1] = 1.0
+    return np.concatenate([rows[:, :n], nap, rows[:, n:], nap], axis=1)  # is_vpu_model.py:218-228
+
+
+def box_vectors(cx, cy, w, h, img=448):
+    """GaussianVector_box.gen_guassian_vector (ops.py:138-202): kernel w//2*2-1, sigma=radius//3
+    (integer), float32 exp, no peak raise; all-zero if a sigma is 0 or the box is all-zero."""
+    zx, zy = np.zeros(img, np.float64), np.zeros(img, np.float64)
+    if cx + cy + w + h == 0:
+        return zx, zy
+    luts, rads = [], []
+    for L in (w, h):
+        k = L // 2 * 2 - 1
+        r = (k - 1) // 2
+        s = r // 3
+        if s == 0:
+            return zx, zy
+        t = np.arange(0, k, 1, np.float32)
+        luts.append(np.exp(-((t - k // 2) ** 2) / (2 * s ** 2)))
+        rads.append(r)
+    return _gauss_pair(int(cx), int(cy), rads[0], rads[1], luts[0], luts[1], img)
+
+
+def pue_box(points, boxes, num_max_points=24, img=448):
+    """_guassinvector_box (is_vpu_model.py:233-291).  boxes [B,5] int32 (xc, yc, w, h, slot)."""
+    pts = np.asarray(points, dtype=np.float32)
+    bx = np.asarray(boxes).astype(np.int64)
+    B, N, _ = pts.shape
+    n = N // 2
+    E = 2 * img + 3
+    rows = pue_click(pts, n, img)  # un-padded [B, N, E]
+    for b in range(B):
+        vx, vy = box_vectors(int(bx[b, 0]), int(bx[b, 1]), int(bx[b, 2]), int(bx[b, 3]), img)
+        slot = int(bx[b, 4])
+        rows[b, slot, :] = 0.0
+        rows[b, slot, :img] = vx
+        rows[b, slot, img:2 * img] = vy
+        rows[b, slot, 2 * img + (0 if slot < n else 1)] = 1.0
+    return _pad_slots(rows, n, num_max_points, E)
+
+
+# ----------------------------------------------------------------------------------------------
+# a2/a3: click disk maps + box outline
+# ----------------------------------------------------------------------------------------------
+def disk_maps(points, H, W, radius=5):
+    """DistMaps.get_coord_features torch path, use_disks=True, spatial_scale=1 (ops.py:347-379).
+    fp32 arithmetic with separately rounded sub/mul/add.  Returns float32 [B,2,H,W] in {0,1}."""
+    pts = np.asarray(points, dtype=np.float32)
+    B, N, _ = pts.shape
+    n = N // 2
+    rr = np.arange(H, dtype=np.float32)[:, None]
+    cc = np.arange(W, dtype=np.float32)[None, :]
+    out = np.zeros((B, 2, H, W), np.float32)
+    thr = np.float32(radius * radius)
+    for b in range(B):
+        for g in range(2):
+            best = np.full((H, W), np.float32(1e6), np.float32)
+            for i in range(g * n, (g + 1) * n):
+                pr, pc = pts[b, i, 0], pts[b, i, 1]
+                if max(pr, pc) < 0:
+                    continue
+                dr = rr - pr
+                dc = cc - pc
+                d = (dr * dr).astype(np.float32) + (dc * dc).astype(np.float32)
+                best = np.minimum(best, d.astype(np.float32))
+            out[b, g] = (best <= thr).astype(np.float32)
+    return out
+
+
+def box_outline(canvas, box, n_points, thickness=3):
+    """ISModel.draw_box (is_model.py:97-121): 3-px rectangle outline OR-ed into channel
+    0 (slot < n) or 1.  PARITY UNPINNED: the reference calls cv2.rectangle, absent here; this
+    rasteriser marks every pixel within (thickness-1)/2 (Chebyshev) of the outline."""
+    xc, yc, w, h, slot = [int(v) for v in box]
+    ch = 0 if slot < n_points else 1
+    x0, x1, y0, y1 = xc - w // 2, xc + w // 2, yc - h // 2, yc + h // 2
+    t = (thickness - 1) // 2
+    H, W = canvas.shape[-2:]
+    ys = np.arange(H)[:, None]
+    xs = np.arange(W)[None, :]
+    inside_outer = (xs >= x0 - t) & (xs <= x1 + t) & (ys >= y0 - t) & (ys <= y1 + t)
+    inside_inner = (xs > x0 + t) & (xs < x1 - t) & (ys > y0 + t) & (ys < y1 - t)
+    band = inside_outer & ~inside_inner
+    # the reference round-trips the channel through uint8 (x.astype(int)*255 // 255): identity on {0,1}
+    canvas[ch] = np.where(band, np.float32(1.0), canvas[ch])
+    return canvas
+
+
+def coord_features(prev_mask, points, boxes=None, prompt_type=0, radius=5):
+    """ISModel.get_coord_features_with_prompt (is_model.py:78-95): cat(prev_mask, disks)."""
+    B, _, H, W = prev_mask.shape
+    d = disk_maps(points.detach().cpu().numpy(), H, W, radius)
+    if prompt_type == 1:
+        n = points.shape[1] // 2
+        bx = boxes.detach().cpu().numpy() if torch.is_tensor(boxes) else np.asarray(boxes)
+        for b in range(B):
+            d[b] = box_outline(d[b], bx[b], n)
+    return torch.cat([prev_mask, torch.from_numpy(d).to(prev_mask.dtype)], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1, a4-a6: normalisation, patch embedding, windowed MAE-ViT
+# ----------------------------------------------------------------------------------------------
+_MEAN = (.485, .456, .406)
+_STD = (.229, .224, .225)
+
+
+def normalize_image(rgb):
+    """BatchImageNormalize (ops.py:398-407)."""
+    m = torch.tensor(_MEAN, dtype=rgb.dtype).view(1, 3, 1, 1)
+    s = torch.tensor(_STD, dtype=rgb.dtype).view(1, 3, 1, 1)
+    return (rgb - m) / s
+
+
+def _ln(x, sd, p, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _lin(x, sd, p):
+    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def _patch_tokens(x, sd, p, P):
+    y = F.conv2d(x, sd[p + ".proj.weight"], sd[p + ".proj.bias"], stride=P)  # models_vit.py:91,100
+    return y.flatten(2).transpose(1, 2)
+
+
+def _to_windows(x, g, wg):
+    """patchify (models_vit.py:225-239): [B, g*g, C] -> [B*nw*nw, wg*wg, C]."""
+    B, N, C = x.shape
+    nw = g // wg
+    return x.view(B, nw, wg, nw, wg, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nw * nw, wg * wg, C)
+
+
+def _from_windows(x, g, wg):
+    """unpatchify (models_vit.py:242-255)."""
+    nw = g // wg
+    B = x.shape[0] // (nw * nw)
+    C = x.shape[-1]
+    return x.view(B, nw, nw, wg, wg, C).permute(0, 1, 3, 2, 4, 5).reshape(B, g * g, C)
+
+
+def _vit_block(x, sd, p, heads):
+    """Block / Attention / Mlp (models_vit.py:9-75), LayerNorm eps 1e-6 (:126)."""
+    B, N, C = x.shape
+    hd = C // heads
+    h = _ln(x, sd, p + "norm1", 1e-6)
+    qkv = _lin(h, sd, p + "attn.qkv").view(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax((qkv[0] @ qkv[1].transpose(-2, -1)) * (hd ** -0.5), dim=-1)
+    o = (att @ qkv[2]).transpose(1, 2).reshape(B, N, C)
+    x = x + _lin(o, sd, p + "attn.proj")
+    h = _ln(x, sd, p + "norm2", 1e-6)
+    h = _lin(F.gelu(_lin(h, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")
+    return x + h
+
+
+def vit_backbone(sd, cfg, rgb_norm, coord, taps=None):
+    """VisionTransformer.forward_backbone (models_vit.py:257-287), shuffle=False."""
+    P = cfg["patch"]
+    g = cfg["img"] // P
+    wg = 224 // P
+    x = _patch_tokens(rgb_norm, sd, "backbone.patch_embed", P) \
+        + _patch_tokens(coord, sd, "patch_embed_coords", P)          # is_vpu_model.py:385, :260
+    x = x + sd["backbone.pos_embed"][:, 1:]
+    if taps is not None:
+        taps["tokens0"] = x
+    depth = cfg["depth"]
+    group = 6 if depth == 12 else depth // 4
+    windowed = False
+    for i in range(1, depth + 1):
+        if i % group:
+            if not windowed:
+                x = _to_windows(x, g, wg)
+                windowed = True
+        else:
+            x = _from_windows(x, g, wg)
+            windowed = False
+        x = _vit_block(x, sd, f"backbone.blocks.{i - 1}.", cfg["num_heads"])
+        if taps is not None:
+            taps[f"block{i}"] = _from_windows(x, g, wg) if windowed else x
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# a10/a11: DMA neck
+# ----------------------------------------------------------------------------------------------
+def pos2d(d_model, height, width):
+    """TwoWayTransformer.pos2d (transformer.py:290-318) -> [1, H*W, d_model]."""
+    pe = torch.zeros(d_model, height, width)
+    half = d_model // 2
+    div = torch.exp(torch.arange(0., half, 2) * -(math.log(10000.0) / half))
+    pw = torch.arange(0., width).unsqueeze(1) * div     # [W, half/2]
+    ph = torch.arange(0., height).unsqueeze(1) * div
+    pe[0:half:2] = torch.sin(pw).t().unsqueeze(1).expand(-1, height, -1)
+    pe[1:half:2] = torch.cos(pw).t().unsqueeze(1).expand(-1, height, -1)
+    pe[half::2] = torch.sin(ph).t().unsqueeze(2).expand(-1, -1, width)
+    pe[half + 1::2] = torch.cos(ph).t().unsqueeze(2).expand(-1, -1, width)
+    return pe.reshape(d_model, height * width).t().unsqueeze(0)
+
+
+def _mha(sd, p, q, k, v, heads=8):
+    """transformer.py Attention.forward (:499-521)."""
+    q, k, v = _lin(q, sd, p + ".q_proj"), _lin(k, sd, p + ".k_proj"), _lin(v, sd, p + ".v_proj")
+    B, nq, ci = q.shape
+    hd = ci // heads
+
+    def split(t):
+        return t.view(B, t.shape[1], heads, hd).transpose(1, 2)
+    a = torch.softmax(split(q) @ split(k).transpose(-2, -1) / math.sqrt(hd), dim=-1)
+    o = (a @ split(v)).transpose(1, 2).reshape(B, nq, ci)
+    return _lin(o, sd, p + ".out_proj")
+
+
+def dma_transformer(sd, queries0, keys0):
+    """TwoWayTransformer.forward with return_intermediate (transformer.py:323-384) and
+    TwoWayAttentionBlock.forward (:432-463).  LayerNorm eps 1e-5 (nn.LayerNorm default)."""
+    B, n_img, C = keys0.shape
+    side = int(math.sqrt(n_img))
+    kpe = pos2d(C, side, side).to(keys0.dtype)
+    qpe = queries0
+    q, k = queries0, keys0
+    outs = []
+    for l in range(3):
+        p = f"neck.att.layers.{l}"
+        if l == 0:
+            q = _mha(sd, p + ".self_attn", q, q, q)
+        else:
+            qq = q + qpe
+            q = q + _mha(sd, p + ".self_attn", qq, qq, q)
+        q = _ln(q, sd, p + ".norm1", 1e-5)
+        q = _ln(q + _mha(sd, p + ".cross_attn_token_to_image", q + qpe, k + kpe, k), sd, p + ".norm2", 1e-5)
+        m = _lin(F.relu(_lin(q, sd, p + ".mlp.lin1")), sd, p + ".mlp.lin2")
+        q = _ln(q + m, sd, p + ".norm3", 1e-5)
+        k = _ln(k + _mha(sd, p + ".cross_attn_image_to_token", k + kpe, q + qpe, q), sd, p + ".norm4", 1e-5)
+        if l != 2:
+            outs.append((q, k))
+    q = _ln(q + _mha(sd, "neck.att.final_attn_token_to_image", q + qpe, k + kpe, k),
+            sd, "neck.att.norm_final_attn", 1e-5)
+    outs.append((q, k))
+    return outs
+
+
+def _gn(x, sd, p):
+    return F.group_norm(x, 1, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def neck_forward(sd, cfg, x, pue, taps=None):
+    """SimpleFPN.forward (is_vpu_model.py:93-136)."""
+    q = _lin(F.relu(_lin(pue.to(x.dtype), sd, "neck.ffn_layer.lin1")), sd, "neck.ffn_layer.lin2")
+    hs = dma_transformer(sd, q, x)
+    q_out = q + hs[0][0] + hs[1][0] + hs[2][0]
+    B, N, C = x.shape
+    g = int(math.sqrt(N))
+    feats = [x]
+    for qi, ki in hs:
+        cg = qi.max(dim=1).values.sigmoid().unsqueeze(1)      # channel gate, max over queries
+        sg = ki.max(dim=2).values.sigmoid().unsqueeze(2)      # spatial gate, max over channels
+        feats.append(x + x * cg + x * sg)
+    maps = [f.transpose(1, 2).reshape(B, C, g, g) for f in feats]
+    if taps is not None:
+        taps["q_ffn"] = q
+        taps["q_out"] = q_out
+        for i, (qi, ki) in enumerate(hs):
+            taps[f"dma_q{i}"] = qi
+            taps[f"dma_k{i}"] = ki
+    d4 = F.conv_transpose2d(maps[0], sd["neck.down_4.0.weight"], sd["neck.down_4.0.bias"], stride=2)
+    d4 = F.gelu(_gn(d4, sd, "neck.down_4.1"))
+    d4 = F.conv_transpose2d(d4, sd["neck.down_4.3.weight"], sd["neck.down_4.3.bias"], stride=2)
+    d4 = _gn(d4, sd, "neck.down_4.4")
+    d4 = F.gelu(_gn(F.conv2d(d4, sd["neck.down_4.5.weight"], sd["neck.down_4.5.bias"]), sd, "neck.down_4.6"))
+    d8 = F.conv_transpose2d(maps[1], sd["neck.down_8.0.weight"], sd["neck.down_8.0.bias"], stride=2)
+    d8 = _gn(d8, sd, "neck.down_8.1")
+    d8 = F.gelu(_gn(F.conv2d(d8, sd["neck.down_8.2.weight"], sd["neck.down_8.2.bias"]), sd, "neck.down_8.3"))
+    d16 = F.gelu(_gn(F.conv2d(maps[2], sd["neck.down_16.0.weight"], sd["neck.down_16.0.bias"]), sd, "neck.down_16.1"))
+    d32 = _gn(F.conv2d(maps[3], sd["neck.down_32.0.weight"], sd["neck.down_32.0.bias"], stride=2), sd, "neck.down_32.1")
+    d32 = F.gelu(_gn(F.conv2d(d32, sd["neck.down_32.2.weight"], sd["neck.down_32.2.bias"]), sd, "neck.down_32.3"))
+    return [d4, d8, d16, d32], q_out
+
+
+# ----------------------------------------------------------------------------------------------
+# a12/a13: segmentation head, P2CL logits, final upsample
+# ----------------------------------------------------------------------------------------------
+def head_forward(sd, cfg, feats, q_out, drop_mask=None, taps=None):
+    """SwinTransfomerSegHead.forward_feat (swin_transformer.py:723-767), upsample='x1'.
+    ``drop_mask`` [B,C,1,1] is the Dropout2d(0.1) keep-mask/(1-p) in train mode (decode_head.py:210-215);
+    None = eval."""
+    size = feats[0].shape[2:]
+    outs = []
+    for i, f in enumerate(feats):
+        y = F.relu(F.conv2d(f, sd[f"head.convs.{i}.conv.weight"], sd[f"head.convs.{i}.conv.bias"]))
+        outs.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
+    fused = F.relu(F.conv2d(torch.cat(outs, 1), sd["head.fusion_conv.conv.weight"],
+                            sd["head.fusion_conv.conv.bias"]))
+    query = _lin(F.relu(_lin(q_out, sd, "head.ffn_layer.lin1")), sd, "head.ffn_layer.lin2")
+    emb = fused.flatten(2)
+    seg_in = fused if drop_mask is None else fused * drop_mask
+    seg = F.conv2d(seg_in, sd["head.conv_seg.weight"], sd["head.conv_seg.bias"])
+    sim = (F.normalize(query, p=2, dim=2) @ F.normalize(emb, p=2, dim=1) + 1) / 2
+    B, Nq, HW = sim.shape
+    if taps is not None:
+        taps["fused"] = fused
+        taps["query"] = query
+    return seg, sim.view(B, Nq, size[0], size[1])
+
+
+def vpu_forward(sd, cfg, image4, points, boxes=None, prompt_type=0, drop_mask=None, taps=None,
+                pue_override=None):
+    """VitMultiGaussianVector_ed_Model.forward (is_vpu_model.py:422-438) with edloss=True."""
+    rgb = normalize_image(image4[:, :3])
+    prev = image4[:, 3:]
+    coord = coord_features(prev, points, boxes, prompt_type)
+    x = vit_backbone(sd, cfg, rgb, coord, taps)
+    if taps is not None:
+        taps["backbone"] = x
+        taps["coord"] = coord
+    if pue_override is not None:
+        pue = pue_override
+    elif prompt_type == 0:
+        pue = pue_click(points.detach().cpu().numpy(), cfg["num_max_points"], cfg["img"])
+    else:
+        pue = pue_box(points.detach().cpu().numpy(),
+                      boxes.detach().cpu().numpy() if torch.is_tensor(boxes) else boxes,
+                      cfg["num_max_points"], cfg["img"])
+    pue = torch.as_tensor(pue)
+    feats, q_out = neck_forward(sd, cfg, x, pue, taps)
+    seg, sim = head_forward(sd, cfg, feats, q_out, drop_mask, taps)
+    if taps is not None:
+        taps["seg_lowres"] = seg
+        taps["sim_lowres"] = sim
+    H = image4.shape[2:]
+    return {"instances": F.interpolate(seg, size=H, mode="bilinear", align_corners=True),
+            "instances_aux": F.interpolate(sim, size=H, mode="bilinear", align_corners=True)}
+
+
+# ----------------------------------------------------------------------------------------------
+# a14/a15: losses
+# ----------------------------------------------------------------------------------------------
+def nfl_loss(logits, label, alpha=0.5, gamma=2, eps=1e-12):
+    """NormalizedFocalLossSigmoid.forward (losses.py:39-87), max_mult=-1, detach_delimeter,
+    size_average, ignore_label=-1, weight 1.  Returns [B]."""
+    pos = label > 0.5
+    w = (label != -1).to(logits.dtype)
+    p = torch.sigmoid(logits)
+    a = torch.where(pos, alpha * w, (1 - alpha) * w)
+    pt = torch.where(w > 0, 1.0 - torch.abs(label - p), torch.ones_like(p))
+    beta = (1 - pt) ** gamma
+    mult = (w.sum(dim=(-2, -1), keepdim=True) / (beta.sum(dim=(-2, -1), keepdim=True) + eps)).detach()
+    beta = beta * mult
+    l = -a * beta * torch.log(torch.clamp_max(pt + eps, 1.0)) * w
+    dims = tuple(range(1, l.dim()))
+    return l.sum(dims) / (w.sum(dims) + eps)
+
+
+def dice_loss_naive(logits, target, eps=1e-3):
+    """DiceLoss(use_sigmoid, activate, naive_dice, reduction='mean') (losses.py:227-363) -> scalar."""
+    p = torch.sigmoid(logits).flatten(1)
+    t = target.flatten(1).float()
+    d = (2 * (p * t).sum(1) + eps) / (p.sum(1) + t.sum(1) + eps)
+    return (1 - d).mean()
+
+
+def bce_from_sigmoid(prob, label):
+    """SigmoidBinaryCrossEntropyLoss(from_sigmoid=True).forward (losses.py:163-176) -> [B]."""
+    w = (label != -1).to(prob.dtype)
+    y = torch.where(w > 0, label, torch.zeros_like(label))
+    l = -(torch.log(prob + 1e-12) * y + torch.log(1. - prob + 1e-12) * (1. - y)) * w
+    return l.mean(dim=tuple(range(1, l.dim())))
+
+
+def ed_mask_label(gt, num_max_points=24):
+    """trainer.py:329-331."""
+    return torch.cat([gt.repeat(1, num_max_points, 1, 1),
+                      torch.logical_not(gt).to(gt.dtype).repeat(1, num_max_points, 1, 1)], dim=1)
+
+
+def step_loss(out, gt, ed_label, iter_weight=1.0):
+    """ISTrainer.add_loss x4 for one click iteration (trainer.py:399-419, :533-554):
+    NFL*1 + Dice*1 + P2CL(BCE)*2, each times the iteration weight."""
+    l_nfl = nfl_loss(out["instances"], gt).mean()
+    l_dice = dice_loss_naive(out["instances"], gt).mean()
+    l_pcl = bce_from_sigmoid(out["instances_aux"], ed_label).mean()
+    total = (1.0 * l_nfl + 1.0 * l_dice + 2.0 * l_pcl) * iter_weight
+    return total, {"nfl": l_nfl, "dice": l_dice, "p2cl": l_pcl}
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic batches -- shared by tests and bench
+# ----------------------------------------------------------------------------------------------
+def synth_batch(B, img=448, seed=0, num_max_points=24, integer_clicks=True):
+    """images U[0,1); gt = ellipse/rectangle union; points [B,48,3] with 1-3 positive clicks inside gt
+    and 0-2 negative outside (row, col, order; -1 pad); boxes [B,5] from the gt bbox (cal_box rule,
+    trainer.py:1113-1125, no jitter, slot = first free positive slot)."""
+    rs = np.random.RandomState(seed)
+    images = hash_uniform(B * 3 * img * img, 1000 + seed).reshape(B, 3, img, img) * 0.5 + 0.5
+    yy, xx = np.mgrid[0:img, 0:img]
+    gt = np.zeros((B, 1, img, img), np.float32)
+    pts = -np.ones((B, 2 * num_max_points, 3), np.float32)
+    boxes = np.zeros((B, 5), np.int32)
+    for b in range(B):
+        cy, cx = rs.randint(img // 4, 3 * img // 4, size=2)
+        ry, rx = rs.randint(img // 10, img // 4, size=2)
+        m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        y0, x0 = rs.randint(img // 8, img // 2, size=2)
+        hh, ww = rs.randint(img // 10, img // 3, size=2)
+        m |= (yy >= y0) & (yy < y0 + hh) & (xx >= x0) & (xx < x0 + ww)
+        gt[b, 0] = m
+        inside = np.argwhere(m)
+        outside = np.argwhere(~m)
+        kp, kn = rs.randint(1, 4), rs.randint(0, 3)
+        order = 0
+        for i in range(kp):
+            r, c = inside[rs.randint(len(inside))]
+            off = 0.0 if integer_clicks else rs.rand() * 0.9
+            pts[b, i] = (r + off, c + off, order); order += 1
+        for i in range(kn):
+            r, c = outside[rs.randint(len(outside))]
+            pts[b, num_max_points + i] = (r, c, order); order += 1
+        ys, xs = inside[:, 0], inside[:, 1]
+        bx0, bx1, by0, by1 = xs.min(), xs.max(), ys.min(), ys.max()
+        boxes[b] = (int(0.5 * (bx0 + bx1)), int(0.5 * (by0 + by1)), int(bx1 - bx0), int(by1 - by0), kp)
+    return {"images": torch.from_numpy(images.astype(np.float32)), "instances": torch.from_numpy(gt),
+            "points": torch.from_numpy(pts), "boxes": torch.from_numpy(boxes)}
