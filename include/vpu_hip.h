@@ -1,0 +1,195 @@
+/* C ABI of libvpu_hip.so -- the MI355X (gfx950) kernels behind the VPUFormer hot path.
+ *
+ * The reference (XuZhang1211/PVPUFormer) is pure Python/PyTorch: its "FFI" for this path is the set of
+ * ATen operator calls made by isegm/model/is_vpu_model.py and the modules it composes.  Each entry point
+ * below names the reference lines whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions:
+ *   - raw DEVICE pointers + explicit shapes / leading dimensions + a hipStream_t (passed as void*);
+ *   - returns 0 on success, a negative VPU_ERR_* otherwise (vpu_last_error() gives the text);
+ *   - never allocates, frees or synchronises; workspaces are passed in by the caller;
+ *   - no global mutable state; safe to call from any host thread on distinct streams; capturable in a hipGraph;
+ *   - dtype codes: VPU_BF16 = 0 (activations bf16, fp32 accumulate), VPU_F32 = 1 (exact-fp32 parity mode).
+ *     Norm parameters, biases, statistics, losses and gradients of parameters are always fp32.
+ */
+#ifndef VPU_HIP_H
+#define VPU_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPU_BF16 0
+#define VPU_F32 1
+
+/* GEMM epilogue flags (applied in this order) */
+#define VPU_EPI_BIAS 1      /* v += bias[n]                                              */
+#define VPU_EPI_PREACT 2    /* preact[m,n] = v                                           */
+#define VPU_EPI_GELU 4      /* v = gelu_erf(v)              models_vit.py:21-27          */
+#define VPU_EPI_RELU 8      /* v = max(v,0)                 common.py:28-42              */
+#define VPU_EPI_DGELU 16    /* v *= gelu'(aux[m,n])         (backward of GELU)           */
+#define VPU_EPI_DRELU 32    /* v *= aux[m,n] > 0            (backward of ReLU)           */
+#define VPU_EPI_RESID 64    /* v += resid[m,n]              models_vit.py:72-75          */
+#define VPU_EPI_AFFINE 128  /* v = v*post_mul + post_add    swin_transformer.py:752      */
+#define VPU_EPI_ACCUM 256   /* v += C[m,n]   (fp32 output only; gradient accumulation)   */
+#define VPU_EPI_OUT_F32 512 /* C is fp32 although dtype is bf16                          */
+
+typedef struct vpu_gemm_desc {
+    const void* A;      /* transA=0: [M][lda] K-contiguous;  transA=1: [K][lda] (M contiguous) */
+    const void* B;      /* transB=0: [N][ldb] K-contiguous (nn.Linear weight); transB=1: [K][ldb] */
+    void* C;            /* [M][ldc] */
+    const float* bias;  /* [N] or NULL */
+    const void* resid;  /* element type = dtype */
+    const void* aux;    /* element type = dtype */
+    void* preact;       /* element type = dtype, leading dimension ldc */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr, ldaux;
+    int32_t batch, inner; /* blockIdx.z = zo*inner + zi */
+    int64_t sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi; /* element strides per outer / inner batch index */
+    int32_t transA, transB;
+    int32_t dtype, flags;
+    int32_t resid_period; /* > 0: resid row = m % period and no batch stride (broadcast pos_embed) */
+    float alpha, post_mul, post_add;
+} vpu_gemm_desc;
+
+const char* vpu_last_error(void);
+int vpu_abi_version(void);
+
+/* C = epilogue(alpha * op(A) op(B)).  Replaces every nn.Linear / 1x1 / patch / 2x2-stride-2 convolution and every
+ * attention matmul on the path (models_vit.py:38-52,16-27,91; transformer.py:484-517; is_vpu_model.py:55-86;
+ * swin_transformer.py:680-756) and their autograd backward (dgrad: transB=1, wgrad: transA=transB=1).
+ * bf16: requires lda, ldb (and column offsets) to be multiples of 8 elements, 16-byte aligned bases; K padded with
+ * zeros to a multiple of 8 by the producer of a K-contiguous operand.  f32: multiples of 4 / 16 bytes. */
+int vpu_gemm(const vpu_gemm_desc* d, void* stream);
+
+/* ---- row-wise ops ---- */
+/* nn.LayerNorm over the last dim (models_vit.py:126 eps 1e-6; transformer.py:417-426 eps 1e-5). */
+int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                      int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
+/* dx = [dres +] LN'(dy); dw/db partial sums go to part[2][nblk][C] (reduced by vpu_colsum_f32). nblk is returned
+ * by vpu_layernorm_bwd_nblk(rows). */
+int vpu_layernorm_bwd_nblk(int64_t rows);
+int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype, void* stream);
+/* out[c] = beta*out[c] + sum_r in[r][c]  (fp32 in) */
+int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream);
+/* out[c] = beta*out[c] + sum_r in[r*ld + c]  (activation dtype in; bias gradients) ; part = workspace [64][C] */
+int vpu_colsum(const void* in, int32_t ld, float* out, float* part, int64_t rows, int32_t C, float beta,
+               int32_t dtype, void* stream);
+/* P = softmax(S) row-wise (models_vit.py:49; transformer.py:514).  S fp32 [rows][lds]; P dtype [rows][ldp];
+ * columns [ncols, ldp) of P are written as zeros. */
+int vpu_softmax_fwd(const float* S, int32_t lds, void* P, int32_t ldp, int64_t rows, int32_t ncols,
+                    int32_t dtype, void* stream);
+/* dS = P * (dP - sum(P*dP)) * scale ; dP fp32 [rows][lddp]; dS dtype [rows][ldp], pad columns zero */
+int vpu_softmax_bwd(const void* P, int32_t ldp, const float* dP, int32_t lddp, void* dS, int64_t rows,
+                    int32_t ncols, float scale, int32_t dtype, void* stream);
+/* y = x / max(||x||_2, 1e-12) per row (F.normalize, swin_transformer.py:750-751); inv = 1/max(norm,eps) */
+int vpu_l2norm_fwd(const void* x, void* y, float* inv, int64_t rows, int32_t C, int32_t dtype, void* stream);
+int vpu_l2norm_bwd(const void* dy, const void* y, const float* inv, void* dx, int64_t rows, int32_t C,
+                   int32_t dtype, void* stream);
+
+/* ---- element-wise ---- */
+/* out[i] = a[i] + b[i % period_b]  (with_pos_embed, transformer.py:320, :430) */
+int vpu_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period_b, int32_t dtype, void* stream);
+/* out = a + b + c + d (q_out, is_vpu_model.py:104); any of b,c,d may be NULL */
+int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n, int32_t dtype,
+             void* stream);
+/* dst[r][c] (dtype_dst, ld_dst) = src[r][c] (fp32/bf16, ld_src), zero-filling columns [cols, cols_pad) */
+int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst,
+               int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
+int vpu_fill_f32(float* p, float v, int64_t n, void* stream);
+
+/* ---- prompts (integer bookkeeping; bit-exact) ---- */
+/* PuE Gaussian vectors: _guassinvector_click/_box (is_vpu_model.py:189-291) + GaussianVector(_box)
+ * (ops.py:39-202).  points fp32 [B][2n][3] (row,col,order); boxes int32 [B][5] or NULL (click mode);
+ * lut = the 19-tap clip (ops.py:51-61).  out dtype [B][2*num_max][ld] with ld >= 2*img+3, pad columns zero.
+ * out64 (optional, may be NULL) receives the float64 rows exactly as the reference returns them. */
+int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
+                   int32_t B, int32_t n, int32_t num_max, int32_t img, int32_t ld, int32_t dtype, void* stream);
+/* DistMaps disks (ops.py:347-379, use_disks, spatial_scale 1) + optional draw_box outline (is_model.py:97-121).
+ * out fp32 [B][2][H][W] in {0,1}. */
+int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H, int32_t W,
+                  float radius, void* stream);
+
+/* ---- patch embedding front end (is_model.py:59-95, ops.py:398-407, models_vit.py:94-104) ---- */
+/* im2col of [normalised rgb | prev_mask | disks] into cols[B*T][6*P*P] (dtype), token rows in WINDOW order
+ * (models_vit.py:225-239 folded into addressing).  image4 fp32 [B][4][H][W]; disks fp32 [B][2][H][W]. */
+int vpu_patch_im2col(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W, int32_t P,
+                     int32_t win_tokens, int32_t dtype, void* stream);
+/* token re-ordering between window order and raster order; dir=0: raster->window, 1: window->raster.
+ * x,y [B][g*g][C] */
+int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, int32_t wg, int32_t C, int32_t dir, int32_t dtype,
+                       void* stream);
+
+/* ---- neck / head spatial ops (channels-last [B][H][W][C]) ---- */
+/* depth-to-space for ConvTranspose2d(2, stride 2) written as a GEMM: in [B*h*w][C*4] with column (c,di,dj)
+ * -> out [B][2h][2w][C], adding bias[c] (is_vpu_model.py:56-59,68).  dir=1: inverse (space-to-depth, no bias),
+ * also the im2col of Conv2d(2, stride 2) (is_vpu_model.py:80). */
+int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, int32_t B, int32_t h, int32_t w, int32_t C,
+                       int32_t dir, int32_t dtype, void* stream);
+/* GroupNorm(1, C) [+ GELU] on channels-last maps (is_vpu_model.py:57-85). stats = workspace fp64 [B][nchunk][2],
+ * mean/rstd fp32 [B]. */
+int vpu_groupnorm_nchunk(void);
+int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, double* stats,
+                      int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu, int32_t dtype, void* stream);
+/* dx; dw/db partials to part[2][B*nchunk][C] (reduce with vpu_colsum_f32); stats = workspace fp64 [B][nchunk][2] */
+int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, const float* b, const float* mean,
+                      const float* rstd, void* dx, float* part, double* stats, int32_t B, int64_t HW, int32_t C,
+                      int32_t gelu, int32_t dtype, void* stream);
+/* bilinear resize of channels-last maps (wrappers.py:8-28, align_corners False) in [B][h][w][C] (ld_in) ->
+ * out [B][H][W][C] (ld_out: row stride in elements, lets the result land in a channel slice of the concat). */
+int vpu_bilinear_cl_fwd(const void* in, int32_t ld_in, void* out, int32_t ld_out, int32_t B, int32_t h, int32_t w,
+                        int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_in, int32_t B, int32_t h, int32_t w,
+                        int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* DMA gates (is_vpu_model.py:106-121): cg[b][c] = sigmoid(max_q Q[b][q][c]), sg[b][n] = sigmoid(max_c K[b][n][c]),
+ * out = x*(1+cg+sg). arg* record the arg-max for backward. */
+int vpu_gate_stats(const void* Q, const void* Kt, float* cg, int32_t* argq, float* sg, int32_t* argc, int32_t B,
+                   int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream);
+int vpu_gate_apply(const void* x, const float* cg, const float* sg, void* out, int32_t B, int32_t N, int32_t C,
+                   int32_t dtype, void* stream);
+/* backward: dx (+)= dout*(1+cg+sg) (accum!=0 adds into dx); dQ[b][argq][c] += dcg*cg*(1-cg);
+ * dK[b][n][argc] += dsg*sg*(1-sg).  dQ / dK must already hold the upstream gradient (they are accumulated into).
+ * part = workspace fp32 [B][nblk][C]. */
+int vpu_gate_bwd(const void* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
+                 const int32_t* argc, void* dx, int32_t accum, void* dQ, void* dK, float* part, int32_t B, int32_t nq,
+                 int32_t N, int32_t C, int32_t dtype, void* stream);
+/* conv_seg: Dropout2d + 1x1 conv to one channel (decode_head.py:210-215).  x [rows][C] channels-last,
+ * rows = B*HW; mask fp32 [B][C] (keep/(1-p)) or NULL; out fp32 [rows]. */
+int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out, int64_t rows,
+                    int64_t HW, int32_t C, int32_t dtype, void* stream);
+/* dx[r][c] = dout[r]*w[c]*mask (accum!=0: added into dx); dw partials -> part[nblk][C]; db partial -> part_b[nblk] */
+int vpu_convseg_bwd_nblk(int64_t rows);
+int vpu_convseg_bwd(const float* dout, const void* x, const float* w, const float* mask, void* dx, int32_t accum,
+                    float* part, float* part_b, int64_t rows, int64_t HW, int32_t C, int32_t dtype, void* stream);
+
+/* ---- output + losses ---- */
+/* F.interpolate(bilinear, align_corners=True) of fp32 planes [P][h][w] -> [P][H][W] (is_vpu_model.py:431-436) */
+int vpu_upsample_ac_fwd(const float* in, float* out, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W,
+                        void* stream);
+int vpu_upsample_ac_bwd(const float* dout, float* din, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W,
+                        void* stream);
+/* P2CL = SigmoidBinaryCrossEntropyLoss(from_sigmoid=True) (losses.py:155-176) against ed_mask_label
+ * (trainer.py:329-331,756,764) built on the fly: label[b][s] = gt[b] for s < S/2, 1-gt[b] otherwise, unless
+ * slot_mask_idx[b][s] >= 0, in which case it is override[slot_mask_idx[b][s]] (an error mask [H][W]).
+ * prob fp32 [B][S][H][W]; loss_part fp32 [B][S] (per-plane sums); dprob (optional) = grad_scale * dloss/dprob. */
+int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_t* slot_mask_idx, const float* override_masks,
+                     float* loss_part, float* dprob, float grad_scale, int32_t B, int32_t S, int32_t H, int32_t W,
+                     void* stream);
+/* NormalizedFocalLossSigmoid(alpha .5, gamma 2) + naive Dice on logits [B][HW] vs gt (losses.py:11-89,227-363).
+ * sums fp64 [B][8] workspace; out fp32 [B][2] = (nfl_b, dice_b); dlogits = w_nfl*dNFL + w_dice*dDice (means over B
+ * folded into w_*). */
+int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, float* out, float* dlogits, float w_nfl,
+                         float w_dice, int32_t B, int64_t HW, void* stream);
+
+/* ---- optimizer (torch.optim.Adam as configured at vpu_base448_cocolvis.py:149-154) ---- */
+/* p,g,m,v fp32 [n]; shadow (bf16, optional) receives the rounded new parameters; lr_mult (optional) fp32 [n_seg] with
+ * seg_of (int32 [n/seg_gran]) is not used in v1 (uniform lr). */
+int vpu_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

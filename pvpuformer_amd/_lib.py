@@ -1,0 +1,106 @@
+"""ctypes binding of libvpu_hip.so (C ABI declared in include/vpu_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises at
+import / first use.  (The CPU oracle under ``oracle/`` is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvpu_hip.so")
+
+BF16, F32 = 0, 1
+
+EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGELU, EPI_DRELU = 1, 2, 4, 8, 16, 32
+EPI_RESID, EPI_AFFINE, EPI_ACCUM, EPI_OUT_F32 = 64, 128, 256, 512
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p),
+        ("aux", C.c_void_p), ("preact", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("ldaux", C.c_int32),
+        ("batch", C.c_int32), ("inner", C.c_int32),
+        ("sAo", C.c_int64), ("sAi", C.c_int64), ("sBo", C.c_int64), ("sBi", C.c_int64),
+        ("sCo", C.c_int64), ("sCi", C.c_int64), ("sRo", C.c_int64), ("sRi", C.c_int64),
+        ("transA", C.c_int32), ("transB", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32),
+        ("resid_period", C.c_int32),
+        ("alpha", C.c_float), ("post_mul", C.c_float), ("post_add", C.c_float),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (every function returns int unless listed in _RET)
+SIGNATURES = {
+    "vpu_gemm": [C.POINTER(GemmDesc), _P],
+    "vpu_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "vpu_layernorm_bwd_nblk": [_L],
+    "vpu_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "vpu_colsum_f32": [_P, _P, _L, _I, _F, _P],
+    "vpu_colsum": [_P, _I, _P, _P, _L, _I, _F, _I, _P],
+    "vpu_softmax_fwd": [_P, _I, _P, _I, _L, _I, _I, _P],
+    "vpu_softmax_bwd": [_P, _I, _P, _I, _P, _L, _I, _F, _I, _P],
+    "vpu_l2norm_fwd": [_P, _P, _P, _L, _I, _I, _P],
+    "vpu_l2norm_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "vpu_add_bcast": [_P, _P, _P, _L, _L, _I, _P],
+    "vpu_add4": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "vpu_cast2d": [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P],
+    "vpu_fill_f32": [_P, _F, _L, _P],
+    "vpu_pue_encode": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_disk_maps": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpu_patch_im2col": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_window_permute": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_pixel_shuffle2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_groupnorm_nchunk": [],
+    "vpu_groupnorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _I, _I, _P],
+    "vpu_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P],
+    "vpu_bilinear_cl_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_bilinear_cl_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_gate_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpu_gate_apply": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpu_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpu_convseg_fwd": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P],
+    "vpu_convseg_bwd_nblk": [_L],
+    "vpu_convseg_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _I, _P],
+    "vpu_upsample_ac_fwd": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "vpu_upsample_ac_bwd": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "vpu_p2cl_fwd_bwd": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
+    "vpu_nfl_dice_fwd_bwd": [_P, _P, _P, _P, _P, _F, _F, _I, _L, _P],
+    "vpu_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "vpu_last_error": [],
+    "vpu_abi_version": [],
+}
+_RET = {"vpu_last_error": C.c_char_p}
+
+_lib = None
+
+
+class VpuError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP extension; raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VpuError(f"{LIB_PATH} not found: build it with pvpuformer_amd/csrc/build.sh "
+                       f"(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RET.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise VpuError(f"{name} failed ({rc}): {lib.vpu_last_error().decode()}")
+    return rc

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libvpu_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value"
+mkdir -p build
+pids=()
+for f in gemm rowops spatial prompt loss optim; do
+  $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+  pids+=($!)
+done
+$HIPCC $FLAGS -c common.cpp -o build/common.o &
+pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libvpu_hip.so build/*.o
+echo "built $(cd .. && pwd)/libvpu_hip.so"

@@ -1,0 +1,322 @@
+// GEMM for the VPUFormer hot path on gfx950 (MI355X).
+//
+//   C[M,N] = epilogue(alpha * op(A)[M,K] * op(B)[K,N])
+//
+// bf16 path: v_mfma_f32_16x16x32_bf16, 128x128x64 block tile, 4 waves (2x2) of 64x64, register-staged
+// global->LDS with XOR-swizzled LDS images.  K-contiguous operands ([rows][K]) are read back with
+// ds_read_b128; K-major operands ([K][cols], i.e. the "transposed" inputs of dgrad / wgrad / P.V) are read with
+// the gfx950 transposing LDS read ds_read_b64_tr_b16, so no operand is ever transposed through HBM.
+// f32 path (parity mode): v_mfma_f32_16x16x4_f32 -- bit-for-bit a k-ordered fp32 fma chain.
+//
+// Replaces cuBLAS/cuDNN calls behind nn.Linear / Conv2d / ConvTranspose2d / matmul of the reference
+// (isegm/model/modeling/models_vit.py:38-52,16-27,91; transformer.py:484-517; is_vpu_model.py:55-86;
+// swin_transformer.py:680-756).
+#include "vpu_common.h"
+#include "../../include/vpu_hip.h"
+
+namespace {
+
+template <typename T> struct EpiIO;
+
+// ------------------------------------------------------------------------------------------------
+// epilogue shared by both precisions
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int m, int n,
+                                               float acc) {
+    const int flags = p.flags;
+    float v = acc * p.alpha;
+    if (flags & VPU_EPI_BIAS) v += p.bias[n];
+    const int64_t ci = coff + (int64_t)m * p.ldc + n;
+    if (flags & VPU_EPI_PREACT) reinterpret_cast<T*>(p.preact)[ci] = from_f32<T>(v);
+    if (flags & VPU_EPI_GELU) v = gelu_f(v);
+    if (flags & VPU_EPI_RELU) v = fmaxf(v, 0.f);
+    if (flags & (VPU_EPI_DGELU | VPU_EPI_DRELU)) {
+        const float a = to_f32(reinterpret_cast<const T*>(p.aux)[coff + (int64_t)m * p.ldaux + n]);
+        v *= (flags & VPU_EPI_DGELU) ? dgelu_f(a) : (a > 0.f ? 1.f : 0.f);
+    }
+    if (flags & VPU_EPI_RESID) {
+        const T* r = reinterpret_cast<const T*>(p.resid);
+        const int64_t ri = p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
+                                              : roff + (int64_t)m * p.ldr + n;
+        v += to_f32(r[ri]);
+    }
+    if (flags & VPU_EPI_AFFINE) v = v * p.post_mul + p.post_add;
+    if (flags & VPU_EPI_OUT_F32) {
+        float* c = reinterpret_cast<float*>(p.C);
+        if (flags & VPU_EPI_ACCUM) v += c[ci];
+        c[ci] = v;
+    } else {
+        T* c = reinterpret_cast<T*>(p.C);
+        if (flags & VPU_EPI_ACCUM) v += to_f32(c[ci]);
+        c[ci] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+// LDS image of a K-contiguous tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk index XOR ((row>>1)&7)
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS image of a K-major tile: [64 k][128 cols] bf16, 256-B rows, 8-B unit index XOR f(k)
+__device__ __forceinline__ int km_off(int k, int unit) {
+    return k * 256 + ((unit ^ ((k & 3) << 2) ^ (((k >> 3) & 1) << 4)) << 3);
+}
+
+template <int TRANS>
+struct TileLoader {
+    // registers for one 128x64 (or 64x128) bf16 tile: 4 x 16 B per thread
+    uint4 r[4];
+    // rows_or_cols_total: extent of the non-K dimension of this operand (M or N)
+    __device__ __forceinline__ void load(const bf16_t* base, int ld, int x0, int X, int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (TRANS == 0) {
+                const int row = c >> 3, kc = c & 7;
+                const int gx = x0 + row, gk = k0 + kc * 8;
+                if (gx < X && gk < K) v = *reinterpret_cast<const uint4*>(base + (int64_t)gx * ld + gk);
+            } else {
+                const int k = c >> 4, cc = c & 15;
+                const int gk = k0 + k, gx = x0 + cc * 8;
+                if (gk < K && gx < X) v = *reinterpret_cast<const uint4*>(base + (int64_t)gk * ld + gx);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            int off;
+            if (TRANS == 0) off = kc_off(c >> 3, c & 7);
+            else off = km_off(c >> 4, (c & 15) * 2);
+            *reinterpret_cast<uint4*>(lds + off) = r[i];
+        }
+    }
+};
+
+// fragment for 16 rows (or cols) starting at x16 within the tile, k-substep ks (0/1)
+template <int TRANS>
+__device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, int lane) {
+    if (TRANS == 0) {
+        const int row = x16 + (lane & 15);
+        const int chunk = ks * 4 + (lane >> 4);
+        const uint4 v = *reinterpret_cast<const uint4*>(lds + kc_off(row, chunk));
+        return __builtin_bit_cast(bf16x8_t, v);
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        const int k = ks * 32 + 8 * g + q;
+        const int unit = (x16 >> 2) + pp;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + km_off(k, unit)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + km_off(k + 4, unit)));
+        s16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+    char* ldsA = lds;
+    char* ldsB = lds + TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+    const int64_t coff = zo * p.sCo + zi * p.sCi;
+    const int64_t roff = zo * p.sRo + zi * p.sRi;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    TileLoader<TA> la;
+    TileLoader<TB> lb;
+    const int nk = (p.K + BK - 1) / BK;
+    la.load(A, p.lda, m0, p.M, 0, p.K, tid);
+    lb.load(B, p.ldb, n0, p.N, 0, p.K, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        la.store(ldsA, tid);
+        lb.store(ldsB, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            la.load(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+            lb.load(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(ldsA, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(ldsB, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fr;
+                if (n < p.N) epilogue_store<bf16_t>(p, coff, roff, m, n, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact-fp32 MFMA kernel (parity mode).  64x64x16 block tile, 4 waves (2x2) of 32x32.
+// LDS images are k-major [16][64+pad] for both operands whatever the source layout.
+// ------------------------------------------------------------------------------------------------
+constexpr int FM = 64, FN = 64, FK = 16, FLD = 68;
+
+template <int TRANS>
+__device__ __forceinline__ void f32_stage(const float* base, int ld, int x0, int X, int k0, int K, float* lds,
+                                          int tid) {
+    // 64 x 16 elements = 256 float4
+    if (TRANS == 0) {
+        const int row = tid >> 2, kc = (tid & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gx = x0 + row, gk = k0 + kc;
+        if (gx < X && gk < K) v = *reinterpret_cast<const float4*>(base + (int64_t)gx * ld + gk);
+        // K is a multiple of 4 for every caller (zero padded), so a float4 is all-valid or all-out
+        lds[(kc + 0) * FLD + row] = v.x;
+        lds[(kc + 1) * FLD + row] = v.y;
+        lds[(kc + 2) * FLD + row] = v.z;
+        lds[(kc + 3) * FLD + row] = v.w;
+    } else {
+        const int k = tid >> 4, cc = (tid & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gk = k0 + k, gx = x0 + cc;
+        if (gk < K && gx < X) v = *reinterpret_cast<const float4*>(base + (int64_t)gk * ld + gx);
+        *reinterpret_cast<float4*>(&lds[k * FLD + cc]) = v;
+    }
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const vpu_gemm_desc p, const int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float ldsA[FK * FLD];
+    __shared__ __attribute__((aligned(16))) float ldsB[FK * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * FM, n0 = tile_n * FN;
+    const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
+    const float* A = reinterpret_cast<const float*>(p.A) + zo * p.sAo + zi * p.sAi;
+    const float* B = reinterpret_cast<const float*>(p.B) + zo * p.sBo + zi * p.sBi;
+    const int64_t coff = zo * p.sCo + zi * p.sCi;
+    const int64_t roff = zo * p.sRo + zi * p.sRi;
+
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = (p.K + FK - 1) / FK;
+    for (int kt = 0; kt < nk; ++kt) {
+        f32_stage<TA>(A, p.lda, m0, p.M, kt * FK, p.K, ldsA, tid);
+        f32_stage<TB>(B, p.ldb, n0, p.N, kt * FK, p.K, ldsB, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + fq;
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = ldsA[k * FLD + wm * 32 + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = ldsB[k * FLD + wn * 32 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 32 + i * 16 + fq * 4 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 32 + j * 16 + fr;
+                if (n < p.N) epilogue_store<float>(p, coff, roff, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) { vpu_set_error("vpu_gemm: null operand"); return VPU_ERR_ARG; }
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->inner <= 0 || d->batch % d->inner) {
+        vpu_set_error("vpu_gemm: bad sizes (M,N,K,batch > 0; batch % inner == 0)");
+        return VPU_ERR_ARG;
+    }
+    const int f = d->flags;
+    if (((f & VPU_EPI_BIAS) && !d->bias) || ((f & VPU_EPI_RESID) && !d->resid) ||
+        ((f & (VPU_EPI_DGELU | VPU_EPI_DRELU)) && !d->aux) || ((f & VPU_EPI_PREACT) && !d->preact)) {
+        vpu_set_error("vpu_gemm: epilogue flag set but its pointer is null");
+        return VPU_ERR_ARG;
+    }
+    const bool bf = d->dtype == VPU_BF16;
+    if (!bf && d->dtype != VPU_F32) { vpu_set_error("vpu_gemm: dtype"); return VPU_ERR_ARG; }
+    const int64_t q = bf ? 8 : 4;  // elements per 16 B
+    const bool strides_ok = d->lda % q == 0 && d->ldb % q == 0 && d->sAo % q == 0 && d->sAi % q == 0 &&
+                            d->sBo % q == 0 && d->sBi % q == 0;
+    if (!strides_ok || !aligned_to(d->A, 16) || !aligned_to(d->B, 16)) {
+        vpu_set_error("vpu_gemm: A/B base, leading dimensions and batch strides must be 16-byte multiples");
+        return VPU_ERR_ALIGN;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int tm = bf ? BM : FM, tn = bf ? BN : FN;
+    const int tiles_m = (d->M + tm - 1) / tm, tiles_n = (d->N + tn - 1) / tn;
+    dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)d->batch), block(256);
+    const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
+    if (bf) {
+        switch (key) {
+            case 0: gemm_bf16_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            case 1: gemm_bf16_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            case 2: gemm_bf16_kernel<1, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            default: gemm_bf16_kernel<1, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
+        }
+    } else {
+        switch (key) {
+            case 0: gemm_f32_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            case 1: gemm_f32_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            case 2: gemm_f32_kernel<1, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            default: gemm_f32_kernel<1, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
+        }
+    }
+    return vpu_check_launch("vpu_gemm");
+}

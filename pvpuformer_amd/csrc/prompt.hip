@@ -1,0 +1,142 @@
+// Prompt-unified Encoder (PuE) Gaussian vectors and click disk maps: integer bookkeeping that must be
+// bit-exact with the reference (isegm/model/is_vpu_model.py:189-291, isegm/model/ops.py:39-202, 347-379,
+// isegm/model/is_model.py:97-121).  Bandwidth-bound pointwise kernels (172.6 KB/img and 1.6 MB/img written).
+#include "vpu_common.h"
+#include "../../include/vpu_hip.h"
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+namespace {
+
+__device__ __forceinline__ bool in_img(int x, int y, int w, int h) { return !(x < 0 || x > w || y < 0 || y > h); }
+// python floor division (b > 0)
+__device__ __forceinline__ int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// One block per output row (b, slot).  All row-level decisions are made redundantly by every thread from the same
+// scalars, so they are wave-uniform.
+template <typename T>
+__global__ __launch_bounds__(256) void pue_encode_kernel(const float* __restrict__ points, const int* __restrict__ boxes,
+                                                         const float* __restrict__ lut, T* __restrict__ out,
+                                                         double* __restrict__ out64, int n, int num_max, int img, int ld) {
+    const int slot = blockIdx.x % (2 * num_max), b = blockIdx.x / (2 * num_max);
+    const int pol = slot / num_max, within = slot % num_max;
+    const int E = 2 * img + 3;
+    // kind: 0 not-a-point, 1 click, 2 box
+    int kind = 0, x = 0, y = 0, rx = 9, ry = 9, sx = 3, sy = 3, label = pol;
+    bool empty = false;  // vectors all zero (corner-drop rule / degenerate box)
+    if (within < n) {
+        const int i = pol * n + within;
+        const float* p = points + ((int64_t)b * 2 * n + i) * 3;
+        if (p[2] != -1.0f) {
+            kind = 1;
+            x = (int)p[0];  // astype(int32): truncation toward zero (ops.py:81)
+            y = (int)p[1];
+        }
+        if (boxes && boxes[b * 5 + 4] == i) {  // is_vpu_model.py:276-277: the box row replaces whatever was there
+            const int* bx = boxes + b * 5;
+            kind = 2;
+            x = bx[0]; y = bx[1];
+            label = i < n ? 0 : 1;
+            const int w = bx[2], h = bx[3];
+            if (bx[0] + bx[1] + w + h == 0) empty = true;
+            const int kw = fdiv(w, 2) * 2 - 1, kh = fdiv(h, 2) * 2 - 1;
+            rx = fdiv(kw - 1, 2); ry = fdiv(kh - 1, 2);
+            sx = fdiv(rx, 3); sy = fdiv(ry, 3);
+            // sigma == 0 -> zero vectors (ops.py:150,161).  A negative sigma (w or h in {0,1}) is NOT caught by the
+            // reference: that axis comes out empty through the slice arithmetic while the other is still drawn.
+            if (sx == 0 || sy == 0) empty = true;
+        }
+        if (kind != 0 && !empty) {
+            const int ulx = x - rx, uly = y - ry, brx = x + rx + 1, bry = y + ry + 1;
+            if (!in_img(ulx, uly, img, img) && !in_img(brx, bry, img, img)) empty = true;
+        }
+    }
+    T* o = out + ((int64_t)b * 2 * num_max + slot) * ld;
+    double* o64 = out64 ? out64 + ((int64_t)b * 2 * num_max + slot) * E : nullptr;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float v = 0.f;
+        if (kind == 0) {
+            v = (j == E - 1) ? 1.f : 0.f;
+        } else if (j < 2 * img) {
+            if (!empty) {
+                const bool isx = j < img;
+                const int pos = isx ? j : j - img;
+                const int c = isx ? x : y, r = isx ? rx : ry, s = isx ? sx : sy;
+                const int d = pos - c;
+                if (d >= -r && d <= r) {
+                    if (kind == 1) v = lut[d + 9];
+                    else v = expf(-((float)(d * d)) / (float)(2 * s * s));
+                }
+            }
+        } else if (j < E) {
+            v = (j - 2 * img == label) ? 1.f : 0.f;
+        }
+        o[j] = from_f32<T>(v);
+        if (o64 && j < E) o64[j] = (double)v;
+    }
+}
+
+// One thread per pixel, both polarity channels.  fp32 with separately rounded sub / mul / add (no FMA
+// contraction) so that the <= r^2 comparison is bit-exact with torch (ops.py:359-375).
+__global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict__ points, const int* __restrict__ boxes,
+                                                        float* __restrict__ out, int n, int H, int W, float r2) {
+    extern __shared__ float sp[];  // [2n][2]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * n; i += 256) {
+        sp[2 * i] = points[((int64_t)b * 2 * n + i) * 3 + 0];
+        sp[2 * i + 1] = points[((int64_t)b * 2 * n + i) * 3 + 1];
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const int r = pix / W, c = pix % W;
+    const float fr = (float)r, fc = (float)c;
+    int bch = -1, x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (boxes) {
+        const int* bx = boxes + b * 5;
+        bch = bx[4] < n ? 0 : 1;
+        // python floor division for the half sizes (is_model.py:107)
+        const int hw = fdiv(bx[2], 2), hh = fdiv(bx[3], 2);
+        x0 = bx[0] - hw; x1 = bx[0] + hw; y0 = bx[1] - hh; y1 = bx[1] + hh;
+    }
+    for (int g = 0; g < 2; ++g) {
+        float best = 1e6f;
+        for (int i = g * n; i < (g + 1) * n; ++i) {
+            const float pr = sp[2 * i], pc = sp[2 * i + 1];
+            if (fmaxf(pr, pc) < 0.f) continue;
+            const float dr = __fsub_rn(fr, pr), dc = __fsub_rn(fc, pc);
+            const float d = __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(dc, dc));
+            best = fminf(best, d);
+        }
+        float v = best <= r2 ? 1.f : 0.f;
+        if (g == bch) {
+            const bool outer = c >= x0 - 1 && c <= x1 + 1 && r >= y0 - 1 && r <= y1 + 1;
+            const bool inner = c > x0 + 1 && c < x1 - 1 && r > y0 + 1 && r < y1 - 1;
+            if (outer && !inner) v = 1.f;
+        }
+        out[(((int64_t)b * 2 + g) * H + r) * W + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
+                              int32_t B, int32_t n, int32_t num_max, int32_t img, int32_t ld, int32_t dtype,
+                              void* stream) {
+    if (n > num_max || ld < 2 * img + 3 || B <= 0) { vpu_set_error("pue_encode: n <= num_max, ld >= 2*img+3"); return VPU_ERR_ARG; }
+    const unsigned grid = (unsigned)(B * 2 * num_max);
+    if (dtype == VPU_BF16)
+        pue_encode_kernel<bf16_t><<<grid, 256, 0, ST>>>(points, boxes, lut, (bf16_t*)out, out64, n, num_max, img, ld);
+    else if (dtype == VPU_F32)
+        pue_encode_kernel<float><<<grid, 256, 0, ST>>>(points, boxes, lut, (float*)out, out64, n, num_max, img, ld);
+    else { vpu_set_error("pue_encode: dtype"); return VPU_ERR_ARG; }
+    return vpu_check_launch("vpu_pue_encode");
+}
+
+extern "C" int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H,
+                             int32_t W, float radius, void* stream) {
+    if (B <= 0 || n <= 0 || n > 1024) { vpu_set_error("disk_maps: sizes"); return VPU_ERR_ARG; }
+    dim3 grid((H * W + 255) / 256, B);
+    disk_maps_kernel<<<grid, 256, 2 * n * 2 * sizeof(float), ST>>>(points, boxes, out, n, H, W, radius * radius);
+    return vpu_check_launch("vpu_disk_maps");
+}

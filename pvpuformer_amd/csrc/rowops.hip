@@ -1,0 +1,419 @@
+// Row-wise and element-wise kernels: LayerNorm, softmax, L2 normalise, column sums, broadcasts, casts.
+// All HBM-bound; 16-byte vector accesses, one wave (64 lanes) per row, fp32 math.
+#include "vpu_common.h"
+#include "../../include/vpu_hip.h"
+
+#define DISPATCH_T(dtype, ...)                                   \
+    if ((dtype) == VPU_BF16) { using T = bf16_t; __VA_ARGS__ }   \
+    else if ((dtype) == VPU_F32) { using T = float; __VA_ARGS__ } \
+    else { vpu_set_error("bad dtype"); return VPU_ERR_ARG; }
+
+namespace {
+
+constexpr int LN_MAXCH = 4;  // 8-element chunks per lane -> C <= 2048
+
+// ---------------------------------------------------------------------------------- LayerNorm fwd
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * C;
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < C) {
+            load8(xr + c, v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[i][j];
+        }
+    }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    T* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < C) {
+            float ww[8], bb[8], o[8];
+            load8(w + c, ww);
+            load8(b + c, bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * ww[j] + bb[j];
+            store8(yr + c, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- LayerNorm bwd
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, float* __restrict__ part, int64_t rows,
+                                                            int C, int nblk) {
+    __shared__ float red[4][8 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dwa[LN_MAXCH][8], dba[LN_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dwa[i][j] = 0.f; dba[i][j] = 0.f; }
+    float ww[LN_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < C) load8(w + c, ww[i]);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nblk * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXCH][8], g[LN_MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                float xv[8], dv[8];
+                load8(x + row * C + c, xv);
+                load8(dy + row * C + c, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    g[i][j] = dv[j] * ww[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                    dwa[i][j] += dv[j] * xh[i][j];
+                    dba[i][j] += dv[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                float o[8];
+                if (dres) load8(dres + row * C + c, o);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += rs * (g[i][j] - s1 - xh[i][j] * s2);
+                store8(dx + row * C + c, o);
+            }
+        }
+    }
+    // reduce the 4 waves' dw / db and write this block's partial row
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave][j * 64 + lane] = which ? dba[i][j] : dwa[i][j];
+            __syncthreads();
+            if (wave == 0 && c < C) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
+                store8(part + ((int64_t)which * nblk + blockIdx.x) * C + c, o);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- column sums
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int64_t rows, int C, float beta) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = grp; r < rows; r += 4) s += in[r * C + c];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + t;
+    }
+}
+
+constexpr int CS_SLABS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ in, int ld, float* __restrict__ part,
+                                                          int64_t rows, int C) {
+    __shared__ float red[4][8 * 64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    const int64_t per = (rows + CS_SLABS - 1) / CS_SLABS;
+    const int64_t r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + grp; r < r1; r += 4) {
+            float v[8];
+            load8(in + r * ld + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[grp][j * 64 + lane] = a[j];
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
+        store8(part + (int64_t)blockIdx.y * C + c, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------- softmax
+constexpr int SM_MAX = 16;  // ncols <= 1024
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, int lds_, T* __restrict__ P,
+                                                          int ldp, int64_t rows, int ncols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * lds_;
+    float v[SM_MAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < ncols ? s[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < ncols ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    T* p = P + row * ldp;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int c = lane + i * 64;
+        if (c < ldp) p[c] = from_f32<T>(v[i] * inv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, int ldp,
+                                                          const float* __restrict__ dP, int lddp, T* __restrict__ dS,
+                                                          int64_t rows, int ncols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* p = P + row * ldp;
+    const float* d = dP + row * lddp;
+    float pv[SM_MAX], dv[SM_MAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int c = lane + i * 64;
+        pv[i] = c < ncols ? to_f32(p[c]) : 0.f;
+        dv[i] = c < ncols ? d[c] : 0.f;
+        dot += pv[i] * dv[i];
+    }
+    dot = wave_sum(dot);
+    T* o = dS + row * ldp;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int c = lane + i * 64;
+        if (c < ldp) o[c] = from_f32<T>(c < ncols ? pv[i] * (dv[i] - dot) * scale : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------- L2 normalise
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         float* __restrict__ inv, int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = to_f32(x[row * C + c]); s += v * v; }
+    const float nrm = sqrtf(wave_sum(s));
+    const float iv = 1.0f / fmaxf(nrm, 1e-12f);
+    if (lane == 0) inv[row] = iv;
+    for (int c = lane; c < C; c += 64) y[row * C + c] = from_f32<T>(to_f32(x[row * C + c]) * iv);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                         const float* __restrict__ inv, T* __restrict__ dx,
+                                                         int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += to_f32(dy[row * C + c]) * to_f32(y[row * C + c]);
+    s = wave_sum(s);
+    const float iv = inv[row];
+    for (int c = lane; c < C; c += 64)
+        dx[row * C + c] = from_f32<T>(iv * (to_f32(dy[row * C + c]) - to_f32(y[row * C + c]) * s));
+}
+
+// ---------------------------------------------------------------------------------- element-wise
+template <typename T>
+__global__ __launch_bounds__(256) void add_bcast_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                        T* __restrict__ out, int64_t nchunk, int64_t pchunk) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * 256) {
+        float x[8], y[8];
+        load8(a + i * 8, x);
+        load8(b + (i % pchunk) * 8, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        store8(out + i * 8, x);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add4_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                   const T* __restrict__ c, const T* __restrict__ d,
+                                                   T* __restrict__ out, int64_t nchunk) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * 256) {
+        float x[8], y[8];
+        load8(a + i * 8, x);
+        if (b) { load8(b + i * 8, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] += y[j]; }
+        if (c) { load8(c + i * 8, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] += y[j]; }
+        if (d) { load8(d + i * 8, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] += y[j]; }
+        store8(out + i * 8, x);
+    }
+}
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast2d_kernel(const TS* __restrict__ src, int64_t ld_src, TD* __restrict__ dst,
+                                                     int64_t ld_dst, int64_t rows, int cols, int cols_pad) {
+    const int64_t total = rows * cols_pad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols_pad;
+        const int c = (int)(i - r * cols_pad);
+        dst[r * ld_dst + c] = from_f32<TD>(c < cols ? to_f32(src[r * ld_src + c]) : 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                 int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+    if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm: C % 8 == 0, C <= 2048"); return VPU_ERR_ARG; }
+    DISPATCH_T(dtype, layernorm_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(
+        (const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps);)
+    return vpu_check_launch("vpu_layernorm_fwd");
+}
+extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
+    int64_t n = rows / 16;
+    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+}
+extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype,
+                                 void* stream) {
+    if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
+    const int nblk = vpu_layernorm_bwd_nblk(rows);
+    DISPATCH_T(dtype, layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, (const T*)x, w, mean, rstd,
+                                                                   (const T*)dres, (T*)dx, part, rows, C, nblk);)
+    return vpu_check_launch("vpu_layernorm_bwd");
+}
+extern "C" int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream) {
+    colsum_f32_kernel<<<(C + 63) / 64, 256, 0, ST>>>(in, out, rows, C, beta);
+    return vpu_check_launch("vpu_colsum_f32");
+}
+extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, int64_t rows, int32_t C, float beta,
+                          int32_t dtype, void* stream) {
+    if (C % 8 || ld % 8) { vpu_set_error("colsum: C, ld % 8"); return VPU_ERR_ARG; }
+    dim3 grid((C / 8 + 63) / 64, CS_SLABS);
+    DISPATCH_T(dtype, colsum_part_kernel<T><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
+    colsum_f32_kernel<<<(C + 63) / 64, 256, 0, ST>>>(part, out, CS_SLABS, C, beta);
+    return vpu_check_launch("vpu_colsum");
+}
+extern "C" int vpu_softmax_fwd(const float* S, int32_t lds_, void* P, int32_t ldp, int64_t rows, int32_t ncols,
+                               int32_t dtype, void* stream) {
+    if (ncols > SM_MAX * 64 || ldp > SM_MAX * 64 || ldp < ncols) { vpu_set_error("softmax: ncols <= 1024"); return VPU_ERR_ARG; }
+    DISPATCH_T(dtype, softmax_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(S, lds_, (T*)P, ldp, rows, ncols);)
+    return vpu_check_launch("vpu_softmax_fwd");
+}
+extern "C" int vpu_softmax_bwd(const void* P, int32_t ldp, const float* dP, int32_t lddp, void* dS, int64_t rows,
+                               int32_t ncols, float scale, int32_t dtype, void* stream) {
+    if (ncols > SM_MAX * 64 || ldp > SM_MAX * 64 || ldp < ncols) { vpu_set_error("softmax_bwd: ncols <= 1024"); return VPU_ERR_ARG; }
+    DISPATCH_T(dtype, softmax_bwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)P, ldp, dP, lddp,
+                                                                                       (T*)dS, rows, ncols, scale);)
+    return vpu_check_launch("vpu_softmax_bwd");
+}
+extern "C" int vpu_l2norm_fwd(const void* x, void* y, float* inv, int64_t rows, int32_t C, int32_t dtype, void* stream) {
+    DISPATCH_T(dtype, l2norm_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)x, (T*)y, inv, rows, C);)
+    return vpu_check_launch("vpu_l2norm_fwd");
+}
+extern "C" int vpu_l2norm_bwd(const void* dy, const void* y, const float* inv, void* dx, int64_t rows, int32_t C,
+                              int32_t dtype, void* stream) {
+    DISPATCH_T(dtype, l2norm_bwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)dy, (const T*)y, inv,
+                                                                                      (T*)dx, rows, C);)
+    return vpu_check_launch("vpu_l2norm_bwd");
+}
+extern "C" int vpu_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period_b, int32_t dtype,
+                             void* stream) {
+    if (n % 8 || period_b % 8 || period_b <= 0) { vpu_set_error("add_bcast: n, period % 8"); return VPU_ERR_ARG; }
+    const int grid = vpu_grid_for(n / 8, 256, 4096);
+    DISPATCH_T(dtype, add_bcast_kernel<T><<<grid, 256, 0, ST>>>((const T*)a, (const T*)b, (T*)out, n / 8, period_b / 8);)
+    return vpu_check_launch("vpu_add_bcast");
+}
+extern "C" int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n,
+                        int32_t dtype, void* stream) {
+    if (n % 8) { vpu_set_error("add4: n % 8"); return VPU_ERR_ARG; }
+    const int grid = vpu_grid_for(n / 8, 256, 4096);
+    DISPATCH_T(dtype, add4_kernel<T><<<grid, 256, 0, ST>>>((const T*)a, (const T*)b, (const T*)c, (const T*)d, (T*)out, n / 8);)
+    return vpu_check_launch("vpu_add4");
+}
+extern "C" int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
+                          int64_t ld_dst, int64_t rows, int32_t cols, int32_t cols_pad, void* stream) {
+    const int grid = vpu_grid_for(rows * cols_pad, 256, 8192);
+    if (src_dtype == VPU_F32 && dst_dtype == VPU_BF16)
+        cast2d_kernel<float, bf16_t><<<grid, 256, 0, ST>>>((const float*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, cols_pad);
+    else if (src_dtype == VPU_F32 && dst_dtype == VPU_F32)
+        cast2d_kernel<float, float><<<grid, 256, 0, ST>>>((const float*)src, ld_src, (float*)dst, ld_dst, rows, cols, cols_pad);
+    else if (src_dtype == VPU_BF16 && dst_dtype == VPU_F32)
+        cast2d_kernel<bf16_t, float><<<grid, 256, 0, ST>>>((const bf16_t*)src, ld_src, (float*)dst, ld_dst, rows, cols, cols_pad);
+    else if (src_dtype == VPU_BF16 && dst_dtype == VPU_BF16)
+        cast2d_kernel<bf16_t, bf16_t><<<grid, 256, 0, ST>>>((const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, cols_pad);
+    else { vpu_set_error("cast2d: dtype"); return VPU_ERR_ARG; }
+    return vpu_check_launch("vpu_cast2d");
+}
+extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
+    fill_kernel<<<vpu_grid_for(n, 256, 4096), 256, 0, ST>>>(p, v, n);
+    return vpu_check_launch("vpu_fill_f32");
+}

@@ -1,0 +1,762 @@
+// Spatial kernels of the VPUFormer path on channels-last maps: patch im2col (window token order), token
+// permutation, pixel shuffle for 2x2/stride-2 (transposed) convolutions, GroupNorm(1,C)[+GELU], bilinear resize,
+// DMA gates, conv_seg, final align_corners=True upsample.  All HBM-bound: vector accesses, fp32 math.
+#include "vpu_common.h"
+#include "../../include/vpu_hip.h"
+
+#define DISPATCH_T(dtype, ...)                                   \
+    if ((dtype) == VPU_BF16) { using T = bf16_t; __VA_ARGS__ }   \
+    else if ((dtype) == VPU_F32) { using T = float; __VA_ARGS__ } \
+    else { vpu_set_error("bad dtype"); return VPU_ERR_ARG; }
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+namespace {
+
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
+
+// ------------------------------------------------------------------------------ patch im2col
+// cols[(b*T + t_win)][ch*P*P + py*P + px], ch: 0-2 normalised rgb (ops.py:403-407), 3 prev mask, 4-5 disks
+template <typename T>
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img4,
+                                                           const float* __restrict__ disks, T* __restrict__ cols,
+                                                           int B, int H, int W, int P, int wg) {
+    const int gw = W / P, gh = H / P;
+    const int Tn = gw * gh, KK = 6 * P * P, chunks = KK / 8;
+    const int64_t total = (int64_t)B * Tn * chunks;
+    const int nwx = gw / wg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t row = i / chunks;
+        const int tw = (int)(row % Tn), b = (int)(row / Tn);
+        const int win = tw / (wg * wg), inner = tw % (wg * wg);
+        const int ty = (win / nwx) * wg + inner / wg, tx = (win % nwx) * wg + inner % wg;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ck * 8 + j;
+            const int ch = k / (P * P), rem = k % (P * P);
+            const int y = ty * P + rem / P, x = tx * P + rem % P;
+            float v;
+            if (ch < 4) {
+                v = img4[(((int64_t)b * 4 + ch) * H + y) * W + x];
+                if (ch < 3) v = (v - c_mean[ch]) / c_std[ch];
+            } else {
+                v = disks[(((int64_t)b * 2 + (ch - 4)) * H + y) * W + x];
+            }
+            o[j] = v;
+        }
+        store8(cols + row * KK + ck * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------ window <-> raster token order
+template <typename T>
+__global__ __launch_bounds__(256) void window_permute_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int g,
+                                                             int wg, int C, int dir) {
+    const int Tn = g * g, chunks = C / 8, nw = g / wg;
+    const int64_t total = (int64_t)B * Tn * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t row = i / chunks;
+        const int t = (int)(row % Tn), b = (int)(row / Tn);
+        // t is a raster index; tw its window-order index
+        const int ty = t / g, tx = t % g;
+        const int tw = ((ty / wg) * nw + tx / wg) * wg * wg + (ty % wg) * wg + tx % wg;
+        const int64_t r_rast = (int64_t)b * Tn + t, r_win = (int64_t)b * Tn + tw;
+        float v[8];
+        if (dir == 0) { load8(x + r_rast * C + ck * 8, v); store8(y + r_win * C + ck * 8, v); }
+        else { load8(x + r_win * C + ck * 8, v); store8(y + r_rast * C + ck * 8, v); }
+    }
+}
+
+// ------------------------------------------------------------------------------ pixel shuffle (2x2)
+// dir 0: in [B*h*w][C*4] (col = c*4+di*2+dj) -> out [B][2h][2w][C] (+bias[c])
+// dir 1: x [B][2h][2w][C] -> in-layout [B*h*w][C*4]
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                             const float* __restrict__ bias, int B, int h, int w, int C,
+                                                             int dir) {
+    const int chunks = C / 8;
+    const int H2 = 2 * h, W2 = 2 * w;
+    const int64_t total = (int64_t)B * H2 * W2 * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t pix = i / chunks;
+        const int X = (int)(pix % W2), Y = (int)((pix / W2) % H2), b = (int)(pix / ((int64_t)W2 * H2));
+        const int64_t m = ((int64_t)b * h + (Y >> 1)) * w + (X >> 1);
+        const int dd = (Y & 1) * 2 + (X & 1);
+        const int64_t fine = pix * C + ck * 8;           // channels-last fine-resolution element
+        const int64_t coarse = m * (C * 4) + (ck * 8) * 4 + dd;  // stride-4 gather
+        if (dir == 0) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = to_f32(src[coarse + j * 4]) + (bias ? bias[ck * 8 + j] : 0.f);
+            store8(dst + fine, v);
+        } else {
+            float v[8];
+            load8(src + fine, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[coarse + j * 4] = from_f32<T>(v[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ GroupNorm(1, C)
+constexpr int GN_CHUNKS = 64;
+
+// thread layout shared by the GroupNorm kernels: a block walks the pixels [p0,p1) of one sample;
+// thread t owns channel chunk (t % tpp) of pixel slot (t / tpp), tpp = C/8.
+struct GnMap {
+    int tpp, slots, cc, slot;
+    bool active;
+    int64_t p0, p1;
+    __device__ GnMap(int C, int64_t HW) {
+        tpp = C / 8;
+        slots = 256 / tpp;
+        if (slots < 1) slots = 1;
+        slot = threadIdx.x / tpp;
+        cc = (threadIdx.x % tpp) * 8;
+        active = slot < slots && tpp <= 256;
+        const int64_t per = (HW + GN_CHUNKS - 1) / GN_CHUNKS;
+        p0 = (int64_t)blockIdx.y * per;
+        p1 = p0 + per < HW ? p0 + per : HW;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int64_t HW,
+                                                       int C) {
+    __shared__ double red[8];
+    GnMap mp(C, HW);
+    const int b = blockIdx.x;
+    float s = 0.f, q = 0.f;
+    double ds = 0.0, dq = 0.0;
+    if (mp.active)
+        for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
+            float v[8];
+            load8(x + ((int64_t)b * HW + p) * C + mp.cc, v);
+            s = 0.f; q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += v[j]; q += v[j] * v[j]; }
+            ds += s; dq += q;
+        }
+    const double S = block_sum_d(ds, red);
+    const double Q = block_sum_d(dq, red);
+    if (threadIdx.x == 0) {
+        stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 0] = S;
+        stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 1] = Q;
+    }
+}
+
+__device__ __forceinline__ void gn_finalize(const double* stats, int b, int64_t n, float eps, float& mu, float& rs,
+                                            double* red) {
+    double s = 0.0, q = 0.0;
+    if (threadIdx.x < GN_CHUNKS) {
+        s = stats[((int64_t)b * GN_CHUNKS + threadIdx.x) * 2 + 0];
+        q = stats[((int64_t)b * GN_CHUNKS + threadIdx.x) * 2 + 1];
+    }
+    const double S = block_sum_d(s, red);
+    const double Q = block_sum_d(q, red);
+    const double m = S / (double)n;
+    double var = Q / (double)n - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bb, T* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                       const double* __restrict__ stats, int64_t HW, int C, float eps,
+                                                       int gelu) {
+    __shared__ double red[8];
+    GnMap mp(C, HW);
+    const int b = blockIdx.x;
+    float mu, rs;
+    gn_finalize(stats, b, HW * C, eps, mu, rs, red);
+    if (blockIdx.y == 0 && threadIdx.x == 0) { mean[b] = mu; rstd[b] = rs; }
+    if (!mp.active) return;
+    float ww[8], bv[8];
+    load8(w + mp.cc, ww);
+    load8(bb + mp.cc, bv);
+    for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
+        float v[8];
+        const int64_t off = ((int64_t)b * HW + p) * C + mp.cc;
+        load8(x + off, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = (v[j] - mu) * rs * ww[j] + bv[j];
+            v[j] = gelu ? gelu_f(t) : t;
+        }
+        store8(y + off, v);
+    }
+}
+
+// backward pass 1: per-sample sums of g and g*xhat (fp64 partials), per-channel dw/db partials
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ bb,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ part,
+                                                           double* __restrict__ stats, int B, int64_t HW, int C,
+                                                           int gelu) {
+    __shared__ double red[8];
+    __shared__ float acc[2048];
+    GnMap mp(C, HW);
+    const int b = blockIdx.x;
+    const float mu = mean[b], rs = rstd[b];
+    float dwa[8], dba[8], ww[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dwa[j] = 0.f; dba[j] = 0.f; ww[j] = 0.f; bv[j] = 0.f; }
+    double d1 = 0.0, d2 = 0.0;
+    if (mp.active) {
+        load8(w + mp.cc, ww);
+        load8(bb + mp.cc, bv);
+        for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
+            float xv[8], dv[8];
+            const int64_t off = ((int64_t)b * HW + p) * C + mp.cc;
+            load8(x + off, xv);
+            load8(dy + off, dv);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[j] - mu) * rs;
+                float d = dv[j];
+                if (gelu) d *= dgelu_f(xh * ww[j] + bv[j]);
+                const float g = d * ww[j];
+                s1 += g; s2 += g * xh;
+                dwa[j] += d * xh; dba[j] += d;
+            }
+            d1 += s1; d2 += s2;
+        }
+    }
+    const double S1 = block_sum_d(d1, red);
+    const double S2 = block_sum_d(d2, red);
+    if (threadIdx.x == 0) {
+        stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 0] = S1;
+        stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 1] = S2;
+    }
+    const int64_t prow = (int64_t)b * GN_CHUNKS + blockIdx.y;
+    const int64_t nrows = (int64_t)B * GN_CHUNKS;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+        if (mp.active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[mp.slot * C + mp.cc + j] = which ? dba[j] : dwa[j];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float t = 0.f;
+            for (int s = 0; s < mp.slots; ++s) t += acc[s * C + c];
+            part[((int64_t)which * nrows + prow) * C + c] = t;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ bb,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        T* __restrict__ dx, const double* __restrict__ stats, int64_t HW,
+                                                        int C, int gelu) {
+    __shared__ double red[8];
+    GnMap mp(C, HW);
+    const int b = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    if (threadIdx.x < GN_CHUNKS) {
+        s = stats[((int64_t)b * GN_CHUNKS + threadIdx.x) * 2 + 0];
+        q = stats[((int64_t)b * GN_CHUNKS + threadIdx.x) * 2 + 1];
+    }
+    const double n = (double)HW * (double)C;
+    const float m1 = (float)(block_sum_d(s, red) / n);
+    const float m2 = (float)(block_sum_d(q, red) / n);
+    if (!mp.active) return;
+    const float mu = mean[b], rs = rstd[b];
+    float ww[8], bv[8];
+    load8(w + mp.cc, ww);
+    load8(bb + mp.cc, bv);
+    for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
+        float xv[8], dv[8];
+        const int64_t off = ((int64_t)b * HW + p) * C + mp.cc;
+        load8(x + off, xv);
+        load8(dy + off, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (xv[j] - mu) * rs;
+            float d = dv[j];
+            if (gelu) d *= dgelu_f(xh * ww[j] + bv[j]);
+            dv[j] = rs * (d * ww[j] - m1 - xh * m2);
+        }
+        store8(dx + off, dv);
+    }
+}
+
+// ------------------------------------------------------------------------------ bilinear, align_corners=False
+__device__ __forceinline__ void src_index_half(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_cl_fwd_kernel(const T* __restrict__ in, int ld_in, T* __restrict__ out,
+                                                              int ld_out, int B, int h, int w, int H, int W, int C) {
+    const int chunks = C / 8;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int64_t total = (int64_t)B * H * W * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t pix = i / chunks;
+        const int X = (int)(pix % W), Y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index_half(Y, sh, h, y0, y1, ly);
+        src_index_half(X, sw, w, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        float a[8], bq[8], c[8], d[8], o[8];
+        const int64_t base = (int64_t)b * h * w;
+        load8(in + (base + (int64_t)y0 * w + x0) * ld_in + ck * 8, a);
+        load8(in + (base + (int64_t)y0 * w + x1) * ld_in + ck * 8, bq);
+        load8(in + (base + (int64_t)y1 * w + x0) * ld_in + ck * 8, c);
+        load8(in + (base + (int64_t)y1 * w + x1) * ld_in + ck * 8, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = hy * (hx * a[j] + lx * bq[j]) + ly * (hx * c[j] + lx * d[j]);
+        store8(out + pix * ld_out + ck * 8, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_cl_bwd_kernel(const T* __restrict__ dout, int ld_out,
+                                                              T* __restrict__ din, int ld_in, int B, int h, int w, int H,
+                                                              int W, int C) {
+    const int chunks = C / 8;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const float fh = (float)H / (float)h, fw = (float)W / (float)w;
+    const int64_t total = (int64_t)B * h * w * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t pix = i / chunks;
+        const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
+        int Ylo = (int)floorf(fh * ((float)y - 0.5f) - 0.5f) - 1, Yhi = (int)ceilf(fh * ((float)y + 1.5f)) + 1;
+        int Xlo = (int)floorf(fw * ((float)x - 0.5f) - 0.5f) - 1, Xhi = (int)ceilf(fw * ((float)x + 1.5f)) + 1;
+        if (y == 0) Ylo = 0;
+        if (x == 0) Xlo = 0;
+        if (Ylo < 0) Ylo = 0;
+        if (Xlo < 0) Xlo = 0;
+        if (Yhi > H - 1 || y == h - 1) Yhi = H - 1;
+        if (Xhi > W - 1 || x == w - 1) Xhi = W - 1;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int Y = Ylo; Y <= Yhi; ++Y) {
+            int y0, y1; float ly;
+            src_index_half(Y, sh, h, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = Xlo; X <= Xhi; ++X) {
+                int x0, x1; float lx;
+                src_index_half(X, sw, w, x0, x1, lx);
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float g[8];
+                load8(dout + (((int64_t)b * H + Y) * W + X) * ld_out + ck * 8, g);
+                const float ww = wy * wx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += ww * g[j];
+            }
+        }
+        store8(din + pix * ld_in + ck * 8, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------ DMA gates
+template <typename T>
+__global__ __launch_bounds__(256) void gate_colmax_kernel(const T* __restrict__ Q, float* __restrict__ cg,
+                                                          int* __restrict__ argq, int B, int nq, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int c = (int)(i % C), b = (int)(i / C);
+    float mx = -INFINITY;
+    int am = 0;
+    for (int q = 0; q < nq; ++q) {
+        const float v = to_f32(Q[((int64_t)b * nq + q) * C + c]);
+        if (v > mx) { mx = v; am = q; }
+    }
+    cg[i] = sigmoid_f(mx);
+    argq[i] = am;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_rowmax_kernel(const T* __restrict__ K, float* __restrict__ sg,
+                                                          int* __restrict__ argc, int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = lane; c < C; c += 64) {
+        const float v = to_f32(K[row * C + c]);
+        if (v > mx) { mx = v; am = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    if (lane == 0) { sg[row] = sigmoid_f(mx); argc[row] = am; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_apply_kernel(const T* __restrict__ x, const float* __restrict__ cg,
+                                                         const float* __restrict__ sg, T* __restrict__ out, int B, int N,
+                                                         int C) {
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)B * N * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t row = i / chunks;
+        const int b = (int)(row / N);
+        float v[8], g[8];
+        load8(x + row * C + ck * 8, v);
+        load8(cg + (int64_t)b * C + ck * 8, g);
+        const float s = sg[row];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * (1.f + g[j] + s);
+        store8(out + row * C + ck * 8, v);
+    }
+}
+
+constexpr int GATE_NBLK = 16;
+// one wave per row n: dx, dsg (+ scatter into dK), per-column partial of dcg
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_rows_kernel(const T* __restrict__ dout, const T* __restrict__ x,
+                                                            const float* __restrict__ cg, const float* __restrict__ sg,
+                                                            const int* __restrict__ argc, T* __restrict__ dx, int accum,
+                                                            T* __restrict__ dK, float* __restrict__ part, int N, int C) {
+    __shared__ float red[4][8 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int per = (N + GATE_NBLK - 1) / GATE_NBLK;
+    const int n0 = blockIdx.y * per, n1 = n0 + per < N ? n0 + per : N;
+    constexpr int MAXCH = 4;
+    float dcg[MAXCH][8], g[MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dcg[i][j] = 0.f; g[i][j] = 0.f; }
+        if (c < C) load8(cg + (int64_t)b * C + c, g[i]);
+    }
+    for (int n = n0 + wave; n < n1; n += 4) {
+        const int64_t row = (int64_t)b * N + n;
+        const float s = sg[row];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                float dv[8], xv[8], o[8];
+                load8(dout + row * C + c, dv);
+                load8(x + row * C + c, xv);
+                if (accum) load8(dx + row * C + c, o);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = dv[j] * xv[j];
+                    dot += t;
+                    dcg[i][j] += t;
+                    o[j] += dv[j] * (1.f + g[i][j] + s);
+                }
+                store8(dx + row * C + c, o);
+            }
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            const int64_t k = row * C + argc[row];
+            dK[k] = from_f32<T>(to_f32(dK[k]) + dot * s * (1.f - s));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][j * 64 + lane] = dcg[i][j];
+        __syncthreads();
+        if (wave == 0 && c < C) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
+            store8(part + ((int64_t)b * GATE_NBLK + blockIdx.y) * C + c, o);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_cols_kernel(const float* __restrict__ part, const float* __restrict__ cg,
+                                                            const int* __restrict__ argq, T* __restrict__ dQ, int B,
+                                                            int nq, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int c = (int)(i % C), b = (int)(i / C);
+    float t = 0.f;
+    for (int k = 0; k < GATE_NBLK; ++k) t += part[((int64_t)b * GATE_NBLK + k) * C + c];
+    const float g = cg[i];
+    const int64_t k = ((int64_t)b * nq + argq[i]) * C + c;
+    dQ[k] = from_f32<T>(to_f32(dQ[k]) + t * g * (1.f - g));
+}
+
+// ------------------------------------------------------------------------------ conv_seg (C -> 1, Dropout2d mask)
+template <typename T>
+__global__ __launch_bounds__(256) void convseg_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ mask, float* __restrict__ out,
+                                                          int64_t rows, int64_t HW, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t b = row / HW;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float t = to_f32(x[row * C + c]) * w[c];
+        if (mask) t *= mask[b * C + c];
+        s += t;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s + bias[0];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void convseg_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ mask,
+                                                          T* __restrict__ dx, int accum, float* __restrict__ part,
+                                                          float* __restrict__ part_b, int64_t rows, int64_t HW, int C,
+                                                          int nblk) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int MAXC = 8;  // C <= 512
+    float dwa[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) dwa[i] = 0.f;
+    float dba = 0.f;
+    const int64_t per = (rows + nblk - 1) / nblk;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    for (int64_t row = r0 + wave; row < r1; row += 4) {
+        const float d = dout[row];
+        const int64_t b = row / HW;
+        dba += d;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < C) {
+                const float mk = mask ? mask[b * C + c] : 1.f;
+                const float xv = to_f32(x[row * C + c]);
+                dwa[i] += d * xv * mk;
+                float o = d * w[c] * mk;
+                if (accum) o += to_f32(dx[row * C + c]);
+                dx[row * C + c] = from_f32<T>(o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        __syncthreads();
+        red[wave][lane] = dwa[i];
+        __syncthreads();
+        if (wave == 0 && c < C) part[(int64_t)blockIdx.x * C + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    }
+    __syncthreads();
+    red[wave][lane] = dba;  // same value in every lane of a wave
+    __syncthreads();
+    if (threadIdx.x == 0) part_b[blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+}
+
+// ------------------------------------------------------------------------------ align_corners=True upsample (planes)
+__device__ __forceinline__ void src_index_ac(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float s = scale * (float)dst;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+__global__ __launch_bounds__(256) void upsample_ac_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int64_t planes, int h, int w, int H, int W) {
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const int64_t total = planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int X = (int)(i % W), Y = (int)((i / W) % H);
+        const int64_t pl = i / ((int64_t)W * H);
+        int y0, y1, x0, x1; float ly, lx;
+        src_index_ac(Y, sh, h, y0, y1, ly);
+        src_index_ac(X, sw, w, x0, x1, lx);
+        const float* p = in + pl * h * w;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        out[i] = hy * (hx * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * (hx * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+    }
+}
+__global__ __launch_bounds__(256) void upsample_ac_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                              int64_t planes, int h, int w, int H, int W) {
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float fh = sh > 0.f ? 1.f / sh : 0.f, fw = sw > 0.f ? 1.f / sw : 0.f;
+    const int64_t total = planes * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const int64_t pl = i / ((int64_t)w * h);
+        int Ylo = (int)floorf(fh * (float)(y - 1)) - 1, Yhi = (int)ceilf(fh * (float)(y + 1)) + 1;
+        int Xlo = (int)floorf(fw * (float)(x - 1)) - 1, Xhi = (int)ceilf(fw * (float)(x + 1)) + 1;
+        if (Ylo < 0) Ylo = 0;
+        if (Xlo < 0) Xlo = 0;
+        if (Yhi > H - 1) Yhi = H - 1;
+        if (Xhi > W - 1) Xhi = W - 1;
+        const float* g = dout + pl * H * W;
+        float acc = 0.f;
+        for (int Y = Ylo; Y <= Yhi; ++Y) {
+            int y0, y1; float ly;
+            src_index_ac(Y, sh, h, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = Xlo; X <= Xhi; ++X) {
+                int x0, x1; float lx;
+                src_index_ac(X, sw, w, x0, x1, lx);
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx != 0.f) acc += wy * wx * g[(int64_t)Y * W + X];
+            }
+        }
+        din[i] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int vpu_patch_im2col(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W,
+                                int32_t P, int32_t win_tokens, int32_t dtype, void* stream) {
+    if (H % P || W % P || (6 * P * P) % 8 || (W / P) % win_tokens || (H / P) % win_tokens) {
+        vpu_set_error("patch_im2col: H,W % P, grid % window, 6*P*P % 8");
+        return VPU_ERR_ARG;
+    }
+    const int64_t total = (int64_t)B * (H / P) * (W / P) * (6 * P * P / 8);
+    DISPATCH_T(dtype, patch_im2col_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+        image4, disks, (T*)cols, B, H, W, P, win_tokens);)
+    return vpu_check_launch("vpu_patch_im2col");
+}
+extern "C" int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, int32_t wg, int32_t C, int32_t dir,
+                                  int32_t dtype, void* stream) {
+    if (C % 8 || g % wg) { vpu_set_error("window_permute: C % 8, g % wg"); return VPU_ERR_ARG; }
+    const int64_t total = (int64_t)B * g * g * (C / 8);
+    DISPATCH_T(dtype, window_permute_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)x, (T*)y, B, g,
+                                                                                               wg, C, dir);)
+    return vpu_check_launch("vpu_window_permute");
+}
+extern "C" int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, int32_t B, int32_t h, int32_t w,
+                                  int32_t C, int32_t dir, int32_t dtype, void* stream) {
+    if (C % 8) { vpu_set_error("pixel_shuffle2: C % 8"); return VPU_ERR_ARG; }
+    const int64_t total = (int64_t)B * 4 * h * w * (C / 8);
+    DISPATCH_T(dtype, pixel_shuffle2_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)in, (T*)out,
+                                                                                               bias, B, h, w, C, dir);)
+    return vpu_check_launch("vpu_pixel_shuffle2");
+}
+extern "C" int vpu_groupnorm_nchunk(void) { return GN_CHUNKS; }
+extern "C" int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                 double* stats, int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu,
+                                 int32_t dtype, void* stream) {
+    if (C % 8 || C > 2048) { vpu_set_error("groupnorm: C % 8, C <= 2048"); return VPU_ERR_ARG; }
+    dim3 grid(B, GN_CHUNKS);
+    DISPATCH_T(dtype, gn_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, stats, HW, C);
+               gn_apply_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, stats, HW, C, eps, gelu);)
+    return vpu_check_launch("vpu_groupnorm_fwd");
+}
+extern "C" int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, const float* b, const float* mean,
+                                 const float* rstd, void* dx, float* part, double* stats, int32_t B, int64_t HW,
+                                 int32_t C, int32_t gelu, int32_t dtype, void* stream) {
+    if (C % 8 || C > 2048) { vpu_set_error("groupnorm_bwd: C % 8, C <= 2048"); return VPU_ERR_ARG; }
+    dim3 grid(B, GN_CHUNKS);
+    DISPATCH_T(dtype,
+               gn_bwd_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, w, b, mean, rstd, part, stats, B,
+                                                            HW, C, gelu);
+               gn_bwd_dx_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, w, b, mean, rstd, (T*)dx, stats, HW,
+                                                         C, gelu);)
+    return vpu_check_launch("vpu_groupnorm_bwd");
+}
+extern "C" int vpu_bilinear_cl_fwd(const void* in, int32_t ld_in, void* out, int32_t ld_out, int32_t B, int32_t h,
+                                   int32_t w, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl: C, ld % 8"); return VPU_ERR_ARG; }
+    const int64_t total = (int64_t)B * H * W * (C / 8);
+    DISPATCH_T(dtype, bilinear_cl_fwd_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+        (const T*)in, ld_in, (T*)out, ld_out, B, h, w, H, W, C);)
+    return vpu_check_launch("vpu_bilinear_cl_fwd");
+}
+extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_in, int32_t B, int32_t h,
+                                   int32_t w, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl_bwd: C, ld % 8"); return VPU_ERR_ARG; }
+    const int64_t total = (int64_t)B * h * w * (C / 8);
+    DISPATCH_T(dtype, bilinear_cl_bwd_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+        (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, H, W, C);)
+    return vpu_check_launch("vpu_bilinear_cl_bwd");
+}
+extern "C" int vpu_gate_stats(const void* Q, const void* Kt, float* cg, int32_t* argq, float* sg, int32_t* argc,
+                              int32_t B, int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream) {
+    DISPATCH_T(dtype,
+               gate_colmax_kernel<T><<<vpu_grid_for((int64_t)B * C, 256), 256, 0, ST>>>((const T*)Q, cg, argq, B, nq, C);
+               gate_rowmax_kernel<T><<<(unsigned)(((int64_t)B * N + 3) / 4), 256, 0, ST>>>((const T*)Kt, sg, argc,
+                                                                                          (int64_t)B * N, C);)
+    return vpu_check_launch("vpu_gate_stats");
+}
+extern "C" int vpu_gate_apply(const void* x, const float* cg, const float* sg, void* out, int32_t B, int32_t N,
+                              int32_t C, int32_t dtype, void* stream) {
+    if (C % 8) { vpu_set_error("gate_apply: C % 8"); return VPU_ERR_ARG; }
+    const int64_t total = (int64_t)B * N * (C / 8);
+    DISPATCH_T(dtype, gate_apply_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)x, cg, sg, (T*)out,
+                                                                                           B, N, C);)
+    return vpu_check_launch("vpu_gate_apply");
+}
+extern "C" int vpu_gate_bwd(const void* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
+                            const int32_t* argc, void* dx, int32_t accum, void* dQ, void* dK, float* part, int32_t B,
+                            int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream) {
+    if (C % 8 || C > 2048) { vpu_set_error("gate_bwd: C % 8, C <= 2048"); return VPU_ERR_ARG; }
+    dim3 grid(B, GATE_NBLK);
+    DISPATCH_T(dtype,
+               gate_bwd_rows_kernel<T><<<grid, 256, 0, ST>>>((const T*)dout, (const T*)x, cg, sg, argc, (T*)dx, accum,
+                                                             (T*)dK, part, N, C);
+               gate_bwd_cols_kernel<T><<<vpu_grid_for((int64_t)B * C, 256), 256, 0, ST>>>(part, cg, argq, (T*)dQ, B, nq,
+                                                                                         C);)
+    return vpu_check_launch("vpu_gate_bwd");
+}
+extern "C" int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out,
+                               int64_t rows, int64_t HW, int32_t C, int32_t dtype, void* stream) {
+    DISPATCH_T(dtype, convseg_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)x, w, bias, mask, out,
+                                                                                       rows, HW, C);)
+    return vpu_check_launch("vpu_convseg_fwd");
+}
+extern "C" int vpu_convseg_bwd_nblk(int64_t rows) {
+    int64_t n = rows / 64;
+    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
+}
+extern "C" int vpu_convseg_bwd(const float* dout, const void* x, const float* w, const float* mask, void* dx,
+                               int32_t accum, float* part, float* part_b, int64_t rows, int64_t HW, int32_t C,
+                               int32_t dtype, void* stream) {
+    if (C > 512) { vpu_set_error("convseg_bwd: C <= 512"); return VPU_ERR_ARG; }
+    const int nblk = vpu_convseg_bwd_nblk(rows);
+    DISPATCH_T(dtype, convseg_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dout, (const T*)x, w, mask, (T*)dx, accum, part,
+                                                                 part_b, rows, HW, C, nblk);)
+    return vpu_check_launch("vpu_convseg_bwd");
+}
+extern "C" int vpu_upsample_ac_fwd(const float* in, float* out, int64_t planes, int32_t h, int32_t w, int32_t H,
+                                   int32_t W, void* stream) {
+    upsample_ac_fwd_kernel<<<vpu_grid_for(planes * H * W, 256, 65536), 256, 0, ST>>>(in, out, planes, h, w, H, W);
+    return vpu_check_launch("vpu_upsample_ac_fwd");
+}
+extern "C" int vpu_upsample_ac_bwd(const float* dout, float* din, int64_t planes, int32_t h, int32_t w, int32_t H,
+                                   int32_t W, void* stream) {
+    upsample_ac_bwd_kernel<<<vpu_grid_for(planes * h * w, 256, 65536), 256, 0, ST>>>(dout, din, planes, h, w, H, W);
+    return vpu_check_launch("vpu_upsample_ac_bwd");
+}

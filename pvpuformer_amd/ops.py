@@ -1,0 +1,207 @@
+"""Thin host wrappers over the C ABI: torch tensors in (device memory + current HIP stream = plumbing), raw
+pointers out.  No arithmetic happens here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (BF16, F32, EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGELU, EPI_DRELU, EPI_RESID, EPI_AFFINE,
+                   EPI_ACCUM, EPI_OUT_F32, GemmDesc)
+
+TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
+
+
+def code_of(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, off=0):
+    """device pointer of tensor ``t`` advanced by ``off`` elements (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, tuple):
+        t, o = t
+        off += o
+    return t.data_ptr() + off * t.element_size()
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, flags=0, bias=None, resid=None,
+         ldr=0, aux=None, ldaux=0, preact=None, alpha=1.0, post_mul=1.0, post_add=0.0, batch=1, inner=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0):
+    """C = epilogue(alpha * op(A) op(B)); see include/vpu_hip.h.  A/B/C/resid/aux/preact may be tensors or
+    (tensor, element_offset) tuples."""
+    d = GemmDesc()
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
+    d.bias, d.resid, d.aux, d.preact = ptr(bias), ptr(resid), ptr(aux), ptr(preact)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr, d.ldaux = lda, ldb, ldc, ldr, ldaux
+    d.batch, d.inner = batch, inner
+    d.sAo, d.sAi = sA
+    d.sBo, d.sBi = sB
+    d.sCo, d.sCi = sC
+    d.sRo, d.sRi = sR
+    d.transA, d.transB = int(transA), int(transB)
+    d.dtype, d.flags = dtype, flags
+    d.resid_period = resid_period
+    d.alpha, d.post_mul, d.post_add = alpha, post_mul, post_add
+    _lib.call("vpu_gemm", C.byref(d), _stream())
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, rows, Cdim, eps):
+    _lib.call("vpu_layernorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, Cdim, eps, code_of(x),
+              _stream())
+
+
+def layernorm_bwd_nblk(rows):
+    return _lib.load().vpu_layernorm_bwd_nblk(rows)
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, Cdim):
+    _lib.call("vpu_layernorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(part), rows,
+              Cdim, code_of(x), _stream())
+
+
+def colsum_f32(inp, out, rows, Cdim, beta=0.0):
+    _lib.call("vpu_colsum_f32", ptr(inp), ptr(out), rows, Cdim, beta, _stream())
+
+
+def colsum(inp, ld, out, part, rows, Cdim, beta=0.0):
+    _lib.call("vpu_colsum", ptr(inp), ld, ptr(out), ptr(part), rows, Cdim, beta, code_of(inp[0] if isinstance(inp, tuple) else inp),
+              _stream())
+
+
+def softmax_fwd(S, lds, P, ldp, rows, ncols):
+    _lib.call("vpu_softmax_fwd", ptr(S), lds, ptr(P), ldp, rows, ncols, code_of(P), _stream())
+
+
+def softmax_bwd(P, ldp, dP, lddp, dS, rows, ncols, scale):
+    _lib.call("vpu_softmax_bwd", ptr(P), ldp, ptr(dP), lddp, ptr(dS), rows, ncols, scale, code_of(P), _stream())
+
+
+def l2norm_fwd(x, y, inv, rows, Cdim):
+    _lib.call("vpu_l2norm_fwd", ptr(x), ptr(y), ptr(inv), rows, Cdim, code_of(x), _stream())
+
+
+def l2norm_bwd(dy, y, inv, dx, rows, Cdim):
+    _lib.call("vpu_l2norm_bwd", ptr(dy), ptr(y), ptr(inv), ptr(dx), rows, Cdim, code_of(y), _stream())
+
+
+def add_bcast(a, b, out, n, period):
+    _lib.call("vpu_add_bcast", ptr(a), ptr(b), ptr(out), n, period, code_of(a), _stream())
+
+
+def add4(a, b, c, d, out, n):
+    _lib.call("vpu_add4", ptr(a), ptr(b), ptr(c), ptr(d), ptr(out), n, code_of(a), _stream())
+
+
+def cast2d(src, ld_src, dst, ld_dst, rows, cols, cols_pad=None):
+    s = src[0] if isinstance(src, tuple) else src
+    d = dst[0] if isinstance(dst, tuple) else dst
+    _lib.call("vpu_cast2d", ptr(src), code_of(s), ld_src, ptr(dst), code_of(d), ld_dst, rows, cols,
+              cols if cols_pad is None else cols_pad, _stream())
+
+
+def fill_f32(t, v, n=None):
+    _lib.call("vpu_fill_f32", ptr(t), v, t.numel() if n is None else n, _stream())
+
+
+def pue_encode(points, boxes, lut, out, out64, B, n, num_max, img, ld):
+    _lib.call("vpu_pue_encode", ptr(points), ptr(boxes), ptr(lut), ptr(out), ptr(out64), B, n, num_max, img, ld,
+              code_of(out), _stream())
+
+
+def disk_maps(points, boxes, out, B, n, H, W, radius):
+    _lib.call("vpu_disk_maps", ptr(points), ptr(boxes), ptr(out), B, n, H, W, float(radius), _stream())
+
+
+def patch_im2col(image4, disks, cols, B, H, W, P, win_tokens):
+    _lib.call("vpu_patch_im2col", ptr(image4), ptr(disks), ptr(cols), B, H, W, P, win_tokens, code_of(cols), _stream())
+
+
+def window_permute(x, y, B, g, wg, Cdim, to_raster):
+    _lib.call("vpu_window_permute", ptr(x), ptr(y), B, g, wg, Cdim, 1 if to_raster else 0, code_of(x), _stream())
+
+
+def pixel_shuffle2(src, dst, bias, B, h, w, Cdim, inverse=False):
+    _lib.call("vpu_pixel_shuffle2", ptr(src), ptr(dst), ptr(bias), B, h, w, Cdim, 1 if inverse else 0, code_of(src),
+              _stream())
+
+
+def groupnorm_nchunk():
+    return _lib.load().vpu_groupnorm_nchunk()
+
+
+def groupnorm_fwd(x, w, b, y, mean, rstd, stats, B, HW, Cdim, eps, gelu):
+    _lib.call("vpu_groupnorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), ptr(stats), B, HW, Cdim, eps,
+              int(gelu), code_of(x), _stream())
+
+
+def groupnorm_bwd(dy, x, w, b, mean, rstd, dx, part, stats, B, HW, Cdim, gelu):
+    _lib.call("vpu_groupnorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dx), ptr(part),
+              ptr(stats), B, HW, Cdim, int(gelu), code_of(x), _stream())
+
+
+def bilinear_cl_fwd(inp, ld_in, out, ld_out, B, h, w, H, W, Cdim, dtype):
+    _lib.call("vpu_bilinear_cl_fwd", ptr(inp), ld_in, ptr(out), ld_out, B, h, w, H, W, Cdim, dtype, _stream())
+
+
+def bilinear_cl_bwd(dout, ld_out, din, ld_in, B, h, w, H, W, Cdim, dtype):
+    _lib.call("vpu_bilinear_cl_bwd", ptr(dout), ld_out, ptr(din), ld_in, B, h, w, H, W, Cdim, dtype, _stream())
+
+
+def gate_stats(Q, Kt, cg, argq, sg, argc, B, nq, N, Cdim):
+    _lib.call("vpu_gate_stats", ptr(Q), ptr(Kt), ptr(cg), ptr(argq), ptr(sg), ptr(argc), B, nq, N, Cdim, code_of(Q),
+              _stream())
+
+
+def gate_apply(x, cg, sg, out, B, N, Cdim):
+    _lib.call("vpu_gate_apply", ptr(x), ptr(cg), ptr(sg), ptr(out), B, N, Cdim, code_of(x), _stream())
+
+
+def gate_bwd(dout, x, cg, argq, sg, argc, dx, accum, dQ, dK, part, B, nq, N, Cdim):
+    _lib.call("vpu_gate_bwd", ptr(dout), ptr(x), ptr(cg), ptr(argq), ptr(sg), ptr(argc), ptr(dx), int(accum), ptr(dQ),
+              ptr(dK), ptr(part), B, nq, N, Cdim, code_of(x), _stream())
+
+
+def convseg_fwd(x, w, bias, mask, out, rows, HW, Cdim):
+    _lib.call("vpu_convseg_fwd", ptr(x), ptr(w), ptr(bias), ptr(mask), ptr(out), rows, HW, Cdim, code_of(x), _stream())
+
+
+def convseg_bwd_nblk(rows):
+    return _lib.load().vpu_convseg_bwd_nblk(rows)
+
+
+def convseg_bwd(dout, x, w, mask, dx, accum, part, part_b, rows, HW, Cdim):
+    _lib.call("vpu_convseg_bwd", ptr(dout), ptr(x), ptr(w), ptr(mask), ptr(dx), int(accum), ptr(part), ptr(part_b),
+              rows, HW, Cdim, code_of(x), _stream())
+
+
+def upsample_ac_fwd(inp, out, planes, h, w, H, W):
+    _lib.call("vpu_upsample_ac_fwd", ptr(inp), ptr(out), planes, h, w, H, W, _stream())
+
+
+def upsample_ac_bwd(dout, din, planes, h, w, H, W):
+    _lib.call("vpu_upsample_ac_bwd", ptr(dout), ptr(din), planes, h, w, H, W, _stream())
+
+
+def p2cl_fwd_bwd(prob, gt, slot_idx, override, loss_part, dprob, grad_scale, B, S, H, W):
+    _lib.call("vpu_p2cl_fwd_bwd", ptr(prob), ptr(gt), ptr(slot_idx), ptr(override), ptr(loss_part), ptr(dprob),
+              grad_scale, B, S, H, W, _stream())
+
+
+def nfl_dice_fwd_bwd(logits, gt, sums, out, dlogits, w_nfl, w_dice, B, HW):
+    _lib.call("vpu_nfl_dice_fwd_bwd", ptr(logits), ptr(gt), ptr(sums), ptr(out), ptr(dlogits), w_nfl, w_dice, B, HW,
+              _stream())
+
+
+def adam_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    _lib.call("vpu_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, lr, b1, b2, eps, wd, step, grad_scale,
+              _stream())

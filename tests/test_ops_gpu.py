@@ -1,0 +1,496 @@
+"""GPU parity tests of every C-ABI kernel against plain torch fp32 / the numpy oracle on the same seeded inputs.
+Integer / index work must be bit-exact; floating point tolerances are written at each assert."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from pvpuformer_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+TD = {0: torch.bfloat16, 1: torch.float32}
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_exact_integers(ops, dtype, tA, tB):
+    """Small-integer operands: every product and sum is exact in bf16 x bf16 -> fp32, so the result must be
+    bit-identical to an fp32 matmul.  Asymmetric data, ragged M/N, K not a multiple of the tile."""
+    M, N, K = 200, 136, 72
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[0, 1] = 3; A[1, 0] = -2; Bm[0, 1] = 1; Bm[1, 0] = -3
+    ref = A @ Bm.t()
+    lda = 208 if tA else 80
+    ldb = 144 if tB else 80
+    Am = torch.zeros((K, lda) if tA else (M, lda))
+    Bs = torch.zeros((K, ldb) if tB else (N, ldb))
+    if tA: Am[:, :M] = A.t()
+    else: Am[:, :K] = A
+    if tB: Bs[:, :N] = Bm.t()
+    else: Bs[:, :K] = Bm
+    Ad, Bd = dev(Am).to(TD[dtype]), dev(Bs).to(TD[dtype])
+    Cd = torch.full((M, 152), 7.0, device="cuda", dtype=TD[dtype])
+    ops.gemm(Ad, Bd, Cd, M, N, K, lda, ldb, 152, dtype, transA=bool(tA), transB=bool(tB))
+    torch.cuda.synchronize()
+    out = Cd.float().cpu()
+    assert torch.equal(out[:, :N], ref), f"max diff {(out[:, :N] - ref).abs().max()}"
+    assert torch.all(out[:, N:] == 7.0), "wrote outside the N range"
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 300, 192, 128
+    A, W = rnd(M, K, seed=2), rnd(N, K, seed=3, scale=0.2)
+    bias, R = rnd(N, seed=4), rnd(M, N, seed=5)
+    td = TD[dtype]
+    Ad, Wd, Rd, bd = dev(A).to(td), dev(W).to(td), dev(R).to(td), dev(bias)
+    Af, Wf, Rf = Ad.float(), Wd.float(), Rd.float()
+    base = Af @ Wf.t()
+    tol = dict(atol=3e-2, rtol=2e-2) if dtype == 0 else dict(atol=2e-5, rtol=1e-5)
+
+    def run(flags, **kw):
+        Cd = torch.zeros(M, N, device="cuda", dtype=torch.float32 if flags & ops.EPI_OUT_F32 else td)
+        ops.gemm(Ad, Wd, Cd, M, N, K, K, K, N, dtype, flags=flags, **kw)
+        torch.cuda.synchronize()
+        return Cd.float()
+
+    # bias + GELU with pre-activation side output + residual
+    pre = torch.zeros(M, N, device="cuda", dtype=td)
+    out = run(ops.EPI_BIAS | ops.EPI_PREACT | ops.EPI_GELU | ops.EPI_RESID, bias=bd, preact=pre, resid=Rd, ldr=N)
+    torch.testing.assert_close(pre.float(), base + bd, **tol)
+    torch.testing.assert_close(out, F.gelu(base + bd) + Rf, **tol)
+    out = run(ops.EPI_BIAS | ops.EPI_RELU, bias=bd)
+    torch.testing.assert_close(out, F.relu(base + bd), **tol)
+    # activation backward epilogues
+    aux = dev(rnd(M, N, seed=6, scale=2.0)).to(td)
+    x = aux.float().clone().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    out = run(ops.EPI_DGELU, aux=aux, ldaux=N)
+    torch.testing.assert_close(out, base * x.grad, **tol)
+    out = run(ops.EPI_DRELU, aux=aux, ldaux=N)
+    torch.testing.assert_close(out, base * (aux.float() > 0).float(), **tol)
+    # alpha, affine, fp32 output with accumulation
+    Cd = torch.full((M, N), 2.0, device="cuda", dtype=torch.float32)
+    ops.gemm(Ad, Wd, Cd, M, N, K, K, K, N, dtype, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM | ops.EPI_AFFINE, alpha=0.5,
+             post_mul=0.5, post_add=0.5)
+    torch.testing.assert_close(Cd, (0.5 * base) * 0.5 + 0.5 + 2.0, **tol)
+    # broadcast residual with a row period (pos_embed)
+    Rp = dev(rnd(100, N, seed=7)).to(td)
+    out = run(ops.EPI_RESID, resid=Rp, ldr=N, resid_period=100)
+    torch.testing.assert_close(out, base + Rp.float().repeat(3, 1), **tol)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gemm_attention_layout(ops, dtype):
+    """Batched two-level strides exactly as the backbone uses them: qkv [B*n, 3*H*d] -> S, P.V, and all backward
+    products, n = 196 (ragged: leading dimension padded to 200)."""
+    Bw, n, H, d = 3, 196, 2, 64
+    D = H * d
+    td = TD[dtype]
+    qkv = dev(rnd(Bw * n, 3 * D, seed=8)).to(td)
+    q = qkv.float().view(Bw, n, 3, H, d).permute(2, 0, 3, 1, 4)
+    ldS = 200
+    S = torch.zeros(Bw * H, n, ldS, device="cuda", dtype=torch.float32)
+    ops.gemm(qkv, (qkv, D), S, n, n, d, 3 * D, 3 * D, ldS, dtype, flags=ops.EPI_OUT_F32, alpha=0.125, batch=Bw * H,
+             inner=H, sA=(n * 3 * D, d), sB=(n * 3 * D, d), sC=(H * n * ldS, n * ldS))
+    Sref = (q[0] @ q[1].transpose(-1, -2)) * 0.125
+    tol = dict(atol=5e-2, rtol=2e-2) if dtype == 0 else dict(atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(S.view(Bw, H, n, ldS)[..., :n], Sref, **tol)
+    P = torch.zeros(Bw * H, n, ldS, device="cuda", dtype=td)
+    ops.softmax_fwd(S, ldS, P, ldS, Bw * H * n, n)
+    Pref = torch.softmax(Sref, -1)
+    torch.testing.assert_close(P.float().view(Bw, H, n, ldS)[..., :n], Pref, atol=2e-3 if dtype == 0 else 1e-6, rtol=1e-2)
+    assert torch.all(P[..., n:] == 0)
+    # O = P V  (B operand K-major with ld 3D), written head-interleaved
+    O = torch.zeros(Bw * n, D, device="cuda", dtype=td)
+    ops.gemm(P, (qkv, 2 * D), O, n, d, n, ldS, 3 * D, D, dtype, transB=True, batch=Bw * H, inner=H,
+             sA=(H * n * ldS, n * ldS), sB=(n * 3 * D, d), sC=(n * D, d))
+    Oref = (P.float().view(Bw, H, n, ldS)[..., :n] @ q[2]).transpose(1, 2).reshape(Bw * n, D)
+    torch.testing.assert_close(O.float(), Oref, **tol)
+    # backward products
+    dO = dev(rnd(Bw * n, D, seed=9)).to(td)
+    dOh = dO.float().view(Bw, n, H, d).transpose(1, 2)
+    dP = torch.zeros(Bw * H, n, ldS, device="cuda", dtype=torch.float32)
+    ops.gemm(dO, (qkv, 2 * D), dP, n, n, d, D, 3 * D, ldS, dtype, flags=ops.EPI_OUT_F32, batch=Bw * H, inner=H,
+             sA=(n * D, d), sB=(n * 3 * D, d), sC=(H * n * ldS, n * ldS))
+    torch.testing.assert_close(dP.view(Bw, H, n, ldS)[..., :n], dOh @ q[2].transpose(-1, -2), **tol)
+    dqkv = torch.zeros(Bw * n, 3 * D, device="cuda", dtype=td)
+    # dV = P^T dO : A = P stored [k = nq][m = nk] (K-major), B = dO [k = nq][d] (K-major)
+    ops.gemm(P, dO, (dqkv, 2 * D), n, d, n, ldS, D, 3 * D, dtype, transA=True, transB=True, batch=Bw * H, inner=H,
+             sA=(H * n * ldS, n * ldS), sB=(n * D, d), sC=(n * 3 * D, d))
+    dVref = (P.float().view(Bw, H, n, ldS)[..., :n].transpose(-1, -2) @ dOh)
+    torch.testing.assert_close(dqkv.float().view(Bw, n, 3, H, d)[:, :, 2].transpose(1, 2), dVref, **tol)
+    dS = torch.zeros(Bw * H, n, ldS, device="cuda", dtype=td)
+    ops.softmax_bwd(P, ldS, dP, ldS, dS, Bw * H * n, n, 0.125)
+    Pf = P.float().view(Bw, H, n, ldS)[..., :n]
+    dPf = dP.view(Bw, H, n, ldS)[..., :n]
+    dSref = Pf * (dPf - (Pf * dPf).sum(-1, keepdim=True)) * 0.125
+    torch.testing.assert_close(dS.float().view(Bw, H, n, ldS)[..., :n], dSref, atol=3e-3 if dtype == 0 else 1e-6, rtol=2e-2)
+    assert torch.all(dS[..., n:] == 0)
+    # dQ = dS K ; dK = dS^T Q
+    ops.gemm(dS, (qkv, D), dqkv, n, d, n, ldS, 3 * D, 3 * D, dtype, transB=True, batch=Bw * H, inner=H,
+             sA=(H * n * ldS, n * ldS), sB=(n * 3 * D, d), sC=(n * 3 * D, d))
+    ops.gemm(dS, qkv, (dqkv, D), n, d, n, ldS, 3 * D, 3 * D, dtype, transA=True, transB=True, batch=Bw * H, inner=H,
+             sA=(H * n * ldS, n * ldS), sB=(n * 3 * D, d), sC=(n * 3 * D, d))
+    dSf = dS.float().view(Bw, H, n, ldS)[..., :n]
+    got = dqkv.float().view(Bw, n, 3, H, d)
+    torch.testing.assert_close(got[:, :, 0].transpose(1, 2), dSf @ q[1], **tol)
+    torch.testing.assert_close(got[:, :, 1].transpose(1, 2), dSf.transpose(-1, -2) @ q[0], **tol)
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C", [64, 768, 1280])
+def test_layernorm(ops, dtype, C):
+    rows = 333
+    td = TD[dtype]
+    x = dev(rnd(rows, C, seed=10, scale=2.0) + 0.3).to(td)
+    w, b = dev(1 + rnd(C, seed=11, scale=0.2)), dev(rnd(C, seed=12, scale=0.2))
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x, w, b, y, mean, rstd, rows, C, 1e-6)
+    xf = x.float().requires_grad_(True)
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (C,), wf, bf, 1e-6)
+    tol = dict(atol=3e-2, rtol=2e-2) if dtype == 0 else dict(atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(y.float(), ref, **tol)
+    dy = dev(rnd(rows, C, seed=13)).to(td)
+    dres = dev(rnd(rows, C, seed=14)).to(td)
+    ref.backward(dy.float())
+    nblk = ops.layernorm_bwd_nblk(rows)
+    part = torch.zeros(2, nblk, C, device="cuda")
+    dx = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, C)
+    dw, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.colsum_f32(part[0], dw, nblk, C)
+    ops.colsum_f32(part[1], db, nblk, C)
+    torch.testing.assert_close(dx.float(), xf.grad + dres.float(), **tol)
+    gtol = dict(atol=0.15, rtol=3e-2) if dtype == 0 else dict(atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dw, wf.grad, **gtol)
+    torch.testing.assert_close(db, bf.grad, **gtol)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_colsum_l2norm_add_cast(ops, dtype):
+    td = TD[dtype]
+    rows, C, ld = 1000, 256, 264
+    x = dev(rnd(rows, ld, seed=15)).to(td)
+    out = torch.ones(C, device="cuda")
+    part = torch.zeros(64, C, device="cuda")
+    ops.colsum(x, ld, out, part, rows, C, beta=1.0)
+    torch.testing.assert_close(out, 1 + x.float()[:, :C].sum(0), atol=1e-2, rtol=1e-4)
+    xs = x[:, :C].contiguous()
+    y, inv = torch.empty_like(xs), torch.empty(rows, device="cuda")
+    ops.l2norm_fwd(xs, y, inv, rows, C)
+    xf = xs.float().requires_grad_(True)
+    ref = F.normalize(xf, p=2, dim=1)
+    tol = dict(atol=1e-2, rtol=2e-2) if dtype == 0 else dict(atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(y.float(), ref, **tol)
+    dy = dev(rnd(rows, C, seed=16)).to(td)
+    ref.backward(dy.float())
+    dx = torch.empty_like(xs)
+    ops.l2norm_bwd(dy, y, inv, dx, rows, C)
+    torch.testing.assert_close(dx.float(), xf.grad, atol=2e-2 if dtype == 0 else 1e-5, rtol=5e-2 if dtype == 0 else 1e-4)
+    a, pe = dev(rnd(6, 40, 64, seed=17)).to(td), dev(rnd(40, 64, seed=18)).to(td)
+    o = torch.empty_like(a)
+    ops.add_bcast(a, pe, o, a.numel(), pe.numel())
+    torch.testing.assert_close(o.float(), (a.float() + pe.float()).to(td).float())
+    o4 = torch.empty_like(a)
+    ops.add4(a, o, None, a, o4, a.numel())
+    torch.testing.assert_close(o4.float(), a.float() * 2 + o.float(), atol=5e-2 if dtype == 0 else 1e-6, rtol=1e-2)
+    src = dev(rnd(10, 899, seed=19))
+    dst = torch.full((10, 904), 5.0, device="cuda", dtype=td)
+    ops.cast2d(src, 899, dst, 904, 10, 899, 904)
+    assert torch.equal(dst[:, :899], src.to(td)) and torch.all(dst[:, 899:] == 0)
+
+
+# ------------------------------------------------------------------------------------------------ prompts
+def test_pue_and_disks_bit_exact(ops, golden_dir):
+    import os
+    import vpu_oracle as vo
+    fx = np.load(os.path.join(golden_dir, "pue.npz"))
+    lut = dev(torch.from_numpy(vo.click_lut()))
+    for key_p, key_o, n in (("points", "pue_click", 24), ("points_n3", "pue_click_n3", 3)):
+        P = fx[key_p]
+        B = P.shape[0]
+        out = torch.zeros(B, 48, 904, device="cuda")
+        out64 = torch.zeros(B, 48, 899, device="cuda", dtype=torch.float64)
+        ops.pue_encode(dev(torch.from_numpy(P)), None, lut, out, out64, B, n, 24, 448, 904)
+        assert np.array_equal(out64.cpu().numpy(), fx[key_o]), "PuE click rows are not bit-exact"
+        assert np.array_equal(out[:, :, :899].cpu().numpy().astype(np.float64), fx[key_o])
+        assert torch.all(out[:, :, 899:] == 0)
+    P, BX = fx["points"], fx["boxes"]
+    out64 = torch.zeros(6, 48, 899, device="cuda", dtype=torch.float64)
+    out = torch.zeros(6, 48, 904, device="cuda", dtype=torch.bfloat16)
+    ops.pue_encode(dev(torch.from_numpy(P)), dev(torch.from_numpy(BX)), lut, out, out64, 6, 24, 24, 448, 904)
+    got = out64.cpu().numpy()
+    assert np.array_equal(got != 0, fx["pue_box"] != 0), "box rows: support differs"
+    np.testing.assert_allclose(got, fx["pue_box"], atol=3e-7, rtol=0)  # float32 exp vs the reference's
+    np.testing.assert_allclose(got, vo.pue_box(P, BX), atol=2e-7, rtol=0)
+    # edge boxes the golden set does not hold: w in {0,1} (negative sigma quirk), and random ones vs the oracle
+    rs = np.random.RandomState(0)
+    BX2 = np.stack([rs.randint(0, 448, 64), rs.randint(0, 448, 64), rs.randint(0, 200, 64), rs.randint(0, 200, 64),
+                    rs.randint(0, 48, 64)], 1).astype(np.int32)
+    BX2[0] = (200, 200, 0, 60, 3); BX2[1] = (200, 200, 1, 60, 30); BX2[2] = (100, 100, 60, 1, 0); BX2[3] = (5, 5, 2, 2, 1)
+    P2 = -np.ones((64, 48, 3), np.float32)
+    P2[:, 0] = (100, 100, 0)
+    out64 = torch.zeros(64, 48, 899, device="cuda", dtype=torch.float64)
+    out = torch.zeros(64, 48, 904, device="cuda")
+    ops.pue_encode(dev(torch.from_numpy(P2)), dev(torch.from_numpy(BX2)), lut, out, out64, 64, 24, 24, 448, 904)
+    ref = vo.pue_box(P2, BX2)
+    assert np.array_equal(out64.cpu().numpy() != 0, ref != 0)
+    np.testing.assert_allclose(out64.cpu().numpy(), ref, atol=2e-7, rtol=0)
+
+    fd = np.load(os.path.join(golden_dir, "disk.npz"))
+    shape = tuple(fd["disks_shape"])
+    ref = np.unpackbits(fd["disks_packed"])[:int(np.prod(shape))].reshape(shape).astype(np.float32)
+    d = torch.zeros(6, 2, 448, 448, device="cuda")
+    ops.disk_maps(dev(torch.from_numpy(fd["points"])), None, d, 6, 24, 448, 448, 5.0)
+    assert np.array_equal(d.cpu().numpy(), ref), "disk maps are not bit-exact"
+    Ps = fd["points_small"]
+    d = torch.zeros(3, 2, 96, 131, device="cuda")
+    ops.disk_maps(dev(torch.from_numpy(Ps)), None, d, 3, 5, 96, 131, 5.0)
+    assert np.array_equal(d.cpu().numpy(), fd["disks_small"].astype(np.float32))
+    # random fractional clicks at full size + box outline, against the oracle
+    rs = np.random.RandomState(1)
+    Pr = -np.ones((4, 48, 3), np.float32)
+    for b in range(4):
+        for i in list(range(5)) + list(range(24, 27)):
+            Pr[b, i] = (rs.rand() * 447, rs.rand() * 447, i)
+    bx = np.array([[224, 200, 101, 60, 2], [30, 400, 50, 50, 30], [0, 0, 0, 0, 0], [440, 440, 30, 30, 1]], np.int32)
+    d = torch.zeros(4, 2, 448, 448, device="cuda")
+    ops.disk_maps(dev(torch.from_numpy(Pr)), dev(torch.from_numpy(bx)), d, 4, 24, 448, 448, 5.0)
+    exp = vo.disk_maps(Pr, 448, 448)
+    for b in range(4):
+        exp[b] = vo.box_outline(exp[b], bx[b], 24)
+    assert np.array_equal(d.cpu().numpy(), exp)
+
+
+# ------------------------------------------------------------------------------------------------ spatial
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_patch_im2col_and_permute(ops, dtype):
+    td = TD[dtype]
+    B, H, P, wg = 2, 448, 16, 14
+    img4 = dev(rnd(B, 4, H, H, seed=20).abs())
+    disks = dev((rnd(B, 2, H, H, seed=21) > 0.9).float())
+    g = H // P
+    cols = torch.empty(B * g * g, 6 * P * P, device="cuda", dtype=td)
+    ops.patch_im2col(img4, disks, cols, B, H, H, P, wg)
+    mean = torch.tensor([.485, .456, .406], device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor([.229, .224, .225], device="cuda").view(1, 3, 1, 1)
+    full = torch.cat([(img4[:, :3] - mean) / std, img4[:, 3:], disks], 1)
+    ref = F.unfold(full, P, stride=P).transpose(1, 2)  # [B, T(raster), 6*P*P]
+    nw = g // wg
+    refw = ref.view(B, nw, wg, nw, wg, -1).permute(0, 1, 3, 2, 4, 5).reshape(B * g * g, -1)
+    assert torch.equal(cols.float(), refw.to(td).float())
+    x = dev(rnd(B, g * g, 64, seed=22)).to(td)
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    ops.window_permute(x, y, B, g, wg, 64, to_raster=False)
+    xw = x.view(B, nw, wg, nw, wg, 64).permute(0, 1, 3, 2, 4, 5).reshape(B, g * g, 64)
+    assert torch.equal(y, xw)
+    ops.window_permute(y, z, B, g, wg, 64, to_raster=True)
+    assert torch.equal(z, x)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_pixel_shuffle_convs(ops, dtype):
+    """ConvTranspose2d(2,2) and Conv2d(2,2) expressed as GEMM + pixel shuffle vs torch."""
+    td = TD[dtype]
+    B, h, Cin, Cout = 2, 6, 32, 16
+    x = dev(rnd(B, h * h, Cin, seed=23)).to(td)           # channels-last tokens
+    Wt = dev(rnd(Cin, Cout, 2, 2, seed=24, scale=0.3)).to(td)
+    bias = dev(rnd(Cout, seed=25))
+    tmp = torch.empty(B * h * h, Cout * 4, device="cuda", dtype=td)
+    ops.gemm(x, Wt, tmp, B * h * h, Cout * 4, Cin, Cin, Cout * 4, Cout * 4, dtype, transB=True)
+    out = torch.empty(B, 2 * h, 2 * h, Cout, device="cuda", dtype=td)
+    ops.pixel_shuffle2(tmp, out, bias, B, h, h, Cout)
+    xin = x.float().view(B, h, h, Cin).permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(xin, Wt.float(), bias, stride=2).permute(0, 2, 3, 1)
+    tol = dict(atol=4e-2, rtol=2e-2) if dtype == 0 else dict(atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(out.float(), ref, **tol)
+    # inverse shuffle (space to depth) == im2col of Conv2d(2, stride 2)
+    Wc = dev(rnd(Cout, Cin, 2, 2, seed=26, scale=0.3)).to(td)
+    fine = dev(rnd(B, 2 * h, 2 * h, Cin, seed=27)).to(td)
+    s2d = torch.empty(B * h * h, Cin * 4, device="cuda", dtype=td)
+    ops.pixel_shuffle2(fine, s2d, None, B, h, h, Cin, inverse=True)
+    o2 = torch.empty(B * h * h, Cout, device="cuda", dtype=td)
+    ops.gemm(s2d, Wc, o2, B * h * h, Cout, Cin * 4, Cin * 4, Cin * 4, Cout, dtype)
+    ref2 = F.conv2d(fine.float().permute(0, 3, 1, 2), Wc.float(), None, stride=2).permute(0, 2, 3, 1).reshape(B * h * h, Cout)
+    torch.testing.assert_close(o2.float(), ref2, **tol)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C,gelu", [(16, 1), (192, 0), (384, 1), (1536, 0)])
+def test_groupnorm(ops, dtype, C, gelu):
+    td = TD[dtype]
+    B, HW = 2, 14 * 14 if C > 1000 else 28 * 28
+    x = dev(rnd(B, HW, C, seed=28, scale=1.5) + 0.2).to(td)
+    w, b = dev(1 + rnd(C, seed=29, scale=0.2)), dev(rnd(C, seed=30, scale=0.2))
+    nch = ops.groupnorm_nchunk()
+    stats = torch.zeros(B, nch, 2, device="cuda", dtype=torch.float64)
+    mean, rstd = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    y = torch.empty_like(x)
+    ops.groupnorm_fwd(x, w, b, y, mean, rstd, stats, B, HW, C, 1e-5, gelu)
+    xf = x.float().requires_grad_(True)
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.group_norm(xf.transpose(1, 2), 1, wf, bf, 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    ref = ref.transpose(1, 2)
+    tol = dict(atol=3e-2, rtol=2e-2) if dtype == 0 else dict(atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(y.float(), ref, **tol)
+    dy = dev(rnd(B, HW, C, seed=31)).to(td)
+    ref.backward(dy.float())
+    part = torch.zeros(2, B * nch, C, device="cuda")
+    dx = torch.empty_like(x)
+    ops.groupnorm_bwd(dy, x, w, b, mean, rstd, dx, part, stats, B, HW, C, gelu)
+    dw, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.colsum_f32(part[0], dw, B * nch, C)
+    ops.colsum_f32(part[1], db, B * nch, C)
+    torch.testing.assert_close(dx.float(), xf.grad, atol=3e-2 if dtype == 0 else 2e-5, rtol=3e-2 if dtype == 0 else 1e-4)
+    gt = dict(atol=0.3, rtol=3e-2) if dtype == 0 else dict(atol=2e-4, rtol=1e-4)
+    torch.testing.assert_close(dw, wf.grad, **gt)
+    torch.testing.assert_close(db, bf.grad, **gt)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("h", [14, 28, 56, 112])
+def test_bilinear_channels_last(ops, dtype, h):
+    td = TD[dtype]
+    B, C, H = 2, 16, 112
+    x = dev(rnd(B, h, h, C, seed=32)).to(td)
+    out = torch.zeros(B, H, H, 48, device="cuda", dtype=td)  # lands in a channel slice [16:32] of a wider map
+    ops.bilinear_cl_fwd(x, C, (out, 16), 48, B, h, h, H, H, C, dtype)
+    xf = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.interpolate(xf, size=(H, H), mode="bilinear", align_corners=False)
+    tol = dict(atol=2e-2, rtol=2e-2) if dtype == 0 else dict(atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(out[..., 16:32].float(), ref.permute(0, 2, 3, 1), **tol)
+    assert torch.all(out[..., :16] == 0) and torch.all(out[..., 32:] == 0)
+    dout = torch.zeros(B, H, H, 48, device="cuda", dtype=td)
+    dout[..., 16:32] = dev(rnd(B, H, H, C, seed=33)).to(td)
+    ref.backward(dout[..., 16:32].float().permute(0, 3, 1, 2))
+    din = torch.empty_like(x)
+    ops.bilinear_cl_bwd((dout, 16), 48, din, C, B, h, h, H, H, C, dtype)
+    torch.testing.assert_close(din.float(), xf.grad.permute(0, 2, 3, 1), atol=0.15 if dtype == 0 else 1e-5, rtol=3e-2 if dtype == 0 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gates_and_convseg(ops, dtype):
+    td = TD[dtype]
+    B, nq, N, C = 2, 48, 784, 64
+    x, Q, K = dev(rnd(B, N, C, seed=34)).to(td), dev(rnd(B, nq, C, seed=35)).to(td), dev(rnd(B, N, C, seed=36)).to(td)
+    cg, sg = torch.empty(B, C, device="cuda"), torch.empty(B, N, device="cuda")
+    aq = torch.empty(B, C, device="cuda", dtype=torch.int32)
+    ac = torch.empty(B, N, device="cuda", dtype=torch.int32)
+    ops.gate_stats(Q, K, cg, aq, sg, ac, B, nq, N, C)
+    out = torch.empty_like(x)
+    ops.gate_apply(x, cg, sg, out, B, N, C)
+    xf, Qf, Kf = (t.float().requires_grad_(True) for t in (x, Q, K))
+    ref = xf + xf * Qf.max(1).values.sigmoid().unsqueeze(1) + xf * Kf.max(2).values.sigmoid().unsqueeze(2)
+    tol = dict(atol=3e-2, rtol=2e-2) if dtype == 0 else dict(atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(out.float(), ref, **tol)
+    dout = dev(rnd(B, N, C, seed=37)).to(td)
+    ref.backward(dout.float())
+    dx = dev(rnd(B, N, C, seed=38)).to(td)
+    dx0 = dx.float().clone()
+    dQ, dK = torch.zeros_like(Q), torch.zeros_like(K)
+    part = torch.zeros(B, 16, C, device="cuda")
+    ops.gate_bwd(dout, x, cg, aq, sg, ac, dx, True, dQ, dK, part, B, nq, N, C)
+    bt = dict(atol=6e-2, rtol=3e-2) if dtype == 0 else dict(atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(dx.float(), dx0 + xf.grad, **bt)
+    torch.testing.assert_close(dQ.float(), Qf.grad, atol=0.2 if dtype == 0 else 1e-4, rtol=3e-2 if dtype == 0 else 1e-4)
+    torch.testing.assert_close(dK.float(), Kf.grad, **bt)
+    # conv_seg with a Dropout2d mask
+    rows, HW, Cc = B * 100, 100, 256
+    f = dev(rnd(rows, Cc, seed=39)).to(td)
+    w, bias = dev(rnd(Cc, seed=40, scale=0.1)), dev(rnd(1, seed=41))
+    mask = dev((rnd(B, Cc, seed=42) > -0.8).float() / 0.9)
+    o = torch.empty(rows, device="cuda")
+    ops.convseg_fwd(f, w, bias, mask, o, rows, HW, Cc)
+    ff, wf = f.float().requires_grad_(True), w.clone().requires_grad_(True)
+    refo = ((ff.view(B, HW, Cc) * mask.view(B, 1, Cc)) * wf).sum(-1).view(rows) + bias
+    torch.testing.assert_close(o, refo, atol=1e-4, rtol=1e-4)
+    do = dev(rnd(rows, seed=43))
+    refo.backward(do)
+    nb = ops.convseg_bwd_nblk(rows)
+    part, part_b = torch.zeros(nb, Cc, device="cuda"), torch.zeros(nb, device="cuda")
+    dfe = torch.empty_like(f)
+    ops.convseg_bwd(do, f, w, mask, dfe, False, part, part_b, rows, HW, Cc)
+    torch.testing.assert_close(dfe.float(), ff.grad, atol=2e-3 if dtype == 0 else 1e-6, rtol=2e-2 if dtype == 0 else 1e-5)
+    torch.testing.assert_close(part.sum(0), wf.grad, atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(part_b.sum(), do.sum(), atol=1e-3, rtol=1e-4)
+
+
+def test_upsample_and_losses(ops):
+    import vpu_oracle as vo
+    B, S, h, H = 2, 8, 28, 112
+    low = dev(torch.sigmoid(rnd(B, S, h, h, seed=44, scale=3.0)))
+    up = torch.empty(B, S, H, H, device="cuda")
+    ops.upsample_ac_fwd(low, up, B * S, h, h, H, H)
+    lf = low.clone().requires_grad_(True)
+    ref = F.interpolate(lf, size=(H, H), mode="bilinear", align_corners=True)
+    torch.testing.assert_close(up, ref, atol=1e-6, rtol=1e-6)
+    gt = dev((rnd(B, 1, H, H, seed=45) > 0.2).float())
+    ed = vo.ed_mask_label(gt, S // 2)
+    ov = dev((rnd(2, H, H, seed=46) > 0.5).float())
+    idx = -torch.ones(B, S, dtype=torch.int32)
+    idx[0, 1] = 0; idx[1, 6] = 1
+    ed[0, 1] = ov[0]; ed[1, 6] = ov[1]
+    loss = vo.bce_from_sigmoid(ref, ed).mean() * 2.0
+    loss.backward()
+    part = torch.empty(B, S, device="cuda")
+    dprob = torch.empty_like(up)
+    ops.p2cl_fwd_bwd(up, gt, dev(idx), ov, part, dprob, 2.0 / (B * S * H * H), B, S, H, H)
+    torch.testing.assert_close(part.sum() * 2.0 / (B * S * H * H), loss.detach(), rtol=1e-5, atol=1e-6)
+    dlow = torch.empty_like(low)
+    ops.upsample_ac_bwd(dprob, dlow, B * S, h, h, H, H)
+    torch.testing.assert_close(dlow, lf.grad, rtol=1e-4, atol=1e-9)
+    # NFL + Dice
+    logits = dev(rnd(B, 1, H, H, seed=47, scale=4.0)).requires_grad_(True)
+    l_n, l_d = vo.nfl_loss(logits, gt).mean(), vo.dice_loss_naive(logits, gt)
+    (1.5 * l_n + 0.7 * l_d).backward()
+    sums = torch.zeros(B, 8, device="cuda", dtype=torch.float64)
+    out = torch.empty(B, 2, device="cuda")
+    dl = torch.empty(B, H * H, device="cuda")
+    ops.nfl_dice_fwd_bwd(logits.detach(), gt, sums, out, dl, 1.5 / B, 0.7 / B, B, H * H)
+    torch.testing.assert_close(out[:, 0].mean(), l_n.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(out[:, 1].mean(), l_d.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(dl.view_as(logits), logits.grad, rtol=2e-4, atol=1e-9)
+
+
+def test_adam_matches_torch(ops):
+    n = 10007
+    p0, g = rnd(n, seed=48), rnd(n, seed=49, scale=0.1)
+    p = dev(p0.clone())
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=5e-5, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(1, 4):
+        pt.grad = g.clone() * step
+        opt.step()
+        ops.adam_step(p, dev(g * step), m, v, sh, n, 5e-5, 0.9, 0.999, 1e-8, 0.0, step)
+    torch.testing.assert_close(p.cpu(), pt.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(sh, p.to(torch.bfloat16))
