@@ -113,8 +113,16 @@ def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_
 
         # ---- oracle vs reference (this is the pin) ----
         taps = {}
+        # box mode: numpy >= 2 makes the reference evaluate the box Gaussians in float64 (np.int32 scalar promotion),
+        # numpy 1.23 (the reference's requirements.txt) and the oracle in float32; the <= 1e-7 difference is checked in
+        # prompt_fixtures().  Feed the reference's own rows here so that everything downstream is compared exactly.
+        pue_ref = None
+        if ptype == 1:
+            with torch.no_grad():
+                pue_ref = model._guassinvector_box(pts, boxes)
+            assert np.abs(vo.pue_box(pts.numpy(), boxes.numpy()) - pue_ref.numpy()).max() <= 2e-7
         with torch.no_grad():
-            o_or = vo.vpu_forward(sd, cfg, img4, pts, boxes, ptype, taps=taps)
+            o_or = vo.vpu_forward(sd, cfg, img4, pts, boxes, ptype, taps=taps, pue_override=pue_ref)
         for k in ("instances", "instances_aux"):
             err = (o_or[k] - out[k]).abs().max().item()
             ref_mag = out[k].abs().max().item()
@@ -160,7 +168,7 @@ def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_
             assert no_grad == sorted(vo.unused_param_names(cfg)), no_grad
             # oracle backward vs reference backward
             sd_g = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
-            o2 = vo.vpu_forward(sd_g, cfg, img4, pts, boxes, ptype)
+            o2 = vo.vpu_forward(sd_g, cfg, img4, pts, boxes, ptype, pue_override=pue_ref)
             t2, _ = vo.step_loss(o2, gt, ed)
             t2.backward()
             worst = 0.0
@@ -201,7 +209,7 @@ def prompt_fixtures(ref_vpu):
     """Known-answer vectors for the integer bookkeeping: PuE click/box rows and disk maps on
     crafted edge cases (corner-drop quirk, truncation, invalid rows, tiny boxes, fewer than 24 slots)."""
     from isegm.model.ops import DistMaps
-    cfg = vo.make_cfg(embed_dim=64, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+    cfg = vo.make_cfg(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
     model, _ = build_reference(cfg, ref_vpu)
     P = -np.ones((6, 48, 3), np.float32)
     # sample 0: interior, fractional, borders
@@ -278,7 +286,7 @@ def main():
     if "pue" in which:
         prompt_fixtures(ref_vpu)
     if "tiny" in which:
-        cfg = vo.make_cfg(embed_dim=64, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+        cfg = vo.make_cfg(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
         run_model_fixture("tiny", cfg, 2, ref_vpu, ref_losses)
     if "vitb" in which:
         run_model_fixture("vitb", vo.make_cfg(), 2, ref_vpu, ref_losses)

@@ -322,6 +322,25 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const TS* __restrict__ src,
         dst[r * ld_dst + c] = from_f32<TD>(c < cols ? to_f32(src[r * ld_src + c]) : 0.f);
     }
 }
+// dz = dy * act'(aux) on a strided 2-D view (rows x cols, cols % 8 == 0); kind 0: relu (aux = output or input),
+// 1: gelu (aux = pre-activation)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, const T* __restrict__ aux,
+                                                      int64_t ld_aux, T* __restrict__ dz, int64_t ld_dz, int64_t rows,
+                                                      int cols, int kind) {
+    const int chunks = cols / 8;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks) * 8;
+        float d[8], a[8];
+        load8(dy + r * ld_dy + c, d);
+        load8(aux + r * ld_aux + c, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] *= kind ? dgelu_f(a[j]) : (a[j] > 0.f ? 1.f : 0.f);
+        store8(dz + r * ld_dz + c, d);
+    }
+}
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
@@ -412,6 +431,14 @@ extern "C" int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, vo
         cast2d_kernel<bf16_t, bf16_t><<<grid, 256, 0, ST>>>((const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, cols_pad);
     else { vpu_set_error("cast2d: dtype"); return VPU_ERR_ARG; }
     return vpu_check_launch("vpu_cast2d");
+}
+extern "C" int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64_t ld_aux, void* dz, int64_t ld_dz,
+                           int64_t rows, int32_t cols, int32_t kind, int32_t dtype, void* stream) {
+    if (cols % 8 || ld_dy % 8 || ld_aux % 8 || ld_dz % 8) { vpu_set_error("act_bwd: cols, ld % 8"); return VPU_ERR_ARG; }
+    const int grid = vpu_grid_for(rows * (cols / 8), 256, 8192);
+    DISPATCH_T(dtype, act_bwd_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, ld_dy, (const T*)aux, ld_aux, (T*)dz, ld_dz,
+                                                             rows, cols, kind);)
+    return vpu_check_launch("vpu_act_bwd");
 }
 extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
     fill_kernel<<<vpu_grid_for(n, 256, 4096), 256, 0, ST>>>(p, v, n);

@@ -1,0 +1,665 @@
+"""Forward / backward executor of the VPUFormer hot path on MI355X.
+
+Composes the C-ABI kernels (``include/vpu_hip.h``) into the model of
+``isegm/model/is_vpu_model.py:383-438`` (reference paths) and its hand-scheduled backward.  Design points:
+
+* one flat fp32 parameter buffer + one flat fp32 gradient buffer (all ``nn.Parameter``s are views), a flat bf16
+  shadow for the MFMA GEMMs -> the optimizer and the data-parallel all-reduce work on a few large contiguous ranges;
+* backbone tokens stay in WINDOW order from the patch embedding to the last block, so ``patchify``/``unpatchify``
+  (``models_vit.py:225-255``) cost nothing: window attention is a batched GEMM over contiguous rows, global
+  attention is permutation-equivariant; one un-permute feeds the neck;
+* every map in the neck / head is channels-last, so each (transposed) convolution is a GEMM plus at most one
+  pixel-shuffle pass, and the four resized head inputs are written straight into their slice of the concat buffer;
+* a tape of backward closures with explicit gradient accumulation -- no autograd graph, no per-op torch dispatch;
+  torch is used for device memory and streams only.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import (BF16, F32, EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGELU, EPI_DRELU, EPI_RESID, EPI_AFFINE,
+                   EPI_ACCUM, EPI_OUT_F32)
+
+
+class Var:
+    """An activation and (lazily) its gradient."""
+    __slots__ = ("t", "g")
+
+    def __init__(self, t):
+        self.t = t
+        self.g = None
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def click_lut():
+    """19-tap PuE clip, float32 (isegm/model/ops.py:51-61)."""
+    t = np.arange(0, 19, 1, np.float32)
+    lut = np.exp(-((t - 9) ** 2) / (2 * 3 ** 2))
+    lut[9] += 1
+    return lut
+
+
+def pos2d_table(d_model, height, width):
+    """TwoWayTransformer.pos2d (isegm/model/modeling/transformer.py:290-318) as a constant [H*W, d_model] table,
+    built once on the host instead of seven times per forward."""
+    pe = torch.zeros(d_model, height, width)
+    half = d_model // 2
+    div = torch.exp(torch.arange(0., half, 2) * -(math.log(10000.0) / half))
+    pw = torch.arange(0., width).unsqueeze(1) * div
+    ph = torch.arange(0., height).unsqueeze(1) * div
+    pe[0:half:2] = torch.sin(pw).t().unsqueeze(1).expand(-1, height, -1)
+    pe[1:half:2] = torch.cos(pw).t().unsqueeze(1).expand(-1, height, -1)
+    pe[half::2] = torch.sin(ph).t().unsqueeze(2).expand(-1, -1, width)
+    pe[half + 1::2] = torch.cos(ph).t().unsqueeze(2).expand(-1, -1, width)
+    return pe.reshape(d_model, height * width).t().contiguous()
+
+
+class Engine:
+    def __init__(self, cfg, dtype="bf16", device="cuda"):
+        self.cfg = dict(cfg)
+        self.dt = BF16 if dtype in ("bf16", BF16) else F32
+        self.td = torch.bfloat16 if self.dt == BF16 else torch.float32
+        self.dev = torch.device(device)
+        c = self.cfg
+        self.D, self.P, self.img = c["embed_dim"], c["patch"], c["img"]
+        self.g = self.img // self.P
+        self.NT = self.g * self.g
+        self.wg = 224 // self.P
+        self.nw = self.g // self.wg
+        self.heads = c["num_heads"]
+        self.depth = c["depth"]
+        self.group = 6 if self.depth == 12 else self.depth // 4
+        self.nmax = c["num_max_points"]
+        self.E = 2 * self.img + 3
+        self.Epad = _rup(self.E, 8)
+        self.C = c["head_channels"]
+        self.out_dims = tuple(c["out_dims"])
+        self.names = None
+        self.tape = []
+        self.training = False
+        self.shadow_valid = False
+        self._const_ready = False
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def bind(self, named_params):
+        """Packs the parameters into one flat fp32 buffer (views keep their identity) and allocates the flat
+        gradient buffer and the bf16 shadow."""
+        self.names = OrderedDict()
+        off = 0
+        for n, p in named_params.items():
+            self.names[n] = (off, tuple(p.shape), p.numel())
+            off = _rup(off + p.numel(), 8)
+        self.total = off
+        self.flat = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        self.gflat = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        for n, p in named_params.items():
+            o, shape, numel = self.names[n]
+            view = self.flat[o:o + numel].view(shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.gflat[o:o + numel].view(shape)
+        self.shadow = torch.zeros(off, device=self.dev, dtype=torch.bfloat16) if self.dt == BF16 else None
+        D, P = self.D, self.P
+        self.w_patch = torch.zeros(D, 6 * P * P, device=self.dev, dtype=self.td)
+        self.b_patch = torch.zeros(D, device=self.dev, dtype=torch.float32)
+        self.w_lin1p = torch.zeros(2048, self.Epad, device=self.dev, dtype=self.td)
+        self.pos_win = torch.zeros(self.NT, D, device=self.dev, dtype=self.td)
+        self.shadow_valid = False
+        if not self._const_ready:
+            self.kpe = pos2d_table(D, self.g, self.g).to(self.dev).to(self.td)
+            self.lut = torch.from_numpy(click_lut()).to(self.dev)
+            self._const_ready = True
+
+    def W(self, name):
+        o = self.names[name][0]
+        return (self.shadow, o) if self.dt == BF16 else (self.flat, o)
+
+    def Pm(self, name):
+        return (self.flat, self.names[name][0])
+
+    def G(self, name):
+        return (self.gflat, self.names[name][0])
+
+    def refresh_weights(self):
+        """fp32 master -> compute-dtype operands (bf16 shadow, fused patch-embed weight, K-padded PuE weight,
+        window-ordered pos_embed).  ~0.75 GB of traffic for ViT-B."""
+        D, P = self.D, self.P
+        if self.dt == BF16:
+            ops.cast2d(self.flat, self.total, self.shadow, self.total, 1, self.total)
+        k3 = 3 * P * P
+        ops.cast2d(self.Pm("backbone.patch_embed.proj.weight"), k3, (self.w_patch, 0), 2 * k3, D, k3)
+        ops.cast2d(self.Pm("patch_embed_coords.proj.weight"), k3, (self.w_patch, k3), 2 * k3, D, k3)
+        ops.add4(self.Pm("backbone.patch_embed.proj.bias"), self.Pm("patch_embed_coords.proj.bias"), None, None,
+                 self.b_patch, D)
+        ops.cast2d(self.Pm("neck.ffn_layer.lin1.weight"), self.E, self.w_lin1p, self.Epad, 2048, self.E, self.Epad)
+        tmp = torch.empty(self.NT, D, device=self.dev, dtype=self.td)
+        po = self.names["backbone.pos_embed"][0]
+        ops.cast2d((self.flat, po + D), D, tmp, D, self.NT, D)
+        ops.window_permute(tmp, self.pos_win, 1, self.g, self.wg, D, to_raster=False)
+        self.shadow_valid = True
+
+    def zero_grad(self):
+        self.gflat.zero_()
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _new(self, *shape, dtype=None):
+        return torch.empty(shape, device=self.dev, dtype=dtype or self.td)
+
+    def acc(self, var, g, take=False):
+        """var.g += g.  ``take``: g may become var.g itself (caller guarantees g is dead afterwards)."""
+        if var.g is None:
+            if take:
+                var.g = g
+            else:
+                var.g = torch.empty_like(g)
+                ops.add4(g, None, None, None, var.g, g.numel())
+        else:
+            ops.add4(var.g, g, None, None, var.g, g.numel())
+
+    def _colsum_to(self, dy, ld, gname, rows, N):
+        part = self._new(64, N, dtype=torch.float32)
+        ops.colsum(dy, ld, self.G(gname), part, rows, N, beta=1.0)
+
+    def _wgrad(self, dy, ld_dy, x, ld_x, gname, N, K, M, ldc=None):
+        """G[N,K] += dy[M,N]^T x[M,K]"""
+        ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
+                 transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
+
+    def _dgrad(self, dy, ld_dy, w, ldw, xvar, M, K, N, flags=0, aux=None, ldaux=0):
+        """x.g (+)= dy[M,N] W[N,K]"""
+        f = flags
+        if xvar.g is None:
+            xvar.g = torch.empty_like(xvar.t)
+        else:
+            f |= EPI_ACCUM
+        ops.gemm(dy, w, xvar.g, M, K, N, ld_dy, ldw, K, self.dt, transB=True, flags=f, aux=aux, ldaux=ldaux)
+
+    # ------------------------------------------------------------------------------------------ ops with backward
+    def linear(self, x, wname, bname, M, N, K, act=None, resid=None, out=None, x_grad=True):
+        """y = act(x W^T + b) [+ resid].  ``out`` = (Var, col_offset, ld) writes into a column slice of a wider map."""
+        assert not (act and resid is not None)
+        if out is None:
+            y = Var(self._new(M, N))
+            yt, yoff, ldc = y.t, 0, N
+        else:
+            y, yoff, ldc = out
+            yt = y.t
+        flags = EPI_BIAS | (EPI_RELU if act == "relu" else 0) | (EPI_RESID if resid is not None else 0)
+        ops.gemm(x.t, self.W(wname), (yt, yoff), M, N, K, K, K, ldc, self.dt, flags=flags, bias=self.Pm(bname),
+                 resid=None if resid is None else resid.t, ldr=N)
+        if self.training:
+            def bwd():
+                if y.g is None:
+                    return
+                dy = (y.g, yoff)
+                if resid is not None:
+                    assert out is None
+                    self.acc(resid, y.g, take=True)
+                if act == "relu":
+                    dz = self._new(M, N)
+                    ops.act_bwd(dy, ldc, (yt, yoff), ldc, dz, N, M, N, 0, self.dt)
+                    dy, ld = dz, N
+                else:
+                    ld = ldc
+                self._wgrad(dy, ld, x.t, K, wname, N, K, M)
+                self._colsum_to(dy, ld, bname, M, N)
+                if x_grad:
+                    self._dgrad(dy, ld, self.W(wname), K, x, M, K, N)
+            self.tape.append(bwd)
+        return y
+
+    def mlp(self, x, p1, p2, M, K, Hd, N, act, resid=None, w1=None, k_grad=None, x_grad=True):
+        """y = act(x W1^T + b1) W2^T + b2 [+ resid], with the activation backward fused into fc2's dgrad epilogue."""
+        Kp = K
+        h = self._new(M, Hd)
+        if act == "gelu":
+            pre = self._new(M, Hd)
+            ops.gemm(x.t, self.W(p1 + ".weight") if w1 is None else w1, h, M, Hd, Kp, Kp, Kp, Hd, self.dt,
+                     flags=EPI_BIAS | EPI_PREACT | EPI_GELU, bias=self.Pm(p1 + ".bias"), preact=pre)
+        else:
+            pre = None
+            ops.gemm(x.t, self.W(p1 + ".weight") if w1 is None else w1, h, M, Hd, Kp, Kp, Kp, Hd, self.dt,
+                     flags=EPI_BIAS | EPI_RELU, bias=self.Pm(p1 + ".bias"))
+        y = Var(self._new(M, N))
+        ops.gemm(h, self.W(p2 + ".weight"), y.t, M, N, Hd, Hd, Hd, N, self.dt,
+                 flags=EPI_BIAS | (EPI_RESID if resid is not None else 0), bias=self.Pm(p2 + ".bias"),
+                 resid=None if resid is None else resid.t, ldr=N)
+        if self.training:
+            def bwd():
+                dy = y.g
+                if dy is None:
+                    return
+                if resid is not None:
+                    self.acc(resid, dy, take=True)
+                self._wgrad(dy, N, h, Hd, p2 + ".weight", N, Hd, M)
+                self._colsum_to(dy, N, p2 + ".bias", M, N)
+                dpre = self._new(M, Hd)
+                ops.gemm(dy, self.W(p2 + ".weight"), dpre, M, Hd, N, N, Hd, Hd, self.dt, transB=True,
+                         flags=EPI_DGELU if act == "gelu" else EPI_DRELU, aux=pre if act == "gelu" else h, ldaux=Hd)
+                kg = K if k_grad is None else k_grad
+                # dW1[Hd, kg] += dpre^T x  (x may be K-padded: ld Kp, only kg columns are real)
+                ops.gemm(dpre, x.t, self.G(p1 + ".weight"), Hd, kg, M, Hd, Kp, kg, self.dt, transA=True, transB=True,
+                         flags=EPI_OUT_F32 | EPI_ACCUM)
+                self._colsum_to(dpre, Hd, p1 + ".bias", M, Hd)
+                if x_grad:
+                    self._dgrad(dpre, Hd, self.W(p1 + ".weight") if w1 is None else w1, Kp, x, M, Kp, Hd)
+            self.tape.append(bwd)
+        return y
+
+    def layernorm(self, x, prefix, rows, Cdim, eps):
+        y = Var(self._new(rows, Cdim))
+        mean, rstd = self._new(rows, dtype=torch.float32), self._new(rows, dtype=torch.float32)
+        ops.layernorm_fwd(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, rows, Cdim, eps)
+        if self.training:
+            def bwd():
+                if y.g is None:
+                    return
+                nblk = ops.layernorm_bwd_nblk(rows)
+                part = self._new(2, nblk, Cdim, dtype=torch.float32)
+                dres = x.g
+                if x.g is None:
+                    x.g = torch.empty_like(x.t)
+                ops.layernorm_bwd(y.g, x.t, self.Pm(prefix + ".weight"), mean, rstd, dres, x.g, part, rows, Cdim)
+                ops.colsum_f32(part[0], self.G(prefix + ".weight"), nblk, Cdim, beta=1.0)
+                ops.colsum_f32(part[1], self.G(prefix + ".bias"), nblk, Cdim, beta=1.0)
+            self.tape.append(bwd)
+        return y
+
+    def sdpa(self, q, k, v, o, nb, H, nq, nk, hd, scale):
+        """softmax(Q K^T * scale) V for nb*H independent (batch, head) problems.  q,k,v,o = (Var, col_off, ld, rows_per_b):
+        head h of batch b starts at element (b*rows_per_b)*ld + col_off + h*hd.  Materialises S (fp32) and P."""
+        (qv, qo, qld, qrows), (kv, ko, kld, krows), (vv, vo, vld, vrows), (ov, oo, old, orows) = q, k, v, o
+        ldS = _rup(nk, 8)
+        S = self._new(nb * H, nq, ldS, dtype=torch.float32)
+        sS = (H * nq * ldS, nq * ldS)
+        ops.gemm((qv.t, qo), (kv.t, ko), S, nq, nk, hd, qld, kld, ldS, self.dt, flags=EPI_OUT_F32, alpha=scale,
+                 batch=nb * H, inner=H, sA=(qrows * qld, hd), sB=(krows * kld, hd), sC=sS)
+        Pm = self._new(nb * H, nq, ldS)
+        ops.softmax_fwd(S, ldS, Pm, ldS, nb * H * nq, nk)
+        del S
+        ops.gemm(Pm, (vv.t, vo), (ov.t, oo), nq, hd, nk, ldS, vld, old, self.dt, transB=True, batch=nb * H, inner=H,
+                 sA=sS, sB=(vrows * vld, hd), sC=(orows * old, hd))
+        if self.training:
+            def bwd():
+                if ov.g is None:
+                    return
+                for var in {id(qv): qv, id(kv): kv, id(vv): vv}.values():
+                    assert var.g is None, "sdpa inputs must be single-use projections"
+                    var.g = torch.empty_like(var.t)
+                dO = (ov.g, oo)
+                dP = self._new(nb * H, nq, ldS, dtype=torch.float32)
+                ops.gemm(dO, (vv.t, vo), dP, nq, nk, hd, old, vld, ldS, self.dt, flags=EPI_OUT_F32, batch=nb * H,
+                         inner=H, sA=(orows * old, hd), sB=(vrows * vld, hd), sC=sS)
+                # dV = P^T dO
+                ops.gemm(Pm, dO, (vv.g, vo), nk, hd, nq, ldS, old, vld, self.dt, transA=True, transB=True, batch=nb * H,
+                         inner=H, sA=sS, sB=(orows * old, hd), sC=(vrows * vld, hd))
+                dS = self._new(nb * H, nq, ldS)
+                ops.softmax_bwd(Pm, ldS, dP, ldS, dS, nb * H * nq, nk, scale)
+                del dP
+                ops.gemm(dS, (kv.t, ko), (qv.g, qo), nq, hd, nk, ldS, kld, qld, self.dt, transB=True, batch=nb * H,
+                         inner=H, sA=sS, sB=(krows * kld, hd), sC=(qrows * qld, hd))
+                ops.gemm(dS, (qv.t, qo), (kv.g, ko), nk, hd, nq, ldS, qld, kld, self.dt, transA=True, transB=True,
+                         batch=nb * H, inner=H, sA=sS, sB=(qrows * qld, hd), sC=(krows * kld, hd))
+            self.tape.append(bwd)
+
+    def add_pe(self, x, pe, n, period, pe_var=None):
+        """y = x + pe (pe broadcast with ``period`` elements; transformer.py:320,430)."""
+        y = Var(torch.empty_like(x.t))
+        ops.add_bcast(x.t, pe, y.t, n, period)
+        if self.training:
+            def bwd():
+                if y.g is None:
+                    return
+                if pe_var is not None:
+                    self.acc(pe_var, y.g)
+                self.acc(x, y.g, take=True)
+            self.tape.append(bwd)
+        return y
+
+    def mha(self, prefix, xq, xk, xv, B, nq, nk, internal, resid=None):
+        """transformer.py Attention.forward (:499-521) + optional residual of the caller."""
+        D, H = self.D, 8
+        hd = internal // H
+        Qp = self.linear(xq, prefix + ".q_proj.weight", prefix + ".q_proj.bias", B * nq, internal, D)
+        Kp = self.linear(xk, prefix + ".k_proj.weight", prefix + ".k_proj.bias", B * nk, internal, D)
+        Vp = self.linear(xv, prefix + ".v_proj.weight", prefix + ".v_proj.bias", B * nk, internal, D)
+        O = Var(self._new(B * nq, internal))
+        self.sdpa((Qp, 0, internal, nq), (Kp, 0, internal, nk), (Vp, 0, internal, nk), (O, 0, internal, nq), B, H, nq,
+                  nk, hd, 1.0 / math.sqrt(hd))
+        return self.linear(O, prefix + ".out_proj.weight", prefix + ".out_proj.bias", B * nq, D, internal, resid=resid)
+
+    def groupnorm(self, x, prefix, B, HW, Cdim, gelu):
+        y = Var(torch.empty_like(x.t))
+        nch = ops.groupnorm_nchunk()
+        stats = self._new(B, nch, 2, dtype=torch.float64)
+        mean, rstd = self._new(B, dtype=torch.float32), self._new(B, dtype=torch.float32)
+        ops.groupnorm_fwd(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, stats, B, HW,
+                          Cdim, 1e-5, gelu)
+        if self.training:
+            def bwd():
+                if y.g is None:
+                    return
+                assert x.g is None
+                x.g = torch.empty_like(x.t)
+                part = self._new(2, B * nch, Cdim, dtype=torch.float32)
+                ops.groupnorm_bwd(y.g, x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), mean, rstd, x.g,
+                                  part, stats, B, HW, Cdim, gelu)
+                ops.colsum_f32(part[0], self.G(prefix + ".weight"), B * nch, Cdim, beta=1.0)
+                ops.colsum_f32(part[1], self.G(prefix + ".bias"), B * nch, Cdim, beta=1.0)
+            self.tape.append(bwd)
+        return y
+
+    def conv_t2(self, x, prefix, B, h, w, Cin, Cout):
+        """ConvTranspose2d(Cin, Cout, 2, stride=2) on channels-last tokens = GEMM + depth-to-space."""
+        M = B * h * w
+        t = self._new(M, 4 * Cout)
+        ops.gemm(x.t, self.W(prefix + ".weight"), t, M, 4 * Cout, Cin, Cin, 4 * Cout, 4 * Cout, self.dt, transB=True)
+        y = Var(self._new(B * 4 * h * w, Cout))
+        ops.pixel_shuffle2(t, y.t, self.Pm(prefix + ".bias"), B, h, w, Cout)
+        del t
+        if self.training:
+            def bwd():
+                if y.g is None:
+                    return
+                dt = self._new(M, 4 * Cout)
+                ops.pixel_shuffle2(y.g, dt, None, B, h, w, Cout, inverse=True)
+                self._colsum_to(y.g, Cout, prefix + ".bias", B * 4 * h * w, Cout)
+                # dW[Cin, 4Cout] += x^T dt
+                ops.gemm(x.t, dt, self.G(prefix + ".weight"), Cin, 4 * Cout, M, Cin, 4 * Cout, 4 * Cout, self.dt,
+                         transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
+                f = 0
+                if x.g is None:
+                    x.g = torch.empty_like(x.t)
+                else:
+                    f = EPI_ACCUM
+                ops.gemm(dt, self.W(prefix + ".weight"), x.g, M, Cin, 4 * Cout, 4 * Cout, 4 * Cout, Cin, self.dt, flags=f)
+            self.tape.append(bwd)
+        return y
+
+    def conv_s2(self, x, prefix, B, h, w, Cin, Cout):
+        """Conv2d(Cin, Cout, 2, stride=2) on a channels-last [B, 2h, 2w, Cin] map = space-to-depth + GEMM."""
+        M = B * h * w
+        s2d = self._new(M, 4 * Cin)
+        ops.pixel_shuffle2(x.t, s2d, None, B, h, w, Cin, inverse=True)
+        y = Var(self._new(M, Cout))
+        ops.gemm(s2d, self.W(prefix + ".weight"), y.t, M, Cout, 4 * Cin, 4 * Cin, 4 * Cin, Cout, self.dt,
+                 flags=EPI_BIAS, bias=self.Pm(prefix + ".bias"))
+        if self.training:
+            def bwd():
+                if y.g is None:
+                    return
+                self._wgrad(y.g, Cout, s2d, 4 * Cin, prefix + ".weight", Cout, 4 * Cin, M)
+                self._colsum_to(y.g, Cout, prefix + ".bias", M, Cout)
+                ds = self._new(M, 4 * Cin)
+                ops.gemm(y.g, self.W(prefix + ".weight"), ds, M, 4 * Cin, Cout, Cout, 4 * Cin, 4 * Cin, self.dt,
+                         transB=True)
+                dx = self._new(B * 4 * h * w, Cin)
+                ops.pixel_shuffle2(ds, dx, None, B, h, w, Cin)
+                self.acc(x, dx, take=True)
+            self.tape.append(bwd)
+        return y
+
+    # ------------------------------------------------------------------------------------------ model
+    def forward(self, image4, points, boxes=None, prompt_type=0, drop_mask=None, training=False, taps=None):
+        """image4 fp32 [B,4,H,W]; points fp32 [B,2n,3]; boxes int32 [B,5] (prompt_type 1).
+        Returns instances fp32 [B,1,H,W] (logits) and instances_aux fp32 [B,S,H,W]."""
+        assert image4.is_cuda and image4.dtype == torch.float32 and image4.is_contiguous()
+        if not self.shadow_valid:
+            self.refresh_weights()
+        self.training = training
+        self.tape = []
+        c = self.cfg
+        B, H, W_ = image4.shape[0], image4.shape[2], image4.shape[3]
+        assert H == self.img and W_ == self.img, "re-gridding for other sizes is not supported by this build"
+        D, P, g, NT, heads = self.D, self.P, self.g, self.NT, self.heads
+        M = B * NT
+        n = points.shape[1] // 2
+        points = points.to(self.dev).contiguous().float()
+        use_box = prompt_type == 1
+        if use_box:
+            boxes = boxes.to(device=self.dev, dtype=torch.int32).contiguous()
+        # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
+        disks = self._new(B, 2, H, W_, dtype=torch.float32)
+        ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, 5.0)
+        cols = self._new(M, 6 * P * P)
+        ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg)
+        x = Var(self._new(M, D))
+        ops.gemm(cols, self.w_patch, x.t, M, D, 6 * P * P, 6 * P * P, 6 * P * P, D, self.dt,
+                 flags=EPI_BIAS | EPI_RESID, bias=self.b_patch, resid=self.pos_win, ldr=D, resid_period=NT)
+        if training:
+            x0 = x
+
+            def bwd_patch():
+                if x0.g is None:
+                    return
+                k3 = 3 * P * P
+                for nm, co in (("backbone.patch_embed.proj", 0), ("patch_embed_coords.proj", k3)):
+                    ops.gemm(x0.g, (cols, co), self.G(nm + ".weight"), D, k3, M, D, 2 * k3, k3, self.dt, transA=True,
+                             transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
+                    self._colsum_to(x0.g, D, nm + ".bias", M, D)
+                # pos_embed[:, 1:] gradient: sum over the batch, back to raster order
+                s = self._new(NT * D, dtype=torch.float32)
+                part = self._new(64, NT * D, dtype=torch.float32)
+                ops.colsum(x0.g, NT * D, s, part, B, NT * D, beta=0.0)
+                r = self._new(NT * D, dtype=torch.float32)
+                ops.window_permute(s, r, 1, g, self.wg, D, to_raster=True)
+                gp = (self.gflat, self.names["backbone.pos_embed"][0] + D)
+                ops.add4(gp, r, None, None, gp, NT * D)
+            self.tape.append(bwd_patch)
+        if taps is not None:
+            taps["tokens0_win"] = x.t
+        # ---- a5/a6: ViT blocks on window-ordered tokens
+        hd = D // heads
+        for i in range(1, self.depth + 1):
+            is_global = (i % self.group) == 0
+            nwin = 1 if is_global else self.nw * self.nw
+            nt = NT // nwin
+            p = f"backbone.blocks.{i - 1}."
+            h1 = self.layernorm(x, p + "norm1", M, D, 1e-6)
+            qkv = self.linear(h1, p + "attn.qkv.weight", p + "attn.qkv.bias", M, 3 * D, D)
+            O = Var(self._new(M, D))
+            self.sdpa((qkv, 0, 3 * D, nt), (qkv, D, 3 * D, nt), (qkv, 2 * D, 3 * D, nt), (O, 0, D, nt), B * nwin, heads,
+                      nt, nt, hd, hd ** -0.5)
+            x1 = self.linear(O, p + "attn.proj.weight", p + "attn.proj.bias", M, D, D, resid=x)
+            h2 = self.layernorm(x1, p + "norm2", M, D, 1e-6)
+            x = self.mlp(h2, p + "mlp.fc1", p + "mlp.fc2", M, D, D * c["mlp_ratio"], D, "gelu", resid=x1)
+        xr = Var(self._new(M, D))
+        ops.window_permute(x.t, xr.t, B, g, self.wg, D, to_raster=True)
+        if training:
+            xw = x
+
+            def bwd_perm():
+                if xr.g is None:
+                    return
+                gw = torch.empty_like(xr.g)
+                ops.window_permute(xr.g, gw, B, g, self.wg, D, to_raster=False)
+                self.acc(xw, gw, take=True)
+            self.tape.append(bwd_perm)
+        if taps is not None:
+            taps["backbone"] = xr.t
+        # ---- a7/a8: PuE vectors
+        nq = 2 * self.nmax
+        pue = Var(self._new(B * nq, self.Epad))
+        ops.pue_encode(points, boxes if use_box else None, self.lut, pue.t, None, B, n, self.nmax, self.img, self.Epad)
+        # ---- a10/a11: DMA neck
+        q0 = self.mlp(pue, "neck.ffn_layer.lin1", "neck.ffn_layer.lin2", B * nq, self.Epad, 2048, D, "relu",
+                      w1=self.w_lin1p, k_grad=self.E, x_grad=False)
+        nQ, nK = B * nq * D, M * D
+        q, k = q0, xr
+        hs = []
+        for l in range(3):
+            p = f"neck.att.layers.{l}"
+            if l == 0:
+                q = self.mha(p + ".self_attn", q, q, q, B, nq, nq, D)
+            else:
+                qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
+                q = self.mha(p + ".self_attn", qq, qq, q, B, nq, nq, D, resid=q)
+            q = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5)
+            qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
+            kk = self.add_pe(k, self.kpe, nK, NT * D)
+            q = self.mha(p + ".cross_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
+            q = self.layernorm(q, p + ".norm2", B * nq, D, 1e-5)
+            q = self.mlp(q, p + ".mlp.lin1", p + ".mlp.lin2", B * nq, D, 1024, D, "relu", resid=q)
+            q = self.layernorm(q, p + ".norm3", B * nq, D, 1e-5)
+            qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
+            k2 = self.mha(p + ".cross_attn_image_to_token", kk, qq, q, B, NT, nq, D // 2, resid=k)
+            k = self.layernorm(k2, p + ".norm4", M, D, 1e-5)
+            if l != 2:
+                hs.append((q, k))
+        qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
+        kk = self.add_pe(k, self.kpe, nK, NT * D)
+        q = self.mha("neck.att.final_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
+        q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
+        hs.append((q, k))
+        q_out = Var(self._new(B * nq, D))
+        ops.add4(q0.t, hs[0][0].t, hs[1][0].t, hs[2][0].t, q_out.t, nQ)
+        if training:
+            def bwd_qout():
+                if q_out.g is None:
+                    return
+                for v in (q0, hs[0][0], hs[1][0], hs[2][0]):
+                    self.acc(v, q_out.g)
+            self.tape.append(bwd_qout)
+        # gates (is_vpu_model.py:106-121)
+        maps = [xr]
+        for qi, ki in hs:
+            cg, sg = self._new(B, D, dtype=torch.float32), self._new(B, NT, dtype=torch.float32)
+            aq = self._new(B, D, dtype=torch.int32)
+            ac = self._new(B, NT, dtype=torch.int32)
+            ops.gate_stats(qi.t, ki.t, cg, aq, sg, ac, B, nq, NT, D)
+            xg = Var(self._new(M, D))
+            ops.gate_apply(xr.t, cg, sg, xg.t, B, NT, D)
+            if training:
+                def bwd_gate(xg=xg, qi=qi, ki=ki, cg=cg, sg=sg, aq=aq, ac=ac):
+                    if xg.g is None:
+                        return
+                    for v in (qi, ki):
+                        if v.g is None:
+                            v.g = torch.zeros_like(v.t)
+                    accum = xr.g is not None
+                    if not accum:
+                        xr.g = torch.empty_like(xr.t)
+                    part = self._new(B, 16, D, dtype=torch.float32)
+                    ops.gate_bwd(xg.g, xr.t, cg, aq, sg, ac, xr.g, accum, qi.g, ki.g, part, B, nq, NT, D)
+                self.tape.append(bwd_gate)
+            maps.append(xg)
+        if taps is not None:
+            taps["q_out"] = q_out.t
+        # FPN branches (is_vpu_model.py:55-86), channels-last
+        o = self.out_dims
+        c4 = max(o[0] * 2, D // 2)
+        a = self.conv_t2(maps[0], "neck.down_4.0", B, g, g, D, c4)
+        a = self.groupnorm(a, "neck.down_4.1", B, 4 * NT, c4, True)
+        a = self.conv_t2(a, "neck.down_4.3", B, 2 * g, 2 * g, c4, c4 // 2)
+        a = self.groupnorm(a, "neck.down_4.4", B, 16 * NT, c4 // 2, False)
+        a = self.linear(a, "neck.down_4.5.weight", "neck.down_4.5.bias", B * 16 * NT, o[0], c4 // 2)
+        d4 = self.groupnorm(a, "neck.down_4.6", B, 16 * NT, o[0], True)
+        c8 = max(o[1], D // 2)
+        a = self.conv_t2(maps[1], "neck.down_8.0", B, g, g, D, c8)
+        a = self.groupnorm(a, "neck.down_8.1", B, 4 * NT, c8, False)
+        a = self.linear(a, "neck.down_8.2.weight", "neck.down_8.2.bias", B * 4 * NT, o[1], c8)
+        d8 = self.groupnorm(a, "neck.down_8.3", B, 4 * NT, o[1], True)
+        a = self.linear(maps[2], "neck.down_16.0.weight", "neck.down_16.0.bias", M, o[2], D)
+        d16 = self.groupnorm(a, "neck.down_16.1", B, NT, o[2], True)
+        c32 = max(o[3], D * 2)
+        a = self.conv_s2(maps[3], "neck.down_32.0", B, g // 2, g // 2, D, c32)
+        a = self.groupnorm(a, "neck.down_32.1", B, NT // 4, c32, False)
+        a = self.linear(a, "neck.down_32.2.weight", "neck.down_32.2.bias", B * NT // 4, o[3], c32)
+        d32 = self.groupnorm(a, "neck.down_32.3", B, NT // 4, o[3], True)
+        feats = [(d4, 4 * g), (d8, 2 * g), (d16, g), (d32, g // 2)]
+        if taps is not None:
+            for i, (f, s) in enumerate(feats):
+                taps[f"fpn{i}"] = f.t
+        # ---- a12: head (swin_transformer.py:723-767)
+        Cc = self.C
+        Hs = 4 * g
+        HW4 = Hs * Hs
+        cat = Var(self._new(B * HW4, 4 * Cc))
+        self.linear(feats[0][0], "head.convs.0.conv.weight", "head.convs.0.conv.bias", B * HW4, Cc, o[0], act="relu",
+                    out=(cat, 0, 4 * Cc))
+        for i in (1, 2, 3):
+            f, s = feats[i]
+            ci = self.linear(f, f"head.convs.{i}.conv.weight", f"head.convs.{i}.conv.bias", B * s * s, Cc, o[i],
+                             act="relu")
+            ops.bilinear_cl_fwd(ci.t, Cc, (cat.t, i * Cc), 4 * Cc, B, s, s, Hs, Hs, Cc, self.dt)
+            if training:
+                def bwd_resize(ci=ci, i=i, s=s):
+                    if cat.g is None:
+                        return
+                    assert ci.g is None
+                    ci.g = torch.empty_like(ci.t)
+                    ops.bilinear_cl_bwd((cat.g, i * Cc), 4 * Cc, ci.g, Cc, B, s, s, Hs, Hs, Cc, self.dt)
+                self.tape.append(bwd_resize)
+        fused = self.linear(cat, "head.fusion_conv.conv.weight", "head.fusion_conv.conv.bias", B * HW4, Cc, 4 * Cc,
+                            act="relu")
+        seg = self._new(B * HW4, dtype=torch.float32)
+        ops.convseg_fwd(fused.t, self.Pm("head.conv_seg.weight"), self.Pm("head.conv_seg.bias"), drop_mask, seg,
+                        B * HW4, HW4, Cc)
+        dm = c["head_d_model"]
+        query = self.mlp(q_out, "head.ffn_layer.lin1", "head.ffn_layer.lin2", B * nq, dm, 2 * dm, Cc, "relu")
+        qn, fn = Var(torch.empty_like(query.t)), Var(torch.empty_like(fused.t))
+        inv_q, inv_f = self._new(B * nq, dtype=torch.float32), self._new(B * HW4, dtype=torch.float32)
+        ops.l2norm_fwd(query.t, qn.t, inv_q, B * nq, Cc)
+        ops.l2norm_fwd(fused.t, fn.t, inv_f, B * HW4, Cc)
+        sim = self._new(B, nq, HW4, dtype=torch.float32)
+        ops.gemm(qn.t, fn.t, sim, nq, HW4, Cc, Cc, Cc, HW4, self.dt, flags=EPI_OUT_F32 | EPI_AFFINE, post_mul=0.5,
+                 post_add=0.5, batch=B, inner=1, sA=(nq * Cc, 0), sB=(HW4 * Cc, 0), sC=(nq * HW4, 0))
+        if taps is not None:
+            taps["seg_lowres"] = seg.view(B, 1, Hs, Hs)
+            taps["sim_lowres"] = sim.view(B, nq, Hs, Hs)
+            taps["fused"] = fused.t
+        # ---- a13: final align_corners=True upsample
+        inst = self._new(B, 1, H, W_, dtype=torch.float32)
+        aux = self._new(B, nq, H, W_, dtype=torch.float32)
+        ops.upsample_ac_fwd(seg, inst, B, Hs, Hs, H, W_)
+        ops.upsample_ac_fwd(sim, aux, B * nq, Hs, Hs, H, W_)
+        self._out_grads = [None, None]
+        if training:
+            def bwd_head():
+                d_inst, d_aux = self._out_grads
+                if d_aux is not None:
+                    dsim = self._new(B, nq, HW4, dtype=torch.float32)
+                    ops.upsample_ac_bwd(d_aux, dsim, B * nq, Hs, Hs, H, W_)
+                    if self.dt == BF16:
+                        dsim_t = self._new(B, nq, HW4)
+                        ops.cast2d(dsim, HW4, dsim_t, HW4, B * nq, HW4)
+                    else:
+                        dsim_t = dsim
+                    qn.g, fn.g = torch.empty_like(qn.t), torch.empty_like(fn.t)
+                    # d qn = 0.5 * dsim fn ;  d fn = 0.5 * dsim^T qn
+                    ops.gemm(dsim_t, fn.t, qn.g, nq, Cc, HW4, HW4, Cc, Cc, self.dt, transB=True, alpha=0.5, batch=B,
+                             inner=1, sA=(nq * HW4, 0), sB=(HW4 * Cc, 0), sC=(nq * Cc, 0))
+                    ops.gemm(dsim_t, qn.t, fn.g, HW4, Cc, nq, HW4, Cc, Cc, self.dt, transA=True, transB=True, alpha=0.5,
+                             batch=B, inner=1, sA=(nq * HW4, 0), sB=(nq * Cc, 0), sC=(HW4 * Cc, 0))
+                    query.g, fused.g = torch.empty_like(query.t), torch.empty_like(fused.t)
+                    ops.l2norm_bwd(qn.g, qn.t, inv_q, query.g, B * nq, Cc)
+                    ops.l2norm_bwd(fn.g, fn.t, inv_f, fused.g, B * HW4, Cc)
+                if d_inst is not None:
+                    dseg = self._new(B * HW4, dtype=torch.float32)
+                    ops.upsample_ac_bwd(d_inst, dseg, B, Hs, Hs, H, W_)
+                    nb = ops.convseg_bwd_nblk(B * HW4)
+                    part, part_b = self._new(nb, Cc, dtype=torch.float32), self._new(nb, dtype=torch.float32)
+                    accum = fused.g is not None
+                    if not accum:
+                        fused.g = torch.empty_like(fused.t)
+                    ops.convseg_bwd(dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask, fused.g, accum, part,
+                                    part_b, B * HW4, HW4, Cc)
+                    ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
+                    ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
+            # must run BEFORE the closures of query / fused: insert at the position just after they were recorded
+            self.tape.append(bwd_head)
+        return inst, aux
+
+    def backward(self, d_inst, d_aux):
+        """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None.  Parameter gradients
+        are ACCUMULATED into the flat gradient buffer (call zero_grad() between optimizer steps)."""
+        self._out_grads = [None if d_inst is None else d_inst.contiguous(), None if d_aux is None else d_aux.contiguous()]
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []

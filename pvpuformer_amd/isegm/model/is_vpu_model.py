@@ -1,0 +1,188 @@
+"""``VitMultiGaussianVector_ed_Model`` -- drop-in for the reference class of the same name and module path
+(isegm/model/is_vpu_model.py:140-449): same constructor keywords, ``_config`` capture, state-dict keys (349 for ViT-B),
+positional call signature ``model(image, points, prompts, as_prompt_type, edloss, pclout)`` and output dict
+``{'instances', 'instances_aux'}``.
+
+All arithmetic runs in the HIP kernels of ``libvpu_hip.so`` through ``pvpuformer_amd.engine.Engine``; the module tree
+below only holds parameters.  There is no CPU / eager fallback: calling the model without a GPU (or without the built
+extension) raises.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from ..utils.serialization import serialize
+from .is_model import ISModel
+from .modeling.models_vit import PatchEmbed, VisionTransformer
+from .param_table import Container, head_shapes, init_like_reference, neck_shapes, register_tree
+
+
+class SimpleFPN(Container):
+    """Parameters of the DMA neck (is_vpu_model.py:18-91)."""
+
+    def __init__(self, in_dim=768, out_dims=[128, 256, 512, 1024], img_size=(448, 448), decoder_type=''):
+        super().__init__()
+        self.d_model, self.hide_dim, self.img_size, self.out_dims = in_dim, 1024, tuple(img_size), list(out_dims)
+        register_tree(self, neck_shapes(in_dim, list(out_dims), tuple(img_size)))
+
+
+class SwinTransfomerSegHead(Container):
+    """Parameters of the segmentation head (swin_transformer.py:654-721, decode_head.py:47-86).  ``d_model`` follows the
+    backbone width (the reference hard-codes 768, swin_transformer.py:668, which only fits ViT-B)."""
+
+    def __init__(self, in_channels, channels, num_classes, in_index=(0, 1, 2, 3), dropout_ratio=0.1, loss_decode=None,
+                 align_corners=False, upsample='x1', ed_loss=True, interpolate_mode='bilinear', d_model=768, **kwargs):
+        super().__init__()
+        if upsample != 'x1' or not ed_loss or align_corners or num_classes != 1 or list(in_index) != [0, 1, 2, 3]:
+            raise NotImplementedError("only the VPU configuration (upsample='x1', ed_loss, 4 inputs) is on the hot path")
+        self.in_channels, self.channels, self.num_classes = list(in_channels), channels, num_classes
+        self.dropout_ratio, self.align_corners, self.unsample = dropout_ratio, align_corners, upsample
+        self.loss_decode = loss_decode  # kept only so that checkpoints' pickled configs round-trip
+        self.d_model = d_model
+        register_tree(self, head_shapes(list(in_channels), channels, num_classes, d_model))
+
+
+class PositionEmbeddingRandom(Container):
+    """Buffer only (is_vpu_model.py:453-465); unused by forward, kept for state-dict compatibility."""
+
+    def __init__(self, num_pos_feats=64, scale=None):
+        super().__init__()
+        self.register_buffer("positional_encoding_gaussian_matrix", torch.zeros(2, num_pos_feats))
+
+
+class _VPUFunction(torch.autograd.Function):
+    """Bridges the engine's tape into torch autograd so that ``loss.backward()`` of an unmodified trainer works.
+    Parameter gradients are accumulated directly into ``param.grad`` (views of the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, image, points, boxes, prompt_type, drop_mask):
+        ctx.engine = model._engine
+        inst, aux = model._engine.forward(image, points, boxes, prompt_type, drop_mask, training=True)
+        return inst, aux
+
+    @staticmethod
+    def backward(ctx, d_inst, d_aux):
+        ctx.engine.backward(d_inst, d_aux)
+        return (None,) * 7
+
+
+class VitMultiGaussianVector_ed_Model(ISModel):
+    @serialize
+    def __init__(self, num_max_points=24, backbone_params={}, neck_params={}, head_params={}, random_split=False,
+                 residual=False, **kwargs):
+        super().__init__(**kwargs)
+        if random_split:
+            raise NotImplementedError("random_split (models_vit.py:193-222) is off in every VPU configuration")
+        self.random_split, self.residual = random_split, residual
+        self.num_max_points = num_max_points
+        self.image_size = tuple(backbone_params['img_size'])
+        self.vit_patch_size = tuple(backbone_params['patch_size'])
+        self.embed_dim = backbone_params['embed_dim']
+        self.out_chans = 256
+        self.patch_embed_coords = PatchEmbed(img_size=self.image_size, patch_size=self.vit_patch_size,
+                                             in_chans=3 if self.with_prev_mask else 2, embed_dim=self.embed_dim)
+        self.backbone = VisionTransformer(**backbone_params)
+        self.neck = SimpleFPN(**neck_params)
+        hp = dict(head_params)
+        hp.setdefault('d_model', self.embed_dim)
+        self.head = SwinTransfomerSegHead(**hp)
+        self.pe_layer = PositionEmbeddingRandom(self.embed_dim // 2)
+        self.num_point_embeddings = 4
+        self.point_embeddings = Container()
+        for i in range(4):
+            m = Container()
+            m.weight = nn.Parameter(torch.zeros(1, self.embed_dim))
+            self.point_embeddings.add_module(str(i), m)
+        self.not_a_point_embed = Container()
+        self.not_a_point_embed.weight = nn.Parameter(torch.zeros(1, self.embed_dim))
+        if self.with_aux_output:
+            self.head_aux = Container()
+            self.head_aux.weight = nn.Parameter(torch.zeros(1, 128, 1, 1))
+            self.head_aux.bias = nn.Parameter(torch.zeros(1))
+        if not self.with_prev_mask:
+            raise NotImplementedError("the VPU configuration feeds the previous mask (with_prev_mask=True)")
+        init_like_reference(self)
+        self._engine = None
+        self._compute_dtype = os.environ.get("VPU_COMPUTE_DTYPE", "bf16")
+        self._anchor = None
+        self.weights_frozen = False
+
+    # ---------------------------------------------------------------------------------------------- engine plumbing
+    def engine_cfg(self):
+        b = self.backbone
+        return dict(embed_dim=self.embed_dim, depth=b.depth, num_heads=b.num_heads, img=self.image_size[0],
+                    patch=self.vit_patch_size[0], mlp_ratio=int(b.mlp_ratio), out_dims=tuple(self.neck.out_dims),
+                    head_channels=self.head.channels, num_max_points=self.num_max_points,
+                    head_d_model=self.head.d_model)
+
+    def set_compute_dtype(self, dtype):
+        """'bf16' (MFMA, default) or 'f32' (exact-fp32 parity mode)."""
+        assert dtype in ("bf16", "f32")
+        if dtype != self._compute_dtype:
+            self._compute_dtype = dtype
+            self._engine = None
+        return self
+
+    def _ensure_engine(self):
+        from pvpuformer_amd.engine import Engine
+        first = next(self.parameters())
+        if not first.is_cuda:
+            raise RuntimeError("VitMultiGaussianVector_ed_Model runs on an MI355X only (move it with .cuda()); "
+                               "there is no CPU path in this package")
+        eng = self._engine
+        stale = eng is None or eng.flat.device != first.device or \
+            first.data_ptr() != eng.flat.data_ptr() + 4 * eng.names[next(iter(eng.names))][0]
+        if stale:
+            eng = Engine(self.engine_cfg(), self._compute_dtype, device=first.device)
+            eng.bind(dict(self.named_parameters()))
+            self._engine = eng
+            self._anchor = torch.zeros((), device=first.device, requires_grad=True)
+        return eng
+
+    def sync_weights(self):
+        """Re-derives the compute-dtype weight copies from the fp32 parameters (after an external optimizer step or a
+        state-dict load).  Called automatically at each forward unless ``weights_frozen`` is set."""
+        self._ensure_engine().refresh_weights()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        if self._engine is not None:
+            self._engine.shadow_valid = False
+        return out
+
+    def zero_grad(self, set_to_none=False):
+        # gradients live in the engine's flat buffer: zero it in one pass instead of per-parameter
+        if self._engine is not None:
+            self._engine.zero_grad()
+        else:
+            super().zero_grad(set_to_none=False)
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, image, points=None, prompts=None, as_prompt_type=0, edloss=True, pclout=False):
+        """image [B,4,H,W] (rgb in [0,1] + previous mask), points [B,2n,3] (row, col, order; -1 pad),
+        prompts = (points, boxes[B,5] int32, scribbles) for as_prompt_type 1 (is_vpu_model.py:383-438)."""
+        eng = self._ensure_engine()
+        if not edloss:
+            raise NotImplementedError("edloss=False (plain head.forward) is not used by the VPU trainer / predictor")
+        boxes = None
+        if as_prompt_type == 1:
+            points, boxes, _ = prompts
+        elif as_prompt_type != 0:
+            raise NotImplementedError("scribble prompts (as_prompt_type=2) are never sampled by the shipped trainer or "
+                                      "evaluator (trainer.py:367, vpu_evaluation.py:51); not built")
+        image = image.contiguous().float()
+        if not self.weights_frozen or not eng.shadow_valid:
+            eng.refresh_weights()
+        drop_mask = None
+        if self.training and self.head.dropout_ratio > 0:
+            keep = 1.0 - self.head.dropout_ratio
+            drop_mask = torch.bernoulli(torch.full((image.shape[0], self.head.channels), keep, device=image.device)) / keep
+        if torch.is_grad_enabled():
+            inst, aux = _VPUFunction.apply(self._anchor, self, image, points, boxes, as_prompt_type, drop_mask)
+        else:
+            inst, aux = eng.forward(image, points, boxes, as_prompt_type, drop_mask, training=False)
+        return {'instances': inst, 'instances_aux': aux if self.with_aux_output else None}
+
+    def backbone_forward(self, *a, **k):
+        raise NotImplementedError("use forward(); the stages are fused inside the engine")

@@ -12,6 +12,8 @@ TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 
 
 def code_of(t):
+    if isinstance(t, tuple):
+        t = t[0]
     if t.dtype == torch.bfloat16:
         return BF16
     if t.dtype == torch.float32:
@@ -107,6 +109,10 @@ def cast2d(src, ld_src, dst, ld_dst, rows, cols, cols_pad=None):
     d = dst[0] if isinstance(dst, tuple) else dst
     _lib.call("vpu_cast2d", ptr(src), code_of(s), ld_src, ptr(dst), code_of(d), ld_dst, rows, cols,
               cols if cols_pad is None else cols_pad, _stream())
+
+
+def act_bwd(dy, ld_dy, aux, ld_aux, dz, ld_dz, rows, cols, kind, dtype):
+    _lib.call("vpu_act_bwd", ptr(dy), ld_dy, ptr(aux), ld_aux, ptr(dz), ld_dz, rows, cols, kind, dtype, _stream())
 
 
 def fill_f32(t, v, n=None):

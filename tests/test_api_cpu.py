@@ -1,0 +1,83 @@
+"""CPU: the nn.Module boundary mirrors the reference's (state-dict keys / shapes / order, _config capture, checkpoint
+round trip, loud failure without a GPU)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import vpu_oracle as vo
+
+
+def make_model(cfg=None, **extra):
+    from pvpuformer_amd.isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model
+    cfg = cfg or vo.make_cfg()
+    bp = dict(img_size=(cfg["img"],) * 2, patch_size=(cfg["patch"],) * 2, in_chans=3, embed_dim=cfg["embed_dim"],
+              depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"], qkv_bias=True)
+    npar = dict(in_dim=cfg["embed_dim"], out_dims=list(cfg["out_dims"]), img_size=(cfg["img"],) * 2)
+    hp = dict(in_channels=list(cfg["out_dims"]), in_index=[0, 1, 2, 3], dropout_ratio=0.1, num_classes=1,
+              loss_decode=None, align_corners=False, upsample='x1', ed_loss=True, channels=cfg["head_channels"])
+    return VitMultiGaussianVector_ed_Model(use_disks=True, norm_radius=5, with_prev_mask=True, backbone_params=bp,
+                                           neck_params=npar, head_params=hp, random_split=False, residual=True,
+                                           with_aux_output=True, **extra)
+
+
+TINY = dict(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+
+
+@pytest.mark.parametrize("cfg_kw", [{}, TINY, dict(embed_dim=1024, depth=24, num_heads=16)])
+def test_state_dict_matches_reference_table(cfg_kw):
+    cfg = vo.make_cfg(**cfg_kw)
+    m = make_model(cfg)
+    shapes = vo.param_shapes(cfg)  # verified against the reference's own state_dict by oracle/make_golden.py
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    if not cfg_kw:
+        assert len(sd) == 349
+        assert sum(p.numel() for p in m.parameters()) == 123122987
+
+
+def test_config_capture_and_checkpoint_roundtrip():
+    from pvpuformer_amd.isegm.utils.serialization import load_model
+    cfg = vo.make_cfg(**TINY)
+    m = make_model(cfg)
+    c = m._config
+    assert c["class"] == "isegm.model.is_vpu_model.VitMultiGaussianVector_ed_Model"
+    assert c["params"]["num_max_points"]["value"] == 24 and not c["params"]["num_max_points"]["specified"]
+    assert c["params"]["use_disks"]["specified"] and c["params"]["backbone_params"]["value"]["embed_dim"] == 128
+    buf = io.BytesIO()
+    torch.save({"state_dict": m.state_dict(), "config": m._config}, buf)  # isegm/utils/misc.py:32-33 format
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    import pvpuformer_amd
+    pvpuformer_amd.install()
+    m2 = load_model(ck["config"])
+    m2.load_state_dict(ck["state_dict"], strict=True)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_init_distributions():
+    torch.manual_seed(0)
+    m = make_model(vo.make_cfg(**TINY))
+    sd = m.state_dict()
+    assert torch.all(sd["backbone.blocks.0.norm1.weight"] == 1) and torch.all(sd["backbone.blocks.0.attn.qkv.bias"] == 0)
+    w = sd["backbone.blocks.0.mlp.fc1.weight"]
+    bound = (6.0 / (w.shape[0] + w.shape[1])) ** 0.5
+    assert w.abs().max() <= bound and w.abs().max() > 0.9 * bound
+    assert abs(sd["backbone.pos_embed"].std().item() - 0.02) < 0.002
+    assert abs(sd["head.logit_scale"].item() - np.log(1 / 0.07)) < 1e-6
+    assert sd["neck.att.layers.0.norm1.weight"].eq(1).all() and sd["neck.down_4.1.bias"].eq(0).all()
+    assert sd["pe_layer.positional_encoding_gaussian_matrix"].std() > 0.5
+
+
+def test_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = make_model(vo.make_cfg(**TINY))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(1, 4, 448, 448), -torch.ones(1, 48, 3))
+    assert m.backbone.no_weight_decay() == {"pos_embed", "cls_token", "dist_token"}
+    assert m.backbone.patch_embed.grid_size == (28, 28) and m.with_prev_mask
