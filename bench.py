@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: 448x448 images/sec, forward+backward(+Adam), ViT-B VPUFormer, bs 12 per GPU, click prompts,
+bf16 MFMA, synthetic data, random-init weights (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one ISTrainer.batch_forward iteration with num_iters fixed to 1 (isegm/engine/trainer.py:310-491) on a
+resident batch: zero grads, forward (train mode, Dropout2d on), NFL + Dice + P2CL losses, backward, bucketed gradient
+all-reduce (N > 1), fused Adam.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMG = {"vitb": 510.16e9, "vitl": 1613.59e9, "vith": 4265.17e9}  # fwd+bwd, SURVEY.md section 8d [probe]
+MODELS = {"vitb": dict(embed_dim=768, depth=12, num_heads=12, patch=16),
+          "vitl": dict(embed_dim=1024, depth=24, num_heads=16, patch=16),
+          "vith": dict(embed_dim=1280, depth=32, num_heads=16, patch=14)}
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (README.md:49-54: 12 on one GPU)")
+    ap.add_argument("--model", default="vitb", choices=sorted(MODELS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch_size):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference, oracle/vpu_oracle.py) timed on this box's host
+    cores on a bounded sample: same step definition (fwd + NFL/Dice/P2CL + bwd), ``batch_size`` images per step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vpu_oracle as vo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = vo.make_cfg()
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in
+          vo.synth_state_dict(vo.param_shapes(cfg), seed=0).items()}
+    b = vo.synth_batch(batch_size, cfg["img"], seed=1)
+    img4 = torch.cat([b["images"], torch.zeros(batch_size, 1, cfg["img"], cfg["img"])], 1)
+    ed = vo.ed_mask_label(b["instances"])
+    times = []
+    for it in range(3):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = vo.vpu_forward(sd, cfg, img4, b["points"])
+        total, _ = vo.step_loss(out, b["instances"], ed)
+        total.backward()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": round(batch_size / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/vpu_oracle.py fp32 torch-CPU, ViT-B/448, {batch_size} images/step fwd+bwd+losses, "
+                      f"best of 2 timed steps after 1 warm-up ({t:.2f} s/step)"}
+
+
+class GemmProbe:
+    """HIP-event timing of every GEMM launch of ONE extra (untimed) step, grouped by kernel variant."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec = ops, ops.gemm, []
+
+    def __enter__(self):
+        def wrapped(A, B, C, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(A, B, C, M, N, K, lda, ldb, ldc, dtype, transA=transA, transB=transB, **kw)
+            e1.record()
+            self.rec.append((f"gemm_{'bf16' if dtype == 0 else 'f32'}_kernel<{int(transA)},{int(transB)}>",
+                             2.0 * M * N * K * kw.get("batch", 1), e0, e1))
+        self.ops.gemm = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, e0, e1 in self.rec:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        return agg
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from pvpuformer_amd import ops
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    from pvpuformer_amd.isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model
+    from pvpuformer_amd.optim import FusedAdam
+    from pvpuformer_amd.parallel import GradReducer, broadcast_parameters
+    from pvpuformer_amd.synth import synth_batch, vitb_model_kwargs
+
+    mk = MODELS[args.model]
+    torch.manual_seed(0)
+    model = VitMultiGaussianVector_ed_Model(**vitb_model_kwargs(embed_dim=mk["embed_dim"], depth=mk["depth"],
+                                                                num_heads=mk["num_heads"], patch=mk["patch"])).to(dev)
+    model.set_compute_dtype(args.dtype)
+    model.train()
+    eng = model._ensure_engine()
+    broadcast_parameters(eng.flat)
+    eng.refresh_weights()
+    opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8)
+    red = GradReducer(eng.gflat)
+    eng.grad_ready_hook = red.ready
+
+    B = args.batch
+    batch = synth_batch(B, 448, seed=100 + rank, device=dev)   # each rank its own shard of the global batch
+    image4 = torch.cat([batch["images"], torch.zeros(B, 1, 448, 448, device=dev)], 1).contiguous()  # trainer.py:324,384
+    gt, points = batch["instances"], batch["points"]
+    keep = 1.0 - model.head.dropout_ratio
+    last = {}
+
+    def step():
+        eng.zero_grad()
+        mask = torch.bernoulli(torch.full((B, model.head.channels), keep, device=dev)) / keep
+        inst, aux = eng.forward(image4, points, None, 0, mask, training=True)
+        losses, d_inst, d_aux = vpu_step_losses(inst, aux, gt, None, None, iter_weight=1.0)
+        red.begin()
+        eng.backward(d_inst, d_aux)
+        opt.step(grad_scale=red.finish())
+        last["loss"] = losses["total"]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(last["loss"].item())
+    value = world * B * args.steps / dt
+
+    roof = None
+    with GemmProbe(ops) as probe:
+        step()
+    agg = probe.summary()
+    if agg:
+        name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+        peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4), "traffic": None,
+                "launches_per_step": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                "all_gemm_variants": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3),
+                                           "launches": v[2]} for k, v in sorted(agg.items())}}
+    if rank == 0:
+        line = {"metric": "448x448 images/sec fwd+bwd, ViT-B VPUFormer", "value": round(value, 2), "unit": "images/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{args.model} 448x448 bs={B}/GPU click-only training step "
+                                       f"(fwd + NFL/Dice/P2CL + bwd + fused Adam), random-init weights",
+                           "global_batch": B * world, "parallelism": f"dp{world}",
+                           "flop_per_image_fwd_bwd": FLOP_PER_IMG[args.model],
+                           "mfma_roofline_frac_end_to_end":
+                               round(value / world * FLOP_PER_IMG[args.model] / (BF16_PEAK_TFLOPS * 1e12), 4),
+                           "final_loss": round(loss_val, 5)},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

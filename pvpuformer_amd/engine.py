@@ -85,6 +85,7 @@ class Engine:
         self.training = False
         self.shadow_valid = False
         self._const_ready = False
+        self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
     # ------------------------------------------------------------------------------------------ parameters
     def bind(self, named_params):
@@ -126,11 +127,12 @@ class Engine:
     def G(self, name):
         return (self.gflat, self.names[name][0])
 
-    def refresh_weights(self):
+    def refresh_weights(self, shadow_is_fresh=False):
         """fp32 master -> compute-dtype operands (bf16 shadow, fused patch-embed weight, K-padded PuE weight,
-        window-ordered pos_embed).  ~0.75 GB of traffic for ViT-B."""
+        window-ordered pos_embed).  ~0.75 GB of traffic for ViT-B; ``shadow_is_fresh``: the fused optimizer has already
+        written the bf16 shadow, only the four small derived operands are rebuilt."""
         D, P = self.D, self.P
-        if self.dt == BF16:
+        if self.dt == BF16 and not shadow_is_fresh:
             ops.cast2d(self.flat, self.total, self.shadow, self.total, 1, self.total)
         k3 = 3 * P * P
         ops.cast2d(self.Pm("backbone.patch_embed.proj.weight"), k3, (self.w_patch, 0), 2 * k3, D, k3)
@@ -457,6 +459,9 @@ class Engine:
         # ---- a5/a6: ViT blocks on window-ordered tokens
         hd = D // heads
         for i in range(1, self.depth + 1):
+            if training:
+                self._mark_ready(f"backbone.blocks.{i - 1}.norm1.weight",
+                                 f"backbone.blocks.{i}.norm1.weight" if i < self.depth else "backbone.fc_norm.weight")
             is_global = (i % self.group) == 0
             nwin = 1 if is_global else self.nw * self.nw
             nt = NT // nwin
@@ -483,6 +488,8 @@ class Engine:
             self.tape.append(bwd_perm)
         if taps is not None:
             taps["backbone"] = xr.t
+        if training:
+            self._mark_ready("backbone.fc_norm.weight", None)  # neck + head + the unused tail: final once they are done
         # ---- a7/a8: PuE vectors
         nq = 2 * self.nmax
         pue = Var(self._new(B * nq, self.Epad))
@@ -656,6 +663,16 @@ class Engine:
             self.tape.append(bwd_head)
         return inst, aux
 
+    def _mark_ready(self, first_name, next_name):
+        """Records a tape marker: when backward reaches it, gflat[offset(first_name) : offset(next_name)) is final."""
+        lo = self.names[first_name][0]
+        hi = self.total if next_name is None else self.names[next_name][0]
+
+        def marker():
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(lo, hi)
+        self.tape.append(marker)
+
     def backward(self, d_inst, d_aux):
         """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None.  Parameter gradients
         are ACCUMULATED into the flat gradient buffer (call zero_grad() between optimizer steps)."""
@@ -663,3 +680,5 @@ class Engine:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0
+            self.grad_ready_hook(0, self.names["backbone.blocks.0.norm1.weight"][0])

@@ -1,0 +1,79 @@
+"""Data-parallel gradient exchange for the VPU training step: one process per GPU, RCCL (torch.distributed backend
+"nccl" on ROCm) over xGMI.  Replaces the reference's DistributedDataParallel wrapper + loss reduce
+(isegm/utils/distributed.py:25-67, isegm/engine/trainer.py:118-120).
+
+The engine keeps all gradients in ONE flat fp32 buffer laid out in parameter order; backward finishes them from the
+tail (head, neck) to the front (block 11 ... block 0, patch embeddings) and reports each finished contiguous range
+through ``Engine.grad_ready_hook``.  The reducer coalesces ranges into buckets of >= ``bucket_bytes`` and launches an
+asynchronous SUM all-reduce per bucket as soon as it is complete, so the exchange overlaps the rest of backward; the
+29 never-used tensors are just zeros inside the flat buffer (no find_unused_parameters machinery).  The mean is folded
+into the optimizer (grad_scale = 1/world_size).  xGMI is point-to-point (7 links x ~153 GB/s): few large buckets keep
+every link busy; ViT-B's 489 MB of fp32 gradients go out in ~8 collectives.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, flat_grad, group=None, bucket_bytes=64 << 20):
+        self.g = flat_grad
+        self.group = group
+        self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self._pending_hi = None   # current open bucket is [lo, hi) growing downwards
+        self._pending_lo = None
+        self._works = []
+        self.launched = []        # (lo, hi) of every collective of the current step (for tests / logging)
+
+    def begin(self):
+        self._pending_hi = self._pending_lo = None
+        self._works = []
+        self.launched = []
+
+    def ready(self, lo, hi):
+        """gflat[lo:hi] is final.  Ranges arrive tail-first and contiguous; anything else is flushed separately."""
+        if not self.enabled or hi <= lo:
+            return
+        if self._pending_lo is not None and hi == self._pending_lo:
+            self._pending_lo = lo
+        else:
+            self._flush()
+            self._pending_lo, self._pending_hi = lo, hi
+        if self._pending_hi - self._pending_lo >= self.bucket_elems:
+            self._flush()
+
+    def _flush(self):
+        if self._pending_lo is None:
+            return
+        lo, hi = self._pending_lo, self._pending_hi
+        self._pending_lo = self._pending_hi = None
+        self._works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append((lo, hi))
+
+    def finish(self):
+        """Launches the last partial bucket and makes the current stream wait for every collective.  Returns the factor
+        the optimizer must apply to the summed gradient."""
+        if self.enabled:
+            self._flush()
+            for w in self._works:
+                w.wait()
+            self._works = []
+        return 1.0 / self.world
+
+
+def broadcast_parameters(flat_param, src=0, group=None):
+    """Identical replicas at start (DDP ctor broadcast, trainer.py:118-120): one collective over the flat buffer."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_param, src=src, group=group)
+
+
+def reduce_loss_dict(losses, group=None):
+    """isegm/utils/distributed.py:25-47: mean of the logged scalar losses over ranks (one small all-reduce)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return losses
+    keys = sorted(losses)
+    t = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+    dist.all_reduce(t, group=group)
+    t /= dist.get_world_size(group)
+    return {k: t[i] for i, k in enumerate(keys)}
