@@ -278,6 +278,7 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 }  // namespace
 
 extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
+    vpu_clear_stale_error();
     if (!d || !d->A || !d->B || !d->C) { vpu_set_error("vpu_gemm: null operand"); return VPU_ERR_ARG; }
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->inner <= 0 || d->batch % d->inner) {
         vpu_set_error("vpu_gemm: bad sizes (M,N,K,batch > 0; batch % inner == 0)");

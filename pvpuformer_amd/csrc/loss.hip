@@ -123,6 +123,7 @@ __global__ __launch_bounds__(1024) void nfl_dice_grad_kernel(const float* __rest
 extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_t* slot_mask_idx,
                                 const float* override_masks, float* loss_part, float* dprob, float grad_scale, int32_t B,
                                 int32_t S, int32_t H, int32_t W, void* stream) {
+    vpu_clear_stale_error();
     const int64_t HW = (int64_t)H * W;
     if (HW % 4 || S % 2) { vpu_set_error("p2cl: H*W % 4, S % 2"); return VPU_ERR_ARG; }
     p2cl_kernel<<<(unsigned)(B * S), 1024, 0, ST>>>(prob, gt, slot_mask_idx, override_masks, loss_part, dprob, grad_scale,
@@ -132,6 +133,7 @@ extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_
 
 extern "C" int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, float* out, float* dlogits,
                                     float w_nfl, float w_dice, int32_t B, int64_t HW, void* stream) {
+    vpu_clear_stale_error();
     nfl_dice_sums_kernel<<<B, 1024, 0, ST>>>(logits, gt, sums, HW);
     nfl_dice_grad_kernel<<<B, 1024, 0, ST>>>(logits, gt, sums, out, dlogits, w_nfl, w_dice, HW);
     return vpu_check_launch("vpu_nfl_dice_fwd_bwd");

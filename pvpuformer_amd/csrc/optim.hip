@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 extern "C" int vpu_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                              void* stream) {
+    vpu_clear_stale_error();
     if (n <= 0 || step < 1) { vpu_set_error("adam: n > 0, step >= 1"); return VPU_ERR_ARG; }
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));

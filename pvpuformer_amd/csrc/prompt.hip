@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict_
 extern "C" int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
                               int32_t B, int32_t n, int32_t num_max, int32_t img, int32_t ld, int32_t dtype,
                               void* stream) {
+    vpu_clear_stale_error();
     if (n > num_max || ld < 2 * img + 3 || B <= 0) { vpu_set_error("pue_encode: n <= num_max, ld >= 2*img+3"); return VPU_ERR_ARG; }
     const unsigned grid = (unsigned)(B * 2 * num_max);
     if (dtype == VPU_BF16)
@@ -135,6 +136,7 @@ extern "C" int vpu_pue_encode(const float* points, const int32_t* boxes, const f
 
 extern "C" int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H,
                              int32_t W, float radius, void* stream) {
+    vpu_clear_stale_error();
     if (B <= 0 || n <= 0 || n > 1024) { vpu_set_error("disk_maps: sizes"); return VPU_ERR_ARG; }
     dim3 grid((H * W + 255) / 256, B);
     disk_maps_kernel<<<grid, 256, 2 * n * 2 * sizeof(float), ST>>>(points, boxes, out, n, H, W, radius * radius);

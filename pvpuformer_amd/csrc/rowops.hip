@@ -351,18 +351,21 @@ __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n)
 
 extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                                  int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm: C % 8 == 0, C <= 2048"); return VPU_ERR_ARG; }
     DISPATCH_T(dtype, layernorm_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(
         (const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps);)
     return vpu_check_launch("vpu_layernorm_fwd");
 }
 extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
+    vpu_clear_stale_error();
     int64_t n = rows / 16;
     return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
 }
 extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                                  const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype,
                                  void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
     const int nblk = vpu_layernorm_bwd_nblk(rows);
     DISPATCH_T(dtype, layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, (const T*)x, w, mean, rstd,
@@ -370,11 +373,13 @@ extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, 
     return vpu_check_launch("vpu_layernorm_bwd");
 }
 extern "C" int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream) {
+    vpu_clear_stale_error();
     colsum_f32_kernel<<<(C + 63) / 64, 256, 0, ST>>>(in, out, rows, C, beta);
     return vpu_check_launch("vpu_colsum_f32");
 }
 extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, int64_t rows, int32_t C, float beta,
                           int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || ld % 8) { vpu_set_error("colsum: C, ld % 8"); return VPU_ERR_ARG; }
     dim3 grid((C / 8 + 63) / 64, CS_SLABS);
     DISPATCH_T(dtype, colsum_part_kernel<T><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
@@ -383,29 +388,34 @@ extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, i
 }
 extern "C" int vpu_softmax_fwd(const float* S, int32_t lds_, void* P, int32_t ldp, int64_t rows, int32_t ncols,
                                int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (ncols > SM_MAX * 64 || ldp > SM_MAX * 64 || ldp < ncols) { vpu_set_error("softmax: ncols <= 1024"); return VPU_ERR_ARG; }
     DISPATCH_T(dtype, softmax_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(S, lds_, (T*)P, ldp, rows, ncols);)
     return vpu_check_launch("vpu_softmax_fwd");
 }
 extern "C" int vpu_softmax_bwd(const void* P, int32_t ldp, const float* dP, int32_t lddp, void* dS, int64_t rows,
                                int32_t ncols, float scale, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (ncols > SM_MAX * 64 || ldp > SM_MAX * 64 || ldp < ncols) { vpu_set_error("softmax_bwd: ncols <= 1024"); return VPU_ERR_ARG; }
     DISPATCH_T(dtype, softmax_bwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)P, ldp, dP, lddp,
                                                                                        (T*)dS, rows, ncols, scale);)
     return vpu_check_launch("vpu_softmax_bwd");
 }
 extern "C" int vpu_l2norm_fwd(const void* x, void* y, float* inv, int64_t rows, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     DISPATCH_T(dtype, l2norm_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)x, (T*)y, inv, rows, C);)
     return vpu_check_launch("vpu_l2norm_fwd");
 }
 extern "C" int vpu_l2norm_bwd(const void* dy, const void* y, const float* inv, void* dx, int64_t rows, int32_t C,
                               int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     DISPATCH_T(dtype, l2norm_bwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)dy, (const T*)y, inv,
                                                                                       (T*)dx, rows, C);)
     return vpu_check_launch("vpu_l2norm_bwd");
 }
 extern "C" int vpu_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period_b, int32_t dtype,
                              void* stream) {
+    vpu_clear_stale_error();
     if (n % 8 || period_b % 8 || period_b <= 0) { vpu_set_error("add_bcast: n, period % 8"); return VPU_ERR_ARG; }
     const int grid = vpu_grid_for(n / 8, 256, 4096);
     DISPATCH_T(dtype, add_bcast_kernel<T><<<grid, 256, 0, ST>>>((const T*)a, (const T*)b, (T*)out, n / 8, period_b / 8);)
@@ -413,6 +423,7 @@ extern "C" int vpu_add_bcast(const void* a, const void* b, void* out, int64_t n,
 }
 extern "C" int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n,
                         int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (n % 8) { vpu_set_error("add4: n % 8"); return VPU_ERR_ARG; }
     const int grid = vpu_grid_for(n / 8, 256, 4096);
     DISPATCH_T(dtype, add4_kernel<T><<<grid, 256, 0, ST>>>((const T*)a, (const T*)b, (const T*)c, (const T*)d, (T*)out, n / 8);)
@@ -420,6 +431,7 @@ extern "C" int vpu_add4(const void* a, const void* b, const void* c, const void*
 }
 extern "C" int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
                           int64_t ld_dst, int64_t rows, int32_t cols, int32_t cols_pad, void* stream) {
+    vpu_clear_stale_error();
     const int grid = vpu_grid_for(rows * cols_pad, 256, 8192);
     if (src_dtype == VPU_F32 && dst_dtype == VPU_BF16)
         cast2d_kernel<float, bf16_t><<<grid, 256, 0, ST>>>((const float*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, cols_pad);
@@ -434,6 +446,7 @@ extern "C" int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, vo
 }
 extern "C" int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64_t ld_aux, void* dz, int64_t ld_dz,
                            int64_t rows, int32_t cols, int32_t kind, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (cols % 8 || ld_dy % 8 || ld_aux % 8 || ld_dz % 8) { vpu_set_error("act_bwd: cols, ld % 8"); return VPU_ERR_ARG; }
     const int grid = vpu_grid_for(rows * (cols / 8), 256, 8192);
     DISPATCH_T(dtype, act_bwd_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, ld_dy, (const T*)aux, ld_aux, (T*)dz, ld_dz,
@@ -441,6 +454,7 @@ extern "C" int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64
     return vpu_check_launch("vpu_act_bwd");
 }
 extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
+    vpu_clear_stale_error();
     fill_kernel<<<vpu_grid_for(n, 256, 4096), 256, 0, ST>>>(p, v, n);
     return vpu_check_launch("vpu_fill_f32");
 }

@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256) void upsample_ac_bwd_kernel(const float* __res
 
 extern "C" int vpu_patch_im2col(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W,
                                 int32_t P, int32_t win_tokens, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (H % P || W % P || (6 * P * P) % 8 || (W / P) % win_tokens || (H / P) % win_tokens) {
         vpu_set_error("patch_im2col: H,W % P, grid % window, 6*P*P % 8");
         return VPU_ERR_ARG;
@@ -651,6 +652,7 @@ extern "C" int vpu_patch_im2col(const float* image4, const float* disks, void* c
 }
 extern "C" int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, int32_t wg, int32_t C, int32_t dir,
                                   int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || g % wg) { vpu_set_error("window_permute: C % 8, g % wg"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * g * g * (C / 8);
     DISPATCH_T(dtype, window_permute_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)x, (T*)y, B, g,
@@ -659,16 +661,19 @@ extern "C" int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, 
 }
 extern "C" int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, int32_t B, int32_t h, int32_t w,
                                   int32_t C, int32_t dir, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8) { vpu_set_error("pixel_shuffle2: C % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * 4 * h * w * (C / 8);
     DISPATCH_T(dtype, pixel_shuffle2_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)in, (T*)out,
                                                                                                bias, B, h, w, C, dir);)
     return vpu_check_launch("vpu_pixel_shuffle2");
 }
-extern "C" int vpu_groupnorm_nchunk(void) { return GN_CHUNKS; }
+extern "C" int vpu_groupnorm_nchunk(void) {
+    vpu_clear_stale_error(); return GN_CHUNKS; }
 extern "C" int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                                  double* stats, int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu,
                                  int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || C > 2048) { vpu_set_error("groupnorm: C % 8, C <= 2048"); return VPU_ERR_ARG; }
     dim3 grid(B, GN_CHUNKS);
     DISPATCH_T(dtype, gn_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, stats, HW, C);
@@ -678,6 +683,7 @@ extern "C" int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, 
 extern "C" int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, const float* b, const float* mean,
                                  const float* rstd, void* dx, float* part, double* stats, int32_t B, int64_t HW,
                                  int32_t C, int32_t gelu, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || C > 2048) { vpu_set_error("groupnorm_bwd: C % 8, C <= 2048"); return VPU_ERR_ARG; }
     dim3 grid(B, GN_CHUNKS);
     DISPATCH_T(dtype,
@@ -689,6 +695,7 @@ extern "C" int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, 
 }
 extern "C" int vpu_bilinear_cl_fwd(const void* in, int32_t ld_in, void* out, int32_t ld_out, int32_t B, int32_t h,
                                    int32_t w, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl: C, ld % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * H * W * (C / 8);
     DISPATCH_T(dtype, bilinear_cl_fwd_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
@@ -697,6 +704,7 @@ extern "C" int vpu_bilinear_cl_fwd(const void* in, int32_t ld_in, void* out, int
 }
 extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_in, int32_t B, int32_t h,
                                    int32_t w, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl_bwd: C, ld % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * h * w * (C / 8);
     DISPATCH_T(dtype, bilinear_cl_bwd_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
@@ -705,6 +713,7 @@ extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, 
 }
 extern "C" int vpu_gate_stats(const void* Q, const void* Kt, float* cg, int32_t* argq, float* sg, int32_t* argc,
                               int32_t B, int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     DISPATCH_T(dtype,
                gate_colmax_kernel<T><<<vpu_grid_for((int64_t)B * C, 256), 256, 0, ST>>>((const T*)Q, cg, argq, B, nq, C);
                gate_rowmax_kernel<T><<<(unsigned)(((int64_t)B * N + 3) / 4), 256, 0, ST>>>((const T*)Kt, sg, argc,
@@ -713,6 +722,7 @@ extern "C" int vpu_gate_stats(const void* Q, const void* Kt, float* cg, int32_t*
 }
 extern "C" int vpu_gate_apply(const void* x, const float* cg, const float* sg, void* out, int32_t B, int32_t N,
                               int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8) { vpu_set_error("gate_apply: C % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * N * (C / 8);
     DISPATCH_T(dtype, gate_apply_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)x, cg, sg, (T*)out,
@@ -722,6 +732,7 @@ extern "C" int vpu_gate_apply(const void* x, const float* cg, const float* sg, v
 extern "C" int vpu_gate_bwd(const void* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
                             const int32_t* argc, void* dx, int32_t accum, void* dQ, void* dK, float* part, int32_t B,
                             int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C % 8 || C > 2048) { vpu_set_error("gate_bwd: C % 8, C <= 2048"); return VPU_ERR_ARG; }
     dim3 grid(B, GATE_NBLK);
     DISPATCH_T(dtype,
@@ -733,17 +744,20 @@ extern "C" int vpu_gate_bwd(const void* dout, const void* x, const float* cg, co
 }
 extern "C" int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out,
                                int64_t rows, int64_t HW, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     DISPATCH_T(dtype, convseg_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)x, w, bias, mask, out,
                                                                                        rows, HW, C);)
     return vpu_check_launch("vpu_convseg_fwd");
 }
 extern "C" int vpu_convseg_bwd_nblk(int64_t rows) {
+    vpu_clear_stale_error();
     int64_t n = rows / 64;
     return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
 }
 extern "C" int vpu_convseg_bwd(const float* dout, const void* x, const float* w, const float* mask, void* dx,
                                int32_t accum, float* part, float* part_b, int64_t rows, int64_t HW, int32_t C,
                                int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
     if (C > 512) { vpu_set_error("convseg_bwd: C <= 512"); return VPU_ERR_ARG; }
     const int nblk = vpu_convseg_bwd_nblk(rows);
     DISPATCH_T(dtype, convseg_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dout, (const T*)x, w, mask, (T*)dx, accum, part,
@@ -752,11 +766,13 @@ extern "C" int vpu_convseg_bwd(const float* dout, const void* x, const float* w,
 }
 extern "C" int vpu_upsample_ac_fwd(const float* in, float* out, int64_t planes, int32_t h, int32_t w, int32_t H,
                                    int32_t W, void* stream) {
+    vpu_clear_stale_error();
     upsample_ac_fwd_kernel<<<vpu_grid_for(planes * H * W, 256, 65536), 256, 0, ST>>>(in, out, planes, h, w, H, W);
     return vpu_check_launch("vpu_upsample_ac_fwd");
 }
 extern "C" int vpu_upsample_ac_bwd(const float* dout, float* din, int64_t planes, int32_t h, int32_t w, int32_t H,
                                    int32_t W, void* stream) {
+    vpu_clear_stale_error();
     upsample_ac_bwd_kernel<<<vpu_grid_for(planes * h * w, 256, 65536), 256, 0, ST>>>(dout, din, planes, h, w, H, W);
     return vpu_check_launch("vpu_upsample_ac_bwd");
 }

@@ -19,6 +19,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 void vpu_set_error(const char* msg);
 int vpu_check_launch(const char* what);
+// hipGetLastError() is per-thread and NOT cleared by successful calls: drop whatever an earlier runtime call of the
+// host program left behind so that vpu_check_launch() reports this launch only.
+static inline void vpu_clear_stale_error() { (void)hipGetLastError(); }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
