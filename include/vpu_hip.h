@@ -51,6 +51,8 @@ typedef struct vpu_gemm_desc {
     int32_t dtype, flags;
     int32_t resid_period; /* > 0: resid row = m % period and no batch stride (broadcast pos_embed) */
     float alpha, post_mul, post_add;
+    void* workspace;         /* optional fp32 scratch for split-K partial tiles (bf16 path); NULL disables split-K */
+    int64_t workspace_bytes; /* split-K needs batch * slices * M * N * 4 bytes */
 } vpu_gemm_desc;
 
 const char* vpu_last_error(void);

@@ -27,6 +27,7 @@ class GemmDesc(C.Structure):
         ("transA", C.c_int32), ("transB", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32),
         ("resid_period", C.c_int32),
         ("alpha", C.c_float), ("post_mul", C.c_float), ("post_add", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -90,6 +91,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VpuError(f"{LIB_PATH} not found: build it with pvpuformer_amd/csrc/build.sh "
                        f"(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # torch must be imported first: it ships its own libamdhip64 and a process must hold exactly ONE HIP runtime -- if
+    # this library is dlopen'ed before torch it binds /opt/rocm's copy and every launch on a torch stream fails with
+    # "no ROCm-capable device is detected" (seen in round 1).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -123,8 +123,75 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, 
     }
 }
 
+// 8 consecutive output columns of one row through the full epilogue with 16-byte accesses.
+// Preconditions (checked on the host, flag `vec`): n % 8 == 0, n + 8 <= N, every leading dimension / batch offset /
+// base pointer involved is a multiple of 8 elements (16 B for bf16, 32 B for fp32).
+__device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int m, int n,
+                                                float (&v)[8]) {
+    const int flags = p.flags;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+    if (flags & VPU_EPI_BIAS) {
+        float b[8];
+        load8(p.bias + n, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
+    }
+    const int64_t ci = coff + (int64_t)m * p.ldc + n;
+    if (flags & VPU_EPI_PREACT) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, v);
+    if (flags & VPU_EPI_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+    }
+    if (flags & VPU_EPI_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    if (flags & (VPU_EPI_DGELU | VPU_EPI_DRELU)) {
+        float a[8];
+        load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= (flags & VPU_EPI_DGELU) ? dgelu_f(a[j]) : (a[j] > 0.f ? 1.f : 0.f);
+    }
+    if (flags & VPU_EPI_RESID) {
+        float r[8];
+        const int64_t ri = p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
+                                              : roff + (int64_t)m * p.ldr + n;
+        load8(reinterpret_cast<const bf16_t*>(p.resid) + ri, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (flags & VPU_EPI_AFFINE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * p.post_mul + p.post_add;
+    }
+    if (flags & VPU_EPI_OUT_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + ci;
+        if (flags & VPU_EPI_ACCUM) {
+            float o[8];
+            load8(c, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        store8(c, v);
+    } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + ci;
+        if (flags & VPU_EPI_ACCUM) {
+            float o[8];
+            load8(c, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        store8(c, v);
+    }
+}
+
+// grid: x = tiles_m * tiles_n, y = split-K slices, z = batch.
+// splitk > 1: every slice writes its raw fp32 partial tile to ws[(z*splitk + slice)][M][N]; splitk_reduce_kernel sums
+// the slices in a fixed order (deterministic) and applies the epilogue.
 template <int TA, int TB>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
+                                                        const int kchunk, float* __restrict__ ws, const int vec) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
     char* ldsA = lds;
     char* ldsB = lds + TILE_BYTES;
@@ -137,6 +204,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
     const int64_t coff = zo * p.sCo + zi * p.sCi;
     const int64_t roff = zo * p.sRo + zi * p.sRi;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < p.K) ? kbeg + kchunk : p.K;
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -146,16 +215,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
 
     TileLoader<TA> la;
     TileLoader<TB> lb;
-    const int nk = (p.K + BK - 1) / BK;
-    la.load(A, p.lda, m0, p.M, 0, p.K, tid);
-    lb.load(B, p.ldb, n0, p.N, 0, p.K, tid);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    la.load(A, p.lda, m0, p.M, kbeg, kend, tid);
+    lb.load(B, p.ldb, n0, p.N, kbeg, kend, tid);
     for (int kt = 0; kt < nk; ++kt) {
         la.store(ldsA, tid);
         lb.store(ldsB, tid);
         __syncthreads();
         if (kt + 1 < nk) {
-            la.load(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
-            lb.load(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+            la.load(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+            lb.load(B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -173,19 +242,59 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
         __syncthreads();
     }
 
+    // ---- epilogue: transpose the accumulators through LDS so that every lane owns 8 consecutive columns of one row
+    // and all global accesses are 16-byte vectors.  Two passes of 32 rows per wave (8 KiB of fp32 per wave each).
     const int fr = lane & 15, fq = lane >> 4;
+    float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
+    float* wsz = ws ? ws + ((int64_t)z * splitk + blockIdx.y) * (int64_t)p.M * p.N : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
-            if (m >= p.M) continue;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fr;
-                if (n < p.N) epilogue_store<bf16_t>(p, coff, roff, m, n, acc[i][j][r]);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ii * 16 + fq * 4 + r;
+                    wl[row * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[pass * 2 + ii][j][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int u = lane + 64 * t;
+            const int row = u >> 3, c8 = (u & 7) * 8;
+            const int m = m0 + wm * 64 + pass * 32 + row;
+            const int n = n0 + wn * 64 + c8;
+            if (m < p.M && n < p.N) {
+                float v[8];
+                load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
+                if (splitk > 1) {
+                    float* o = wsz + (int64_t)m * p.N + n;
+                    if ((p.N & 3) == 0 && n + 8 <= p.N) store8(o, v);
+                    else
+                        for (int j = 0; j < 8 && n + j < p.N; ++j) o[j] = v[j];
+                } else if (vec && n + 8 <= p.N) {
+                    epilogue_store8(p, coff, roff, m, n, v);
+                } else {
+                    for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
+                }
             }
         }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc p, const int splitk,
+                                                            const float* __restrict__ ws) {
+    const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
+    const int64_t coff = zo * p.sCo + zi * p.sCi, roff = zo * p.sRo + zi * p.sRi;
+    const int64_t mn = (int64_t)p.M * p.N;
+    const float* w = ws + (int64_t)z * splitk * mn;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < splitk; ++s) v += w[s * mn + i];
+        epilogue_store<T>(p, coff, roff, (int)(i / p.N), (int)(i % p.N), v);
     }
 }
 
@@ -302,16 +411,46 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tm = bf ? BM : FM, tn = bf ? BN : FN;
     const int tiles_m = (d->M + tm - 1) / tm, tiles_n = (d->N + tn - 1) / tn;
-    dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)d->batch), block(256);
     const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
     if (bf) {
+        // vector epilogue: everything the epilogue touches is addressable in 8-element (16/32 B) units
+        const size_t cbytes = (f & VPU_EPI_OUT_F32) ? 32 : 16;
+        bool vec = d->N % 8 == 0 && d->ldc % 8 == 0 && d->sCo % 8 == 0 && d->sCi % 8 == 0 && aligned_to(d->C, cbytes);
+        if (f & VPU_EPI_BIAS) vec = vec && aligned_to(d->bias, 32);
+        if (f & VPU_EPI_PREACT) vec = vec && aligned_to(d->preact, 16);
+        if (f & (VPU_EPI_DGELU | VPU_EPI_DRELU)) vec = vec && d->ldaux % 8 == 0 && aligned_to(d->aux, 16);
+        if (f & VPU_EPI_RESID)
+            vec = vec && d->ldr % 8 == 0 && d->sRo % 8 == 0 && d->sRi % 8 == 0 && aligned_to(d->resid, 16);
+        // split-K: few output tiles and a long reduction (weight gradients, cosine-logit gradients)
+        const int64_t tiles = (int64_t)tiles_m * tiles_n * d->batch;
+        int splitk = 1, kchunk = (d->K + BK - 1) / BK * BK;
+        if (d->workspace && tiles < 192 && d->K >= 8 * BK) {
+            int64_t want = (384 + tiles - 1) / tiles;
+            const int64_t max_by_k = d->K / (4 * BK);
+            const int64_t max_by_ws = d->workspace_bytes / ((int64_t)d->batch * d->M * d->N * 4);
+            if (want > max_by_k) want = max_by_k;
+            if (want > max_by_ws) want = max_by_ws;
+            if (want > 128) want = 128;
+            if (want > 1) {
+                kchunk = (int)(((d->K + want - 1) / want + BK - 1) / BK * BK);
+                splitk = (d->K + kchunk - 1) / kchunk;
+            }
+        }
+        float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
+        dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
         switch (key) {
-            case 0: gemm_bf16_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
-            case 1: gemm_bf16_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
-            case 2: gemm_bf16_kernel<1, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
-            default: gemm_bf16_kernel<1, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
+            case 0: gemm_bf16_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+            case 1: gemm_bf16_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+            case 2: gemm_bf16_kernel<1, 0><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+            default: gemm_bf16_kernel<1, 1><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+        }
+        if (splitk > 1) {
+            const int64_t mn = (int64_t)d->M * d->N;
+            dim3 rgrid((unsigned)vpu_grid_for(mn, 256, 4096), 1, (unsigned)d->batch);
+            splitk_reduce_kernel<bf16_t><<<rgrid, block, 0, s>>>(*d, splitk, ws);
         }
     } else {
+        dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)d->batch), block(256);
         switch (key) {
             case 0: gemm_f32_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
             case 1: gemm_f32_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;

@@ -35,9 +35,23 @@ def ptr(t, off=0):
     return t.data_ptr() + off * t.element_size()
 
 
+_WORKSPACE = {}
+
+
+def split_k_workspace(device, nbytes=128 << 20):
+    """fp32 scratch shared by every GEMM launched on ``device`` (launches on one stream are serialised, so one buffer
+    is enough).  Passed to vpu_gemm, whose host side decides per launch whether to split K."""
+    key = str(device)
+    ws = _WORKSPACE.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        _WORKSPACE[key] = ws
+    return ws
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, flags=0, bias=None, resid=None,
          ldr=0, aux=None, ldaux=0, preact=None, alpha=1.0, post_mul=1.0, post_add=0.0, batch=1, inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto"):
     """C = epilogue(alpha * op(A) op(B)); see include/vpu_hip.h.  A/B/C/resid/aux/preact may be tensors or
     (tensor, element_offset) tuples."""
     d = GemmDesc()
@@ -54,6 +68,11 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, 
     d.dtype, d.flags = dtype, flags
     d.resid_period = resid_period
     d.alpha, d.post_mul, d.post_add = alpha, post_mul, post_add
+    if workspace == "auto":
+        c0 = Cout[0] if isinstance(Cout, tuple) else Cout
+        workspace = split_k_workspace(c0.device)
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     _lib.call("vpu_gemm", C.byref(d), _stream())
 
 

@@ -494,3 +494,33 @@ def test_adam_matches_torch(ops):
         ops.adam_step(p, dev(g * step), m, v, sh, n, 5e-5, 0.9, 0.999, 1e-8, 0.0, step)
     torch.testing.assert_close(p.cpu(), pt.detach(), rtol=1e-6, atol=1e-7)
     assert torch.equal(sh, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("tA,tB", [(1, 1), (0, 0), (0, 1)])
+def test_gemm_split_k_and_vector_epilogue(ops, tA, tB):
+    """Long-K / few-tile shapes take the split-K path (fp32 slabs + ordered reduce); the result must equal the
+    unsplit launch bit for bit on exact-integer data and stay within bf16 tolerance on random data, for plain, ACCUM
+    and full-epilogue launches.  Also ragged N (scalar tail of the vector epilogue)."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 256, 136, 8192
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+    ref = A @ Bm.t()
+    Ad = dev(A.t().contiguous() if tA else A).to(torch.bfloat16)
+    Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+    lda, ldb = (M if tA else K), (N if tB else K)
+    for ws in ("auto", None):
+        C32 = torch.full((M, N), 1.0, device="cuda")
+        ops.gemm(Ad, Bd, C32, M, N, K, lda, ldb, N, 0, transA=bool(tA), transB=bool(tB),
+                 flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, workspace=ws)
+        assert torch.equal(C32.cpu(), ref + 1.0), ws
+    bias, R = dev(rnd(N, seed=50)), dev(rnd(M, N, seed=51)).to(torch.bfloat16)
+    outs = []
+    for ws in ("auto", None):
+        Cb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(Ad, Bd, Cb, M, N, K, lda, ldb, N, 0, transA=bool(tA), transB=bool(tB),
+                 flags=ops.EPI_BIAS | ops.EPI_RESID, bias=bias, resid=R, ldr=N, alpha=1.0 / 64, workspace=ws)
+        outs.append(Cb.float().cpu())
+    expect = (ref / 64 + bias.cpu() + R.float().cpu())
+    torch.testing.assert_close(outs[0], expect, atol=0.2, rtol=2e-2)
+    torch.testing.assert_close(outs[0], outs[1], atol=0.13, rtol=1e-2)
