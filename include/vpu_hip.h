@@ -34,6 +34,9 @@ extern "C" {
 #define VPU_EPI_AFFINE 128  /* v = v*post_mul + post_add    swin_transformer.py:752      */
 #define VPU_EPI_ACCUM 256   /* v += C[m,n]   (fp32 output only; gradient accumulation)   */
 #define VPU_EPI_OUT_F32 512 /* C is fp32 although dtype is bf16                          */
+#define VPU_EPI_SAVE_DGELU 1024 /* with GELU: preact[m,n] = gelu'(v) (shares the erf) -- the backward of the MLP then
+                                   needs no transcendental: its dgrad epilogue is VPU_EPI_MULAUX           */
+#define VPU_EPI_MULAUX 2048 /* v *= aux[m,n]  (applied where DGELU/DRELU would be)                     */
 
 typedef struct vpu_gemm_desc {
     const void* A;      /* transA=0: [M][lda] K-contiguous;  transA=1: [K][lda] (M contiguous) */

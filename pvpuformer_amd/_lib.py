@@ -13,6 +13,7 @@ BF16, F32 = 0, 1
 
 EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGELU, EPI_DRELU = 1, 2, 4, 8, 16, 32
 EPI_RESID, EPI_AFFINE, EPI_ACCUM, EPI_OUT_F32 = 64, 128, 256, 512
+EPI_SAVE_DGELU, EPI_MULAUX = 1024, 2048
 
 
 class GemmDesc(C.Structure):

@@ -29,12 +29,14 @@ __device__ __forceinline__ void epilogue_store(const vpu_gemm_desc& p, int64_t c
     if (flags & VPU_EPI_BIAS) v += p.bias[n];
     const int64_t ci = coff + (int64_t)m * p.ldc + n;
     if (flags & VPU_EPI_PREACT) reinterpret_cast<T*>(p.preact)[ci] = from_f32<T>(v);
+    if (flags & VPU_EPI_SAVE_DGELU) reinterpret_cast<T*>(p.preact)[ci] = from_f32<T>(dgelu_f(v));
     if (flags & VPU_EPI_GELU) v = gelu_f(v);
     if (flags & VPU_EPI_RELU) v = fmaxf(v, 0.f);
     if (flags & (VPU_EPI_DGELU | VPU_EPI_DRELU)) {
         const float a = to_f32(reinterpret_cast<const T*>(p.aux)[coff + (int64_t)m * p.ldaux + n]);
         v *= (flags & VPU_EPI_DGELU) ? dgelu_f(a) : (a > 0.f ? 1.f : 0.f);
     }
+    if (flags & VPU_EPI_MULAUX) v *= to_f32(reinterpret_cast<const T*>(p.aux)[coff + (int64_t)m * p.ldaux + n]);
     if (flags & VPU_EPI_RESID) {
         const T* r = reinterpret_cast<const T*>(p.resid);
         const int64_t ri = p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
@@ -139,7 +141,18 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
     }
     const int64_t ci = coff + (int64_t)m * p.ldc + n;
     if (flags & VPU_EPI_PREACT) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, v);
-    if (flags & VPU_EPI_GELU) {
+    if (flags & VPU_EPI_SAVE_DGELU) {
+        // gelu and gelu' share the erf: phi = 0.5*(1+erf(x/sqrt2)); gelu = x*phi; gelu' = phi + x*pdf(x)
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[j];
+            const float phi = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            d[j] = phi + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+            v[j] = x * phi;
+        }
+        store8(reinterpret_cast<bf16_t*>(p.preact) + ci, d);
+    } else if (flags & VPU_EPI_GELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
     }
@@ -152,6 +165,12 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
         load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= (flags & VPU_EPI_DGELU) ? dgelu_f(a[j]) : (a[j] > 0.f ? 1.f : 0.f);
+    }
+    if (flags & VPU_EPI_MULAUX) {
+        float a[8];
+        load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= a[j];
     }
     if (flags & VPU_EPI_RESID) {
         float r[8];
@@ -395,7 +414,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     }
     const int f = d->flags;
     if (((f & VPU_EPI_BIAS) && !d->bias) || ((f & VPU_EPI_RESID) && !d->resid) ||
-        ((f & (VPU_EPI_DGELU | VPU_EPI_DRELU)) && !d->aux) || ((f & VPU_EPI_PREACT) && !d->preact)) {
+        ((f & (VPU_EPI_DGELU | VPU_EPI_DRELU | VPU_EPI_MULAUX)) && !d->aux) ||
+        ((f & (VPU_EPI_PREACT | VPU_EPI_SAVE_DGELU)) && !d->preact) ||
+        ((f & VPU_EPI_SAVE_DGELU) && (!(f & VPU_EPI_GELU) || (f & VPU_EPI_PREACT)))) {
         vpu_set_error("vpu_gemm: epilogue flag set but its pointer is null");
         return VPU_ERR_ARG;
     }
@@ -415,10 +436,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     if (bf) {
         // vector epilogue: everything the epilogue touches is addressable in 8-element (16/32 B) units
         const size_t cbytes = (f & VPU_EPI_OUT_F32) ? 32 : 16;
-        bool vec = d->N % 8 == 0 && d->ldc % 8 == 0 && d->sCo % 8 == 0 && d->sCi % 8 == 0 && aligned_to(d->C, cbytes);
+        // (a ragged N is fine: the kernel sends the last partial group of 8 columns through the scalar path)
+        bool vec = d->ldc % 8 == 0 && d->sCo % 8 == 0 && d->sCi % 8 == 0 && aligned_to(d->C, cbytes);
         if (f & VPU_EPI_BIAS) vec = vec && aligned_to(d->bias, 32);
-        if (f & VPU_EPI_PREACT) vec = vec && aligned_to(d->preact, 16);
-        if (f & (VPU_EPI_DGELU | VPU_EPI_DRELU)) vec = vec && d->ldaux % 8 == 0 && aligned_to(d->aux, 16);
+        if (f & (VPU_EPI_PREACT | VPU_EPI_SAVE_DGELU)) vec = vec && aligned_to(d->preact, 16);
+        if (f & (VPU_EPI_DGELU | VPU_EPI_DRELU | VPU_EPI_MULAUX)) vec = vec && d->ldaux % 8 == 0 && aligned_to(d->aux, 16);
         if (f & VPU_EPI_RESID)
             vec = vec && d->ldr % 8 == 0 && d->sRo % 8 == 0 && d->sRi % 8 == 0 && aligned_to(d->resid, 16);
         // split-K: few output tiles and a long reduction (weight gradients, cosine-logit gradients)

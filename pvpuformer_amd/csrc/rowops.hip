@@ -159,34 +159,46 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     }
 }
 
-constexpr int CS_SLABS = 64;
+constexpr int CS_SLABS = 64;   // rows of the caller's partial buffer ([64][C], include/vpu_hip.h)
+// block = 16 column-lanes (8 columns each = 128 columns) x 16 row groups; grid = (C/128, 64 row slabs)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ in, int ld, float* __restrict__ part,
                                                           int64_t rows, int C) {
-    __shared__ float red[4][8 * 64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 8;
+    __shared__ float red[16][129];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = (blockIdx.x * 16 + cl) * 8;
     const int64_t per = (rows + CS_SLABS - 1) / CS_SLABS;
     const int64_t r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    if (c < C)
-        for (int64_t r = r0 + grp; r < r1; r += 4) {
+    if (c < C) {
+        int64_t r = r0 + grp;
+        for (; r + 16 < r1; r += 32) {  // two independent 16-byte loads in flight per lane
+            float v0[8], v1[8];
+            load8(in + r * ld + c, v0);
+            load8(in + (r + 16) * ld + c, v1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v0[j] + v1[j];
+        }
+        for (; r < r1; r += 16) {
             float v[8];
             load8(in + r * ld + c, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += v[j];
         }
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[grp][j * 64 + lane] = a[j];
+    for (int j = 0; j < 8; ++j) red[grp][cl * 8 + j] = a[j];
     __syncthreads();
-    if (grp == 0 && c < C) {
-        float o[8];
+    if (threadIdx.x < 128) {
+        const int cc = blockIdx.x * 128 + threadIdx.x;
+        if (cc < C) {
+            float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
-        store8(part + (int64_t)blockIdx.y * C + c, o);
+            for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+            part[(int64_t)blockIdx.y * C + cc] = t;
+        }
     }
 }
 
@@ -381,7 +393,7 @@ extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, i
                           int32_t dtype, void* stream) {
     vpu_clear_stale_error();
     if (C % 8 || ld % 8) { vpu_set_error("colsum: C, ld % 8"); return VPU_ERR_ARG; }
-    dim3 grid((C / 8 + 63) / 64, CS_SLABS);
+    dim3 grid((C + 127) / 128, CS_SLABS);
     DISPATCH_T(dtype, colsum_part_kernel<T><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
     colsum_f32_kernel<<<(C + 63) / 64, 256, 0, ST>>>(part, out, CS_SLABS, C, beta);
     return vpu_check_launch("vpu_colsum");

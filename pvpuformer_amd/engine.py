@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from ._lib import (BF16, F32, EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGELU, EPI_DRELU, EPI_RESID, EPI_AFFINE,
-                   EPI_ACCUM, EPI_OUT_F32)
+                   EPI_ACCUM, EPI_OUT_F32, EPI_SAVE_DGELU, EPI_MULAUX)
 
 
 class Var:
@@ -223,7 +223,7 @@ class Engine:
         if act == "gelu":
             pre = self._new(M, Hd)
             ops.gemm(x.t, self.W(p1 + ".weight") if w1 is None else w1, h, M, Hd, Kp, Kp, Kp, Hd, self.dt,
-                     flags=EPI_BIAS | EPI_PREACT | EPI_GELU, bias=self.Pm(p1 + ".bias"), preact=pre)
+                     flags=EPI_BIAS | EPI_SAVE_DGELU | EPI_GELU, bias=self.Pm(p1 + ".bias"), preact=pre)
         else:
             pre = None
             ops.gemm(x.t, self.W(p1 + ".weight") if w1 is None else w1, h, M, Hd, Kp, Kp, Kp, Hd, self.dt,
@@ -243,7 +243,7 @@ class Engine:
                 self._colsum_to(dy, N, p2 + ".bias", M, N)
                 dpre = self._new(M, Hd)
                 ops.gemm(dy, self.W(p2 + ".weight"), dpre, M, Hd, N, N, Hd, Hd, self.dt, transB=True,
-                         flags=EPI_DGELU if act == "gelu" else EPI_DRELU, aux=pre if act == "gelu" else h, ldaux=Hd)
+                         flags=EPI_MULAUX if act == "gelu" else EPI_DRELU, aux=pre if act == "gelu" else h, ldaux=Hd)
                 kg = K if k_grad is None else k_grad
                 # dW1[Hd, kg] += dpre^T x  (x may be K-padded: ld Kp, only kg columns are real)
                 ops.gemm(dpre, x.t, self.G(p1 + ".weight"), Hd, kg, M, Hd, Kp, kg, self.dt, transA=True, transB=True,

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 from ._lib import (BF16, F32, EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGELU, EPI_DRELU, EPI_RESID, EPI_AFFINE,
-                   EPI_ACCUM, EPI_OUT_F32, GemmDesc)
+                   EPI_ACCUM, EPI_OUT_F32, EPI_SAVE_DGELU, EPI_MULAUX, GemmDesc)
 
 TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 

@@ -37,7 +37,12 @@ def run_smoke():
         losses, d_inst, d_aux = vpu_step_losses(inst, aux, b["instances"].cuda())
         eng.backward(d_inst, d_aux)
         assert torch.isfinite(eng.gflat).all() and eng.gflat.abs().max() > 0
-        FusedAdam(model).step()
         torch.cuda.synchronize()
         print(f"smoke[{dtype}]: logits rel err {err:.2e}, aux abs err {err2:.2e}, loss {losses['total'].item():.5f}")
+    # one fused-Adam step (after the parity checks: it changes the weights the oracle output was computed with)
+    before = eng.flat.clone()
+    FusedAdam(model).step()
+    torch.cuda.synchronize()
+    delta = (eng.flat - before).abs().max().item()
+    assert 0 < delta < 1e-3 and torch.equal(eng.shadow, eng.flat.to(torch.bfloat16)), delta
     print("smoke ok")
