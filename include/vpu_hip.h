@@ -55,7 +55,9 @@ typedef struct vpu_gemm_desc {
     int32_t resid_period; /* > 0: resid row = m % period and no batch stride (broadcast pos_embed) */
     float alpha, post_mul, post_add;
     void* workspace;         /* optional fp32 scratch for split-K partial tiles (bf16 path); NULL disables split-K */
-    int64_t workspace_bytes; /* split-K needs batch * slices * M * N * 4 bytes */
+    int64_t workspace_bytes; /* split-K needs batch * slices * M * (N + 1) * 4 bytes */
+    float* colsum;           /* optional (bf16, transA=1, batch=1): colsum[m] += sum_k op(A)[m][k] -- the bias gradient
+                                fused into the weight-gradient GEMM whose A operand is dY */
 } vpu_gemm_desc;
 
 const char* vpu_last_error(void);

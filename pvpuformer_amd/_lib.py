@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("transA", C.c_int32), ("transB", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32),
         ("resid_period", C.c_int32),
         ("alpha", C.c_float), ("post_mul", C.c_float), ("post_add", C.c_float),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("colsum", C.c_void_p),
     ]
 
 

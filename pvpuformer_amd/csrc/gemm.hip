@@ -235,11 +235,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     TileLoader<TA> la;
     TileLoader<TB> lb;
     const int nk = (kend - kbeg + BK - 1) / BK;
+    // fused bias gradient: out[m] += sum_k A[k][m] for the K-major A of a weight-gradient GEMM (A = dY).  Thread t always
+    // stages the same 8 columns ((t & 15) * 8 ...) of 4 different k rows, so the sums live in 8 registers.
+    const bool do_cs = TA == 1 && p.colsum != nullptr && tile_n == 0;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     la.load(A, p.lda, m0, p.M, kbeg, kend, tid);
     lb.load(B, p.ldb, n0, p.N, kbeg, kend, tid);
     for (int kt = 0; kt < nk; ++kt) {
         la.store(ldsA, tid);
         lb.store(ldsB, tid);
+        if (TA == 1 && do_cs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8_t e = __builtin_bit_cast(bf16x8_t, la.r[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[j] += (float)e[j];
+            }
+        }
         __syncthreads();
         if (kt + 1 < nk) {
             la.load(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
@@ -266,6 +280,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const int fr = lane & 15, fq = lane >> 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
     float* wsz = ws ? ws + ((int64_t)z * splitk + blockIdx.y) * (int64_t)p.M * p.N : nullptr;
+    if (TA == 1 && p.colsum != nullptr) {  // block-uniform condition
+        float* red = reinterpret_cast<float*>(lds);
+        if (do_cs) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(tid >> 4) * 128 + (tid & 15) * 8 + j] = bsum[j];
+        }
+        __syncthreads();
+        if (do_cs && tid < 128 && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
+            if (splitk > 1) ws[(int64_t)gridDim.z * splitk * p.M * p.N + ((int64_t)z * splitk + blockIdx.y) * p.M + m0 + tid] = t;
+            else p.colsum[m0 + tid] += t;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -314,6 +344,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc 
         float v = 0.f;
         for (int s = 0; s < splitk; ++s) v += w[s * mn + i];
         epilogue_store<T>(p, coff, roff, (int)(i / p.N), (int)(i % p.N), v);
+    }
+    if (p.colsum != nullptr && z == 0) {
+        const float* wb = ws + (int64_t)gridDim.z * splitk * mn;
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
+            float t = 0.f;
+            for (int s = 0; s < splitk; ++s) t += wb[(int64_t)s * p.M + m];
+            p.colsum[m] += t;
+        }
     }
 }
 
@@ -422,6 +460,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     }
     const bool bf = d->dtype == VPU_BF16;
     if (!bf && d->dtype != VPU_F32) { vpu_set_error("vpu_gemm: dtype"); return VPU_ERR_ARG; }
+    if (d->colsum && (!bf || !d->transA || d->batch != 1)) {
+        vpu_set_error("vpu_gemm: colsum needs the bf16 path, transA=1 and batch=1");
+        return VPU_ERR_ARG;
+    }
     const int64_t q = bf ? 8 : 4;  // elements per 16 B
     const bool strides_ok = d->lda % q == 0 && d->ldb % q == 0 && d->sAo % q == 0 && d->sAi % q == 0 &&
                             d->sBo % q == 0 && d->sBi % q == 0;
@@ -449,7 +491,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         if (d->workspace && tiles < 192 && d->K >= 8 * BK) {
             int64_t want = (384 + tiles - 1) / tiles;
             const int64_t max_by_k = d->K / (4 * BK);
-            const int64_t max_by_ws = d->workspace_bytes / ((int64_t)d->batch * d->M * d->N * 4);
+            const int64_t max_by_ws = d->workspace_bytes / ((int64_t)d->batch * d->M * (d->N + 1) * 4);
             if (want > max_by_k) want = max_by_k;
             if (want > max_by_ws) want = max_by_ws;
             if (want > 128) want = 128;

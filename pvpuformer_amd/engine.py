@@ -168,10 +168,14 @@ class Engine:
         part = self._new(64, N, dtype=torch.float32)
         ops.colsum(dy, ld, self.G(gname), part, rows, N, beta=1.0)
 
-    def _wgrad(self, dy, ld_dy, x, ld_x, gname, N, K, M, ldc=None):
-        """G[N,K] += dy[M,N]^T x[M,K]"""
+    def _wgrad(self, dy, ld_dy, x, ld_x, gname, N, K, M, ldc=None, bias=None):
+        """G[N,K] += dy[M,N]^T x[M,K];  optionally G[bias][N] += column sums of dy, fused into the same launch (bf16
+        path; the fp32 parity path uses the stand-alone column-sum kernel)."""
+        fuse = bias is not None and self.dt == BF16
         ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
-                 transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
+                 transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
+        if bias is not None and not fuse:
+            self._colsum_to(dy, ld_dy, bias, M, N)
 
     def _dgrad(self, dy, ld_dy, w, ldw, xvar, M, K, N, flags=0, aux=None, ldaux=0):
         """x.g (+)= dy[M,N] W[N,K]"""
@@ -209,8 +213,7 @@ class Engine:
                     dy, ld = dz, N
                 else:
                     ld = ldc
-                self._wgrad(dy, ld, x.t, K, wname, N, K, M)
-                self._colsum_to(dy, ld, bname, M, N)
+                self._wgrad(dy, ld, x.t, K, wname, N, K, M, bias=bname)
                 if x_grad:
                     self._dgrad(dy, ld, self.W(wname), K, x, M, K, N)
             self.tape.append(bwd)
@@ -239,16 +242,13 @@ class Engine:
                     return
                 if resid is not None:
                     self.acc(resid, dy, take=True)
-                self._wgrad(dy, N, h, Hd, p2 + ".weight", N, Hd, M)
-                self._colsum_to(dy, N, p2 + ".bias", M, N)
+                self._wgrad(dy, N, h, Hd, p2 + ".weight", N, Hd, M, bias=p2 + ".bias")
                 dpre = self._new(M, Hd)
                 ops.gemm(dy, self.W(p2 + ".weight"), dpre, M, Hd, N, N, Hd, Hd, self.dt, transB=True,
                          flags=EPI_MULAUX if act == "gelu" else EPI_DRELU, aux=pre if act == "gelu" else h, ldaux=Hd)
                 kg = K if k_grad is None else k_grad
                 # dW1[Hd, kg] += dpre^T x  (x may be K-padded: ld Kp, only kg columns are real)
-                ops.gemm(dpre, x.t, self.G(p1 + ".weight"), Hd, kg, M, Hd, Kp, kg, self.dt, transA=True, transB=True,
-                         flags=EPI_OUT_F32 | EPI_ACCUM)
-                self._colsum_to(dpre, Hd, p1 + ".bias", M, Hd)
+                self._wgrad(dpre, Hd, x.t, Kp, p1 + ".weight", Hd, kg, M, bias=p1 + ".bias")
                 if x_grad:
                     self._dgrad(dpre, Hd, self.W(p1 + ".weight") if w1 is None else w1, Kp, x, M, Kp, Hd)
             self.tape.append(bwd)
@@ -396,8 +396,7 @@ class Engine:
             def bwd():
                 if y.g is None:
                     return
-                self._wgrad(y.g, Cout, s2d, 4 * Cin, prefix + ".weight", Cout, 4 * Cin, M)
-                self._colsum_to(y.g, Cout, prefix + ".bias", M, Cout)
+                self._wgrad(y.g, Cout, s2d, 4 * Cin, prefix + ".weight", Cout, 4 * Cin, M, bias=prefix + ".bias")
                 ds = self._new(M, 4 * Cin)
                 ops.gemm(y.g, self.W(prefix + ".weight"), ds, M, 4 * Cin, Cout, Cout, 4 * Cin, 4 * Cin, self.dt,
                          transB=True)
@@ -442,9 +441,7 @@ class Engine:
                     return
                 k3 = 3 * P * P
                 for nm, co in (("backbone.patch_embed.proj", 0), ("patch_embed_coords.proj", k3)):
-                    ops.gemm(x0.g, (cols, co), self.G(nm + ".weight"), D, k3, M, D, 2 * k3, k3, self.dt, transA=True,
-                             transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
-                    self._colsum_to(x0.g, D, nm + ".bias", M, D)
+                    self._wgrad(x0.g, D, (cols, co), 2 * k3, nm + ".weight", D, k3, M, bias=nm + ".bias")
                 # pos_embed[:, 1:] gradient: sum over the batch, back to raster order
                 s = self._new(NT * D, dtype=torch.float32)
                 part = self._new(64, NT * D, dtype=torch.float32)

@@ -51,7 +51,7 @@ def split_k_workspace(device, nbytes=128 << 20):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, flags=0, bias=None, resid=None,
          ldr=0, aux=None, ldaux=0, preact=None, alpha=1.0, post_mul=1.0, post_add=0.0, batch=1, inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto"):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto", colsum=None):
     """C = epilogue(alpha * op(A) op(B)); see include/vpu_hip.h.  A/B/C/resid/aux/preact may be tensors or
     (tensor, element_offset) tuples."""
     d = GemmDesc()
@@ -68,6 +68,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, 
     d.dtype, d.flags = dtype, flags
     d.resid_period = resid_period
     d.alpha, d.post_mul, d.post_add = alpha, post_mul, post_add
+    d.colsum = ptr(colsum)
     if workspace == "auto":
         c0 = Cout[0] if isinstance(Cout, tuple) else Cout
         workspace = split_k_workspace(c0.device)

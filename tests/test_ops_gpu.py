@@ -524,3 +524,20 @@ def test_gemm_split_k_and_vector_epilogue(ops, tA, tB):
     expect = (ref / 64 + bias.cpu() + R.float().cpu())
     torch.testing.assert_close(outs[0], expect, atol=0.2, rtol=2e-2)
     torch.testing.assert_close(outs[0], outs[1], atol=0.13, rtol=1e-2)
+
+
+@pytest.mark.parametrize("K", [512, 8192])
+def test_gemm_fused_bias_gradient(ops, K):
+    """wgrad GEMM with the bias-gradient column sums fused in (split-K for the long K, direct for the short one)."""
+    g = torch.Generator().manual_seed(4)
+    M, N = 200, 136                      # M = out features (rows of dW), N = in features
+    dY = torch.randint(-2, 3, (K, M), generator=g).float()   # [tokens, out]  -> A, K-major
+    X = torch.randint(-2, 3, (K, N), generator=g).float()    # [tokens, in]   -> B, K-major
+    dYd, Xd = torch.zeros(K, 208), torch.zeros(K, 136)
+    dYd[:, :M], Xd[:, :N] = dY, X
+    dW = torch.full((M, N), 2.0, device="cuda")
+    db = torch.full((M,), 3.0, device="cuda")
+    ops.gemm(dev(dYd).to(torch.bfloat16), dev(Xd).to(torch.bfloat16), dW, M, N, K, 208, 136, N, 0, transA=True,
+             transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=db)
+    assert torch.equal(dW.cpu(), dY.t() @ X + 2.0)
+    assert torch.equal(db.cpu(), dY.sum(0) + 3.0)
