@@ -70,39 +70,34 @@ __device__ __forceinline__ int km_off(int k, int unit) {
     return k * 256 + ((unit ^ ((k & 3) << 2) ^ (((k >> 3) & 1) << 4)) << 3);
 }
 
+typedef __attribute__((address_space(3))) void* lds_vptr;
+constexpr int OOB_OFFSET = (int)0x80000000;  // >= num_records of the descriptors below: the load returns zeros
+
+// LDS-DMA staging of one 128x64 (K-contiguous) or 64x128 (K-major) bf16 tile: 16 pieces of 1 KiB, each one
+// `buffer_load_dwordx4 ... lds` wave-instruction (64 lanes x 16 B, landing at piece_base + 16*lane, no VGPRs).  The LDS
+// image is linear per piece, so the XOR swizzle is applied to the per-lane SOURCE chunk (cdna guide, rule 21); rows /
+// k beyond the operand (ragged M, N, K, split-K slice ends) get the out-of-range offset and arrive as zeros.
 template <int TRANS>
-struct TileLoader {
-    // registers for one 128x64 (or 64x128) bf16 tile: 4 x 16 B per thread
-    uint4 r[4];
-    // rows_or_cols_total: extent of the non-K dimension of this operand (M or N)
-    __device__ __forceinline__ void load(const bf16_t* base, int ld, int x0, int X, int k0, int K, int tid) {
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, int x0, int X, int k0, int kend,
+                                           char* lds_tile, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (TRANS == 0) {
-                const int row = c >> 3, kc = c & 7;
-                const int gx = x0 + row, gk = k0 + kc * 8;
-                if (gx < X && gk < K) v = *reinterpret_cast<const uint4*>(base + (int64_t)gx * ld + gk);
-            } else {
-                const int k = c >> 4, cc = c & 15;
-                const int gk = k0 + k, gx = x0 + cc * 8;
-                if (gk < K && gx < X) v = *reinterpret_cast<const uint4*>(base + (int64_t)gk * ld + gx);
-            }
-            r[i] = v;
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 4 * i;
+        int voff;
+        if (TRANS == 0) {
+            const int row = piece * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int gx = x0 + row, gk = k0 + chunk * 8;
+            voff = (gx < X && gk < kend) ? (gx * ld + gk) * 2 : OOB_OFFSET;
+        } else {
+            const int k = piece * 4 + (lane >> 4);
+            const int chunk = (lane & 15) ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
+            const int gk = k0 + k, gx = x0 + chunk * 8;
+            voff = (gk < kend && gx < X) ? (gk * ld + gx) * 2 : OOB_OFFSET;
         }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(lds_tile + piece * 1024), 16, voff, 0, 0, 0);
     }
-    __device__ __forceinline__ void store(char* lds, int tid) const {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256;
-            int off;
-            if (TRANS == 0) off = kc_off(c >> 3, c & 7);
-            else off = km_off(c >> 4, (c & 15) * 2);
-            *reinterpret_cast<uint4*>(lds + off) = r[i];
-        }
-    }
-};
+}
 
 // fragment for 16 rows (or cols) starting at x16 within the tile, k-substep ks (0/1)
 template <int TRANS>
@@ -211,10 +206,10 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
                                                         const int kchunk, float* __restrict__ ws, const int vec) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
-    char* ldsA = lds;
-    char* ldsB = lds + TILE_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // two stages of (A tile 16 KiB + B tile 16 KiB); the first 32 KiB double as the epilogue staging area
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -225,39 +220,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const int64_t roff = zo * p.sRo + zi * p.sRi;
     const int kbeg = blockIdx.y * kchunk;
     const int kend = (kbeg + kchunk < p.K) ? kbeg + kchunk : p.K;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
 
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // fused bias gradient (weight-gradient form, A = dY K-major): colsum[m] += sum_k A[m][k] as one extra MFMA per
+    // A fragment against a fragment that is 1 in output column 0 -- only the wn == 0 waves of the tile_n == 0 blocks.
+    const bool do_cs = TA == 1 && p.colsum != nullptr && tile_n == 0 && wn == 0;
+    f32x4_t acc_cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
 
-    TileLoader<TA> la;
-    TileLoader<TB> lb;
     const int nk = (kend - kbeg + BK - 1) / BK;
-    // fused bias gradient: out[m] += sum_k A[k][m] for the K-major A of a weight-gradient GEMM (A = dY).  Thread t always
-    // stages the same 8 columns ((t & 15) * 8 ...) of 4 different k rows, so the sums live in 8 registers.
-    const bool do_cs = TA == 1 && p.colsum != nullptr && tile_n == 0;
-    float bsum[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    la.load(A, p.lda, m0, p.M, kbeg, kend, tid);
-    lb.load(B, p.ldb, n0, p.N, kbeg, kend, tid);
+    stage_tile<TA>(rA, p.lda, m0, p.M, kbeg, kend, lds, wave, lane);
+    stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg, kend, lds + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        la.store(ldsA, tid);
-        lb.store(ldsB, tid);
-        if (TA == 1 && do_cs) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8_t e = __builtin_bit_cast(bf16x8_t, la.r[i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum[j] += (float)e[j];
-            }
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            la.load(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
-            lb.load(B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+        const char* ldsA = lds + (kt & 1) * 2 * TILE_BYTES;
+        const char* ldsB = ldsA + TILE_BYTES;
+        if (kt + 1 < nk) {  // DMA of the next tile into the other stage overlaps this tile's MFMAs
+            char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile<TA>(rA, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, nxt, wave, lane);
+            stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, nxt + TILE_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -271,7 +263,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (TA == 1 && do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -280,17 +278,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const int fr = lane & 15, fq = lane >> 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
     float* wsz = ws ? ws + ((int64_t)z * splitk + blockIdx.y) * (int64_t)p.M * p.N : nullptr;
-    if (TA == 1 && p.colsum != nullptr) {  // block-uniform condition
+    if (TA == 1 && p.colsum != nullptr && tile_n == 0) {  // block-uniform condition
         float* red = reinterpret_cast<float*>(lds);
-        if (do_cs) {
+        if (do_cs && fr == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[(tid >> 4) * 128 + (tid & 15) * 8 + j] = bsum[j];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wm * 64 + i * 16 + fq * 4 + r] = acc_cs[i][r];
         }
         __syncthreads();
-        if (do_cs && tid < 128 && m0 + tid < p.M) {
-            float t = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
+        if (tid < 128 && m0 + tid < p.M) {
+            const float t = red[tid];
             if (splitk > 1) ws[(int64_t)gridDim.z * splitk * p.M * p.N + ((int64_t)z * splitk + blockIdx.y) * p.M + m0 + tid] = t;
             else p.colsum[m0 + tid] += t;
         }
@@ -470,6 +468,14 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     if (!strides_ok || !aligned_to(d->A, 16) || !aligned_to(d->B, 16)) {
         vpu_set_error("vpu_gemm: A/B base, leading dimensions and batch strides must be 16-byte multiples");
         return VPU_ERR_ALIGN;
+    }
+    if (bf) {  // LDS-DMA staging addresses each operand with a 31-bit byte offset from its (per-batch) base
+        const int64_t ea = d->transA ? (int64_t)d->K * d->lda : (int64_t)d->M * d->lda;
+        const int64_t eb = d->transB ? (int64_t)d->K * d->ldb : (int64_t)d->N * d->ldb;
+        if (ea * 2 >= 0x7FFFFFF0LL || eb * 2 >= 0x7FFFFFF0LL) {
+            vpu_set_error("vpu_gemm: an operand spans more than 2 GiB per batch entry");
+            return VPU_ERR_ARG;
+        }
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tm = bf ? BM : FM, tn = bf ? BN : FN;
