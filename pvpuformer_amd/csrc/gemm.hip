@@ -11,12 +11,12 @@
 // Replaces cuBLAS/cuDNN calls behind nn.Linear / Conv2d / ConvTranspose2d / matmul of the reference
 // (isegm/model/modeling/models_vit.py:38-52,16-27,91; transformer.py:484-517; is_vpu_model.py:55-86;
 // swin_transformer.py:680-756).
+#include <stdlib.h>
 #include "vpu_common.h"
 #include "../../include/vpu_hip.h"
 
 namespace {
 
-template <typename T> struct EpiIO;
 
 // ------------------------------------------------------------------------------------------------
 // epilogue shared by both precisions
@@ -69,6 +69,37 @@ __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + (
 __device__ __forceinline__ int km_off(int k, int unit) {
     return k * 256 + ((unit ^ ((k & 3) << 2) ^ (((k >> 3) & 1) << 4)) << 3);
 }
+
+// Register staging of one tile: 4 x 16 B per thread, global -> VGPR -> ds_write_b128 into the swizzled image.
+template <int TRANS>
+struct TileLoader {
+    uint4 r[4];
+    __device__ __forceinline__ void load(const bf16_t* base, int ld, int x0, int X, int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (TRANS == 0) {
+                const int row = c >> 3, kc = c & 7;
+                const int gx = x0 + row, gk = k0 + kc * 8;
+                if (gx < X && gk < K) v = *reinterpret_cast<const uint4*>(base + (int64_t)gx * ld + gk);
+            } else {
+                const int k = c >> 4, cc = c & 15;
+                const int gk = k0 + k, gx = x0 + cc * 8;
+                if (gk < K && gx < X) v = *reinterpret_cast<const uint4*>(base + (int64_t)gk * ld + gx);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            const int off = TRANS == 0 ? kc_off(c >> 3, c & 7) : km_off(c >> 4, (c & 15) * 2);
+            *reinterpret_cast<uint4*>(lds + off) = r[i];
+        }
+    }
+};
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 constexpr int OOB_OFFSET = (int)0x80000000;  // >= num_records of the descriptors below: the load returns zeros
@@ -203,11 +234,12 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
 // grid: x = tiles_m * tiles_n, y = split-K slices, z = batch.
 // splitk > 1: every slice writes its raw fp32 partial tile to ws[(z*splitk + slice)][M][N]; splitk_reduce_kernel sums
 // the slices in a fixed order (deterministic) and applies the epilogue.
-template <int TA, int TB>
+// DMA = false: register staging, one 32-KiB LDS stage, ~3 blocks per CU (default: measured faster at this tile size).
+// DMA = true : LDS-DMA staging, two 32-KiB stages, one barrier per K-tile (kept selectable: VPU_GEMM_DMA=1).
+template <int TA, int TB, bool DMA>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
                                                         const int kchunk, float* __restrict__ ws, const int vec) {
-    // two stages of (A tile 16 KiB + B tile 16 KiB); the first 32 KiB double as the epilogue staging area
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // 32 KiB (register staging) or 64 KiB (DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -239,17 +271,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    stage_tile<TA>(rA, p.lda, m0, p.M, kbeg, kend, lds, wave, lane);
-    stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg, kend, lds + TILE_BYTES, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (DMA) {
+        stage_tile<TA>(rA, p.lda, m0, p.M, kbeg, kend, lds, wave, lane);
+        stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg, kend, lds + TILE_BYTES, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    TileLoader<TA> la;
+    TileLoader<TB> lb;
+    if (!DMA) {
+        la.load(A, p.lda, m0, p.M, kbeg, kend, tid);
+        lb.load(B, p.ldb, n0, p.N, kbeg, kend, tid);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        const char* ldsA = lds + (kt & 1) * 2 * TILE_BYTES;
+        const char* ldsA = DMA ? lds + (kt & 1) * 2 * TILE_BYTES : lds;
         const char* ldsB = ldsA + TILE_BYTES;
-        if (kt + 1 < nk) {  // DMA of the next tile into the other stage overlaps this tile's MFMAs
-            char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile<TA>(rA, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, nxt, wave, lane);
-            stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, nxt + TILE_BYTES, wave, lane);
+        if (DMA) {
+            if (kt + 1 < nk) {  // DMA of the next tile into the other stage overlaps this tile's MFMAs
+                char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+                stage_tile<TA>(rA, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, nxt, wave, lane);
+                stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, nxt + TILE_BYTES, wave, lane);
+            }
+        } else {
+            la.store(lds, tid);
+            lb.store(lds + TILE_BYTES, tid);
+            __syncthreads();
+            if (kt + 1 < nk) {  // global loads of the next tile fly during this tile's MFMAs
+                la.load(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+                lb.load(B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -269,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
                     acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -508,12 +558,19 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
+        static const bool use_dma = [] { const char* e = getenv("VPU_GEMM_DMA"); return e && e[0] == '1'; }();
+#define VPU_LAUNCH(TA_, TB_)                                                                                         \
+    do {                                                                                                             \
+        if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); \
+        else gemm_bf16_kernel<TA_, TB_, false><<<grid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec);       \
+    } while (0)
         switch (key) {
-            case 0: gemm_bf16_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
-            case 1: gemm_bf16_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
-            case 2: gemm_bf16_kernel<1, 0><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
-            default: gemm_bf16_kernel<1, 1><<<grid, block, 0, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+            case 0: VPU_LAUNCH(0, 0); break;
+            case 1: VPU_LAUNCH(0, 1); break;
+            case 2: VPU_LAUNCH(1, 0); break;
+            default: VPU_LAUNCH(1, 1); break;
         }
+#undef VPU_LAUNCH
         if (splitk > 1) {
             const int64_t mn = (int64_t)d->M * d->N;
             dim3 rgrid((unsigned)vpu_grid_for(mn, 256, 4096), 1, (unsigned)d->batch);

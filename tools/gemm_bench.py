@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Micro-benchmark of vpu_gemm on the VPUFormer ViT-B bs=12 shapes (random bf16 data).  Prints TFLOP/s per shape.
+usage: python tools/gemm_bench.py [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pvpuformer_amd import ops  # noqa: E402
+
+M = 9408
+SHAPES = [  # name, tA, tB, M, N, K, flags
+    ("qkv fwd", 0, 0, M, 2304, 768, ops.EPI_BIAS),
+    ("proj fwd+res", 0, 0, M, 768, 768, ops.EPI_BIAS | ops.EPI_RESID),
+    ("fc1 fwd gelu", 0, 0, M, 3072, 768, ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU),
+    ("fc2 fwd+res", 0, 0, M, 768, 3072, ops.EPI_BIAS | ops.EPI_RESID),
+    ("fc2 dgrad*aux", 0, 1, M, 3072, 768, ops.EPI_MULAUX),
+    ("fc1 dgrad", 0, 1, M, 768, 3072, 0),
+    ("qkv dgrad", 0, 1, M, 768, 2304, 0),
+    ("proj dgrad", 0, 1, M, 768, 768, 0),
+    ("fc1 wgrad", 1, 1, 3072, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("fc2 wgrad", 1, 1, 768, 3072, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("qkv wgrad", 1, 1, 2304, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("proj wgrad", 1, 1, 768, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("square 4096", 0, 0, 4096, 4096, 4096, 0),
+]
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    dev = "cuda"
+    tot_t, tot_f = 0.0, 0.0
+    for name, tA, tB, m, n, k, flags in SHAPES:
+        A = (torch.rand((k, m) if tA else (m, k), device=dev) - 0.5).to(torch.bfloat16)
+        Bm = (torch.rand((k, n) if tB else (n, k), device=dev) - 0.5).to(torch.bfloat16)
+        out_f32 = bool(flags & ops.EPI_OUT_F32)
+        C = torch.zeros(m, n, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        bias = torch.rand(n, device=dev)
+        R = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
+        aux = torch.ones(m, n, device=dev, dtype=torch.bfloat16)
+        pre = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
+        kw = dict(transA=bool(tA), transB=bool(tB), flags=flags, bias=bias, resid=R, ldr=n, aux=aux, ldaux=n, preact=pre)
+        lda, ldb = (m if tA else k), (n if tB else k)
+        for _ in range(3):
+            ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        fl = 2.0 * m * n * k
+        if "square" not in name:
+            tot_t += t; tot_f += fl
+        print(f"{name:16s} tA={tA} tB={tB} M={m:6d} N={n:5d} K={k:5d}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
+    print(f"{'block total':16s} {tot_t * 1e6:8.1f} us  {tot_f / tot_t / 1e12:7.1f} TFLOP/s (one ViT block's 12 GEMMs)")
+
+
+if __name__ == "__main__":
+    main()
