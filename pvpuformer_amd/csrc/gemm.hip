@@ -558,7 +558,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
-        static const bool use_dma = [] { const char* e = getenv("VPU_GEMM_DMA"); return e && e[0] == '1'; }();
+        // staging choice (tools/gemm_bench.py, random data, ViT-B bs 12): LDS-DMA + two stages wins on long K and on every
+        // K-major operand (wgrad 500 vs 347 TFLOP/s, fc2 651 vs 557); register staging + 3 blocks/CU wins on the short-K
+        // NT forward GEMMs with heavy epilogues (fc1+GELU 460 vs 345).  VPU_GEMM_DMA=0/1 forces one path.
+        static const int force_dma = [] { const char* e = getenv("VPU_GEMM_DMA"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        const bool use_dma = force_dma >= 0 ? force_dma == 1 : !(key == 0 && d->K <= 1024);
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
         if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); \
