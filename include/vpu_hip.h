@@ -96,6 +96,17 @@ int vpu_l2norm_fwd(const void* x, void* y, float* inv, int64_t rows, int32_t C, 
 int vpu_l2norm_bwd(const void* dy, const void* y, const float* inv, void* dx, int64_t rows, int32_t C,
                    int32_t dtype, void* stream);
 
+/* Fused (flash-style) self-attention of the ViT blocks, bf16, head dim 32 or 64 (models_vit.py:43-52): q,k,v are
+ * column slices of the fused qkv activation (row stride ld, head h at column h*hd); out [rows][ldo]; nb independent
+ * runs of n consecutive rows (batch x windows); lse fp32 [nb*H][n] is saved for the backward. */
+int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H, int32_t n,
+                 int32_t hd, int32_t ld, int32_t ldo, float scale, void* stream);
+/* backward: dq/dk/dv (row stride ldg, same head layout) from o, d_o and lse; delta fp32 [nb*H][n] is workspace.
+ * Deterministic (no atomics): one kernel owns key blocks (dk, dv), one owns query blocks (dq). */
+int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                 float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H, int32_t n, int32_t hd, int32_t ld,
+                 int32_t ldo, int32_t ldg, float scale, void* stream);
+
 /* ---- element-wise ---- */
 /* out[i] = a[i] + b[i % period_b]  (with_pos_embed, transformer.py:320, :430) */
 int vpu_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period_b, int32_t dtype, void* stream);

@@ -1,0 +1,366 @@
+// Fused (flash-style) multi-head self-attention for the MAE-ViT blocks, bf16, head dim 32 or 64, gfx950.
+//
+// Replaces  attn = softmax(q k^T * scale); x = attn v   (isegm/model/modeling/models_vit.py:43-52) and its autograd
+// backward without materialising the [B, heads, n, n] score / probability tensors (354 MB fp32 per global block at
+// bs 12 in the unfused path).  Window attention (models_vit.py:225-255) is the same kernel with n = 196: tokens are
+// kept in window order, so a (batch, window) pair is a contiguous run of rows.
+//
+// Layout: q, k, v are column slices of the fused qkv activation [rows, ld] (head h at column h*HD of each slice);
+// o / d_o are [rows, ldo].  One "batch" entry = n consecutive rows.
+//
+// MFMA plan (v_mfma_f32_16x16x32_bf16; D[row = 4*(lane>>4)+r][col = lane&15]):
+//   forward, per wave 16 queries:  S^T[key][q] = K_tile . Q^T  puts the query on the lane, so the softmax statistics
+//   are per-lane scalars (max/sum over keys = in-lane over r + two xor-shuffles over the 4 lane groups), and two
+//   16-key accumulator tiles ARE the A fragment of the P.V product (k order permuted; V is read with the matching row
+//   permutation through ds_read_b64_tr_b16) -- P never goes through LDS.
+//   backward: the same trick with the roles swapped: dK/dV kernel keeps 16 keys per wave and sums over queries,
+//   dQ kernel keeps 16 queries per wave and sums over keys (probabilities are recomputed from the saved
+//   log-sum-exp; no atomics, bitwise reproducible).
+#include "vpu_common.h"
+#include "../../include/vpu_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+constexpr int CH = 32;  // keys (or queries) staged per iteration
+
+// row-contiguous image [CH][HD]: 16-B chunk index XOR-swizzled, read back with ds_read_b128 (MFMA A operand)
+template <int HD> __device__ __forceinline__ int rc_off(int row, int chunk) {
+    return row * (HD * 2) + ((chunk ^ ((row >> 1) & (HD / 8 - 1))) << 4);
+}
+// image for transposing reads [CH][HD]: 8-B unit index XOR-swizzled, read with ds_read_b64_tr_b16 (MFMA B operand, k = row)
+template <int HD> __device__ __forceinline__ int tr_off(int row, int unit) {
+    return row * (HD * 2) + ((unit ^ ((((row >> 1) & 3) << 2) & (HD / 4 - 1))) << 3);
+}
+
+// stage rows [r0, r0+CH) x HD columns of a [*, ld] matrix into an LDS image (rows >= n are zero)
+template <int HD, bool TR>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int ld, int r0, int n, char* lds, int tid) {
+    constexpr int CPR = HD / 8;  // 16-B chunks per row
+    for (int c = tid; c < CH * CPR; c += 256) {
+        const int row = c / CPR, ch = c % CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + row < n) v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
+        const int off = TR ? tr_off<HD>(row, ch * 2) : rc_off<HD>(row, ch);
+        *reinterpret_cast<uint4*>(lds + off) = v;
+    }
+}
+
+template <int HD> __device__ __forceinline__ bf16x8_t frag_rc(const char* lds, int row16, int ks, int lane) {
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + rc_off<HD>(row16 + (lane & 15), ks * 4 + (lane >> 4)));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// B fragment of a product that sums over the CH staged rows in the PERMUTED k order of an accumulator pair:
+// k-slot (g, j) <-> row 4g + j (j < 4) or 16 + 4g + (j - 4); columns [16*dt, 16*dt + 16)
+template <int HD> __device__ __forceinline__ bf16x8_t frag_tr_perm(const char* lds, int dt, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int unit = dt * 4 + p;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + tr_off<HD>(4 * g + q, unit)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + tr_off<HD>(16 + 4 * g + q, unit)));
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// 16 rows x HD of a global matrix as MFMA B fragments (col = row index on the lane), zero beyond n
+template <int HD>
+__device__ __forceinline__ void load_rows_as_b(const bf16_t* __restrict__ base, int ld, int row0, int n, int lane,
+                                               bf16x8_t (&f)[HD / 32]) {
+    const int row = row0 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < n) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + ks * 32 + (lane >> 4) * 8);
+        f[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+__device__ __forceinline__ bf16x8_t pack_pair(const f32x4_t& a, const f32x4_t& b) {
+    bf16x8_t f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = (bf16_t)a[j]; f[4 + j] = (bf16_t)b[j]; }
+    return f;
+}
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v;   // slices of qkv (already offset to column 0 of the slice)
+    const bf16_t *o, *d_o;
+    bf16_t *out, *dq, *dk, *dv;
+    float *lse, *delta;
+    int n, H, ld, ldo, ldg;    // ld: row stride of q/k/v; ldo: of o/d_o/out; ldg: of dq/dk/dv
+    float scale;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char ldsK[CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsV[CH * HD * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, n = a.n;
+    const int64_t rb = (int64_t)bw * n;
+    const bf16_t* q = a.q + rb * a.ld + h * HD;
+    const bf16_t* k = a.k + rb * a.ld + h * HD;
+    const bf16_t* v = a.v + rb * a.ld + h * HD;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    bf16x8_t qf[HD / 32];
+    load_rows_as_b<HD>(q, a.ld, q0, n, lane, qf);
+    float m = -INFINITY, l = 0.f;
+    f32x4_t acc[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < n; kc += CH) {
+        __syncthreads();
+        stage_rows<HD, false>(k, a.ld, kc, n, ldsK, tid);
+        stage_rows<HD, true>(v, a.ld, kc, n, ldsV, tid);
+        __syncthreads();
+        f32x4_t s[2];
+        float mx = m;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsK, 16 * t, ks, lane), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = (kc + 16 * t + 4 * g + r < n) ? s[t][r] * a.scale : -INFINITY;
+                s[t][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float alpha = __expf(m - mx);
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - mx); ps += s[t][r]; }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = mx;
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);
+        const bf16x8_t pf = pack_pair(s[0], s[1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[dt][r] *= ar[r];
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(ldsV, dt, lane), acc[dt], 0, 0, 0);
+        }
+    }
+    const float il = 1.0f / l;
+    if (g == 0 && q0 + c < n) a.lse[(int64_t)bh * n + q0 + c] = m + __logf(l);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float s1 = __shfl(il, 4 * g + r, 64);
+        const int qq = q0 + 4 * g + r;
+        if (qq < n) {
+            bf16_t* orow = a.out + (rb + qq) * a.ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) orow[dt * 16 + c] = (bf16_t)(acc[dt][r] * s1);
+        }
+    }
+}
+
+// delta[bh][q] = sum_d dO[q][d] * O[q][d]
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int qq = (int)(i % a.n);
+    const int bh = (int)(i / a.n), bw = bh / a.H, h = bh % a.H;
+    const int64_t off = ((int64_t)bw * a.n + qq) * a.ldo + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < HD / 8; ++ch) {
+        float x[8], y[8];
+        load8(a.d_o + off + ch * 8, x);
+        load8(a.o + off + ch * 8, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j] * y[j];
+    }
+    a.delta[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char ldsQr[CH * HD * 2], ldsQt[CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsOr[CH * HD * 2], ldsOt[CH * HD * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, n = a.n;
+    const int64_t rb = (int64_t)bw * n;
+    const bf16_t* q = a.q + rb * a.ld + h * HD;
+    const bf16_t* k = a.k + rb * a.ld + h * HD;
+    const bf16_t* v = a.v + rb * a.ld + h * HD;
+    const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
+    const float* lse = a.lse + (int64_t)bh * n;
+    const float* dl = a.delta + (int64_t)bh * n;
+    const int key0 = blockIdx.x * 64 + wave * 16;
+    const bool key_ok = key0 + c < n;
+    bf16x8_t kf[HD / 32], vf[HD / 32];
+    load_rows_as_b<HD>(k, a.ld, key0, n, lane, kf);
+    load_rows_as_b<HD>(v, a.ld, key0, n, lane, vf);
+    f32x4_t adk[HD / 16], adv[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
+    for (int qc = 0; qc < n; qc += CH) {
+        __syncthreads();
+        stage_rows<HD, false>(q, a.ld, qc, n, ldsQr, tid);
+        stage_rows<HD, true>(q, a.ld, qc, n, ldsQt, tid);
+        stage_rows<HD, false>(d_o, a.ldo, qc, n, ldsOr, tid);
+        stage_rows<HD, true>(d_o, a.ldo, qc, n, ldsOt, tid);
+        __syncthreads();
+        f32x4_t P[2], dS[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsQr, 16 * t, ks, lane), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsOr, 16 * t, ks, lane), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // element [query = qc+16t+4g+r][key = key0+c]
+                const int qq = qc + 16 * t + 4 * g + r;
+                float p = 0.f, ds = 0.f;
+                if (qq < n && key_ok) {
+                    p = __expf(s[r] * a.scale - lse[qq]);
+                    ds = p * (dp[r] - dl[qq]) * a.scale;
+                }
+                P[t][r] = p; dS[t][r] = ds;
+            }
+        }
+        const bf16x8_t pf = pack_pair(P[0], P[1]), dsf = pack_pair(dS[0], dS[1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(ldsOt, dt, lane), adv[dt], 0, 0, 0);
+            adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(ldsQt, dt, lane), adk[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kk = key0 + 4 * g + r;
+        if (kk < n) {
+            bf16_t* kr = a.dk + (rb + kk) * a.ldg + h * HD;
+            bf16_t* vr = a.dv + (rb + kk) * a.ldg + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) {
+                kr[dt * 16 + c] = (bf16_t)adk[dt][r];
+                vr[dt * 16 + c] = (bf16_t)adv[dt][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char ldsKr[CH * HD * 2], ldsKt[CH * HD * 2], ldsVr[CH * HD * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, n = a.n;
+    const int64_t rb = (int64_t)bw * n;
+    const bf16_t* q = a.q + rb * a.ld + h * HD;
+    const bf16_t* k = a.k + rb * a.ld + h * HD;
+    const bf16_t* v = a.v + rb * a.ld + h * HD;
+    const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const bool q_ok = q0 + c < n;
+    const float lse_q = q_ok ? a.lse[(int64_t)bh * n + q0 + c] : 0.f;
+    const float dl_q = q_ok ? a.delta[(int64_t)bh * n + q0 + c] : 0.f;
+    bf16x8_t qf[HD / 32], dof[HD / 32];
+    load_rows_as_b<HD>(q, a.ld, q0, n, lane, qf);
+    load_rows_as_b<HD>(d_o, a.ldo, q0, n, lane, dof);
+    f32x4_t adq[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < n; kc += CH) {
+        __syncthreads();
+        stage_rows<HD, false>(k, a.ld, kc, n, ldsKr, tid);
+        stage_rows<HD, true>(k, a.ld, kc, n, ldsKt, tid);
+        stage_rows<HD, false>(v, a.ld, kc, n, ldsVr, tid);
+        __syncthreads();
+        f32x4_t dS[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsKr, 16 * t, ks, lane), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsVr, 16 * t, ks, lane), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // element [key = kc+16t+4g+r][query = q0+c]
+                float ds = 0.f;
+                if (q_ok && kc + 16 * t + 4 * g + r < n)
+                    ds = __expf(s[r] * a.scale - lse_q) * (dp[r] - dl_q) * a.scale;
+                dS[t][r] = ds;
+            }
+        }
+        const bf16x8_t dsf = pack_pair(dS[0], dS[1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt)
+            adq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(ldsKt, dt, lane), adq[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qq = q0 + 4 * g + r;
+        if (qq < n) {
+            bf16_t* qr = a.dq + (rb + qq) * a.ldg + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) qr[dt * 16 + c] = (bf16_t)adq[dt][r];
+        }
+    }
+}
+
+inline bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
+                            int32_t n, int32_t hd, int32_t ld, int32_t ldo, float scale, void* stream) {
+    vpu_clear_stale_error();
+    if ((hd != 32 && hd != 64) || ld % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || nb <= 0 || H <= 0 || n <= 0) {
+        vpu_set_error("attn_fwd: head dim 32/64, 16-byte aligned slices, ld % 8 == 0");
+        return VPU_ERR_ARG;
+    }
+    AttnArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
+    a.n = n; a.H = H; a.ld = ld; a.ldo = ldo; a.scale = scale;
+    dim3 grid((n + 63) / 64, nb * H);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hd == 64) attn_fwd_kernel<64><<<grid, 256, 0, s>>>(a);
+    else attn_fwd_kernel<32><<<grid, 256, 0, s>>>(a);
+    return vpu_check_launch("vpu_attn_fwd");
+}
+
+extern "C" int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                            const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
+                            int32_t n, int32_t hd, int32_t ld, int32_t ldo, int32_t ldg, float scale, void* stream) {
+    vpu_clear_stale_error();
+    if ((hd != 32 && hd != 64) || ld % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || !ok16(o) || !ok16(d_o)) {
+        vpu_set_error("attn_bwd: head dim 32/64, 16-byte aligned slices, ld % 8 == 0");
+        return VPU_ERR_ARG;
+    }
+    AttnArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
+    a.d_o = (const bf16_t*)d_o; a.lse = const_cast<float*>(lse); a.delta = delta;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+    a.n = n; a.H = H; a.ld = ld; a.ldo = ldo; a.ldg = ldg; a.scale = scale;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)nb * H * n;
+    dim3 grid((n + 63) / 64, nb * H);
+    if (hd == 64) {
+        attn_delta_kernel<64><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a, total);
+        attn_bwd_dkdv_kernel<64><<<grid, 256, 0, s>>>(a);
+        attn_bwd_dq_kernel<64><<<grid, 256, 0, s>>>(a);
+    } else {
+        attn_delta_kernel<32><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a, total);
+        attn_bwd_dkdv_kernel<32><<<grid, 256, 0, s>>>(a);
+        attn_bwd_dq_kernel<32><<<grid, 256, 0, s>>>(a);
+    }
+    return vpu_check_launch("vpu_attn_bwd");
+}

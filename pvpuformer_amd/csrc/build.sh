@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value"
 mkdir -p build
 pids=()
-for f in gemm rowops spatial prompt loss optim; do
+for f in gemm attention rowops spatial prompt loss optim; do
   $HIPCC $FLAGS -c $f.hip -o build/$f.o &
   pids+=($!)
 done

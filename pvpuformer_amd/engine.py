@@ -85,6 +85,8 @@ class Engine:
         self.training = False
         self.shadow_valid = False
         self._const_ready = False
+        import os
+        self.use_flash = os.environ.get("VPU_FLASH_ATTN", "1") != "0"   # 0: unfused S/P path (also used for fp32 / other head dims)
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -310,6 +312,21 @@ class Engine:
                          batch=nb * H, inner=H, sA=sS, sB=(qrows * qld, hd), sC=(krows * kld, hd))
             self.tape.append(bwd)
 
+    def flash_attention(self, qkv, O, nb, H, n, hd, D, scale):
+        """Fused attention of one ViT block on the fused qkv activation [rows, 3D] -> O [rows, D] (bf16, hd 32/64)."""
+        lse = self._new(nb * H, n, dtype=torch.float32)
+        ops.attn_fwd((qkv.t, 0), (qkv.t, D), (qkv.t, 2 * D), O.t, lse, nb, H, n, hd, 3 * D, D, scale)
+        if self.training:
+            def bwd():
+                if O.g is None:
+                    return
+                assert qkv.g is None
+                qkv.g = torch.empty_like(qkv.t)
+                delta = self._new(nb * H, n, dtype=torch.float32)
+                ops.attn_bwd((qkv.t, 0), (qkv.t, D), (qkv.t, 2 * D), O.t, O.g, lse, delta, (qkv.g, 0), (qkv.g, D),
+                             (qkv.g, 2 * D), nb, H, n, hd, 3 * D, D, 3 * D, scale)
+            self.tape.append(bwd)
+
     def add_pe(self, x, pe, n, period, pe_var=None):
         """y = x + pe (pe broadcast with ``period`` elements; transformer.py:320,430)."""
         y = Var(torch.empty_like(x.t))
@@ -466,8 +483,11 @@ class Engine:
             h1 = self.layernorm(x, p + "norm1", M, D, 1e-6)
             qkv = self.linear(h1, p + "attn.qkv.weight", p + "attn.qkv.bias", M, 3 * D, D)
             O = Var(self._new(M, D))
-            self.sdpa((qkv, 0, 3 * D, nt), (qkv, D, 3 * D, nt), (qkv, 2 * D, 3 * D, nt), (O, 0, D, nt), B * nwin, heads,
-                      nt, nt, hd, hd ** -0.5)
+            if self.dt == BF16 and hd in (32, 64) and self.use_flash:
+                self.flash_attention(qkv, O, B * nwin, heads, nt, hd, D, hd ** -0.5)
+            else:
+                self.sdpa((qkv, 0, 3 * D, nt), (qkv, D, 3 * D, nt), (qkv, 2 * D, 3 * D, nt), (O, 0, D, nt), B * nwin,
+                          heads, nt, nt, hd, hd ** -0.5)
             x1 = self.linear(O, p + "attn.proj.weight", p + "attn.proj.bias", M, D, D, resid=x)
             h2 = self.layernorm(x1, p + "norm2", M, D, 1e-6)
             x = self.mlp(h2, p + "mlp.fc1", p + "mlp.fc2", M, D, D * c["mlp_ratio"], D, "gelu", resid=x1)

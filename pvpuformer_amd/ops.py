@@ -116,6 +116,15 @@ def l2norm_bwd(dy, y, inv, dx, rows, Cdim):
     _lib.call("vpu_l2norm_bwd", ptr(dy), ptr(y), ptr(inv), ptr(dx), rows, Cdim, code_of(y), _stream())
 
 
+def attn_fwd(q, k, v, out, lse, nb, H, n, hd, ld, ldo, scale):
+    _lib.call("vpu_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), nb, H, n, hd, ld, ldo, scale, _stream())
+
+
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, n, hd, ld, ldo, ldg, scale):
+    _lib.call("vpu_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
+              ptr(dv), nb, H, n, hd, ld, ldo, ldg, scale, _stream())
+
+
 def add_bcast(a, b, out, n, period):
     _lib.call("vpu_add_bcast", ptr(a), ptr(b), ptr(out), n, period, code_of(a), _stream())
 

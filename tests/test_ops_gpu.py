@@ -541,3 +541,32 @@ def test_gemm_fused_bias_gradient(ops, K):
              transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=db)
     assert torch.equal(dW.cpu(), dY.t() @ X + 2.0)
     assert torch.equal(db.cpu(), dY.sum(0) + 3.0)
+
+
+@pytest.mark.parametrize("hd,n,nb", [(64, 196, 3), (64, 784, 1), (32, 196, 2), (64, 50, 2)])
+def test_flash_attention_fwd_bwd(ops, hd, n, nb):
+    """Fused attention vs torch fp32 on the bf16-rounded inputs: forward within bf16 output rounding, gradients
+    within 2e-2 of their scale.  n = 196 (window), 784 (global), 50 (ragged: masks keys and queries)."""
+    H = 3
+    D = H * hd
+    qkv = dev(rnd(nb * n, 3 * D, seed=60, scale=1.5)).to(torch.bfloat16)
+    O = torch.zeros(nb * n, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(nb * H, n, device="cuda")
+    scale = hd ** -0.5
+    ops.attn_fwd(qkv, (qkv, D), (qkv, 2 * D), O, lse, nb, H, n, hd, 3 * D, D, scale)
+    x = qkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+    S = (x[0] @ x[1].transpose(-1, -2)) * scale
+    ref = (torch.softmax(S, -1) @ x[2])
+    torch.testing.assert_close(O.float().view(nb, n, H, hd).transpose(1, 2), ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.view(nb, H, n), torch.logsumexp(S, -1), atol=2e-3, rtol=1e-4)
+    dO = dev(rnd(nb * n, D, seed=61)).to(torch.bfloat16)
+    ref.backward(dO.float().view(nb, n, H, hd).transpose(1, 2))
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.zeros(nb * H, n, device="cuda")
+    ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, delta, dqkv, (dqkv, D), (dqkv, 2 * D), nb, H, n, hd, 3 * D, D,
+                 3 * D, scale)
+    got = dqkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4)
+    for i, name in enumerate("qkv"):
+        ref_g = x.grad[i]
+        tol = 2e-2 * ref_g.abs().max().item()
+        assert (got[i] - ref_g).abs().max().item() < tol, (name, (got[i] - ref_g).abs().max().item(), tol)
