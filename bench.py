@@ -163,10 +163,10 @@ def main():
     def step():
         eng.zero_grad()
         mask = torch.bernoulli(torch.full((B, model.head.channels), keep, device=dev)) / keep
-        inst, aux = eng.forward(image4, points, None, 0, mask, training=True)
-        losses, d_inst, d_aux = vpu_step_losses(inst, aux, gt, None, None, iter_weight=1.0)
+        inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
+        losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
         red.begin()
-        eng.backward(d_inst, d_aux)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
         opt.step(grad_scale=red.finish())
         last["loss"] = losses["total"]
 

@@ -74,7 +74,8 @@ int vpu_gemm(const vpu_gemm_desc* d, void* stream);
 /* nn.LayerNorm over the last dim (models_vit.py:126 eps 1e-6; transformer.py:417-426 eps 1e-5). */
 int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                       int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
-/* dx = [dres +] LN'(dy); dw/db partial sums go to part[2][nblk][C] (reduced by vpu_colsum_f32). nblk is returned
+/* dx = [dres +] LN'(dy); dw/db partial sums go to part[nblk][2][C] (one vpu_colsum_f32 over [nblk][2C] yields both,
+ * the two gradients being adjacent in the flat gradient buffer). nblk is returned
  * by vpu_layernorm_bwd_nblk(rows). */
 int vpu_layernorm_bwd_nblk(int64_t rows);
 int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
@@ -155,7 +156,7 @@ int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, int32_t B, 
 int vpu_groupnorm_nchunk(void);
 int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, double* stats,
                       int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu, int32_t dtype, void* stream);
-/* dx; dw/db partials to part[2][B*nchunk][C] (reduce with vpu_colsum_f32); stats = workspace fp64 [B][nchunk][2] */
+/* dx; dw/db partials to part[B*nchunk][2][C] (reduce with vpu_colsum_f32); stats = workspace fp64 [B][nchunk][2] */
 int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, const float* b, const float* mean,
                       const float* rstd, void* dx, float* part, double* stats, int32_t B, int64_t HW, int32_t C,
                       int32_t gelu, int32_t dtype, void* stream);
@@ -199,6 +200,11 @@ int vpu_upsample_ac_bwd(const float* dout, float* din, int64_t planes, int32_t h
 int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_t* slot_mask_idx, const float* override_masks,
                      float* loss_part, float* dprob, float grad_scale, int32_t B, int32_t S, int32_t H, int32_t W,
                      void* stream);
+/* The same loss taken on the LOW-resolution similarities: fuses the align_corners=True upsample (is_vpu_model.py:434-436),
+ * the loss and both backward passes; sim_low fp32 [B][S][h][w], dsim_low (optional) its gradient.  loss_part as above. */
+int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const int32_t* slot_mask_idx, const float* override_masks,
+                        float* loss_part, float* dsim_low, float grad_scale, int32_t B, int32_t S, int32_t h, int32_t w,
+                        int32_t H, int32_t W, void* stream);
 /* NormalizedFocalLossSigmoid(alpha .5, gamma 2) + naive Dice on logits [B][HW] vs gt (losses.py:11-89,227-363).
  * sums fp64 [B][8] workspace; out fp32 [B][2] = (nfl_b, dice_b); dlogits = w_nfl*dNFL + w_dice*dDice (means over B
  * folded into w_*). */

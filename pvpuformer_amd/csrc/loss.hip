@@ -50,6 +50,90 @@ __global__ __launch_bounds__(1024) void p2cl_kernel(const float* __restrict__ pr
     if (threadIdx.x == 0) loss_part[plane] = (float)t;
 }
 
+// Fused  F.interpolate(sim, align_corners=True)  ->  P2CL  ->  gradient w.r.t. the LOW-resolution similarities
+// (is_vpu_model.py:431-436 + losses.py:155-176 + their backward).  The unfused chain writes / reads the [B,S,H,W]
+// upsampled tensor and its gradient four times (1.85 GB per step at bs 12); this kernel reads one 50-KB plane into LDS,
+// evaluates every full-resolution pixel exactly once and writes one 50-KB gradient plane.
+// One block per (b, slot) plane.  Each thread owns low-resolution cells (y0, x0); the pixels whose bilinear anchor is
+// that cell contribute to the 4 cell corners, accumulated in registers and added to the LDS gradient plane in four
+// barrier-separated phases (in each phase every LDS word has exactly one writer -> bitwise reproducible, no atomics).
+__device__ __forceinline__ int ac_i0(int dst, float scale, int in_size) {
+    int i0 = (int)(scale * (float)dst);
+    return i0 > in_size - 1 ? in_size - 1 : i0;
+}
+__global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
+                                                       const int* __restrict__ slot_idx,
+                                                       const float* __restrict__ override_masks,
+                                                       float* __restrict__ loss_part, float* __restrict__ dlow,
+                                                       float grad_scale, int S, int h, int w, int H, int W) {
+    extern __shared__ float sm[];          // [h*w] values, [h*w] gradients
+    __shared__ double red[16];
+    float* sv = sm;
+    float* sg = sm + h * w;
+    const int plane = blockIdx.x, b = plane / S, s = plane % S;
+    const int ov = slot_idx ? slot_idx[plane] : -1;
+    const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
+    const bool invert = ov < 0 && s >= S / 2;
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float fh = sh > 0.f ? 1.f / sh : 0.f, fw = sw > 0.f ? 1.f / sw : 0.f;
+    for (int i = threadIdx.x; i < h * w; i += blockDim.x) { sv[i] = low[(int64_t)plane * h * w + i]; sg[i] = 0.f; }
+    __syncthreads();
+    double acc = 0.0;
+    const int ncell = h * w;
+    const int iters = (ncell + blockDim.x - 1) / blockDim.x;
+    for (int it = 0; it < iters; ++it) {
+        const int cell = it * blockDim.x + threadIdx.x;
+        const bool live = cell < ncell;
+        const int y0 = live ? cell / w : 0, x0 = live ? cell % w : 0;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f, part = 0.f;
+        if (live) {
+            const float v00 = sv[y0 * w + x0], v01 = sv[y0 * w + x1], v10 = sv[y1 * w + x0], v11 = sv[y1 * w + x1];
+            int Ya = (int)floorf(fh * (float)y0) - 1, Yb = (int)ceilf(fh * (float)(y0 + 1)) + 1;
+            int Xa = (int)floorf(fw * (float)x0) - 1, Xb = (int)ceilf(fw * (float)(x0 + 1)) + 1;
+            Ya = Ya < 0 ? 0 : Ya; Xa = Xa < 0 ? 0 : Xa;
+            Yb = Yb > H - 1 ? H - 1 : Yb; Xb = Xb > W - 1 ? W - 1 : Xb;
+            for (int Y = Ya; Y <= Yb; ++Y) {
+                if (ac_i0(Y, sh, h) != y0) continue;
+                const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+                for (int X = Xa; X <= Xb; ++X) {
+                    if (ac_i0(X, sw, w) != x0) continue;
+                    const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
+                    const float p = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                    float y = lab[(int64_t)Y * W + X];
+                    const bool valid = y != -1.0f;
+                    if (invert) y = (y != 0.f) ? 0.f : 1.f;
+                    if (!valid) y = 0.f;
+                    const float a = p + 1e-12f, c = 1.f - p + 1e-12f;
+                    if (valid) {
+                        part += -(logf(a) * y + logf(c) * (1.f - y));
+                        const float g = grad_scale * (-(y / a) + (1.f - y) / c);
+                        g00 += g * hy * hx; g01 += g * hy * lx; g10 += g * ly * hx; g11 += g * ly * lx;
+                    }
+                }
+            }
+        }
+        acc += part;
+        if (dlow) {   // four phases: one writer per LDS word in each
+            if (live) sg[y0 * w + x0] += g00;
+            __syncthreads();
+            if (live) sg[y0 * w + x1] += g01;
+            __syncthreads();
+            if (live) sg[y1 * w + x0] += g10;
+            __syncthreads();
+            if (live) sg[y1 * w + x1] += g11;
+            __syncthreads();
+        }
+    }
+    const double t = block_sum_d(acc, red);
+    if (threadIdx.x == 0) loss_part[plane] = (float)t;
+    if (dlow) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < h * w; i += blockDim.x) dlow[(int64_t)plane * h * w + i] = sg[i];
+    }
+}
+
 // sums[b][0..4] = sum w, sum beta, sum p*t, sum p, sum t
 __global__ __launch_bounds__(1024) void nfl_dice_sums_kernel(const float* __restrict__ logits,
                                                              const float* __restrict__ gt, double* __restrict__ sums,
@@ -129,6 +213,23 @@ extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_
     p2cl_kernel<<<(unsigned)(B * S), 1024, 0, ST>>>(prob, gt, slot_mask_idx, override_masks, loss_part, dprob, grad_scale,
                                                    S, HW);
     return vpu_check_launch("vpu_p2cl_fwd_bwd");
+}
+
+extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const int32_t* slot_mask_idx,
+                                   const float* override_masks, float* loss_part, float* dsim_low, float grad_scale,
+                                   int32_t B, int32_t S, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
+    vpu_clear_stale_error();
+    const size_t shmem = (size_t)2 * h * w * sizeof(float);
+    if (S % 2 || shmem > 150 * 1024) { vpu_set_error("p2cl_up: S % 2, low-res plane must fit LDS twice"); return VPU_ERR_ARG; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        attr_set = true;
+    }
+    p2cl_up_kernel<<<(unsigned)(B * S), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part, dsim_low,
+                                                         grad_scale, S, h, w, H, W);
+    return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
 }
 
 extern "C" int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, float* out, float* dlogits,

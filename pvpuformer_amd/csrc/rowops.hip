@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
-                store8(part + ((int64_t)which * nblk + blockIdx.x) * C + c, o);
+                store8(part + ((int64_t)blockIdx.x * 2 + which) * C + c, o);
             }
         }
     }
@@ -145,18 +145,47 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------- column sums
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                          int64_t rows, int C, float beta) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < C)
-        for (int64_t r = grp; r < rows; r += 4) s += in[r * C + c];
-    red[grp][lane] = s;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int64_t r = grp;
+        for (; r + 8 < rows; r += 16) { s0 += in[r * C + c]; s1 += in[(r + 8) * C + c]; }
+        if (r < rows) s0 += in[r * C + c];
+    }
+    red[grp][cl] = s0 + s1;
     __syncthreads();
     if (grp == 0 && c < C) {
-        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][cl];
         out[c] = (beta != 0.f ? beta * out[c] : 0.f) + t;
     }
+}
+
+// few rows (<= 64): one pass, no partials.  out[c] = beta*out[c] + sum_r in[r*ld + c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ in, int64_t ld, float* __restrict__ out,
+                                                           int rows, int64_t C, float beta) {
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= C) return;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        float v[8];
+        load8(in + r * ld + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+    if (beta != 0.f) {
+        float o[8];
+        load8(out + c, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += beta * o[j];
+    }
+    store8(out + c, a);
 }
 
 constexpr int CS_SLABS = 64;   // rows of the caller's partial buffer ([64][C], include/vpu_hip.h)
@@ -386,16 +415,21 @@ extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, 
 }
 extern "C" int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream) {
     vpu_clear_stale_error();
-    colsum_f32_kernel<<<(C + 63) / 64, 256, 0, ST>>>(in, out, rows, C, beta);
+    colsum_f32_kernel<<<(C + 31) / 32, 256, 0, ST>>>(in, out, rows, C, beta);
     return vpu_check_launch("vpu_colsum_f32");
 }
 extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, int64_t rows, int32_t C, float beta,
                           int32_t dtype, void* stream) {
     vpu_clear_stale_error();
     if (C % 8 || ld % 8) { vpu_set_error("colsum: C, ld % 8"); return VPU_ERR_ARG; }
+    if (rows <= 64) {  // e.g. the batch sum of the pos_embed gradient: rows = B, C = tokens*dim
+        const unsigned g = (unsigned)((C / 8 + 255) / 256);
+        DISPATCH_T(dtype, colsum_small_kernel<T><<<g, 256, 0, ST>>>((const T*)in, ld, out, (int)rows, C, beta);)
+        return vpu_check_launch("vpu_colsum");
+    }
     dim3 grid((C + 127) / 128, CS_SLABS);
     DISPATCH_T(dtype, colsum_part_kernel<T><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
-    colsum_f32_kernel<<<(C + 63) / 64, 256, 0, ST>>>(part, out, CS_SLABS, C, beta);
+    colsum_f32_kernel<<<(C + 31) / 32, 256, 0, ST>>>(part, out, CS_SLABS, C, beta);
     return vpu_check_launch("vpu_colsum");
 }
 extern "C" int vpu_softmax_fwd(const float* S, int32_t lds_, void* P, int32_t ldp, int64_t rows, int32_t ncols,

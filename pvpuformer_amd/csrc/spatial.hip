@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
         for (int c = threadIdx.x; c < C; c += 256) {
             float t = 0.f;
             for (int s = 0; s < mp.slots; ++s) t += acc[s * C + c];
-            part[((int64_t)which * nrows + prow) * C + c] = t;
+            part[(prow * 2 + which) * C + c] = t;
         }
     }
 }

@@ -166,6 +166,16 @@ class Engine:
         else:
             ops.add4(var.g, g, None, None, var.g, g.numel())
 
+    def _reduce_wb(self, part, nrows, prefix, Cdim):
+        """part [nrows][2][C] -> G[prefix.weight] += sum part[:,0], G[prefix.bias] += sum part[:,1]; ONE launch when the two
+        gradients are adjacent in the flat buffer (always the case for the norm layers: C % 8 == 0)."""
+        ow, ob = self.names[prefix + ".weight"][0], self.names[prefix + ".bias"][0]
+        if ob == ow + Cdim:
+            ops.colsum_f32(part, self.G(prefix + ".weight"), nrows, 2 * Cdim, beta=1.0)
+        else:
+            ops.colsum_f32(part.view(nrows, 2 * Cdim)[:, :Cdim].contiguous(), self.G(prefix + ".weight"), nrows, Cdim, beta=1.0)
+            ops.colsum_f32(part.view(nrows, 2 * Cdim)[:, Cdim:].contiguous(), self.G(prefix + ".bias"), nrows, Cdim, beta=1.0)
+
     def _colsum_to(self, dy, ld, gname, rows, N):
         part = self._new(64, N, dtype=torch.float32)
         ops.colsum(dy, ld, self.G(gname), part, rows, N, beta=1.0)
@@ -265,13 +275,12 @@ class Engine:
                 if y.g is None:
                     return
                 nblk = ops.layernorm_bwd_nblk(rows)
-                part = self._new(2, nblk, Cdim, dtype=torch.float32)
+                part = self._new(nblk, 2, Cdim, dtype=torch.float32)
                 dres = x.g
                 if x.g is None:
                     x.g = torch.empty_like(x.t)
                 ops.layernorm_bwd(y.g, x.t, self.Pm(prefix + ".weight"), mean, rstd, dres, x.g, part, rows, Cdim)
-                ops.colsum_f32(part[0], self.G(prefix + ".weight"), nblk, Cdim, beta=1.0)
-                ops.colsum_f32(part[1], self.G(prefix + ".bias"), nblk, Cdim, beta=1.0)
+                self._reduce_wb(part, nblk, prefix, Cdim)
             self.tape.append(bwd)
         return y
 
@@ -366,11 +375,10 @@ class Engine:
                     return
                 assert x.g is None
                 x.g = torch.empty_like(x.t)
-                part = self._new(2, B * nch, Cdim, dtype=torch.float32)
+                part = self._new(B * nch, 2, Cdim, dtype=torch.float32)
                 ops.groupnorm_bwd(y.g, x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), mean, rstd, x.g,
                                   part, stats, B, HW, Cdim, gelu)
-                ops.colsum_f32(part[0], self.G(prefix + ".weight"), B * nch, Cdim, beta=1.0)
-                ops.colsum_f32(part[1], self.G(prefix + ".bias"), B * nch, Cdim, beta=1.0)
+                self._reduce_wb(part, B * nch, prefix, Cdim)
             self.tape.append(bwd)
         return y
 
@@ -424,9 +432,12 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------------------------------ model
-    def forward(self, image4, points, boxes=None, prompt_type=0, drop_mask=None, training=False, taps=None):
+    def forward(self, image4, points, boxes=None, prompt_type=0, drop_mask=None, training=False, taps=None,
+                materialize_aux=True):
         """image4 fp32 [B,4,H,W]; points fp32 [B,2n,3]; boxes int32 [B,5] (prompt_type 1).
-        Returns instances fp32 [B,1,H,W] (logits) and instances_aux fp32 [B,S,H,W]."""
+        Returns instances fp32 [B,1,H,W] (logits) and instances_aux fp32 [B,S,H,W].  ``materialize_aux=False`` skips the
+        38.5 MB/img upsample of the P2CL similarities: aux is None, the low-resolution planes stay in ``self.sim_low``
+        [B,S,h,w] for the fused loss (ops.p2cl_up_fwd_bwd) and backward() takes their gradient as ``d_sim_low``."""
         assert image4.is_cuda and image4.dtype == torch.float32 and image4.is_contiguous()
         if not self.shadow_valid:
             self.refresh_weights()
@@ -461,8 +472,7 @@ class Engine:
                     self._wgrad(x0.g, D, (cols, co), 2 * k3, nm + ".weight", D, k3, M, bias=nm + ".bias")
                 # pos_embed[:, 1:] gradient: sum over the batch, back to raster order
                 s = self._new(NT * D, dtype=torch.float32)
-                part = self._new(64, NT * D, dtype=torch.float32)
-                ops.colsum(x0.g, NT * D, s, part, B, NT * D, beta=0.0)
+                ops.colsum(x0.g, NT * D, s, None, B, NT * D, beta=0.0)   # rows = B <= 64: single-pass kernel
                 r = self._new(NT * D, dtype=torch.float32)
                 ops.window_permute(s, r, 1, g, self.wg, D, to_raster=True)
                 gp = (self.gflat, self.names["backbone.pos_embed"][0] + D)
@@ -640,16 +650,22 @@ class Engine:
             taps["fused"] = fused.t
         # ---- a13: final align_corners=True upsample
         inst = self._new(B, 1, H, W_, dtype=torch.float32)
-        aux = self._new(B, nq, H, W_, dtype=torch.float32)
         ops.upsample_ac_fwd(seg, inst, B, Hs, Hs, H, W_)
-        ops.upsample_ac_fwd(sim, aux, B * nq, Hs, Hs, H, W_)
-        self._out_grads = [None, None]
+        aux = None
+        self.sim_low = sim.view(B, nq, Hs, Hs)
+        if materialize_aux:
+            aux = self._new(B, nq, H, W_, dtype=torch.float32)
+            ops.upsample_ac_fwd(sim, aux, B * nq, Hs, Hs, H, W_)
+        self._out_grads = [None, None, None]
         if training:
             def bwd_head():
-                d_inst, d_aux = self._out_grads
-                if d_aux is not None:
-                    dsim = self._new(B, nq, HW4, dtype=torch.float32)
-                    ops.upsample_ac_bwd(d_aux, dsim, B * nq, Hs, Hs, H, W_)
+                d_inst, d_aux, d_sim_low = self._out_grads
+                if d_aux is not None or d_sim_low is not None:
+                    if d_sim_low is not None:
+                        dsim = d_sim_low.view(B, nq, HW4)
+                    else:
+                        dsim = self._new(B, nq, HW4, dtype=torch.float32)
+                        ops.upsample_ac_bwd(d_aux, dsim, B * nq, Hs, Hs, H, W_)
                     if self.dt == BF16:
                         dsim_t = self._new(B, nq, HW4)
                         ops.cast2d(dsim, HW4, dsim_t, HW4, B * nq, HW4)
@@ -690,10 +706,12 @@ class Engine:
                 self.grad_ready_hook(lo, hi)
         self.tape.append(marker)
 
-    def backward(self, d_inst, d_aux):
-        """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None.  Parameter gradients
-        are ACCUMULATED into the flat gradient buffer (call zero_grad() between optimizer steps)."""
-        self._out_grads = [None if d_inst is None else d_inst.contiguous(), None if d_aux is None else d_aux.contiguous()]
+    def backward(self, d_inst, d_aux, d_sim_low=None):
+        """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None (or d_sim_low fp32
+        [B,S,h,w], the gradient of the low-resolution similarities from the fused loss).  Parameter gradients are
+        ACCUMULATED into the flat gradient buffer (call zero_grad() between optimizer steps)."""
+        self._out_grads = [None if d_inst is None else d_inst.contiguous(), None if d_aux is None else d_aux.contiguous(),
+                           None if d_sim_low is None else d_sim_low.contiguous()]
         for fn in reversed(self.tape):
             fn()
         self.tape = []

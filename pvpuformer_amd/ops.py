@@ -232,6 +232,11 @@ def p2cl_fwd_bwd(prob, gt, slot_idx, override, loss_part, dprob, grad_scale, B, 
               grad_scale, B, S, H, W, _stream())
 
 
+def p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, loss_part, dsim_low, grad_scale, B, S, h, w, H, W):
+    _lib.call("vpu_p2cl_up_fwd_bwd", ptr(sim_low), ptr(gt), ptr(slot_idx), ptr(override), ptr(loss_part), ptr(dsim_low),
+              grad_scale, B, S, h, w, H, W, _stream())
+
+
 def nfl_dice_fwd_bwd(logits, gt, sums, out, dlogits, w_nfl, w_dice, B, HW):
     _lib.call("vpu_nfl_dice_fwd_bwd", ptr(logits), ptr(gt), ptr(sums), ptr(out), ptr(dlogits), w_nfl, w_dice, B, HW,
               _stream())

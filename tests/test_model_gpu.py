@@ -146,6 +146,17 @@ def test_fused_loss_kernels_match_torch_losses(golden_dir):
         if ref[n].norm() > 1e-7:
             err = (p.grad - ref[n]).norm() / ref[n].norm()
             assert err < 2e-3, (n, float(err))
+    # the fully fused path: aux never materialised, upsample + P2CL + both backward passes in one kernel
+    model.zero_grad()
+    inst, aux = eng.forward(img4.cuda(), batch["points"].cuda(), None, 0, None, training=True, materialize_aux=False)
+    assert aux is None
+    losses2, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+    eng.backward(d_inst, None, d_sim_low=d_sim)
+    assert abs(losses2["total"].item() - total.item()) < 1e-5 * abs(total.item())
+    for n, p in model.named_parameters():
+        if ref[n].norm() > 1e-7:
+            err = (p.grad - ref[n]).norm() / ref[n].norm()
+            assert err < 2e-3, (n, float(err))
 
 
 def test_vitb_forward_matches_reference(golden_dir):

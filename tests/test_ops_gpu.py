@@ -180,12 +180,12 @@ def test_layernorm(ops, dtype, C):
     dres = dev(rnd(rows, C, seed=14)).to(td)
     ref.backward(dy.float())
     nblk = ops.layernorm_bwd_nblk(rows)
-    part = torch.zeros(2, nblk, C, device="cuda")
+    part = torch.zeros(nblk, 2, C, device="cuda")
     dx = torch.empty_like(x)
     ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, C)
-    dw, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    ops.colsum_f32(part[0], dw, nblk, C)
-    ops.colsum_f32(part[1], db, nblk, C)
+    dwb = torch.zeros(2 * C, device="cuda")
+    ops.colsum_f32(part, dwb, nblk, 2 * C)
+    dw, db = dwb[:C], dwb[C:]
     torch.testing.assert_close(dx.float(), xf.grad + dres.float(), **tol)
     gtol = dict(atol=0.15, rtol=3e-2) if dtype == 0 else dict(atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(dw, wf.grad, **gtol)
@@ -201,6 +201,9 @@ def test_colsum_l2norm_add_cast(ops, dtype):
     part = torch.zeros(64, C, device="cuda")
     ops.colsum(x, ld, out, part, rows, C, beta=1.0)
     torch.testing.assert_close(out, 1 + x.float()[:, :C].sum(0), atol=1e-2, rtol=1e-4)
+    out2 = torch.ones(C, device="cuda")
+    ops.colsum(x, ld, out2, None, 12, C, beta=1.0)   # <= 64 rows: single-pass kernel, no partial buffer
+    torch.testing.assert_close(out2, 1 + x.float()[:12, :C].sum(0), atol=1e-3, rtol=1e-4)
     xs = x[:, :C].contiguous()
     y, inv = torch.empty_like(xs), torch.empty(rows, device="cuda")
     ops.l2norm_fwd(xs, y, inv, rows, C)
@@ -363,12 +366,12 @@ def test_groupnorm(ops, dtype, C, gelu):
     torch.testing.assert_close(y.float(), ref, **tol)
     dy = dev(rnd(B, HW, C, seed=31)).to(td)
     ref.backward(dy.float())
-    part = torch.zeros(2, B * nch, C, device="cuda")
+    part = torch.zeros(B * nch, 2, C, device="cuda")
     dx = torch.empty_like(x)
     ops.groupnorm_bwd(dy, x, w, b, mean, rstd, dx, part, stats, B, HW, C, gelu)
-    dw, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    ops.colsum_f32(part[0], dw, B * nch, C)
-    ops.colsum_f32(part[1], db, B * nch, C)
+    dwb = torch.zeros(2 * C, device="cuda")
+    ops.colsum_f32(part, dwb, B * nch, 2 * C)
+    dw, db = dwb[:C], dwb[C:]
     torch.testing.assert_close(dx.float(), xf.grad, atol=3e-2 if dtype == 0 else 2e-5, rtol=3e-2 if dtype == 0 else 1e-4)
     gt = dict(atol=0.3, rtol=3e-2) if dtype == 0 else dict(atol=2e-4, rtol=1e-4)
     torch.testing.assert_close(dw, wf.grad, **gt)
@@ -570,3 +573,28 @@ def test_flash_attention_fwd_bwd(ops, hd, n, nb):
         ref_g = x.grad[i]
         tol = 2e-2 * ref_g.abs().max().item()
         assert (got[i] - ref_g).abs().max().item() < tol, (name, (got[i] - ref_g).abs().max().item(), tol)
+
+
+def test_fused_upsample_p2cl_matches_unfused(ops):
+    """p2cl_up (upsample + loss + both backward passes, one kernel) == upsample_ac_fwd -> p2cl -> upsample_ac_bwd,
+    with per-slot override masks, and it is bitwise reproducible."""
+    B, S, h, H = 2, 8, 28, 112
+    low = dev(torch.sigmoid(rnd(B, S, h, h, seed=70, scale=3.0)))
+    gt = dev((rnd(B, 1, H, H, seed=71) > 0.2).float())
+    ov = dev((rnd(2, H, H, seed=72) > 0.5).float())
+    idx = -torch.ones(B, S, dtype=torch.int32)
+    idx[0, 1] = 0; idx[1, 6] = 1
+    idx = dev(idx)
+    gs = 2.0 / (B * S * H * H)
+    up = torch.empty(B, S, H, H, device="cuda")
+    ops.upsample_ac_fwd(low, up, B * S, h, h, H, H)
+    part, dprob, dlow = torch.empty(B, S, device="cuda"), torch.empty_like(up), torch.empty_like(low)
+    ops.p2cl_fwd_bwd(up, gt, idx, ov, part, dprob, gs, B, S, H, H)
+    ops.upsample_ac_bwd(dprob, dlow, B * S, h, h, H, H)
+    part2, dlow2 = torch.empty(B, S, device="cuda"), torch.empty_like(low)
+    ops.p2cl_up_fwd_bwd(low, gt, idx, ov, part2, dlow2, gs, B, S, h, h, H, H)
+    torch.testing.assert_close(part2, part, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(dlow2, dlow, rtol=1e-4, atol=1e-9)
+    part3, dlow3 = torch.empty(B, S, device="cuda"), torch.empty_like(low)
+    ops.p2cl_up_fwd_bwd(low, gt, idx, ov, part3, dlow3, gs, B, S, h, h, H, H)
+    assert torch.equal(dlow3, dlow2) and torch.equal(part3, part2)
