@@ -116,13 +116,18 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         }
         acc += part;
         if (dlow) {   // four phases: one writer per LDS word in each
+            // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
+            // corner terms into the cell's own word and skip the write
+            const bool bx = x1 != x0, by = y1 != y0;
+            if (!bx) { g00 += g01; g10 += g11; }
+            if (!by) { g00 += g10; if (bx) g01 += g11; }
             if (live) sg[y0 * w + x0] += g00;
             __syncthreads();
-            if (live) sg[y0 * w + x1] += g01;
+            if (live && bx) sg[y0 * w + x1] += g01;
             __syncthreads();
-            if (live) sg[y1 * w + x0] += g10;
+            if (live && by) sg[y1 * w + x0] += g10;
             __syncthreads();
-            if (live) sg[y1 * w + x1] += g11;
+            if (live && bx && by) sg[y1 * w + x1] += g11;
             __syncthreads();
         }
     }
