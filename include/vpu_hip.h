@@ -118,6 +118,10 @@ int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* o
 int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst,
                int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
 int vpu_fill_f32(float* p, float v, int64_t n, void* stream);
+/* out[b][channel][:] = sigmoid(logits[b][:]) for an fp32 [B][channels][HW] tensor: the previous-mask channel of the next
+ * click iteration's input (isegm/engine/trainer.py:428, :384) */
+int vpu_sigmoid_to_channel(const float* logits, float* out, int32_t B, int64_t HW, int32_t channels, int32_t channel,
+                           void* stream);
 /* dz = dy * act'(aux) on strided 2-D views; kind 0 = ReLU (aux = its output), 1 = GELU (aux = pre-activation).
  * Backward of mmcv ConvModule's ReLU (swin_transformer.py:680-695) where no GEMM epilogue can absorb it. */
 int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64_t ld_aux, void* dz, int64_t ld_dz, int64_t rows,

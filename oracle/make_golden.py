@@ -277,12 +277,72 @@ def prompt_fixtures(ref_vpu):
     print("disk counts sample0:", ref_d[0].sum(axis=(1, 2)), " half-integer click:", ref_d[2, 0].sum())
 
 
+def simulator_fixtures():
+    """a16 / a18 bookkeeping: the reference's get_next_promts (click slot / order / label-mask / box logic) and
+    BasePredictor.get_points_nd (click packing), run on seeded inputs.  OpenCV / skimage calls inside are replaced by the
+    stand-ins of ref_import.install_simulator_standins(); cal_scribble (bezier, unused by click / box prompts) is disabled."""
+    import random
+    ref_import.install_simulator_standins()
+    import isegm.engine.trainer as rt
+    from isegm.inference.predictors.base import BasePredictor
+    from isegm.inference.clicker import Click
+    rt.cal_scribble = lambda *a, **k: None
+    B, H = 4, 448
+    batch = vo.synth_batch(B, H, seed=11)
+    gt = batch["instances"]
+    yy, xx = np.mgrid[0:H, 0:H]
+    fx = {}
+    rs = np.random.RandomState(5)
+    for rnd_i, jitter in enumerate((True, False, True)):
+        # a plausible prediction: gt shifted / eroded per sample plus a spurious blob
+        pred = np.zeros((B, 1, H, H), np.float32)
+        for b in range(B):
+            sh = rs.randint(-30, 30, size=2)
+            pred[b, 0] = np.roll(gt[b, 0].numpy(), tuple(sh), axis=(0, 1)) * 0.9
+            cy, cx, r = rs.randint(50, 400), rs.randint(50, 400), rs.randint(10, 40)
+            pred[b, 0] = np.maximum(pred[b, 0], (((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r) * 0.8)
+        if rnd_i == 2:
+            pred[0] = 0.0      # first-iteration situation: nothing predicted yet
+            pred[1, 0] = gt[1, 0].numpy()   # perfect prediction: no click is added
+        pts = batch["points"].clone()
+        if rnd_i == 1:
+            pts[0, :24, 2] = torch.arange(24).float()      # all positive slots taken -> falls back to slot n-1
+            pts[0, :24, :2] = 5.0
+        ed = vo.ed_mask_label(gt).clone()
+        np.random.seed(100 + rnd_i); random.seed(200 + rnd_i)
+        new_pts, boxes, _, ed_out = rt.get_next_promts(torch.from_numpy(pred), gt, pts, ed, as_allmask=False,
+                                                       jitter_box=jitter)
+        changed = (ed_out != vo.ed_mask_label(gt)).flatten(2).any(2).numpy()          # [B, 48]
+        fx[f"r{rnd_i}_pred"] = np.packbits(pred > 0.49)
+        fx[f"r{rnd_i}_pred_vals"] = np.unique(pred)
+        fx[f"r{rnd_i}_points_in"] = pts.numpy()
+        fx[f"r{rnd_i}_points_out"] = new_pts.numpy()
+        fx[f"r{rnd_i}_boxes"] = boxes.numpy()
+        fx[f"r{rnd_i}_changed_slots"] = changed
+        fx[f"r{rnd_i}_changed_sums"] = (ed_out.sum(dim=(2, 3)) * torch.from_numpy(changed)).numpy()
+        fx[f"r{rnd_i}_jitter"] = np.asarray(jitter)
+    fx["gt_seed"] = np.asarray(11)
+    # click packing of the predictor (base.py:195-213)
+    bp = BasePredictor.__new__(BasePredictor)
+    bp.net_clicks_limit, bp.device = None, "cpu"
+    lists = [[Click(True, (10, 20), 0), Click(False, (30, 40), 1), Click(True, (50, 60), 2)],
+             [Click(False, (1, 2), 0)]]
+    fx["points_nd_a"] = bp.get_points_nd(lists).numpy()
+    fx["points_nd_b"] = bp.get_points_nd([[Click(True, (7, 8), 0)]]).numpy()
+    bp.net_clicks_limit = 2
+    fx["points_nd_limit2"] = bp.get_points_nd(lists).numpy()
+    np.savez_compressed(os.path.join(OUT, "sim.npz"), **fx)
+    print("[sim] written; boxes round0:", fx["r0_boxes"].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "vitb"]
+    which = sys.argv[1:] or ["pue", "tiny", "vitb", "sim"]
+    if "sim" in which:
+        simulator_fixtures()
     if "pue" in which:
         prompt_fixtures(ref_vpu)
     if "tiny" in which:

@@ -187,8 +187,24 @@ def install_stubs():
     par.is_module_wrapper = lambda m: False
     mmcv.utils, mmcv.cnn, mmcv.runner, mmcv.fileio, mmcv.parallel = u, cnn, run, fio, par
 
+    _mod("bezier")            # imported at the top of isegm/engine/trainer.py, used by the scribble simulator only
+    _mod("tqdm").tqdm = lambda it, *a, **k: it
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def install_simulator_standins():
+    """Stand-ins for the two third-party calls inside the click / box simulators (isegm/engine/trainer.py:628,736,1176),
+    so that the reference's BOOKKEEPING around them can be run here: cv2.distanceTransform(DIST_L2, 5) -> exact
+    Euclidean transform, skimage.measure.label(connectivity=2) -> scipy 8-connected labelling.  Parity of the click
+    COORDINATES against real OpenCV therefore stays unpinned."""
+    from scipy import ndimage
+    cv2 = sys.modules["cv2"]
+    cv2.distanceTransform = lambda m, dist_type, mask_size: ndimage.distance_transform_edt(m).astype(np.float32)
+    sk = _mod("skimage")
+    skm = _mod("skimage.measure")
+    sk.measure = skm
+    skm.label = lambda mask, connectivity=2: ndimage.label(mask, structure=np.ones((3, 3), bool))[0]
 
 
 def import_reference():

@@ -17,6 +17,7 @@ def install():
     sys.modules["isegm"] = pkg
     prefix = "pvpuformer_amd.isegm."
     for name in ("model", "model.is_model", "model.is_vpu_model", "model.modeling", "model.modeling.models_vit",
-                 "model.modeling.pos_embed", "utils", "utils.serialization"):
+                 "model.modeling.pos_embed", "utils", "utils.serialization", "engine", "engine.trainer", "inference",
+                 "inference.clicker", "inference.utils", "inference.predictors", "inference.predictors.base"):
         sys.modules["isegm." + name] = importlib.import_module(prefix + name)
     return pkg

@@ -382,6 +382,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
         store8(dz + r * ld_dz + c, d);
     }
 }
+// prev_mask = sigmoid(logits) written straight into channel `ch` of the next iteration's [B,C,H,W] network input
+// (trainer.py:428 + :384)
+__global__ __launch_bounds__(256) void sigmoid_to_channel_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                                 int64_t HW, int64_t batch_stride, int64_t ch_off,
+                                                                 int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / HW, r = i - b * HW;
+        out[b * batch_stride + ch_off + r] = 1.0f / (1.0f + expf(-logits[i]));
+    }
+}
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
@@ -498,6 +508,14 @@ extern "C" int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64
     DISPATCH_T(dtype, act_bwd_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, ld_dy, (const T*)aux, ld_aux, (T*)dz, ld_dz,
                                                              rows, cols, kind);)
     return vpu_check_launch("vpu_act_bwd");
+}
+extern "C" int vpu_sigmoid_to_channel(const float* logits, float* out, int32_t B, int64_t HW, int32_t channels,
+                                      int32_t channel, void* stream) {
+    vpu_clear_stale_error();
+    const int64_t total = (int64_t)B * HW;
+    sigmoid_to_channel_kernel<<<vpu_grid_for(total, 256, 4096), 256, 0, ST>>>(logits, out, HW, (int64_t)channels * HW,
+                                                                             (int64_t)channel * HW, total);
+    return vpu_check_launch("vpu_sigmoid_to_channel");
 }
 extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
     vpu_clear_stale_error();

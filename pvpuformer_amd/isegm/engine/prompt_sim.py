@@ -1,0 +1,166 @@
+"""Host-side prompt simulation of the training / evaluation loops: where the next click goes, which slot it takes,
+which error mask the P2CL label of that slot becomes, and the box prompt.  Mirrors
+``get_next_points`` / ``get_next_promts`` / ``cal_box`` / ``max_connected_regions`` of the reference
+(isegm/engine/trainer.py:615-768, 1061-1131, 1175-1190).  SURVEY.md section 8f ranks a GPU-resident version as the next
+row; this one keeps the reference's CPU structure (numpy + scipy) so that the integer bookkeeping is identical.
+
+PARITY NOTE: the reference calls ``cv2.distanceTransform(mask, DIST_L2, 5)`` (5x5 chamfer approximation) and
+``skimage.measure.label(connectivity=2)``; neither library is in this image.  ``scipy.ndimage.distance_transform_edt``
+(exact Euclidean) and ``scipy.ndimage.label`` (8-connected) stand in, so click COORDINATES are parity-unpinned while slot
+/ order / label-mask / box bookkeeping is pinned by ``tests/golden/sim.npz`` (generated from the reference with the same
+two stand-ins).
+"""
+import random
+
+import numpy as np
+import torch
+from scipy import ndimage
+
+_EIGHT = np.ones((3, 3), dtype=bool)
+
+
+def distance_transform(mask_u8):
+    """Distance of every non-zero pixel to the nearest zero pixel (stand-in for cv2.distanceTransform DIST_L2)."""
+    return ndimage.distance_transform_edt(mask_u8).astype(np.float32)
+
+
+def max_connected_regions(mask):
+    """trainer.py:1175-1190 incl. its quirk: every component larger than 10 % of the foreground is merged into the
+    largest-so-far label while scanning labels in ascending order."""
+    labels, n = ndimage.label(mask, structure=_EIGHT)
+    labels = labels.astype(np.int64)
+    if n == 0:
+        return labels
+    max_num, max_pixel = 0, 0
+    for j in range(1, n + 1):
+        cnt = int(np.sum(labels == j))
+        if cnt > max_num:
+            max_num, max_pixel = cnt, j
+        if cnt > 0.1 * np.sum(labels != 0):
+            labels[labels == j] = max_pixel
+    labels[labels != max_pixel] = 0
+    labels[labels == max_pixel] = 1
+    return labels.astype(np.int8)
+
+
+def _first_free(points_b, lo, hi, default):
+    """index of the first row in [lo, hi) whose order (column 2) is < 0, else ``default``."""
+    free = np.nonzero(points_b[lo:hi, 2] < 0)[0]
+    return lo + int(free[0]) if len(free) else default
+
+
+def cal_box(gt_mask, fn_mask, fp_mask, points, as_allmask=True, jitter_box=True, set_offset=10, rng=random):
+    """trainer.py:1061-1131.  gt/fn/fp: bool [B,H,W]; points: float array [B,2n,3].  Returns int32 [B,5]
+    (x_center, y_center, width, height, slot)."""
+    B, H, W = gt_mask.shape
+    n = points.shape[1] // 2
+    out = np.zeros((B, 5), np.int32)
+    for b in range(B):
+        if as_allmask:
+            idx = np.argwhere(gt_mask[b])
+            loc = _first_free(points[b], 0, n, n - 1)
+        else:
+            if np.sum(fn_mask[b]) > np.sum(fp_mask[b]):
+                idx = np.argwhere(max_connected_regions(fn_mask[b]) == 1)
+                loc = n - 1                                           # trainer.py:1088 (always the last positive slot)
+            else:
+                idx = np.argwhere(max_connected_regions(fp_mask[b]) == 1)
+                loc = _first_free(points[b], n, 2 * n, 2 * n - 1)
+        if len(idx) == 0:
+            continue
+        y0, y1, x0, x1 = idx[:, 0].min(), idx[:, 0].max(), idx[:, 1].min(), idx[:, 1].max()
+        if jitter_box:
+            off = rng.randint(-set_offset, 0)
+            bx = min(max(x0 + off, 0), W - set_offset)
+            off = rng.randint(0, set_offset)
+            ex = max(min(x1 + off, W), bx + set_offset)
+            off = rng.randint(-set_offset, 0)
+            by = min(max(y0 + off, 0), H - set_offset)
+            off = rng.randint(0, set_offset)
+            ey = max(min(y1 + off, H), by + set_offset)
+            y0, y1, x0, x1 = by, ey, bx, ex
+        xc, yc, bw, bh = int(0.5 * (x0 + x1)), int(0.5 * (y0 + y1)), int(x1 - x0), int(y1 - y0)
+        if xc >= 1 and yc >= 1 and bw >= 1 and bh >= 1:
+            out[b] = (xc, yc, bw, bh, loc)
+    return out
+
+
+def next_click(pred, gt, points, pred_thresh=0.49, np_rng=np.random):
+    """The shared body of get_next_points / get_next_promts (trainer.py:615-654, 733-764): for each sample the new
+    click (or None), its slot, and whether it is positive.  pred: float [B,H,W]; gt: bool [B,H,W]; points float
+    [B,2n,3] (modified copy is returned).  Also returns the false-negative / false-positive masks."""
+    fn = np.logical_and(gt, pred < pred_thresh)
+    fp = np.logical_and(np.logical_not(gt), pred > pred_thresh)
+    fn_p = np.pad(fn, ((0, 0), (1, 1), (1, 1)), "constant").astype(np.uint8)
+    fp_p = np.pad(fp, ((0, 0), (1, 1), (1, 1)), "constant").astype(np.uint8)
+    n = points.shape[1] // 2
+    points = points.copy()
+    picks = []
+    for b in range(gt.shape[0]):
+        fn_dt = distance_transform(fn_p[b])[1:-1, 1:-1]
+        fp_dt = distance_transform(fp_p[b])[1:-1, 1:-1]
+        fn_max, fp_max = float(np.max(fn_dt)), float(np.max(fp_dt))
+        is_pos = fn_max > fp_max
+        dt = fn_dt if is_pos else fp_dt
+        inner = np.argwhere(dt > max(fn_max, fp_max) / 2.0)
+        if len(inner) == 0:
+            picks.append(None)
+            continue
+        coords = inner[np_rng.randint(0, len(inner))]
+        order = max(float(points[b, :, 2].max()), 0.0) + 1
+        loc = _first_free(points[b], 0, n, n - 1) if is_pos else _first_free(points[b], n, 2 * n, 2 * n - 1)
+        points[b, loc] = (float(coords[0]), float(coords[1]), float(order))
+        picks.append((loc, bool(is_pos)))
+    return points, picks, fn, fp
+
+
+class PromptState:
+    """The P2CL label (``ed_mask_label``, trainer.py:329-331) kept in factored form for the fused loss kernel:
+    label[b][s] = gt[b] (s < S/2) or 1 - gt[b], unless slot_idx[b][s] >= 0, then override[slot_idx[b][s]]."""
+
+    def __init__(self, B, S, H, W, device, max_rounds=3):
+        self.slot_idx = -torch.ones(B, S, dtype=torch.int32, device=device)
+        self.override = torch.zeros(max_rounds * B, H, W, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def assign(self, b, slot, mask_np):
+        self.override[self.used].copy_(torch.from_numpy(np.ascontiguousarray(mask_np, dtype=np.float32)))
+        self.slot_idx[b, slot] = self.used
+        self.used += 1
+
+    def dense(self, gt):
+        """Materialises ed_mask_label [B,S,H,W] (tests only)."""
+        B, S = self.slot_idx.shape
+        lab = torch.cat([gt.repeat(1, S // 2, 1, 1), (1 - gt).repeat(1, S // 2, 1, 1)], 1).clone()
+        idx = self.slot_idx.cpu().numpy()
+        for b in range(B):
+            for s in range(S):
+                if idx[b, s] >= 0:
+                    lab[b, s] = self.override[idx[b, s]]
+        return lab
+
+
+def get_next_promts(pred, gt, points, state=None, pred_thresh=0.49, as_allmask=False, jitter_box=True,
+                    np_rng=np.random, rng=random):
+    """trainer.py:703-768.  pred [B,1,H,W] probabilities, gt [B,1,H,W], points [B,2n,3] (tensors).  Returns
+    (points, boxes int32 [B,5]) as tensors on points' device and updates ``state`` (the slot that received the click now
+    predicts the false-negative / false-positive mask of this round)."""
+    dev = points.device
+    pred_np = pred.detach().float().cpu().numpy()[:, 0]
+    gt_np = gt.detach().cpu().numpy()[:, 0] > 0.5
+    pts_np = points.detach().float().cpu().numpy()
+    fn0 = np.logical_and(gt_np, pred_np < pred_thresh)
+    fp0 = np.logical_and(np.logical_not(gt_np), pred_np > pred_thresh)
+    boxes = cal_box(gt_np, fn0, fp0, pts_np, as_allmask=as_allmask, jitter_box=jitter_box, rng=rng)
+    new_pts, picks, fn, fp = next_click(pred_np, gt_np, pts_np, pred_thresh, np_rng)
+    if state is not None:
+        for b, pk in enumerate(picks):
+            if pk is not None:
+                state.assign(b, pk[0], fn[b] if pk[1] else fp[b])
+    return torch.from_numpy(new_pts).to(dev), torch.from_numpy(boxes).to(dev)
+
+
+def get_iou(pred, gt, pred_thresh=0.49):
+    """trainer.py:1045-1051."""
+    pm, gm = pred > pred_thresh, gt > 0.5
+    return (pm & gm).sum() / (pm | gm).sum()

@@ -1,0 +1,93 @@
+"""Oracle click simulation of the NoBRS evaluation loop, API-compatible with isegm/inference/clicker.py:7-118.
+``cv2.distanceTransform(DIST_L2, 0)`` (precise) is replaced by the exact Euclidean transform of scipy (same
+definition; cv2 is not installable here)."""
+from copy import deepcopy
+
+import numpy as np
+from scipy import ndimage
+
+
+class Click:
+    def __init__(self, is_positive, coords, indx=None):
+        self.is_positive, self.coords, self.indx = is_positive, coords, indx
+
+    @property
+    def coords_and_indx(self):
+        return (*self.coords, self.indx)
+
+    def copy(self, **kwargs):
+        c = deepcopy(self)
+        for k, v in kwargs.items():
+            setattr(c, k, v)
+        return c
+
+
+class Clicker:
+    def __init__(self, gt_mask=None, init_clicks=None, ignore_label=-1, click_indx_offset=0):
+        self.click_indx_offset = click_indx_offset
+        if gt_mask is not None:
+            self.gt_mask = gt_mask == 1
+            self.not_ignore_mask = gt_mask != ignore_label
+        else:
+            self.gt_mask = None
+        self.reset_clicks()
+        for click in (init_clicks or []):
+            self.add_click(click)
+
+    def make_next_click(self, pred_mask):
+        assert self.gt_mask is not None
+        self.add_click(self._get_next_click(pred_mask))
+
+    def get_clicks(self, clicks_limit=None):
+        return self.clicks_list[:clicks_limit]
+
+    def _get_next_click(self, pred_mask, padding=True):
+        fn = np.logical_and(np.logical_and(self.gt_mask, np.logical_not(pred_mask)), self.not_ignore_mask)
+        fp = np.logical_and(np.logical_and(np.logical_not(self.gt_mask), pred_mask), self.not_ignore_mask)
+        if padding:
+            fn, fp = np.pad(fn, ((1, 1), (1, 1)), "constant"), np.pad(fp, ((1, 1), (1, 1)), "constant")
+        fn_dt = ndimage.distance_transform_edt(fn).astype(np.float32)
+        fp_dt = ndimage.distance_transform_edt(fp).astype(np.float32)
+        if padding:
+            fn_dt, fp_dt = fn_dt[1:-1, 1:-1], fp_dt[1:-1, 1:-1]
+        fn_dt, fp_dt = fn_dt * self.not_clicked_map, fp_dt * self.not_clicked_map
+        fn_max, fp_max = np.max(fn_dt), np.max(fp_dt)
+        is_positive = fn_max > fp_max
+        ys, xs = np.where(fn_dt == fn_max) if is_positive else np.where(fp_dt == fp_max)
+        return Click(is_positive=bool(is_positive), coords=(ys[0], xs[0]))
+
+    def add_click(self, click):
+        click.indx = self.click_indx_offset + self.num_pos_clicks + self.num_neg_clicks
+        if click.is_positive:
+            self.num_pos_clicks += 1
+        else:
+            self.num_neg_clicks += 1
+        self.clicks_list.append(click)
+        if self.gt_mask is not None:
+            self.not_clicked_map[click.coords[0], click.coords[1]] = False
+
+    def _remove_last_click(self):
+        click = self.clicks_list.pop()
+        if click.is_positive:
+            self.num_pos_clicks -= 1
+        else:
+            self.num_neg_clicks -= 1
+        if self.gt_mask is not None:
+            self.not_clicked_map[click.coords[0], click.coords[1]] = True
+
+    def reset_clicks(self):
+        if self.gt_mask is not None:
+            self.not_clicked_map = np.ones_like(self.gt_mask, dtype=bool)
+        self.num_pos_clicks = self.num_neg_clicks = 0
+        self.clicks_list = []
+
+    def get_state(self):
+        return deepcopy(self.clicks_list)
+
+    def set_state(self, state):
+        self.reset_clicks()
+        for click in state:
+            self.add_click(click)
+
+    def __len__(self):
+        return len(self.clicks_list)

@@ -144,6 +144,10 @@ def act_bwd(dy, ld_dy, aux, ld_aux, dz, ld_dz, rows, cols, kind, dtype):
     _lib.call("vpu_act_bwd", ptr(dy), ld_dy, ptr(aux), ld_aux, ptr(dz), ld_dz, rows, cols, kind, dtype, _stream())
 
 
+def sigmoid_to_channel(logits, out, B, HW, channels, channel):
+    _lib.call("vpu_sigmoid_to_channel", ptr(logits), ptr(out), B, HW, channels, channel, _stream())
+
+
 def fill_f32(t, v, n=None):
     _lib.call("vpu_fill_f32", ptr(t), v, t.numel() if n is None else n, _stream())
 

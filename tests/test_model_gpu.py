@@ -192,3 +192,41 @@ def test_vitb_bf16_backward_grad_norms(golden_dir):
     rel = {n: abs(float(params[n].grad.norm()) - norms[n]) / norms[n] for n in names if norms[n] > 1e-3}
     worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] < 0.1, worst
+
+
+def test_train_step_multi_iteration_matches_oracle(golden_dir):
+    """a16: three click iterations (click / box prompts, iteration weights 1,2,3, per-slot error-mask labels, prev mask
+    fed back) through VPUTrainStep == the oracle replaying the same prompts, loss summed and back-propagated once."""
+    import random
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    from pvpuformer_amd.isegm.engine.trainer import VPUTrainStep
+    from pvpuformer_amd.isegm.engine.prompt_sim import PromptState
+    dev_batch = {k: v.cuda() for k, v in batch.items()}
+    random.seed(5); np.random.seed(6)
+    rec = []
+    step = VPUTrainStep(model)
+    logged, _ = step.batch_forward(dev_batch, num_iters=3, record=rec)
+    assert len(rec) == 3 and rec[1]["net_input"][:, 3].abs().sum() > 0 and (rec[2]["slot_idx"] >= 0).sum() >= 1
+    # oracle replay
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    gt = batch["instances"]
+    total = 0
+    for it, r in enumerate(rec):
+        out = vo.vpu_forward(sdg, cfg, r["net_input"].cpu(), r["points"].cpu(), r["boxes"].cpu(), r["ptype"])
+        st = PromptState(2, 48, 448, 448, "cpu")
+        st.slot_idx, st.override = r["slot_idx"].cpu(), r["override"].cpu()
+        t, _ = vo.step_loss(out, gt, st.dense(gt), iter_weight=float(it + 1))
+        total = total + t
+        assert abs(logged[f"total_{it}_{it + 1}"].item() - t.item()) < 2e-4 * abs(t.item())
+        if it + 1 < len(rec):   # the prev mask the engine fed to the next iteration
+            nxt = rec[it + 1]["net_input"][:, 3:4].cpu()
+            assert (torch.sigmoid(out["instances"].detach()) - nxt).abs().max() < 1e-4
+    total.backward()
+    bad = []
+    for n, p in model.named_parameters():
+        g = sdg[n].grad
+        if g is not None and g.norm() > 1e-6:
+            err = (p.grad.cpu() - g).norm() / g.norm()
+            if err > 3e-3:
+                bad.append((n, float(err)))
+    assert not bad, bad[:8]

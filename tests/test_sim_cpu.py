@@ -1,0 +1,70 @@
+"""CPU: click / box bookkeeping of the training-loop simulators and the predictor's click packing against fixtures
+produced by the reference itself (tests/golden/sim.npz, see oracle/make_golden.py: OpenCV / skimage calls stood in)."""
+import os
+import random
+
+import numpy as np
+import torch
+
+import vpu_oracle as vo
+from pvpuformer_amd.isegm.engine import prompt_sim as ps
+from pvpuformer_amd.isegm.inference.clicker import Click, Clicker
+from pvpuformer_amd.isegm.inference.predictors.base import BasePredictor
+
+
+def test_get_next_promts_bookkeeping_bit_exact(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "sim.npz"))
+    B, H = 4, 448
+    gt = vo.synth_batch(B, H, seed=int(fx["gt_seed"]))["instances"]
+    for r in range(3):
+        pred = np.unpackbits(fx[f"r{r}_pred"])[:B * H * H].reshape(B, 1, H, H).astype(np.float32) * 0.9
+        pts = torch.from_numpy(fx[f"r{r}_points_in"])
+        state = ps.PromptState(B, 48, H, H, "cpu")
+        np.random.seed(100 + r); random.seed(200 + r)
+        new_pts, boxes = ps.get_next_promts(torch.from_numpy(pred), gt, pts, state, as_allmask=False,
+                                            jitter_box=bool(fx[f"r{r}_jitter"]))
+        assert np.array_equal(new_pts.numpy(), fx[f"r{r}_points_out"]), f"round {r}: click slot / order / coordinates"
+        assert np.array_equal(boxes.numpy(), fx[f"r{r}_boxes"]), f"round {r}: boxes"
+        changed = (state.slot_idx >= 0).numpy()
+        dense = state.dense(gt)
+        same_as_default = (dense == vo.ed_mask_label(gt)).flatten(2).all(2).numpy()
+        # slots the reference rewrote with a mask different from the default label
+        assert np.array_equal(changed & ~same_as_default, fx[f"r{r}_changed_slots"])
+        sums = (dense.sum(dim=(2, 3)).numpy() * fx[f"r{r}_changed_slots"])
+        np.testing.assert_array_equal(sums, fx[f"r{r}_changed_sums"])
+
+
+def test_points_nd_packing_bit_exact(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "sim.npz"))
+    bp = BasePredictor.__new__(BasePredictor)
+    bp.net_clicks_limit, bp.device = None, "cpu"
+    lists = [[Click(True, (10, 20), 0), Click(False, (30, 40), 1), Click(True, (50, 60), 2)], [Click(False, (1, 2), 0)]]
+    assert np.array_equal(bp.get_points_nd(lists).numpy(), fx["points_nd_a"])
+    assert np.array_equal(bp.get_points_nd([[Click(True, (7, 8), 0)]]).numpy(), fx["points_nd_b"])
+    bp.net_clicks_limit = 2
+    assert np.array_equal(bp.get_points_nd(lists).numpy(), fx["points_nd_limit2"])
+
+
+def test_clicker_targets_largest_error_region():
+    gt = np.zeros((64, 64), np.int32)
+    gt[10:40, 10:40] = 1
+    ck = Clicker(gt_mask=gt)
+    ck.make_next_click(np.zeros_like(gt, dtype=bool))
+    c = ck.get_clicks()[0]
+    assert c.is_positive and c.indx == 0 and gt[c.coords[0], c.coords[1]] == 1
+    pred = np.zeros_like(gt, dtype=bool); pred[5:60, 5:60] = True
+    ck.make_next_click(pred)
+    c2 = ck.get_clicks()[1]
+    assert (not c2.is_positive) and c2.indx == 1 and gt[c2.coords[0], c2.coords[1]] == 0
+    assert len(ck) == 2 and ck.num_pos_clicks == 1
+
+
+def test_max_connected_regions_and_cal_box():
+    m = np.zeros((1, 50, 50), bool)
+    m[0, 5:20, 5:30] = True      # 375 px
+    m[0, 40:43, 40:43] = True    # 9 px < 10 %
+    r = ps.max_connected_regions(m[0])
+    assert r.sum() == 375 and r[41, 41] == 0
+    pts = -np.ones((1, 48, 3), np.float32)
+    box = ps.cal_box(m, m, np.zeros_like(m), pts, as_allmask=False, jitter_box=False)
+    assert box.tolist() == [[int(0.5 * (5 + 29)), int(0.5 * (5 + 19)), 24, 14, 23]]
