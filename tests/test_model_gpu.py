@@ -230,3 +230,47 @@ def test_train_step_multi_iteration_matches_oracle(golden_dir):
             if err > 3e-3:
                 bad.append((n, float(err)))
     assert not bad, bad[:8]
+
+
+def test_nobrs_click_loop_iou_parity(golden_dir):
+    """a18 / config 3: the NoBRS evaluation loop (oracle clicks from the Clicker, flip TTA, prev-mask feedback,
+    box prompt derived each click) driven through the predictor mirror on the HIP model vs the same loop on the CPU
+    oracle network: IoU-per-click series within +-0.1 (north star), click packing identical."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    from pvpuformer_amd.isegm.inference.clicker import Clicker
+    from pvpuformer_amd.isegm.inference.predictors import get_predictor
+    from pvpuformer_amd.isegm.inference.utils import get_iou
+
+    class OracleNet:
+        with_prev_mask = True
+
+        def __call__(self, image, points, prompts=None, as_prompt_type=0):
+            boxes = prompts[1].cpu() if prompts is not None else None
+            with torch.no_grad():
+                return vo.vpu_forward(sd, cfg, image.cpu().float(), points.cpu().float(), boxes, as_prompt_type)
+
+    image = (batch["images"][0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    gt = batch["instances"][0, 0].numpy().astype(np.int32)
+    series = {}
+    for name, net, device in (("oracle", OracleNet(), "cpu"), ("hip_f32", model, "cuda"), ("hip_bf16", None, "cuda")):
+        if name == "hip_bf16":
+            model.set_compute_dtype("bf16")
+            net = model
+        model.weights_frozen = True
+        pred = get_predictor(net, "NoBRS", device, with_flip=True)
+        pred.set_input_image(image)
+        clicker = Clicker(gt_mask=gt)
+        mask = np.zeros_like(gt, dtype=bool)
+        ious, packed = [], []
+        for i in range(4):
+            clicker.make_next_click(mask)
+            probs, prompts = pred.get_vqu_prediction(clicker, gt_mask=gt, as_prompt_type=i % 2, click_indx=i)
+            packed.append(prompts[0].cpu().numpy())
+            mask = probs > 0.49
+            ious.append(float(get_iou(gt, mask)))
+        series[name] = (ious, packed)
+    for name in ("hip_f32", "hip_bf16"):
+        for a, b in zip(series[name][0], series["oracle"][0]):
+            assert abs(a - b) <= (1e-3 if name == "hip_f32" else 0.1), (name, series[name][0], series["oracle"][0])
+    for a, b in zip(series["hip_f32"][1], series["oracle"][1]):
+        assert np.array_equal(a, b)
