@@ -109,6 +109,24 @@ constexpr int OOB_OFFSET = (int)0x80000000;  // >= num_records of the descriptor
 // image is linear per piece, so the XOR swizzle is applied to the per-lane SOURCE chunk (cdna guide, rule 21); rows /
 // k beyond the operand (ragged M, N, K, split-K slice ends) get the out-of-range offset and arrive as zeros.
 template <int TRANS>
+__device__ __forceinline__ void stage_piece(__amdgpu_buffer_rsrc_t rsrc, int ld, int x0, int X, int k0, int kend,
+                                            char* lds_tile, int piece, int lane) {
+    int voff;
+    if (TRANS == 0) {
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int gx = x0 + row, gk = k0 + chunk * 8;
+        voff = (gx < X && gk < kend) ? (gx * ld + gk) * 2 : OOB_OFFSET;
+    } else {
+        const int k = piece * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
+        const int gk = k0 + k, gx = x0 + chunk * 8;
+        voff = (gk < kend && gx < X) ? (gk * ld + gx) * 2 : OOB_OFFSET;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(lds_tile + piece * 1024), 16, voff, 0, 0, 0);
+}
+
+template <int TRANS>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, int x0, int X, int k0, int kend,
                                            char* lds_tile, int wave, int lane) {
 #pragma unroll
@@ -243,7 +261,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2 each), so give
+    // XCD x the contiguous range of tiles [start(x), start(x+1)) -- neighbouring tiles (same A row-panel) then hit the
+    // same L2.  Bijective for any grid size (guide T1).
+    int tile;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
@@ -338,6 +364,159 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
         }
         __syncthreads();
         if (tid < 128 && m0 + tid < p.M) {
+            const float t = red[tid];
+            if (splitk > 1) ws[(int64_t)gridDim.z * splitk * p.M * p.N + ((int64_t)z * splitk + blockIdx.y) * p.M + m0 + tid] = t;
+            else p.colsum[m0 + tid] += t;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ii * 16 + fq * 4 + r;
+                    wl[row * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[pass * 2 + ii][j][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int u = lane + 64 * t;
+            const int row = u >> 3, c8 = (u & 7) * 8;
+            const int m = m0 + wm * 64 + pass * 32 + row;
+            const int n = n0 + wn * 64 + c8;
+            if (m < p.M && n < p.N) {
+                float v[8];
+                load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
+                if (splitk > 1) {
+                    float* o = wsz + (int64_t)m * p.N + n;
+                    if ((p.N & 3) == 0 && n + 8 <= p.N) store8(o, v);
+                    else
+                        for (int j = 0; j < 8 && n + j < p.N; ++j) o[j] = v[j];
+                } else if (vec && n + 8 <= p.N) {
+                    epilogue_store8(p, coff, roff, m, n, v);
+                } else {
+                    for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 waves (4x2, each 64x64 -- the same per-wave code as above), THREE 48-KiB LDS stages fed by LDS-DMA:
+// tile kt+2 is issued before tile kt is computed, a counted s_waitcnt vmcnt(6) (the 6 pieces of the newest tile may stay
+// in flight) + a raw s_barrier close the iteration, so two tiles of HBM/L2 latency are covered by MFMA work and the DMA
+// is never drained inside the loop (cdna guide T3/T4).  One block per CU (144 KiB of LDS), two waves per SIMD.
+// ------------------------------------------------------------------------------------------------
+constexpr int BM2 = 256;
+constexpr int STAGE2 = 3 * TILE_BYTES;  // A rows 0-127 | A rows 128-255 | B
+
+template <int TA, int TB>
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
+                                                            const int kchunk, float* __restrict__ ws, const int vec) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * BM2, n0 = tile_n * BN;
+    const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+    const int64_t coff = zo * p.sCo + zi * p.sCi;
+    const int64_t roff = zo * p.sRo + zi * p.sRi;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < p.K) ? kbeg + kchunk : p.K;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = TA == 1 && p.colsum != nullptr && tile_n == 0 && wn == 0;
+    f32x4_t acc_cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
+
+    // 48 pieces per stage; wave w issues pieces w, w+8, ..., w+40 (A: 0-31 in two 128-row sub-tiles, B: 32-47)
+    auto issue = [&](int kt_, char* st) {
+        const int k0 = kbeg + kt_ * BK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pc = wave + 8 * i;
+            if (i < 4) stage_piece<TA>(rA, p.lda, m0 + (pc >> 4) * 128, p.M, k0, kend, st + (pc >> 4) * TILE_BYTES, pc & 15, lane);
+            else stage_piece<TB>(rB, p.ldb, n0, p.N, k0, kend, st + 2 * TILE_BYTES, pc - 32, lane);
+        }
+    };
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    char* s0 = lds;
+    char* s1 = lds + STAGE2;
+    char* s2 = lds + 2 * STAGE2;
+    issue(0, s0);
+    if (nk > 1) {
+        issue(1, s1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        if (more) issue(kt + 2, s2);
+        const char* ldsA = s0 + (wm >> 1) * TILE_BYTES;
+        const char* ldsB = s0 + 2 * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(ldsA, (wm & 1) * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(ldsB, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (TA == 1 && do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+            }
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* t = s0; s0 = s1; s1 = s2; s2 = t;   // rotate stages
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
+    float* wsz = ws ? ws + ((int64_t)z * splitk + blockIdx.y) * (int64_t)p.M * p.N : nullptr;
+    if (TA == 1 && p.colsum != nullptr && tile_n == 0) {
+        float* red = reinterpret_cast<float*>(lds);
+        if (do_cs && fr == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wm * 64 + i * 16 + fq * 4 + r] = acc_cs[i][r];
+        }
+        __syncthreads();
+        if (tid < BM2 && m0 + tid < p.M) {
             const float t = red[tid];
             if (splitk > 1) ws[(int64_t)gridDim.z * splitk * p.M * p.N + ((int64_t)z * splitk + blockIdx.y) * p.M + m0 + tid] = t;
             else p.colsum[m0 + tid] += t;
@@ -528,7 +707,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int tm = bf ? BM : FM, tn = bf ? BN : FN;
+    static const int force_big = [] { const char* e = getenv("VPU_GEMM_BIG"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool big = bf && (force_big >= 0 ? force_big == 1 : (d->M >= 1024 && d->N >= 128 && d->K >= 256));
+    const int tm = bf ? (big ? BM2 : BM) : FM, tn = bf ? BN : FN;
     const int tiles_m = (d->M + tm - 1) / tm, tiles_n = (d->N + tn - 1) / tn;
     const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
     if (bf) {
@@ -568,11 +749,30 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); \
         else gemm_bf16_kernel<TA_, TB_, false><<<grid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec);       \
     } while (0)
-        switch (key) {
-            case 0: VPU_LAUNCH(0, 0); break;
-            case 1: VPU_LAUNCH(0, 1); break;
-            case 2: VPU_LAUNCH(1, 0); break;
-            default: VPU_LAUNCH(1, 1); break;
+        if (big) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                const int sz = 3 * STAGE2;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
+                attr_done = true;
+            }
+            dim3 block2(512);
+            switch (key) {
+                case 0: gemm_bf16_big_kernel<0, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+                case 1: gemm_bf16_big_kernel<0, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+                case 2: gemm_bf16_big_kernel<1, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+                default: gemm_bf16_big_kernel<1, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+            }
+        } else {
+            switch (key) {
+                case 0: VPU_LAUNCH(0, 0); break;
+                case 1: VPU_LAUNCH(0, 1); break;
+                case 2: VPU_LAUNCH(1, 0); break;
+                default: VPU_LAUNCH(1, 1); break;
+            }
         }
 #undef VPU_LAUNCH
         if (splitk > 1) {
