@@ -189,8 +189,35 @@ __device__ __forceinline__ void tile_coords(int tiles_n, int& tile_m, int& tile_
 // 8 consecutive output columns of one row through the full epilogue with 16-byte accesses.
 // Preconditions (checked on the host, flag `vec`): n % 8 == 0, n + 8 <= N, every leading dimension / batch offset /
 // base pointer involved is a multiple of 8 elements (16 B for bf16, 32 B for fp32).
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+    const bf16x8_t e = __builtin_bit_cast(bf16x8_t, u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)e[j];
+}
+// prefetch of the residual / aux values one lane will need in the epilogue: [pass][t] as laid out by the LDS staging
+__device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int mbase, int nbase,
+                                             int lane, uint4 (&pre)[2][4]) {
+    const bool is_res = (p.flags & VPU_EPI_RESID) != 0;
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(is_res ? p.resid : p.aux);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int u = lane + 64 * t;
+            const int m = mbase + pass * 32 + (u >> 3), n = nbase + (u & 7) * 8;
+            pre[pass][t] = make_uint4(0, 0, 0, 0);
+            if (m < p.M && n + 8 <= p.N) {
+                const int64_t idx = is_res ? (p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
+                                                                 : roff + (int64_t)m * p.ldr + n)
+                                           : coff + (int64_t)m * p.ldaux + n;
+                pre[pass][t] = *reinterpret_cast<const uint4*>(src + idx);
+            }
+        }
+}
+// `pre` (optional): the 8 bf16 of the residual (VPU_EPI_RESID) or of aux (DGELU/DRELU/MULAUX) for this position, fetched
+// before the main loop so that their HBM latency is hidden behind the MFMA work.
 __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int m, int n,
-                                                float (&v)[8]) {
+                                                float (&v)[8], const uint4* pre = nullptr) {
     const int flags = p.flags;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
@@ -202,42 +229,45 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
     }
     const int64_t ci = coff + (int64_t)m * p.ldc + n;
     if (flags & VPU_EPI_PREACT) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, v);
-    if (flags & VPU_EPI_SAVE_DGELU) {
-        // gelu and gelu' share the erf: phi = 0.5*(1+erf(x/sqrt2)); gelu = x*phi; gelu' = phi + x*pdf(x)
+    if (flags & (VPU_EPI_SAVE_DGELU | VPU_EPI_GELU)) {
+        // gelu = x*Phi(x), gelu' = Phi(x) + x*pdf(x) from ONE exp and ONE rcp per element: with u = exp(-x^2/2),
+        // erf(|x|/sqrt2) = 1 - poly(t)*u (Abramowitz-Stegun 7.1.26 on z = |x|/sqrt2, t = 1/(1+0.3275911 z),
+        // |error| <= 1.5e-7, far below bf16 resolution) and pdf(x) = u/sqrt(2 pi).  (The fp32 parity path keeps erff.)
         float d[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float x = v[j];
-            const float phi = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-            d[j] = phi + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+            const float u = __expf(-0.5f * x * x);
+            const float z = fabsf(x) * 0.70710678118654752f;
+            const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+            const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+            const float erfa = 1.0f - poly * u;            // erf(|x|/sqrt2)
+            const float phi = 0.5f * (1.0f + (x < 0.f ? -erfa : erfa));
+            d[j] = phi + x * 0.3989422804014327f * u;
             v[j] = x * phi;
         }
-        store8(reinterpret_cast<bf16_t*>(p.preact) + ci, d);
-    } else if (flags & VPU_EPI_GELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        if (flags & VPU_EPI_SAVE_DGELU) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, d);
     }
     if (flags & VPU_EPI_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
     }
-    if (flags & (VPU_EPI_DGELU | VPU_EPI_DRELU)) {
+    if (flags & (VPU_EPI_DGELU | VPU_EPI_DRELU | VPU_EPI_MULAUX)) {
         float a[8];
-        load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
+        if (pre) unpack8(*pre, a);
+        else load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= (flags & VPU_EPI_DGELU) ? dgelu_f(a[j]) : (a[j] > 0.f ? 1.f : 0.f);
-    }
-    if (flags & VPU_EPI_MULAUX) {
-        float a[8];
-        load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= a[j];
+        for (int j = 0; j < 8; ++j)
+            v[j] *= (flags & VPU_EPI_MULAUX) ? a[j] : ((flags & VPU_EPI_DGELU) ? dgelu_f(a[j]) : (a[j] > 0.f ? 1.f : 0.f));
     }
     if (flags & VPU_EPI_RESID) {
         float r[8];
-        const int64_t ri = p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
-                                              : roff + (int64_t)m * p.ldr + n;
-        load8(reinterpret_cast<const bf16_t*>(p.resid) + ri, r);
+        if (pre) unpack8(*pre, r);
+        else {
+            const int64_t ri = p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
+                                                  : roff + (int64_t)m * p.ldr + n;
+            load8(reinterpret_cast<const bf16_t*>(p.resid) + ri, r);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
@@ -290,6 +320,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const int kend = (kbeg + kchunk < p.K) ? kbeg + kchunk : p.K;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
+
+    // residual / aux tile of this wave, requested now so that it is in registers when the epilogue needs it
+    const bool use_pre = vec == 1 && splitk == 1 &&
+                         (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
+                         !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
+    uint4 pre[2][4];
+    if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -359,6 +396,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
         __syncthreads();
     }
 
+    if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
+        return;
+    }
     // ---- epilogue: transpose the accumulators through LDS so that every lane owns 8 consecutive columns of one row
     // and all global accesses are 16-byte vectors.  Two passes of 32 rows per wave (8 KiB of fp32 per wave each).
     const int fr = lane & 15, fq = lane >> 4;
@@ -407,7 +453,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
                     else
                         for (int j = 0; j < 8 && n + j < p.N; ++j) o[j] = v[j];
                 } else if (vec && n + 8 <= p.N) {
-                    epilogue_store8(p, coff, roff, m, n, v);
+                    epilogue_store8(p, coff, roff, m, n, v, use_pre ? &pre[pass][t] : nullptr);
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
                 }
@@ -445,6 +491,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
     const int kend = (kbeg + kchunk < p.K) ? kbeg + kchunk : p.K;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
+
+    const bool use_pre = vec == 1 && splitk == 1 &&
+                         (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
+                         !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
+    uint4 pre[2][4];
+    if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -510,6 +562,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
         char* t = s0; s0 = s1; s1 = s2; s2 = t;   // rotate stages
     }
 
+    if (vec == 9) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
+        return;
+    }
     const int fr = lane & 15, fq = lane >> 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
     float* wsz = ws ? ws + ((int64_t)z * splitk + blockIdx.y) * (int64_t)p.M * p.N : nullptr;
@@ -556,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
                     else
                         for (int j = 0; j < 8 && n + j < p.N; ++j) o[j] = v[j];
                 } else if (vec && n + 8 <= p.N) {
-                    epilogue_store8(p, coff, roff, m, n, v);
+                    epilogue_store8(p, coff, roff, m, n, v, use_pre ? &pre[pass][t] : nullptr);
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
                 }
@@ -743,6 +804,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 splitk = (d->K + kchunk - 1) / kchunk;
             }
         }
+        static const bool noepi = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+        const int vec_arg = noepi ? 9 : (vec ? 1 : 0);
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
         // staging choice (tools/gemm_bench.py, random data, ViT-B bs 12): LDS-DMA + two stages wins on long K and on every
@@ -752,8 +815,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool use_dma = force_dma >= 0 ? force_dma == 1 : !(key == 0 && d->K <= 1024);
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
-        if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); \
-        else gemm_bf16_kernel<TA_, TB_, false><<<grid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec);       \
+        if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); \
+        else gemm_bf16_kernel<TA_, TB_, false><<<grid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg);       \
     } while (0)
         if (big) {
             static bool attr_done = false;
@@ -767,10 +830,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
             dim3 block2(512);
             switch (key) {
-                case 0: gemm_bf16_big_kernel<0, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
-                case 1: gemm_bf16_big_kernel<0, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
-                case 2: gemm_bf16_big_kernel<1, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
-                default: gemm_bf16_big_kernel<1, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec); break;
+                case 0: gemm_bf16_big_kernel<0, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
+                case 1: gemm_bf16_big_kernel<0, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
+                case 2: gemm_bf16_big_kernel<1, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
+                default: gemm_bf16_big_kernel<1, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
             }
         } else {
             switch (key) {
