@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
 
     // residual / aux tile of this wave, requested now so that it is in registers when the epilogue needs it
-    const bool use_pre = vec == 1 && splitk == 1 &&
+    // (measured: requesting the tile up front costs more than it hides at 2-3 blocks per CU -- disabled)
+    const bool use_pre = false && vec == 1 && splitk == 1 &&
                          (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
                          !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
     uint4 pre[2][4];
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
 
-    const bool use_pre = vec == 1 && splitk == 1 &&
+    // (measured: requesting the tile up front costs more than it hides at 2-3 blocks per CU -- disabled)
+    const bool use_pre = false && vec == 1 && splitk == 1 &&
                          (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
                          !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
     uint4 pre[2][4];
@@ -775,7 +777,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const int force_big = [] { const char* e = getenv("VPU_GEMM_BIG"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool big = bf && (force_big >= 0 ? force_big == 1 : (d->M >= 1024 && d->N >= 128 && d->K >= 256));
+    // the 256x128 three-stage kernel is kept selectable (VPU_GEMM_BIG=1) but is off by default: at these problem sizes
+    // (<= 3.5 rounds of tiles) it measured 5-25 % slower than two co-resident 128x128 blocks per CU (round 1).
+    const bool big = bf && force_big == 1 && d->M >= 1024 && d->N >= 128 && d->K >= 256;
     const int tm = bf ? (big ? BM2 : BM) : FM, tn = bf ? BN : FN;
     const int tiles_m = (d->M + tm - 1) / tm, tiles_n = (d->N + tn - 1) / tn;
     const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
