@@ -87,6 +87,10 @@ class Engine:
         self._const_ready = False
         import os
         self.use_flash = os.environ.get("VPU_FLASH_ATTN", "1") != "0"   # 0: unfused S/P path (also used for fp32 / other head dims)
+        # weight gradients are only consumed by the optimizer: run them on a second HIP stream so that their under-filled
+        # grids (few output tiles, split-K) overlap the dgrad / LayerNorm / attention chain on the main stream
+        self.use_side = os.environ.get("VPU_WGRAD_STREAM", "1") != "0"
+        self.side = None
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -184,10 +188,23 @@ class Engine:
         """G[N,K] += dy[M,N]^T x[M,K];  optionally G[bias][N] += column sums of dy, fused into the same launch (bf16
         path; the fp32 parity path uses the stand-alone column-sum kernel)."""
         fuse = bias is not None and self.dt == BF16
-        ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
-                 transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
-        if bias is not None and not fuse:
-            self._colsum_to(dy, ld_dy, bias, M, N)
+        if not self.use_side:
+            ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
+                     transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
+            if bias is not None and not fuse:
+                self._colsum_to(dy, ld_dy, bias, M, N)
+            return
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(main)                      # dy and x are produced by work already queued on the main stream
+        for t in (dy, x):
+            (t[0] if isinstance(t, tuple) else t).record_stream(self.side)   # keep them alive for the side stream
+        with torch.cuda.stream(self.side):
+            ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
+                     transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
+            if bias is not None and not fuse:
+                self._colsum_to(dy, ld_dy, bias, M, N)
 
     def _dgrad(self, dy, ld_dy, w, ldw, xvar, M, K, N, flags=0, aux=None, ldaux=0):
         """x.g (+)= dy[M,N] W[N,K]"""
@@ -703,8 +720,14 @@ class Engine:
 
         def marker():
             if self.grad_ready_hook is not None:
+                self.join_side()
                 self.grad_ready_hook(lo, hi)
         self.tape.append(marker)
+
+    def join_side(self):
+        """main stream waits for every weight-gradient GEMM queued on the side stream."""
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
     def backward(self, d_inst, d_aux, d_sim_low=None):
         """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None (or d_sim_low fp32
@@ -715,5 +738,6 @@ class Engine:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.join_side()
         if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0
             self.grad_ready_hook(0, self.names["backbone.blocks.0.norm1.weight"][0])

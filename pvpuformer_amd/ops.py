@@ -41,7 +41,7 @@ _WORKSPACE = {}
 def split_k_workspace(device, nbytes=128 << 20):
     """fp32 scratch shared by every GEMM launched on ``device`` (launches on one stream are serialised, so one buffer
     is enough).  Passed to vpu_gemm, whose host side decides per launch whether to split K."""
-    key = str(device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)   # one scratch buffer per stream
     ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
