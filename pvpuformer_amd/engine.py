@@ -91,6 +91,7 @@ class Engine:
         # grids (few output tiles, split-K) overlap the dgrad / LayerNorm / attention chain on the main stream
         self.use_side = os.environ.get("VPU_WGRAD_STREAM", "1") != "0"
         self.side = None
+        self._frozen = set()   # data_ptr of gradient buffers a queued side-stream GEMM still reads: no in-place writes
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -168,6 +169,7 @@ class Engine:
                 var.g = torch.empty_like(g)
                 ops.add4(g, None, None, None, var.g, g.numel())
         else:
+            self._writable(var.g)
             ops.add4(var.g, g, None, None, var.g, g.numel())
 
     def _reduce_wb(self, part, nrows, prefix, Cdim):
@@ -199,7 +201,9 @@ class Engine:
         main = torch.cuda.current_stream(self.dev)
         self.side.wait_stream(main)                      # dy and x are produced by work already queued on the main stream
         for t in (dy, x):
-            (t[0] if isinstance(t, tuple) else t).record_stream(self.side)   # keep them alive for the side stream
+            tt = t[0] if isinstance(t, tuple) else t
+            tt.record_stream(self.side)                  # the allocator must not recycle them under the side stream
+            self._frozen.add(tt.data_ptr())
         with torch.cuda.stream(self.side):
             ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
                      transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
@@ -212,6 +216,7 @@ class Engine:
         if xvar.g is None:
             xvar.g = torch.empty_like(xvar.t)
         else:
+            self._writable(xvar.g)
             f |= EPI_ACCUM
         ops.gemm(dy, w, xvar.g, M, K, N, ld_dy, ldw, K, self.dt, transB=True, flags=f, aux=aux, ldaux=ldaux)
 
@@ -294,8 +299,8 @@ class Engine:
                 nblk = ops.layernorm_bwd_nblk(rows)
                 part = self._new(nblk, 2, Cdim, dtype=torch.float32)
                 dres = x.g
-                if x.g is None:
-                    x.g = torch.empty_like(x.t)
+                if x.g is None or x.g.data_ptr() in self._frozen:
+                    x.g = torch.empty_like(x.t)   # (a frozen dres is read, the sum goes to a fresh buffer: no wait needed)
                 ops.layernorm_bwd(y.g, x.t, self.Pm(prefix + ".weight"), mean, rstd, dres, x.g, part, rows, Cdim)
                 self._reduce_wb(part, nblk, prefix, Cdim)
             self.tape.append(bwd)
@@ -421,6 +426,7 @@ class Engine:
                 if x.g is None:
                     x.g = torch.empty_like(x.t)
                 else:
+                    self._writable(x.g)
                     f = EPI_ACCUM
                 ops.gemm(dt, self.W(prefix + ".weight"), x.g, M, Cin, 4 * Cout, 4 * Cout, 4 * Cout, Cin, self.dt, flags=f)
             self.tape.append(bwd)
@@ -596,6 +602,8 @@ class Engine:
                     accum = xr.g is not None
                     if not accum:
                         xr.g = torch.empty_like(xr.t)
+                    for t_ in (xr.g, qi.g, ki.g):
+                        self._writable(t_)
                     part = self._new(B, 16, D, dtype=torch.float32)
                     ops.gate_bwd(xg.g, xr.t, cg, aq, sg, ac, xr.g, accum, qi.g, ki.g, part, B, nq, NT, D)
                 self.tape.append(bwd_gate)
@@ -705,6 +713,7 @@ class Engine:
                     accum = fused.g is not None
                     if not accum:
                         fused.g = torch.empty_like(fused.t)
+                    self._writable(fused.g)
                     ops.convseg_bwd(dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask, fused.g, accum, part,
                                     part_b, B * HW4, HW4, Cc)
                     ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
@@ -728,6 +737,12 @@ class Engine:
         """main stream waits for every weight-gradient GEMM queued on the side stream."""
         if self.side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        self._frozen.clear()
+
+    def _writable(self, t):
+        """Call before modifying gradient buffer ``t`` in place: if a queued side-stream GEMM still reads it, wait."""
+        if t is not None and t.data_ptr() in self._frozen:
+            self.join_side()
 
     def backward(self, d_inst, d_aux, d_sim_low=None):
         """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None (or d_sim_low fp32
