@@ -360,13 +360,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     for (int kt = 0; kt < nk; ++kt) {
         const char* ldsA = DMA ? lds + (kt & 1) * 2 * TILE_BYTES : lds;
         const char* ldsB = ldsA + TILE_BYTES;
-        if (DMA) {
-            if (kt + 1 < nk) {  // DMA of the next tile into the other stage overlaps this tile's MFMAs
-                char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
-                stage_tile<TA>(rA, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, nxt, wave, lane);
-                stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, nxt + TILE_BYTES, wave, lane);
-            }
-        } else {
+        if (!DMA) {
             la.store(lds, tid);
             lb.store(lds + TILE_BYTES, tid);
             __syncthreads();
@@ -375,25 +369,46 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
                 lb.load(B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
             }
         }
+        // All fragment reads of this K-tile are issued BEFORE the DMA of the next tile: hipcc puts s_waitcnt vmcnt(0) in
+        // front of any ds_read that follows a pending LDS-DMA in program order (it cannot prove the stages disjoint),
+        // which would drain the prefetch before the tile is computed (seen in the ISA, round 1).  In this order the DMA
+        // flies under the 32 MFMAs of the tile.
+        bf16x8_t af[2][4], bfr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(ldsA, wm * 64 + i * 16, ks, lane);
+            for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<TA>(ldsA, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(ldsB, wn * 64 + j * 16, ks, lane);
+            for (int j = 0; j < 4; ++j) bfr[ks][j] = read_frag<TB>(ldsB, wn * 64 + j * 16, ks, lane);
+        }
+        if (DMA) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+                stage_tile<TA>(rA, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, nxt, wave, lane);
+                stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, nxt + TILE_BYTES, wave, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
             if (TA == 1 && do_cs) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], ones, acc_cs[i], 0, 0, 0);
             }
         }
-        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DMA) {
+            // keep the (register-only) MFMAs above the wait: hipcc otherwise sinks them below the barrier and the DMA
+            // latency is exposed again (guide rule 18)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     }
 
