@@ -827,11 +827,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const int vec_arg = noepi ? 9 : (vec ? 1 : 0);
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
-        // staging choice (tools/gemm_bench.py, random data, ViT-B bs 12): LDS-DMA + two stages wins on long K and on every
-        // K-major operand (wgrad 500 vs 347 TFLOP/s, fc2 651 vs 557); register staging + 3 blocks/CU wins on the short-K
-        // NT forward GEMMs with heavy epilogues (fc1+GELU 460 vs 345).  VPU_GEMM_DMA=0/1 forces one path.
+        // staging: LDS-DMA + two stages (fragment reads -> DMA of the next tile -> MFMAs) is the default; it beats register
+        // staging on every ViT-B shape once the DMA is no longer drained by the compiler's vmcnt(0) (tools/gemm_bench.py:
+        // qkv fwd 599 vs 503, fc2 fwd 803 vs 692, wgrad 576 vs 347 TFLOP/s).  VPU_GEMM_DMA=0 selects register staging.
         static const int force_dma = [] { const char* e = getenv("VPU_GEMM_DMA"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-        const bool use_dma = force_dma >= 0 ? force_dma == 1 : !(key == 0 && d->K <= 1024);
+        const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
         if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); \
