@@ -175,9 +175,9 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, 
 //     (~1.8 MB for fc1 at bs 12) stay resident in the XCD's L2 while each B (weight) tile is fetched once per chunk.
 //     With the N-fastest order every row-panel re-streamed the whole weight (4.7 MB > L2): L2 hit rate 65 %,
 //     fabric fetch 160 MB for 19 MB of unique inputs (rocprofv3 TCC_HIT/MISS, FETCH_SIZE, round 1).
-__device__ __forceinline__ void tile_coords(int tiles_n, int& tile_m, int& tile_n) {
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+__device__ __forceinline__ void tile_coords(int bid, int nwg, int tiles_n, int& tile_m, int& tile_n) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tiles_m = nwg / tiles_n;
     const int cm = (tiles_m + 7) >> 3;
     const int chunk = v / (cm * tiles_n), rem = v - chunk * (cm * tiles_n);
@@ -303,20 +303,29 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
 // DMA = true : LDS-DMA staging, two 32-KiB stages, one barrier per K-tile (kept selectable: VPU_GEMM_DMA=1).
 template <int TA, int TB, bool DMA>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
-                                                        const int kchunk, float* __restrict__ ws, const int vec) {
+                                                        const int kchunk, float* __restrict__ ws, const int vec,
+                                                        const int tiles_m_arg, const int nbatch) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 32 KiB (register staging) or 64 KiB (DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    // PERSISTENT tile loop: at most two workgroups per CU walk the (tile, split-K slice, batch) work list.  A workgroup
+    // that exits holds its CU slot until its stores are acknowledged and its successor pays launch + first-tile latency;
+    // at K = 768 that bubble was 30-45 % of a tile's life (round-1 measurement: main loop 880 vs 600 TFLOP/s end to end).
+    const int ntiles = tiles_n * tiles_m_arg;
+    const int total_work = ntiles * splitk * nbatch;
+    for (int work = blockIdx.x; work < total_work; work += gridDim.x) {
+    const int tile_lin = work % ntiles, rest = work / ntiles;
+    const int split = rest % splitk, z = rest / splitk;
     int tile_m, tile_n;
-    tile_coords(tiles_n, tile_m, tile_n);
+    tile_coords(tile_lin, ntiles, tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
+    const int zo = z / p.inner, zi = z % p.inner;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
     const int64_t coff = zo * p.sCo + zi * p.sCi;
     const int64_t roff = zo * p.sRo + zi * p.sRi;
-    const int kbeg = blockIdx.y * kchunk;
+    const int kbeg = split * kchunk;
     const int kend = (kbeg + kchunk < p.K) ? kbeg + kchunk : p.K;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
@@ -419,13 +428,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
 #pragma unroll
             for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
-        return;
+        continue;
     }
     // ---- epilogue: transpose the accumulators through LDS so that every lane owns 8 consecutive columns of one row
     // and all global accesses are 16-byte vectors.  Two passes of 32 rows per wave (8 KiB of fp32 per wave each).
     const int fr = lane & 15, fq = lane >> 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
-    float* wsz = ws ? ws + ((int64_t)z * splitk + blockIdx.y) * (int64_t)p.M * p.N : nullptr;
+    float* wsz = ws ? ws + ((int64_t)z * splitk + split) * (int64_t)p.M * p.N : nullptr;
     if (TA == 1 && p.colsum != nullptr && tile_n == 0) {  // block-uniform condition
         float* red = reinterpret_cast<float*>(lds);
         if (do_cs && fr == 0) {
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
         __syncthreads();
         if (tid < 128 && m0 + tid < p.M) {
             const float t = red[tid];
-            if (splitk > 1) ws[(int64_t)gridDim.z * splitk * p.M * p.N + ((int64_t)z * splitk + blockIdx.y) * p.M + m0 + tid] = t;
+            if (splitk > 1) ws[(int64_t)nbatch * splitk * p.M * p.N + ((int64_t)z * splitk + split) * p.M + m0 + tid] = t;
             else p.colsum[m0 + tid] += t;
         }
         __syncthreads();
@@ -477,6 +486,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
         }
         __syncthreads();
     }
+    }  // persistent work loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int tile_m, tile_n;
-    tile_coords(tiles_n, tile_m, tile_n);
+    tile_coords(blockIdx.x, gridDim.x, tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM2, n0 = tile_n * BN;
     const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
@@ -827,6 +837,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const int vec_arg = noepi ? 9 : (vec ? 1 : 0);
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
+        // persistent launch of the 128x128 kernel: at most VPU_GEMM_PERSIST (default 2 per CU = 512) workgroups walk the
+        // (tile, split-K slice, batch) list
+        const int64_t total_work = (int64_t)tiles_m * tiles_n * splitk * d->batch;
+        static const int persist_cap = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 512; }();
+        dim3 pgrid((unsigned)(total_work < persist_cap ? total_work : persist_cap), 1, 1);
         // staging: LDS-DMA + two stages (fragment reads -> DMA of the next tile -> MFMAs) is the default; it beats register
         // staging on every ViT-B shape once the DMA is no longer drained by the compiler's vmcnt(0) (tools/gemm_bench.py:
         // qkv fwd 599 vs 503, fc2 fwd 803 vs 692, wgrad 576 vs 347 TFLOP/s).  VPU_GEMM_DMA=0 selects register staging.
@@ -834,8 +849,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
-        if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<grid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); \
-        else gemm_bf16_kernel<TA_, TB_, false><<<grid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg);       \
+        if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch); \
+        else gemm_bf16_kernel<TA_, TB_, false><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
     } while (0)
         if (big) {
             static bool attr_done = false;
