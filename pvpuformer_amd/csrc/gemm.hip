@@ -301,8 +301,10 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
 // the slices in a fixed order (deterministic) and applies the epilogue.
 // DMA = false: register staging, one 32-KiB LDS stage, ~3 blocks per CU (default: measured faster at this tile size).
 // DMA = true : LDS-DMA staging, two 32-KiB stages, one barrier per K-tile (kept selectable: VPU_GEMM_DMA=1).
-template <int TA, int TB, bool DMA>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
+// CS: with the fused bias-gradient column sums (only instantiated for TA = 1); kept out of the plain kernels so that they
+// do not carry its 16 accumulators + ones fragment.  __launch_bounds__(256, 2): two workgroups per CU.
+template <int TA, int TB, bool DMA, bool CS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
                                                         const int kchunk, float* __restrict__ ws, const int vec,
                                                         const int tiles_m_arg, const int nbatch) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 32 KiB (register staging) or 64 KiB (DMA)
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // fused bias gradient (weight-gradient form, A = dY K-major): colsum[m] += sum_k A[m][k] as one extra MFMA per
     // A fragment against a fragment that is 1 in output column 0 -- only the wn == 0 waves of the tile_n == 0 blocks.
-    const bool do_cs = TA == 1 && p.colsum != nullptr && tile_n == 0 && wn == 0;
+    const bool do_cs = CS && TA == 1 && p.colsum != nullptr && tile_n == 0 && wn == 0;
     f32x4_t acc_cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-            if (TA == 1 && do_cs) {
+            if (CS && TA == 1 && do_cs) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], ones, acc_cs[i], 0, 0, 0);
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const vpu_gemm_desc p, c
     const int fr = lane & 15, fq = lane >> 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
     float* wsz = ws ? ws + ((int64_t)z * splitk + split) * (int64_t)p.M * p.N : nullptr;
-    if (TA == 1 && p.colsum != nullptr && tile_n == 0) {  // block-uniform condition
+    if (CS && TA == 1 && p.colsum != nullptr && tile_n == 0) {  // block-uniform condition
         float* red = reinterpret_cast<float*>(lds);
         if (do_cs && fr == 0) {
 #pragma unroll
@@ -849,8 +851,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
-        if (use_dma) gemm_bf16_kernel<TA_, TB_, true><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch); \
-        else gemm_bf16_kernel<TA_, TB_, false><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
+        if (use_dma) gemm_bf16_kernel<TA_, TB_, true, false><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch); \
+        else gemm_bf16_kernel<TA_, TB_, false, false><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
     } while (0)
         if (big) {
             static bool attr_done = false;
@@ -870,6 +872,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 default: gemm_bf16_big_kernel<1, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
             }
         } else {
+            if (d->colsum) {  // weight-gradient GEMM with the fused bias gradient (always transA = transB = 1 in the engine)
+                if (key == 3) gemm_bf16_kernel<1, 1, true, true><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+                else gemm_bf16_kernel<1, 0, true, true><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+            } else
             switch (key) {
                 case 0: VPU_LAUNCH(0, 0); break;
                 case 1: VPU_LAUNCH(0, 1); break;
