@@ -217,15 +217,20 @@ __device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, int64_t cof
 // `pre` (optional): the 8 bf16 of the residual (VPU_EPI_RESID) or of aux (DGELU/DRELU/MULAUX) for this position, fetched
 // before the main loop so that their HBM latency is hidden behind the MFMA work.
 __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int m, int n,
-                                                float (&v)[8], const uint4* pre = nullptr) {
+                                                float (&v)[8], const uint4* pre = nullptr, const float* bias8 = nullptr) {
     const int flags = p.flags;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
     if (flags & VPU_EPI_BIAS) {
-        float b[8];
-        load8(p.bias + n, b);
+        if (bias8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += b[j];
+            for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+        } else {
+            float b[8];
+            load8(p.bias + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+        }
     }
     const int64_t ci = coff + (int64_t)m * p.ldc + n;
     if (flags & VPU_EPI_PREACT) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, v);
@@ -332,14 +337,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
 
-    // residual / aux tile of this wave, requested now so that it is in registers when the epilogue needs it
-    // (measured: requesting the tile up front costs more than it hides at 2-3 blocks per CU -- disabled)
-    const bool use_pre = false && vec == 1 && splitk == 1 &&
-                         (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
-                         !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
-    uint4 pre[2][4];
-    if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
-
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -432,6 +429,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
         if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
         continue;
     }
+    // Everything the epilogue READS from global memory is requested here, before its first store: vmcnt counts stores
+    // too on CDNA4, so a load issued after a store makes the wave wait for that store's round trip (the ISA of the first
+    // version had 8 such serialised waits per tile: 12-30 us per GEMM).  A lane always handles the same 8 columns.
+    const bool use_pre = vec == 1 && splitk == 1 &&
+                         (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
+                         !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
+    uint4 pre[2][4];
+    if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
+    float bias8[8];
+    const int ncol = n0 + wn * 64 + (lane & 7) * 8;
+    const bool use_bias8 = vec == 1 && splitk == 1 && (p.flags & VPU_EPI_BIAS) && ncol + 8 <= p.N;
+    if (use_bias8) load8(p.bias + ncol, bias8);
     // ---- epilogue: transpose the accumulators through LDS so that every lane owns 8 consecutive columns of one row
     // and all global accesses are 16-byte vectors.  Two passes of 32 rows per wave (8 KiB of fp32 per wave each).
     const int fr = lane & 15, fq = lane >> 4;
@@ -479,8 +488,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                     if ((p.N & 3) == 0 && n + 8 <= p.N) store8(o, v);
                     else
                         for (int j = 0; j < 8 && n + j < p.N; ++j) o[j] = v[j];
+                } else if (vec == 8) {   // diagnostic: LDS transpose + math, no global store
+                    float tsum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tsum += v[j];
+                    if (tsum == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = tsum;
                 } else if (vec && n + 8 <= p.N) {
-                    epilogue_store8(p, coff, roff, m, n, v, use_pre ? &pre[pass][t] : nullptr);
+                    epilogue_store8(p, coff, roff, m, n, v, use_pre ? &pre[pass][t] : nullptr, use_bias8 ? bias8 : nullptr);
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
                 }
@@ -836,7 +850,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         }
         static const bool noepi = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
-        const int vec_arg = noepi ? 9 : (vec ? 1 : 0);
+        static const bool nostore = [] { const char* e = getenv("VPU_GEMM_NOSTORE"); return e && e[0] == '1'; }();
+        const int vec_arg = noepi ? 9 : (nostore ? 8 : (vec ? 1 : 0));
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
         // persistent launch of the 128x128 kernel: at most VPU_GEMM_PERSIST (default 2 per CU = 512) workgroups walk the
