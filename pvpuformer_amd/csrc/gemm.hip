@@ -216,15 +216,23 @@ __device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, int64_t cof
 }
 // `pre` (optional): the 8 bf16 of the residual (VPU_EPI_RESID) or of aux (DGELU/DRELU/MULAUX) for this position, fetched
 // before the main loop so that their HBM latency is hidden behind the MFMA work.
+// (everything by value / whole-array reference: a pointer to one element of a local array forces it into scratch)
+struct EpiPre {
+    bool has_pre, has_bias;
+    uint4 pre;        // 8 bf16 of resid or aux for this position
+    float bias[8];
+};
 __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int m, int n,
-                                                float (&v)[8], const uint4* pre = nullptr, const float* bias8 = nullptr) {
+                                                float (&v)[8], const EpiPre& e) {
     const int flags = p.flags;
+    const bool has_pre = e.has_pre;
+    const uint4* pre = &e.pre;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
     if (flags & VPU_EPI_BIAS) {
-        if (bias8) {
+        if (e.has_bias) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+            for (int j = 0; j < 8; ++j) v[j] += e.bias[j];
         } else {
             float b[8];
             load8(p.bias + n, b);
@@ -259,7 +267,7 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
     }
     if (flags & (VPU_EPI_DGELU | VPU_EPI_DRELU | VPU_EPI_MULAUX)) {
         float a[8];
-        if (pre) unpack8(*pre, a);
+        if (has_pre) unpack8(*pre, a);
         else load8(reinterpret_cast<const bf16_t*>(p.aux) + coff + (int64_t)m * p.ldaux + n, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -267,7 +275,7 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
     }
     if (flags & VPU_EPI_RESID) {
         float r[8];
-        if (pre) unpack8(*pre, r);
+        if (has_pre) unpack8(*pre, r);
         else {
             const int64_t ri = p.resid_period > 0 ? (int64_t)(m % p.resid_period) * p.ldr + n
                                                   : roff + (int64_t)m * p.ldr + n;
@@ -436,8 +444,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                          (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
                          !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
     uint4 pre[2][4];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_) pre[a_][b_] = make_uint4(0, 0, 0, 0);
     if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
-    float bias8[8];
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int ncol = n0 + wn * 64 + (lane & 7) * 8;
     const bool use_bias8 = vec == 1 && splitk == 1 && (p.flags & VPU_EPI_BIAS) && ncol + 8 <= p.N;
     if (use_bias8) load8(p.bias + ncol, bias8);
@@ -494,7 +506,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                     for (int j = 0; j < 8; ++j) tsum += v[j];
                     if (tsum == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = tsum;
                 } else if (vec && n + 8 <= p.N) {
-                    epilogue_store8(p, coff, roff, m, n, v, use_pre ? &pre[pass][t] : nullptr, use_bias8 ? bias8 : nullptr);
+                    {
+                        EpiPre e;
+                        e.has_pre = use_pre; e.has_bias = use_bias8; e.pre = pre[pass][t];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) e.bias[j] = bias8[j];
+                        epilogue_store8(p, coff, roff, m, n, v, e);
+                    }
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
                 }
@@ -660,7 +678,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
                     else
                         for (int j = 0; j < 8 && n + j < p.N; ++j) o[j] = v[j];
                 } else if (vec && n + 8 <= p.N) {
-                    epilogue_store8(p, coff, roff, m, n, v, use_pre ? &pre[pass][t] : nullptr);
+                    {
+                        EpiPre e;
+                        e.has_pre = false; e.has_bias = false; e.pre = make_uint4(0, 0, 0, 0);
+                        epilogue_store8(p, coff, roff, m, n, v, e);
+                    }
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
                 }
