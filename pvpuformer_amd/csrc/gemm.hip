@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the wave that holds its fragments owns the MFMA pipe; the co-resident workgroup's wave reads / waits in the gaps
+        // (+3-5 % on the main loop, tools/gemm_bench.py with VPU_GEMM_NOEPI=1)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                     acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], ones, acc_cs[i], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (DMA) {
             // keep the (register-only) MFMAs above the wait: hipcc otherwise sinks them below the barrier and the DMA
             // latency is exposed again (guide rule 18)

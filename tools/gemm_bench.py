@@ -25,13 +25,27 @@ SHAPES = [  # name, tA, tB, M, N, K, flags
     ("proj wgrad", 1, 1, 768, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
     ("square 4096", 0, 0, 4096, 4096, 4096, 0),
 ]
+NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
+    ("tok lin 768", 0, 0, 576, 768, 768, ops.EPI_BIAS),
+    ("tok lin 384", 0, 0, 576, 384, 768, ops.EPI_BIAS),
+    ("tok out 384", 0, 0, 576, 768, 384, ops.EPI_BIAS | ops.EPI_RESID),
+    ("tok dgrad", 0, 1, 576, 768, 768, 0),
+    ("tok wgrad", 1, 1, 768, 768, 576, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("img kproj 384", 0, 0, M, 384, 768, ops.EPI_BIAS),
+    ("img kproj dgrad", 0, 1, M, 768, 384, 0),
+    ("img kproj wgrad", 1, 1, 384, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("img out 384", 0, 0, M, 768, 384, ops.EPI_BIAS | ops.EPI_RESID),
+    ("fpn wgrad", 1, 1, 256, 1024, 150528, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("head wgrad", 1, 1, 256, 128, 150528, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+]
 
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     dev = "cuda"
     tot_t, tot_f = 0.0, 0.0
-    for name, tA, tB, m, n, k, flags in SHAPES:
+    with_torch = os.environ.get("GEMM_BENCH_TORCH", "0") == "1"
+    for name, tA, tB, m, n, k, flags in SHAPES + NECK:
         A = (torch.rand((k, m) if tA else (m, k), device=dev) - 0.5).to(torch.bfloat16)
         Bm = (torch.rand((k, n) if tB else (n, k), device=dev) - 0.5).to(torch.bfloat16)
         out_f32 = bool(flags & ops.EPI_OUT_F32)
@@ -52,9 +66,22 @@ def main():
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
         fl = 2.0 * m * n * k
-        if "square" not in name:
+        if (name, tA, tB, m, n, k, flags) in SHAPES and "square" not in name:
             tot_t += t; tot_f += fl
-        print(f"{name:16s} tA={tA} tB={tB} M={m:6d} N={n:5d} K={k:5d}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
+        extra = ""
+        if with_torch:   # library GEMM (hipBLASLt/rocBLAS through torch.matmul) on the same operands, no epilogue: calibration only
+            a2 = A.t() if tA else A
+            b2 = Bm if tB else Bm.t()
+            for _ in range(3):
+                torch.matmul(a2, b2)
+            e0.record()
+            for _ in range(reps):
+                torch.matmul(a2, b2)
+            e1.record()
+            torch.cuda.synchronize()
+            tt = e0.elapsed_time(e1) * 1e-3 / reps
+            extra = f"   | torch.matmul {tt * 1e6:8.1f} us {fl / tt / 1e12:7.1f} TFLOP/s"
+        print(f"{name:16s} tA={tA} tB={tB} M={m:6d} N={n:5d} K={k:5d}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s{extra}")
     print(f"{'block total':16s} {tot_t * 1e6:8.1f} us  {tot_f / tot_t / 1e12:7.1f} TFLOP/s (one ViT block's 12 GEMMs)")
 
 
