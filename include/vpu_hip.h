@@ -97,7 +97,7 @@ int vpu_l2norm_fwd(const void* x, void* y, float* inv, int64_t rows, int32_t C, 
 int vpu_l2norm_bwd(const void* dy, const void* y, const float* inv, void* dx, int64_t rows, int32_t C,
                    int32_t dtype, void* stream);
 
-/* Fused (flash-style) self-attention of the ViT blocks, bf16, head dim 32 or 64 (models_vit.py:43-52): q,k,v are
+/* Fused (flash-style) self-attention of the ViT blocks, bf16 (models_vit.py:43-52): q,k,v are
  * column slices of the fused qkv activation (row stride ld, head h at column h*hd); out [rows][ldo]; nb independent
  * runs of n consecutive rows (batch x windows); lse fp32 [nb*H][n] is saved for the backward. */
 int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H, int32_t n,
@@ -107,6 +107,14 @@ int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
 int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                  float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H, int32_t n, int32_t hd, int32_t ld,
                  int32_t ldo, int32_t ldg, float scale, void* stream);
+/* General form (the DMA neck's Attention, transformer.py:484-521): queries are rows [b*nq, (b+1)*nq) of a matrix with
+ * row stride ldq, keys / values rows [b*nk, (b+1)*nk) of matrices with row stride ldk; hd % 16 == 0, hd <= 128;
+ * lse / delta fp32 [nb*H][nq]; dq has row stride ldgq, dk / dv ldgk. */
+int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H, int32_t nq,
+                  int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream);
+int vpu_xattn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                  float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H, int32_t nq, int32_t nk, int32_t hd,
+                  int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq, int32_t ldgk, float scale, void* stream);
 
 /* ---- element-wise ---- */
 /* out[i] = a[i] + b[i % period_b]  (with_pos_embed, transformer.py:320, :430) */

@@ -1,12 +1,16 @@
-// Fused (flash-style) multi-head self-attention for the MAE-ViT blocks, bf16, head dim 32 or 64, gfx950.
+// Fused (flash-style) multi-head attention, bf16, gfx950: the self-attention of the MAE-ViT blocks (head dim 32 / 64)
+// and the prompt<->image attention of the DMA neck (transformer.py:484-521: 48 prompt tokens x 784 image tokens, head
+// dim 48 or 96, query and key/value rows in different matrices).
 //
 // Replaces  attn = softmax(q k^T * scale); x = attn v   (isegm/model/modeling/models_vit.py:43-52) and its autograd
 // backward without materialising the [B, heads, n, n] score / probability tensors (354 MB fp32 per global block at
 // bs 12 in the unfused path).  Window attention (models_vit.py:225-255) is the same kernel with n = 196: tokens are
 // kept in window order, so a (batch, window) pair is a contiguous run of rows.
 //
-// Layout: q, k, v are column slices of the fused qkv activation [rows, ld] (head h at column h*HD of each slice);
-// o / d_o are [rows, ldo].  One "batch" entry = n consecutive rows.
+// Layout: q is a column slice of a [*, ldq] matrix, k and v of [*, ldk] matrices (head h at column h*hd of each slice);
+// o / d_o are [*, ldo].  Batch entry b = rows [b*nq, (b+1)*nq) of q/o and rows [b*nk, (b+1)*nk) of k/v.
+// The kernels are instantiated for HD = 32, 64, 128 columns of LDS image; a head dim of 48 / 96 runs in the 64 / 128
+// instantiation with the columns >= hd staged as zeros (hd % 16 == 0).
 //
 // MFMA plan (v_mfma_f32_16x16x32_bf16; D[row = 4*(lane>>4)+r][col = lane&15]):
 //   forward, per wave 16 queries:  S^T[key][q] = K_tile . Q^T  puts the query on the lane, so the softmax statistics
@@ -35,12 +39,13 @@ template <int HD> __device__ __forceinline__ int tr_off(int row, int unit) {
 
 // stage rows [r0, r0+CH) x HD columns of a [*, ld] matrix into an LDS image (rows >= n are zero)
 template <int HD, bool TR>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int ld, int r0, int n, char* lds, int tid) {
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int ld, int r0, int n, char* lds, int tid,
+                                           int hd) {
     constexpr int CPR = HD / 8;  // 16-B chunks per row
     for (int c = tid; c < CH * CPR; c += 256) {
         const int row = c / CPR, ch = c % CPR;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + row < n) v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
+        if (r0 + row < n && ch * 8 < hd) v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
         const int off = TR ? tr_off<HD>(row, ch * 2) : rc_off<HD>(row, ch);
         *reinterpret_cast<uint4*>(lds + off) = v;
     }
@@ -65,12 +70,13 @@ template <int HD> __device__ __forceinline__ bf16x8_t frag_tr_perm(const char* l
 // 16 rows x HD of a global matrix as MFMA B fragments (col = row index on the lane), zero beyond n
 template <int HD>
 __device__ __forceinline__ void load_rows_as_b(const bf16_t* __restrict__ base, int ld, int row0, int n, int lane,
-                                               bf16x8_t (&f)[HD / 32]) {
+                                               bf16x8_t (&f)[HD / 32], int hd) {
     const int row = row0 + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < n) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + ks * 32 + (lane >> 4) * 8);
+        const int col = ks * 32 + (lane >> 4) * 8;
+        if (row < n && col < hd) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + col);
         f[ks] = __builtin_bit_cast(bf16x8_t, v);
     }
 }
@@ -86,7 +92,9 @@ struct AttnArgs {
     const bf16_t *o, *d_o;
     bf16_t *out, *dq, *dk, *dv;
     float *lse, *delta;
-    int n, H, ld, ldo, ldg;    // ld: row stride of q/k/v; ldo: of o/d_o/out; ldg: of dq/dk/dv
+    int nq, nk, H, hd;         // hd: real head dim (<= HD of the instantiation)
+    int ldq, ldk, ldo;         // row strides of q, of k/v, of o/d_o/out
+    int ldgq, ldgk;            // row strides of dq and of dk/dv
     float scale;
 };
 
@@ -96,22 +104,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char ldsK[CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsV[CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, n = a.n;
-    const int64_t rb = (int64_t)bw * n;
-    const bf16_t* q = a.q + rb * a.ld + h * HD;
-    const bf16_t* k = a.k + rb * a.ld + h * HD;
-    const bf16_t* v = a.v + rb * a.ld + h * HD;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const bf16_t* q = a.q + rbq * a.ldq + h * hd;
+    const bf16_t* k = a.k + rbk * a.ldk + h * hd;
+    const bf16_t* v = a.v + rbk * a.ldk + h * hd;
     const int q0 = blockIdx.x * 64 + wave * 16;
     bf16x8_t qf[HD / 32];
-    load_rows_as_b<HD>(q, a.ld, q0, n, lane, qf);
+    load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
     float m = -INFINITY, l = 0.f;
     f32x4_t acc[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < n; kc += CH) {
+    for (int kc = 0; kc < nk; kc += CH) {
         __syncthreads();
-        stage_rows<HD, false>(k, a.ld, kc, n, ldsK, tid);
-        stage_rows<HD, true>(v, a.ld, kc, n, ldsV, tid);
+        stage_rows<HD, false>(k, a.ldk, kc, nk, ldsK, tid, hd);
+        stage_rows<HD, true>(v, a.ldk, kc, nk, ldsV, tid, hd);
         __syncthreads();
         f32x4_t s[2];
         float mx = m;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsK, 16 * t, ks, lane), qf[ks], s[t], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = (kc + 16 * t + 4 * g + r < n) ? s[t][r] * a.scale : -INFINITY;
+                const float x = (kc + 16 * t + 4 * g + r < nk) ? s[t][r] * a.scale : -INFINITY;
                 s[t][r] = x;
                 mx = fmaxf(mx, x);
             }
@@ -152,15 +160,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         }
     }
     const float il = 1.0f / l;
-    if (g == 0 && q0 + c < n) a.lse[(int64_t)bh * n + q0 + c] = m + __logf(l);
+    if (g == 0 && q0 + c < nq) a.lse[(int64_t)bh * nq + q0 + c] = m + __logf(l);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float s1 = __shfl(il, 4 * g + r, 64);
         const int qq = q0 + 4 * g + r;
-        if (qq < n) {
-            bf16_t* orow = a.out + (rb + qq) * a.ldo + h * HD;
+        if (qq < nq) {
+            bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) orow[dt * 16 + c] = (bf16_t)(acc[dt][r] * s1);
+            for (int dt = 0; dt < HD / 16; ++dt)
+                if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[dt][r] * s1);
         }
     }
 }
@@ -170,12 +179,13 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int qq = (int)(i % a.n);
-    const int bh = (int)(i / a.n), bw = bh / a.H, h = bh % a.H;
-    const int64_t off = ((int64_t)bw * a.n + qq) * a.ldo + h * HD;
+    const int qq = (int)(i % a.nq);
+    const int bh = (int)(i / a.nq), bw = bh / a.H, h = bh % a.H;
+    const int64_t off = ((int64_t)bw * a.nq + qq) * a.ldo + h * a.hd;
     float s = 0.f;
 #pragma unroll
     for (int ch = 0; ch < HD / 8; ++ch) {
+        if (ch * 8 >= a.hd) break;
         float x[8], y[8];
         load8(a.d_o + off + ch * 8, x);
         load8(a.o + off + ch * 8, y);
@@ -191,28 +201,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char ldsQr[CH * HD * 2], ldsQt[CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsOr[CH * HD * 2], ldsOt[CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, n = a.n;
-    const int64_t rb = (int64_t)bw * n;
-    const bf16_t* q = a.q + rb * a.ld + h * HD;
-    const bf16_t* k = a.k + rb * a.ld + h * HD;
-    const bf16_t* v = a.v + rb * a.ld + h * HD;
-    const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
-    const float* lse = a.lse + (int64_t)bh * n;
-    const float* dl = a.delta + (int64_t)bh * n;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const bf16_t* q = a.q + rbq * a.ldq + h * hd;
+    const bf16_t* k = a.k + rbk * a.ldk + h * hd;
+    const bf16_t* v = a.v + rbk * a.ldk + h * hd;
+    const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
+    const float* lse = a.lse + (int64_t)bh * nq;
+    const float* dl = a.delta + (int64_t)bh * nq;
     const int key0 = blockIdx.x * 64 + wave * 16;
-    const bool key_ok = key0 + c < n;
+    const bool key_ok = key0 + c < nk;
     bf16x8_t kf[HD / 32], vf[HD / 32];
-    load_rows_as_b<HD>(k, a.ld, key0, n, lane, kf);
-    load_rows_as_b<HD>(v, a.ld, key0, n, lane, vf);
+    load_rows_as_b<HD>(k, a.ldk, key0, nk, lane, kf, hd);
+    load_rows_as_b<HD>(v, a.ldk, key0, nk, lane, vf, hd);
     f32x4_t adk[HD / 16], adv[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
-    for (int qc = 0; qc < n; qc += CH) {
+    for (int qc = 0; qc < nq; qc += CH) {
         __syncthreads();
-        stage_rows<HD, false>(q, a.ld, qc, n, ldsQr, tid);
-        stage_rows<HD, true>(q, a.ld, qc, n, ldsQt, tid);
-        stage_rows<HD, false>(d_o, a.ldo, qc, n, ldsOr, tid);
-        stage_rows<HD, true>(d_o, a.ldo, qc, n, ldsOt, tid);
+        stage_rows<HD, false>(q, a.ldq, qc, nq, ldsQr, tid, hd);
+        stage_rows<HD, true>(q, a.ldq, qc, nq, ldsQt, tid, hd);
+        stage_rows<HD, false>(d_o, a.ldo, qc, nq, ldsOr, tid, hd);
+        stage_rows<HD, true>(d_o, a.ldo, qc, nq, ldsOt, tid, hd);
         __syncthreads();
         f32x4_t P[2], dS[2];
 #pragma unroll
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
             for (int r = 0; r < 4; ++r) {   // element [query = qc+16t+4g+r][key = key0+c]
                 const int qq = qc + 16 * t + 4 * g + r;
                 float p = 0.f, ds = 0.f;
-                if (qq < n && key_ok) {
+                if (qq < nq && key_ok) {
                     p = __expf(s[r] * a.scale - lse[qq]);
                     ds = p * (dp[r] - dl[qq]) * a.scale;
                 }
@@ -244,14 +254,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int kk = key0 + 4 * g + r;
-        if (kk < n) {
-            bf16_t* kr = a.dk + (rb + kk) * a.ldg + h * HD;
-            bf16_t* vr = a.dv + (rb + kk) * a.ldg + h * HD;
+        if (kk < nk) {
+            bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd;
+            bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd;
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) {
-                kr[dt * 16 + c] = (bf16_t)adk[dt][r];
-                vr[dt * 16 + c] = (bf16_t)adv[dt][r];
-            }
+            for (int dt = 0; dt < HD / 16; ++dt)
+                if (dt * 16 < hd) {
+                    kr[dt * 16 + c] = (bf16_t)adk[dt][r];
+                    vr[dt * 16 + c] = (bf16_t)adv[dt][r];
+                }
         }
     }
 }
@@ -261,27 +272,27 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char ldsKr[CH * HD * 2], ldsKt[CH * HD * 2], ldsVr[CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, n = a.n;
-    const int64_t rb = (int64_t)bw * n;
-    const bf16_t* q = a.q + rb * a.ld + h * HD;
-    const bf16_t* k = a.k + rb * a.ld + h * HD;
-    const bf16_t* v = a.v + rb * a.ld + h * HD;
-    const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const bf16_t* q = a.q + rbq * a.ldq + h * hd;
+    const bf16_t* k = a.k + rbk * a.ldk + h * hd;
+    const bf16_t* v = a.v + rbk * a.ldk + h * hd;
+    const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
     const int q0 = blockIdx.x * 64 + wave * 16;
-    const bool q_ok = q0 + c < n;
-    const float lse_q = q_ok ? a.lse[(int64_t)bh * n + q0 + c] : 0.f;
-    const float dl_q = q_ok ? a.delta[(int64_t)bh * n + q0 + c] : 0.f;
+    const bool q_ok = q0 + c < nq;
+    const float lse_q = q_ok ? a.lse[(int64_t)bh * nq + q0 + c] : 0.f;
+    const float dl_q = q_ok ? a.delta[(int64_t)bh * nq + q0 + c] : 0.f;
     bf16x8_t qf[HD / 32], dof[HD / 32];
-    load_rows_as_b<HD>(q, a.ld, q0, n, lane, qf);
-    load_rows_as_b<HD>(d_o, a.ldo, q0, n, lane, dof);
+    load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
+    load_rows_as_b<HD>(d_o, a.ldo, q0, nq, lane, dof, hd);
     f32x4_t adq[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < n; kc += CH) {
+    for (int kc = 0; kc < nk; kc += CH) {
         __syncthreads();
-        stage_rows<HD, false>(k, a.ld, kc, n, ldsKr, tid);
-        stage_rows<HD, true>(k, a.ld, kc, n, ldsKt, tid);
-        stage_rows<HD, false>(v, a.ld, kc, n, ldsVr, tid);
+        stage_rows<HD, false>(k, a.ldk, kc, nk, ldsKr, tid, hd);
+        stage_rows<HD, true>(k, a.ldk, kc, nk, ldsKt, tid, hd);
+        stage_rows<HD, false>(v, a.ldk, kc, nk, ldsVr, tid, hd);
         __syncthreads();
         f32x4_t dS[2];
 #pragma unroll
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {   // element [key = kc+16t+4g+r][query = q0+c]
                 float ds = 0.f;
-                if (q_ok && kc + 16 * t + 4 * g + r < n)
+                if (q_ok && kc + 16 * t + 4 * g + r < nk)
                     ds = __expf(s[r] * a.scale - lse_q) * (dp[r] - dl_q) * a.scale;
                 dS[t][r] = ds;
             }
@@ -308,59 +319,91 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qq = q0 + 4 * g + r;
-        if (qq < n) {
-            bf16_t* qr = a.dq + (rb + qq) * a.ldg + h * HD;
+        if (qq < nq) {
+            bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd;
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) qr[dt * 16 + c] = (bf16_t)adq[dt][r];
+            for (int dt = 0; dt < HD / 16; ++dt)
+                if (dt * 16 < hd) qr[dt * 16 + c] = (bf16_t)adq[dt][r];
         }
     }
 }
 
 inline bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int hd_image(int hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : 128); }
+
 }  // namespace
 
-extern "C" int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
-                            int32_t n, int32_t hd, int32_t ld, int32_t ldo, float scale, void* stream) {
+extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
+                             int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                             void* stream) {
     vpu_clear_stale_error();
-    if ((hd != 32 && hd != 64) || ld % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || nb <= 0 || H <= 0 || n <= 0) {
-        vpu_set_error("attn_fwd: head dim 32/64, 16-byte aligned slices, ld % 8 == 0");
+    if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || nb <= 0 ||
+        H <= 0 || nq <= 0 || nk <= 0) {
+        vpu_set_error("xattn_fwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0");
         return VPU_ERR_ARG;
     }
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
-    a.n = n; a.H = H; a.ld = ld; a.ldo = ldo; a.scale = scale;
-    dim3 grid((n + 63) / 64, nb * H);
+    a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale;
+    dim3 grid((nq + 63) / 64, nb * H);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (hd == 64) attn_fwd_kernel<64><<<grid, 256, 0, s>>>(a);
-    else attn_fwd_kernel<32><<<grid, 256, 0, s>>>(a);
-    return vpu_check_launch("vpu_attn_fwd");
+    switch (hd_image(hd)) {
+        case 32: attn_fwd_kernel<32><<<grid, 256, 0, s>>>(a); break;
+        case 64: attn_fwd_kernel<64><<<grid, 256, 0, s>>>(a); break;
+        default: attn_fwd_kernel<128><<<grid, 256, 0, s>>>(a); break;
+    }
+    return vpu_check_launch("vpu_xattn_fwd");
 }
 
-extern "C" int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                            const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
-                            int32_t n, int32_t hd, int32_t ld, int32_t ldo, int32_t ldg, float scale, void* stream) {
+extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                             const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
+                             int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq,
+                             int32_t ldgk, float scale, void* stream) {
     vpu_clear_stale_error();
-    if ((hd != 32 && hd != 64) || ld % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || !ok16(o) || !ok16(d_o)) {
-        vpu_set_error("attn_bwd: head dim 32/64, 16-byte aligned slices, ld % 8 == 0");
+    if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || !ok16(o) ||
+        !ok16(d_o) || nb <= 0 || H <= 0 || nq <= 0 || nk <= 0) {
+        vpu_set_error("xattn_bwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0");
         return VPU_ERR_ARG;
     }
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
     a.d_o = (const bf16_t*)d_o; a.lse = const_cast<float*>(lse); a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-    a.n = n; a.H = H; a.ld = ld; a.ldo = ldo; a.ldg = ldg; a.scale = scale;
+    a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
+    a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int64_t total = (int64_t)nb * H * n;
-    dim3 grid((n + 63) / 64, nb * H);
-    if (hd == 64) {
-        attn_delta_kernel<64><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a, total);
-        attn_bwd_dkdv_kernel<64><<<grid, 256, 0, s>>>(a);
-        attn_bwd_dq_kernel<64><<<grid, 256, 0, s>>>(a);
-    } else {
-        attn_delta_kernel<32><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a, total);
-        attn_bwd_dkdv_kernel<32><<<grid, 256, 0, s>>>(a);
-        attn_bwd_dq_kernel<32><<<grid, 256, 0, s>>>(a);
+    const int64_t total = (int64_t)nb * H * nq;
+    const unsigned dgrid = (unsigned)((total + 255) / 256);
+    dim3 gk((nk + 63) / 64, nb * H), gq((nq + 63) / 64, nb * H);
+    switch (hd_image(hd)) {
+        case 32:
+            attn_delta_kernel<32><<<dgrid, 256, 0, s>>>(a, total);
+            attn_bwd_dkdv_kernel<32><<<gk, 256, 0, s>>>(a);
+            attn_bwd_dq_kernel<32><<<gq, 256, 0, s>>>(a);
+            break;
+        case 64:
+            attn_delta_kernel<64><<<dgrid, 256, 0, s>>>(a, total);
+            attn_bwd_dkdv_kernel<64><<<gk, 256, 0, s>>>(a);
+            attn_bwd_dq_kernel<64><<<gq, 256, 0, s>>>(a);
+            break;
+        default:
+            attn_delta_kernel<128><<<dgrid, 256, 0, s>>>(a, total);
+            attn_bwd_dkdv_kernel<128><<<gk, 256, 0, s>>>(a);
+            attn_bwd_dq_kernel<128><<<gq, 256, 0, s>>>(a);
+            break;
     }
-    return vpu_check_launch("vpu_attn_bwd");
+    return vpu_check_launch("vpu_xattn_bwd");
+}
+
+// self-attention on a fused qkv activation: the same kernels with nq = nk and one row stride
+extern "C" int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
+                            int32_t n, int32_t hd, int32_t ld, int32_t ldo, float scale, void* stream) {
+    return vpu_xattn_fwd(q, k, v, out, lse, nb, H, n, n, hd, ld, ld, ldo, scale, stream);
+}
+
+extern "C" int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                            const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
+                            int32_t n, int32_t hd, int32_t ld, int32_t ldo, int32_t ldg, float scale, void* stream) {
+    return vpu_xattn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, n, n, hd, ld, ld, ldo, ldg, ldg, scale, stream);
 }

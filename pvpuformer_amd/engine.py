@@ -358,6 +358,23 @@ class Engine:
                              (qkv.g, 2 * D), nb, H, n, hd, 3 * D, D, 3 * D, scale)
             self.tape.append(bwd)
 
+    def cross_attention(self, Qp, Kp, Vp, O, nb, H, nq, nk, hd, ld, scale):
+        """Fused attention of the DMA neck: projected queries [nb*nq, ld], keys / values [nb*nk, ld] -> O [nb*nq, ld]
+        (bf16; the [nb, H, nq, nk] scores are never materialised)."""
+        lse = self._new(nb * H, nq, dtype=torch.float32)
+        ops.xattn_fwd(Qp.t, Kp.t, Vp.t, O.t, lse, nb, H, nq, nk, hd, ld, ld, ld, scale)
+        if self.training:
+            def bwd():
+                if O.g is None:
+                    return
+                for var in {id(Qp): Qp, id(Kp): Kp, id(Vp): Vp}.values():
+                    assert var.g is None, "attention inputs must be single-use projections"
+                    var.g = torch.empty_like(var.t)
+                delta = self._new(nb * H, nq, dtype=torch.float32)
+                ops.xattn_bwd(Qp.t, Kp.t, Vp.t, O.t, O.g, lse, delta, Qp.g, Kp.g, Vp.g, nb, H, nq, nk, hd, ld, ld, ld,
+                              ld, ld, scale)
+            self.tape.append(bwd)
+
     def add_pe(self, x, pe, n, period, pe_var=None):
         """y = x + pe (pe broadcast with ``period`` elements; transformer.py:320,430)."""
         y = Var(torch.empty_like(x.t))
@@ -380,8 +397,11 @@ class Engine:
         Kp = self.linear(xk, prefix + ".k_proj.weight", prefix + ".k_proj.bias", B * nk, internal, D)
         Vp = self.linear(xv, prefix + ".v_proj.weight", prefix + ".v_proj.bias", B * nk, internal, D)
         O = Var(self._new(B * nq, internal))
-        self.sdpa((Qp, 0, internal, nq), (Kp, 0, internal, nk), (Vp, 0, internal, nk), (O, 0, internal, nq), B, H, nq,
-                  nk, hd, 1.0 / math.sqrt(hd))
+        if self.dt == BF16 and self.use_flash and hd % 16 == 0 and hd <= 128:
+            self.cross_attention(Qp, Kp, Vp, O, B, H, nq, nk, hd, internal, 1.0 / math.sqrt(hd))
+        else:
+            self.sdpa((Qp, 0, internal, nq), (Kp, 0, internal, nk), (Vp, 0, internal, nk), (O, 0, internal, nq), B, H,
+                      nq, nk, hd, 1.0 / math.sqrt(hd))
         return self.linear(O, prefix + ".out_proj.weight", prefix + ".out_proj.bias", B * nq, D, internal, resid=resid)
 
     def groupnorm(self, x, prefix, B, HW, Cdim, gelu):

@@ -120,6 +120,16 @@ def attn_fwd(q, k, v, out, lse, nb, H, n, hd, ld, ldo, scale):
     _lib.call("vpu_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), nb, H, n, hd, ld, ldo, scale, _stream())
 
 
+def xattn_fwd(q, k, v, out, lse, nb, H, nq, nk, hd, ldq, ldk, ldo, scale):
+    _lib.call("vpu_xattn_fwd", ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), nb, H, nq, nk, hd, ldq, ldk, ldo, scale,
+              _stream())
+
+
+def xattn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale):
+    _lib.call("vpu_xattn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
+              ptr(dv), nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale, _stream())
+
+
 def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, n, hd, ld, ldo, ldg, scale):
     _lib.call("vpu_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
               ptr(dv), nb, H, n, hd, ld, ldo, ldg, scale, _stream())

@@ -575,6 +575,37 @@ def test_flash_attention_fwd_bwd(ops, hd, n, nb):
         assert (got[i] - ref_g).abs().max().item() < tol, (name, (got[i] - ref_g).abs().max().item(), tol)
 
 
+@pytest.mark.parametrize("hd,nq,nk,nb", [(96, 48, 48, 2), (48, 48, 784, 2), (48, 784, 48, 2), (48, 50, 70, 1), (16, 20, 33, 3)])
+def test_cross_attention_fwd_bwd(ops, hd, nq, nk, nb):
+    """The DMA neck's attention (transformer.py:499-521): separate query and key/value matrices, head dims 48 / 96 (run in
+    the 64 / 128-column instantiation with zero-staged padding), ragged nq / nk.  Same tolerances as the self-attention."""
+    H = 8
+    D = H * hd
+    Q = dev(rnd(nb * nq, D, seed=62, scale=1.5)).to(torch.bfloat16)
+    K = dev(rnd(nb * nk, D, seed=63, scale=1.5)).to(torch.bfloat16)
+    V = dev(rnd(nb * nk, D, seed=64, scale=1.5)).to(torch.bfloat16)
+    O = torch.zeros(nb * nq, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(nb * H, nq, device="cuda")
+    scale = hd ** -0.5
+    ops.xattn_fwd(Q, K, V, O, lse, nb, H, nq, nk, hd, D, D, D, scale)
+    q = Q.float().view(nb, nq, H, hd).transpose(1, 2).clone().requires_grad_(True)
+    k = K.float().view(nb, nk, H, hd).transpose(1, 2).clone().requires_grad_(True)
+    v = V.float().view(nb, nk, H, hd).transpose(1, 2).clone().requires_grad_(True)
+    S = (q @ k.transpose(-1, -2)) * scale
+    ref = torch.softmax(S, -1) @ v
+    torch.testing.assert_close(O.float().view(nb, nq, H, hd).transpose(1, 2), ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.view(nb, H, nq), torch.logsumexp(S, -1), atol=2e-3, rtol=1e-4)
+    dO = dev(rnd(nb * nq, D, seed=65)).to(torch.bfloat16)
+    ref.backward(dO.float().view(nb, nq, H, hd).transpose(1, 2))
+    dQ, dK, dV = torch.zeros_like(Q), torch.zeros_like(K), torch.zeros_like(V)
+    delta = torch.zeros(nb * H, nq, device="cuda")
+    ops.xattn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, nb, H, nq, nk, hd, D, D, D, D, D, scale)
+    for got, ref_g, n_, name in ((dQ, q.grad, nq, "q"), (dK, k.grad, nk, "k"), (dV, v.grad, nk, "v")):
+        got = got.float().view(nb, n_, H, hd).transpose(1, 2)
+        tol = 2e-2 * ref_g.abs().max().item()
+        assert (got - ref_g).abs().max().item() < tol, (name, (got - ref_g).abs().max().item(), tol)
+
+
 def test_fused_upsample_p2cl_matches_unfused(ops):
     """p2cl_up (upsample + loss + both backward passes, one kernel) == upsample_ac_fwd -> p2cl -> upsample_ac_bwd,
     with per-slot override masks, and it is bitwise reproducible."""
