@@ -37,17 +37,36 @@ template <int HD> __device__ __forceinline__ int tr_off(int row, int unit) {
     return row * (HD * 2) + ((unit ^ ((((row >> 1) & 3) << 2) & (HD / 4 - 1))) << 3);
 }
 
-// stage rows [r0, r0+CH) x HD columns of a [*, ld] matrix into an LDS image (rows >= n are zero)
-template <int HD, bool TR>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int ld, int r0, int n, char* lds, int tid,
-                                           int hd) {
+// rows [r0, r0+CH) x HD columns of a [*, ld] matrix: fetch_rows pulls this thread's 16-B chunks into registers (rows >= n
+// and columns >= hd as zeros), put_rows writes them into an LDS image.  The loops below fetch chunk i+1 right after
+// chunk i has been put, so that its global-memory latency is covered by the MFMA work on chunk i (with 96 workgroups on
+// 256 CUs -- the neck's 48-token side -- nothing else hides it).
+template <int HD> struct RowChunk { uint4 v[(CH * HD / 8 + 255) / 256]; };
+template <int HD>
+__device__ __forceinline__ void fetch_rows(const bf16_t* __restrict__ base, int ld, int r0, int n, int tid, int hd,
+                                           RowChunk<HD>& rc) {
     constexpr int CPR = HD / 8;  // 16-B chunks per row
-    for (int c = tid; c < CH * CPR; c += 256) {
+#pragma unroll
+    for (int i = 0; i < (CH * CPR + 255) / 256; ++i) {
+        const int c = tid + i * 256;
         const int row = c / CPR, ch = c % CPR;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + row < n && ch * 8 < hd) v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
-        const int off = TR ? tr_off<HD>(row, ch * 2) : rc_off<HD>(row, ch);
-        *reinterpret_cast<uint4*>(lds + off) = v;
+        if (c < CH * CPR && r0 + row < n && ch * 8 < hd)
+            v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
+        rc.v[i] = v;
+    }
+}
+template <int HD, bool TR>
+__device__ __forceinline__ void put_rows(char* lds, int tid, const RowChunk<HD>& rc) {
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int i = 0; i < (CH * CPR + 255) / 256; ++i) {
+        const int c = tid + i * 256;
+        if (c < CH * CPR) {
+            const int row = c / CPR, ch = c % CPR;
+            const int off = TR ? tr_off<HD>(row, ch * 2) : rc_off<HD>(row, ch);
+            *reinterpret_cast<uint4*>(lds + off) = rc.v[i];
+        }
     }
 }
 
@@ -116,11 +135,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     f32x4_t acc[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    RowChunk<HD> pk, pv;
+    fetch_rows<HD>(k, a.ldk, 0, nk, tid, hd, pk);
+    fetch_rows<HD>(v, a.ldk, 0, nk, tid, hd, pv);
     for (int kc = 0; kc < nk; kc += CH) {
         __syncthreads();
-        stage_rows<HD, false>(k, a.ldk, kc, nk, ldsK, tid, hd);
-        stage_rows<HD, true>(v, a.ldk, kc, nk, ldsV, tid, hd);
+        put_rows<HD, false>(ldsK, tid, pk);
+        put_rows<HD, true>(ldsV, tid, pv);
         __syncthreads();
+        if (kc + CH < nk) {
+            fetch_rows<HD>(k, a.ldk, kc + CH, nk, tid, hd, pk);
+            fetch_rows<HD>(v, a.ldk, kc + CH, nk, tid, hd, pv);
+        }
         f32x4_t s[2];
         float mx = m;
 #pragma unroll
@@ -217,13 +243,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
     f32x4_t adk[HD / 16], adv[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
+    RowChunk<HD> pq, po;
+    fetch_rows<HD>(q, a.ldq, 0, nq, tid, hd, pq);
+    fetch_rows<HD>(d_o, a.ldo, 0, nq, tid, hd, po);
     for (int qc = 0; qc < nq; qc += CH) {
         __syncthreads();
-        stage_rows<HD, false>(q, a.ldq, qc, nq, ldsQr, tid, hd);
-        stage_rows<HD, true>(q, a.ldq, qc, nq, ldsQt, tid, hd);
-        stage_rows<HD, false>(d_o, a.ldo, qc, nq, ldsOr, tid, hd);
-        stage_rows<HD, true>(d_o, a.ldo, qc, nq, ldsOt, tid, hd);
+        put_rows<HD, false>(ldsQr, tid, pq);
+        put_rows<HD, true>(ldsQt, tid, pq);
+        put_rows<HD, false>(ldsOr, tid, po);
+        put_rows<HD, true>(ldsOt, tid, po);
         __syncthreads();
+        if (qc + CH < nq) {
+            fetch_rows<HD>(q, a.ldq, qc + CH, nq, tid, hd, pq);
+            fetch_rows<HD>(d_o, a.ldo, qc + CH, nq, tid, hd, po);
+        }
         f32x4_t P[2], dS[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -288,12 +321,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     f32x4_t adq[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    RowChunk<HD> pk, pv;
+    fetch_rows<HD>(k, a.ldk, 0, nk, tid, hd, pk);
+    fetch_rows<HD>(v, a.ldk, 0, nk, tid, hd, pv);
     for (int kc = 0; kc < nk; kc += CH) {
         __syncthreads();
-        stage_rows<HD, false>(k, a.ldk, kc, nk, ldsKr, tid, hd);
-        stage_rows<HD, true>(k, a.ldk, kc, nk, ldsKt, tid, hd);
-        stage_rows<HD, false>(v, a.ldk, kc, nk, ldsVr, tid, hd);
+        put_rows<HD, false>(ldsKr, tid, pk);
+        put_rows<HD, true>(ldsKt, tid, pk);
+        put_rows<HD, false>(ldsVr, tid, pv);
         __syncthreads();
+        if (kc + CH < nk) {
+            fetch_rows<HD>(k, a.ldk, kc + CH, nk, tid, hd, pk);
+            fetch_rows<HD>(v, a.ldk, kc + CH, nk, tid, hd, pv);
+        }
         f32x4_t dS[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
