@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int LN_MAXCH = 4;  // 8-element chunks per lane -> C <= 2048
+constexpr int LN_BWD_WAVES = 16;
 
 // ---------------------------------------------------------------------------------- LayerNorm fwd
 template <typename T>
@@ -61,32 +62,34 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm bwd
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// NCH: 512-column chunks per row (C <= 512*NCH); NW waves per workgroup, one row per wave and trip: 16 rows in
+// flight per CU (one 1024-thread workgroup per CU) instead of 4 -- the kernel is a latency-bound stream of 3 KB rows.
+template <typename T, int NCH, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, float* __restrict__ part, int64_t rows,
                                                             int C, int nblk) {
-    __shared__ float red[4][8 * 64];
+    __shared__ float red[NW][8 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dwa[LN_MAXCH][8], dba[LN_MAXCH][8];
+    float dwa[NCH][8], dba[NCH][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i)
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dwa[i][j] = 0.f; dba[i][j] = 0.f; }
-    float ww[LN_MAXCH][8];
+    float ww[NCH][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = (lane + i * 64) * 8;
         if (c < C) load8(w + c, ww[i]);
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nblk * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < rows; row += (int64_t)nblk * NW) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXCH][8], g[LN_MAXCH][8];
+        float xh[NCH][8], g[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = (lane + i * 64) * 8;
             if (c < C) {
                 float xv[8], dv[8];
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         s1 = wave_sum(s1) / C;
         s2 = wave_sum(s2) / C;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = (lane + i * 64) * 8;
             if (c < C) {
                 float o[8];
@@ -121,11 +124,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    // reduce the 4 waves' dw / db and write this block's partial row
+    // reduce the waves' dw / db and write this block's partial row
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = (lane + i * 64) * 8;
             __syncthreads();
 #pragma unroll
@@ -134,8 +137,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             if (wave == 0 && c < C) {
                 float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
+                for (int j = 0; j < 8; ++j) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w_ = 0; w_ < NW; ++w_) t += red[w_][j * 64 + lane];
+                    o[j] = t;
+                }
                 store8(part + ((int64_t)blockIdx.x * 2 + which) * C + c, o);
             }
         }
@@ -410,7 +417,7 @@ extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, 
 }
 extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
-    int64_t n = rows / 16;
+    int64_t n = rows / (2 * LN_BWD_WAVES);
     return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
 }
 extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
@@ -419,8 +426,12 @@ extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, 
     vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
     const int nblk = vpu_layernorm_bwd_nblk(rows);
-    DISPATCH_T(dtype, layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, (const T*)x, w, mean, rstd,
-                                                                   (const T*)dres, (T*)dx, part, rows, C, nblk);)
+#define VPU_LN_BWD(NCH_, NW_)                                                                                         \
+    DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_><<<nblk, 64 * NW_, 0, ST>>>(                                 \
+                          (const T*)dy, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);)
+    // (C > 1024 keeps 8 waves: its 4 chunks per lane need the 256-register budget)
+    if (C <= 512) { VPU_LN_BWD(1, 16) } else if (C <= 1024) { VPU_LN_BWD(2, 16) } else { VPU_LN_BWD(4, 8) }
+#undef VPU_LN_BWD
     return vpu_check_launch("vpu_layernorm_bwd");
 }
 extern "C" int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream) {
