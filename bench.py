@@ -26,6 +26,7 @@ MODELS = {"vitb": dict(embed_dim=768, depth=12, num_heads=12, patch=16),
           "vitl": dict(embed_dim=1024, depth=24, num_heads=16, patch=16),
           "vith": dict(embed_dim=1280, depth=32, num_heads=16, patch=14)}
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
+NAMES = {"vitb": "ViT-B", "vitl": "ViT-L", "vith": "ViT-H"}
 
 
 def parse():
@@ -209,7 +210,7 @@ def main():
                 "all_gemm_variants": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3),
                                            "launches": v[2]} for k, v in sorted(agg.items())}}
     if rank == 0:
-        line = {"metric": "448x448 images/sec fwd+bwd, ViT-B VPUFormer", "value": round(value, 2), "unit": "images/sec",
+        line = {"metric": f"448x448 images/sec fwd+bwd, {NAMES[args.model]} VPUFormer", "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -340,7 +340,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "vitb", "sim"]
+    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim"]
     if "sim" in which:
         simulator_fixtures()
     if "pue" in which:
@@ -348,6 +348,9 @@ def main():
     if "tiny" in which:
         cfg = vo.make_cfg(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
         run_model_fixture("tiny", cfg, 2, ref_vpu, ref_losses)
+    if "tinyh" in which:   # ViT-H geometry in small: patch 14 (32 x 32 tokens, 16 x 16 windows), head dim 80
+        cfg = vo.make_cfg(embed_dim=640, depth=8, num_heads=8, patch=14, out_dims=(16, 32, 64, 128), head_channels=32)
+        run_model_fixture("tinyh", cfg, 2, ref_vpu, ref_losses)
     if "vitb" in which:
         run_model_fixture("vitb", vo.make_cfg(), 2, ref_vpu, ref_losses)
 

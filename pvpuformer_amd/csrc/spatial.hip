@@ -22,7 +22,10 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
                                                            const float* __restrict__ disks, T* __restrict__ cols,
                                                            int B, int H, int W, int P, int wg) {
     const int gw = W / P, gh = H / P;
-    const int Tn = gw * gh, KK = 6 * P * P, chunks = KK / 8;
+    // columns: [image half | coordinate half], each 3*P*P wide and zero-padded to a multiple of 8 (P = 14: 588 -> 592) so
+    // that both halves start 16-byte aligned
+    const int K3 = 3 * P * P, K3P = (K3 + 7) / 8 * 8;
+    const int Tn = gw * gh, KK = 2 * K3P, chunks = KK / 8;
     const int64_t total = (int64_t)B * Tn * chunks;
     const int nwx = gw / wg;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -35,14 +38,17 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = ck * 8 + j;
-            const int ch = k / (P * P), rem = k % (P * P);
-            const int y = ty * P + rem / P, x = tx * P + rem % P;
-            float v;
-            if (ch < 4) {
-                v = img4[(((int64_t)b * 4 + ch) * H + y) * W + x];
-                if (ch < 3) v = (v - c_mean[ch]) / c_std[ch];
-            } else {
-                v = disks[(((int64_t)b * 2 + (ch - 4)) * H + y) * W + x];
+            const int half = k / K3P, kk = k % K3P;
+            float v = 0.f;
+            if (kk < K3) {
+                const int ch = half * 3 + kk / (P * P), rem = kk % (P * P);
+                const int y = ty * P + rem / P, x = tx * P + rem % P;
+                if (ch < 4) {
+                    v = img4[(((int64_t)b * 4 + ch) * H + y) * W + x];
+                    if (ch < 3) v = (v - c_mean[ch]) / c_std[ch];
+                } else {
+                    v = disks[(((int64_t)b * 2 + (ch - 4)) * H + y) * W + x];
+                }
             }
             o[j] = v;
         }
@@ -106,13 +112,17 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* __restrict
 constexpr int GN_CHUNKS = 64;
 
 // thread layout shared by the GroupNorm kernels: a block walks the pixels [p0,p1) of one sample;
-// thread t owns channel chunk (t % tpp) of pixel slot (t / tpp), tpp = C/8.
+// thread t owns channel chunks (t % tpp) + r * tpp (r < nrep) of pixel slot (t / tpp); nrep = 1 up to C = 2048, 2 up to
+// C = 4096 (ViT-H's 2560-channel stride-32 branch).
+constexpr int GN_MAXREP = 2;
 struct GnMap {
-    int tpp, slots, cc, slot;
+    int tpp, slots, cc, slot, nrep, cstep;
     bool active;
     int64_t p0, p1;
     __device__ GnMap(int C, int64_t HW) {
-        tpp = C / 8;
+        nrep = (C / 8 + 255) / 256;
+        tpp = C / 8 / nrep;
+        cstep = tpp * 8;
         slots = 256 / tpp;
         if (slots < 1) slots = 1;
         slot = threadIdx.x / tpp;
@@ -133,14 +143,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     float s = 0.f, q = 0.f;
     double ds = 0.0, dq = 0.0;
     if (mp.active)
-        for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
-            float v[8];
-            load8(x + ((int64_t)b * HW + p) * C + mp.cc, v);
-            s = 0.f; q = 0.f;
+        for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots)
+            for (int r = 0; r < mp.nrep; ++r) {
+                float v[8];
+                load8(x + ((int64_t)b * HW + p) * C + mp.cc + r * mp.cstep, v);
+                s = 0.f; q = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s += v[j]; q += v[j] * v[j]; }
-            ds += s; dq += q;
-        }
+                for (int j = 0; j < 8; ++j) { s += v[j]; q += v[j] * v[j]; }
+                ds += s; dq += q;
+            }
     const double S = block_sum_d(ds, red);
     const double Q = block_sum_d(dq, red);
     if (threadIdx.x == 0) {
@@ -178,20 +189,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     gn_finalize(stats, b, HW * C, eps, mu, rs, red);
     if (blockIdx.y == 0 && threadIdx.x == 0) { mean[b] = mu; rstd[b] = rs; }
     if (!mp.active) return;
-    float ww[8], bv[8];
-    load8(w + mp.cc, ww);
-    load8(bb + mp.cc, bv);
-    for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
-        float v[8];
-        const int64_t off = ((int64_t)b * HW + p) * C + mp.cc;
-        load8(x + off, v);
+    float ww[GN_MAXREP][8], bv[GN_MAXREP][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float t = (v[j] - mu) * rs * ww[j] + bv[j];
-            v[j] = gelu ? gelu_f(t) : t;
-        }
-        store8(y + off, v);
-    }
+    for (int r = 0; r < GN_MAXREP; ++r)
+        if (r < mp.nrep) { load8(w + mp.cc + r * mp.cstep, ww[r]); load8(bb + mp.cc + r * mp.cstep, bv[r]); }
+    for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots)
+#pragma unroll
+        for (int r = 0; r < GN_MAXREP; ++r)
+            if (r < mp.nrep) {
+                float v[8];
+                const int64_t off = ((int64_t)b * HW + p) * C + mp.cc + r * mp.cstep;
+                load8(x + off, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = (v[j] - mu) * rs * ww[r][j] + bv[r][j];
+                    v[j] = gelu ? gelu_f(t) : t;
+                }
+                store8(y + off, v);
+            }
 }
 
 // backward pass 1: per-sample sums of g and g*xhat (fp64 partials), per-channel dw/db partials
@@ -203,34 +218,40 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
                                                            double* __restrict__ stats, int B, int64_t HW, int C,
                                                            int gelu) {
     __shared__ double red[8];
-    __shared__ float acc[2048];
+    __shared__ float acc[4096];
     GnMap mp(C, HW);
     const int b = blockIdx.x;
     const float mu = mean[b], rs = rstd[b];
-    float dwa[8], dba[8], ww[8], bv[8];
+    float dwa[GN_MAXREP][8], dba[GN_MAXREP][8], ww[GN_MAXREP][8], bv[GN_MAXREP][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { dwa[j] = 0.f; dba[j] = 0.f; ww[j] = 0.f; bv[j] = 0.f; }
+    for (int r = 0; r < GN_MAXREP; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dwa[r][j] = 0.f; dba[r][j] = 0.f; ww[r][j] = 0.f; bv[r][j] = 0.f; }
     double d1 = 0.0, d2 = 0.0;
     if (mp.active) {
-        load8(w + mp.cc, ww);
-        load8(bb + mp.cc, bv);
-        for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
-            float xv[8], dv[8];
-            const int64_t off = ((int64_t)b * HW + p) * C + mp.cc;
-            load8(x + off, xv);
-            load8(dy + off, dv);
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (xv[j] - mu) * rs;
-                float d = dv[j];
-                if (gelu) d *= dgelu_f(xh * ww[j] + bv[j]);
-                const float g = d * ww[j];
-                s1 += g; s2 += g * xh;
-                dwa[j] += d * xh; dba[j] += d;
-            }
-            d1 += s1; d2 += s2;
-        }
+        for (int r = 0; r < GN_MAXREP; ++r)
+            if (r < mp.nrep) { load8(w + mp.cc + r * mp.cstep, ww[r]); load8(bb + mp.cc + r * mp.cstep, bv[r]); }
+        for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots)
+#pragma unroll
+            for (int r = 0; r < GN_MAXREP; ++r)
+                if (r < mp.nrep) {
+                    float xv[8], dv[8];
+                    const int64_t off = ((int64_t)b * HW + p) * C + mp.cc + r * mp.cstep;
+                    load8(x + off, xv);
+                    load8(dy + off, dv);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xh = (xv[j] - mu) * rs;
+                        float d = dv[j];
+                        if (gelu) d *= dgelu_f(xh * ww[r][j] + bv[r][j]);
+                        const float g = d * ww[r][j];
+                        s1 += g; s2 += g * xh;
+                        dwa[r][j] += d * xh; dba[r][j] += d;
+                    }
+                    d1 += s1; d2 += s2;
+                }
     }
     const double S1 = block_sum_d(d1, red);
     const double S2 = block_sum_d(d2, red);
@@ -239,13 +260,17 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
         stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 1] = S2;
     }
     const int64_t prow = (int64_t)b * GN_CHUNKS + blockIdx.y;
-    const int64_t nrows = (int64_t)B * GN_CHUNKS;
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         __syncthreads();
         if (mp.active) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[mp.slot * C + mp.cc + j] = which ? dba[j] : dwa[j];
+            for (int r = 0; r < GN_MAXREP; ++r)
+                if (r < mp.nrep) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[mp.slot * C + mp.cc + r * mp.cstep + j] = which ? dba[r][j] : dwa[r][j];
+                }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -275,23 +300,27 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ dy
     const float m2 = (float)(block_sum_d(q, red) / n);
     if (!mp.active) return;
     const float mu = mean[b], rs = rstd[b];
-    float ww[8], bv[8];
-    load8(w + mp.cc, ww);
-    load8(bb + mp.cc, bv);
-    for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots) {
-        float xv[8], dv[8];
-        const int64_t off = ((int64_t)b * HW + p) * C + mp.cc;
-        load8(x + off, xv);
-        load8(dy + off, dv);
+    float ww[GN_MAXREP][8], bv[GN_MAXREP][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (xv[j] - mu) * rs;
-            float d = dv[j];
-            if (gelu) d *= dgelu_f(xh * ww[j] + bv[j]);
-            dv[j] = rs * (d * ww[j] - m1 - xh * m2);
-        }
-        store8(dx + off, dv);
-    }
+    for (int r = 0; r < GN_MAXREP; ++r)
+        if (r < mp.nrep) { load8(w + mp.cc + r * mp.cstep, ww[r]); load8(bb + mp.cc + r * mp.cstep, bv[r]); }
+    for (int64_t p = mp.p0 + mp.slot; p < mp.p1; p += mp.slots)
+#pragma unroll
+        for (int r = 0; r < GN_MAXREP; ++r)
+            if (r < mp.nrep) {
+                float xv[8], dv[8];
+                const int64_t off = ((int64_t)b * HW + p) * C + mp.cc + r * mp.cstep;
+                load8(x + off, xv);
+                load8(dy + off, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (xv[j] - mu) * rs;
+                    float d = dv[j];
+                    if (gelu) d *= dgelu_f(xh * ww[r][j] + bv[r][j]);
+                    dv[j] = rs * (d * ww[r][j] - m1 - xh * m2);
+                }
+                store8(dx + off, dv);
+            }
 }
 
 // ------------------------------------------------------------------------------ bilinear, align_corners=False
@@ -641,11 +670,11 @@ __global__ __launch_bounds__(256) void upsample_ac_bwd_kernel(const float* __res
 extern "C" int vpu_patch_im2col(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W,
                                 int32_t P, int32_t win_tokens, int32_t dtype, void* stream) {
     vpu_clear_stale_error();
-    if (H % P || W % P || (6 * P * P) % 8 || (W / P) % win_tokens || (H / P) % win_tokens) {
-        vpu_set_error("patch_im2col: H,W % P, grid % window, 6*P*P % 8");
+    if (H % P || W % P || (W / P) % win_tokens || (H / P) % win_tokens) {
+        vpu_set_error("patch_im2col: H,W % P, grid % window");
         return VPU_ERR_ARG;
     }
-    const int64_t total = (int64_t)B * (H / P) * (W / P) * (6 * P * P / 8);
+    const int64_t total = (int64_t)B * (H / P) * (W / P) * (2 * ((3 * P * P + 7) / 8));
     DISPATCH_T(dtype, patch_im2col_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
         image4, disks, (T*)cols, B, H, W, P, win_tokens);)
     return vpu_check_launch("vpu_patch_im2col");
@@ -674,7 +703,7 @@ extern "C" int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, 
                                  double* stats, int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu,
                                  int32_t dtype, void* stream) {
     vpu_clear_stale_error();
-    if (C % 8 || C > 2048) { vpu_set_error("groupnorm: C % 8, C <= 2048"); return VPU_ERR_ARG; }
+    if (C % 8 || C > 4096 || (C > 2048 && C % 16)) { vpu_set_error("groupnorm: C % 8 (16 above 2048), C <= 4096"); return VPU_ERR_ARG; }
     dim3 grid(B, GN_CHUNKS);
     DISPATCH_T(dtype, gn_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, stats, HW, C);
                gn_apply_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, stats, HW, C, eps, gelu);)
@@ -684,7 +713,7 @@ extern "C" int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, 
                                  const float* rstd, void* dx, float* part, double* stats, int32_t B, int64_t HW,
                                  int32_t C, int32_t gelu, int32_t dtype, void* stream) {
     vpu_clear_stale_error();
-    if (C % 8 || C > 2048) { vpu_set_error("groupnorm_bwd: C % 8, C <= 2048"); return VPU_ERR_ARG; }
+    if (C % 8 || C > 4096 || (C > 2048 && C % 16)) { vpu_set_error("groupnorm_bwd: C % 8 (16 above 2048), C <= 4096"); return VPU_ERR_ARG; }
     dim3 grid(B, GN_CHUNKS);
     DISPATCH_T(dtype,
                gn_bwd_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, w, b, mean, rstd, part, stats, B,

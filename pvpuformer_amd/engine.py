@@ -114,7 +114,8 @@ class Engine:
             p.grad = self.gflat[o:o + numel].view(shape)
         self.shadow = torch.zeros(off, device=self.dev, dtype=torch.bfloat16) if self.dt == BF16 else None
         D, P = self.D, self.P
-        self.w_patch = torch.zeros(D, 6 * P * P, device=self.dev, dtype=self.td)
+        self.k3p = _rup(3 * P * P, 8)   # each half of the fused patch-embed K is padded to 16 bytes (P = 14: 588 -> 592)
+        self.w_patch = torch.zeros(D, 2 * self.k3p, device=self.dev, dtype=self.td)
         self.b_patch = torch.zeros(D, device=self.dev, dtype=torch.float32)
         self.w_lin1p = torch.zeros(2048, self.Epad, device=self.dev, dtype=self.td)
         self.pos_win = torch.zeros(self.NT, D, device=self.dev, dtype=self.td)
@@ -142,8 +143,8 @@ class Engine:
         if self.dt == BF16 and not shadow_is_fresh:
             ops.cast2d(self.flat, self.total, self.shadow, self.total, 1, self.total)
         k3 = 3 * P * P
-        ops.cast2d(self.Pm("backbone.patch_embed.proj.weight"), k3, (self.w_patch, 0), 2 * k3, D, k3)
-        ops.cast2d(self.Pm("patch_embed_coords.proj.weight"), k3, (self.w_patch, k3), 2 * k3, D, k3)
+        ops.cast2d(self.Pm("backbone.patch_embed.proj.weight"), k3, (self.w_patch, 0), 2 * self.k3p, D, k3)
+        ops.cast2d(self.Pm("patch_embed_coords.proj.weight"), k3, (self.w_patch, self.k3p), 2 * self.k3p, D, k3)
         ops.add4(self.Pm("backbone.patch_embed.proj.bias"), self.Pm("patch_embed_coords.proj.bias"), None, None,
                  self.b_patch, D)
         ops.cast2d(self.Pm("neck.ffn_layer.lin1.weight"), self.E, self.w_lin1p, self.Epad, 2048, self.E, self.Epad)
@@ -499,10 +500,11 @@ class Engine:
         # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
         disks = self._new(B, 2, H, W_, dtype=torch.float32)
         ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, 5.0)
-        cols = self._new(M, 6 * P * P)
+        KP = 2 * self.k3p
+        cols = self._new(M, KP)
         ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg)
         x = Var(self._new(M, D))
-        ops.gemm(cols, self.w_patch, x.t, M, D, 6 * P * P, 6 * P * P, 6 * P * P, D, self.dt,
+        ops.gemm(cols, self.w_patch, x.t, M, D, KP, KP, KP, D, self.dt,
                  flags=EPI_BIAS | EPI_RESID, bias=self.b_patch, resid=self.pos_win, ldr=D, resid_period=NT)
         if training:
             x0 = x
@@ -511,8 +513,8 @@ class Engine:
                 if x0.g is None:
                     return
                 k3 = 3 * P * P
-                for nm, co in (("backbone.patch_embed.proj", 0), ("patch_embed_coords.proj", k3)):
-                    self._wgrad(x0.g, D, (cols, co), 2 * k3, nm + ".weight", D, k3, M, bias=nm + ".bias")
+                for nm, co in (("backbone.patch_embed.proj", 0), ("patch_embed_coords.proj", self.k3p)):
+                    self._wgrad(x0.g, D, (cols, co), KP, nm + ".weight", D, k3, M, bias=nm + ".bias")
                 # pos_embed[:, 1:] gradient: sum over the batch, back to raster order
                 s = self._new(NT * D, dtype=torch.float32)
                 ops.colsum(x0.g, NT * D, s, None, B, NT * D, beta=0.0)   # rows = B <= 64: single-pass kernel
@@ -536,7 +538,7 @@ class Engine:
             h1 = self.layernorm(x, p + "norm1", M, D, 1e-6)
             qkv = self.linear(h1, p + "attn.qkv.weight", p + "attn.qkv.bias", M, 3 * D, D)
             O = Var(self._new(M, D))
-            if self.dt == BF16 and hd in (32, 64) and self.use_flash:
+            if self.dt == BF16 and hd % 16 == 0 and hd <= 128 and self.use_flash:
                 self.flash_attention(qkv, O, B * nwin, heads, nt, hd, D, hd ** -0.5)
             else:
                 self.sdpa((qkv, 0, 3 * D, nt), (qkv, D, 3 * D, nt), (qkv, 2 * D, 3 * D, nt), (O, 0, D, nt), B * nwin,

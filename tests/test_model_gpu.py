@@ -44,9 +44,10 @@ def _run(model, img4, batch, ptype):
     return model(img4.cuda(), pts, prompts, ptype)
 
 
+@pytest.mark.parametrize("fixture", ["tiny.npz", "tinyh.npz"])   # tinyh: ViT-H geometry (patch 14, head dim 80) in small
 @pytest.mark.parametrize("mode,ptype", [("click", 0), ("box", 1)])
-def test_tiny_fp32_forward_backward_matches_reference(golden_dir, mode, ptype):
-    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+def test_tiny_fp32_forward_backward_matches_reference(golden_dir, mode, ptype, fixture):
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "f32")
     taps = {}
     eng = model._ensure_engine()
     eng.refresh_weights()
@@ -97,10 +98,12 @@ def test_tiny_fp32_forward_backward_matches_reference(golden_dir, mode, ptype):
                                atol=1e-3 * np.abs(g).max() + 1e-9)
 
 
-def test_tiny_bf16_close_to_reference(golden_dir):
+@pytest.mark.parametrize("fixture", ["tiny.npz", "tinyh.npz"])
+def test_tiny_bf16_close_to_reference(golden_dir, fixture):
     """bf16 MFMA mode: bf16 activations / weights, fp32 accumulate.  Bound: 3e-2 of the logit range (bf16 has 8
-    significant bits; ~60 layers deep), gradients within 6 % in norm and cosine > 0.99 on the checked tensors."""
-    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "bf16")
+    significant bits; ~60 layers deep), gradients within 6 % in norm and cosine > 0.99 on the checked tensors.
+    tinyh runs the fused attention in its 128-column instantiation (head dim 80) and the padded patch-14 im2col."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
     model.zero_grad()
     out = _run(model, img4, batch, 0)
     assert _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["click_instances_sub"]) < 3e-2

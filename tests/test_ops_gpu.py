@@ -308,6 +308,17 @@ def test_patch_im2col_and_permute(ops, dtype):
     nw = g // wg
     refw = ref.view(B, nw, wg, nw, wg, -1).permute(0, 1, 3, 2, 4, 5).reshape(B * g * g, -1)
     assert torch.equal(cols.float(), refw.to(td).float())
+    # patch 14 (ViT-H): each half (3*14*14 = 588 columns) is zero-padded to 592 so that it starts 16-byte aligned
+    P2, wg2 = 14, 16
+    g2 = H // P2
+    cols2 = torch.empty(B * g2 * g2, 2 * 592, device="cuda", dtype=td)
+    ops.patch_im2col(img4, disks, cols2, B, H, H, P2, wg2)
+    ref2 = F.unfold(full, P2, stride=P2).transpose(1, 2)
+    nw2 = g2 // wg2
+    ref2w = ref2.view(B, nw2, wg2, nw2, wg2, -1).permute(0, 1, 3, 2, 4, 5).reshape(B * g2 * g2, -1).to(td).float()
+    c2 = cols2.float()
+    assert torch.equal(c2[:, :588], ref2w[:, :588]) and torch.equal(c2[:, 592:592 + 588], ref2w[:, 588:])
+    assert c2[:, 588:592].abs().max().item() == 0.0 and c2[:, 592 + 588:].abs().max().item() == 0.0
     x = dev(rnd(B, g * g, 64, seed=22)).to(td)
     y, z = torch.empty_like(x), torch.empty_like(x)
     ops.window_permute(x, y, B, g, wg, 64, to_raster=False)
@@ -345,7 +356,7 @@ def test_pixel_shuffle_convs(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("C,gelu", [(16, 1), (192, 0), (384, 1), (1536, 0)])
+@pytest.mark.parametrize("C,gelu", [(16, 1), (192, 0), (384, 1), (1536, 0), (2560, 0), (2560, 1)])
 def test_groupnorm(ops, dtype, C, gelu):
     td = TD[dtype]
     B, HW = 2, 14 * 14 if C > 1000 else 28 * 28
