@@ -335,12 +335,61 @@ def simulator_fixtures():
     print("[sim] written; boxes round0:", fx["r0_boxes"].tolist())
 
 
+def zoom_fixtures():
+    """ZoomIn / LimitLongestSide bookkeeping and resizes of the reference (isegm/inference/transforms/zoom_in.py,
+    limit_longest_side.py) on a seeded click sequence: regions of interest, re-mapped click coordinates, the cropped +
+    resized network input and the un-zoomed probability map (sub-sampled)."""
+    from isegm.inference.transforms import ZoomIn, LimitLongestSide
+    from isegm.inference.clicker import Click
+    H, W = 300, 420
+    g = torch.Generator().manual_seed(11)
+    image_nd = torch.rand(1, 4, H, W, generator=g)
+    yy, xx = np.mgrid[0:H, 0:W]
+    blob1 = (((yy - 140) / 60.0) ** 2 + ((xx - 200) / 90.0) ** 2 < 1).astype(np.float32)
+    blob2 = (((yy - 90) / 30.0) ** 2 + ((xx - 330) / 40.0) ** 2 < 1).astype(np.float32)
+    clicks = [Click(True, (140, 200), 0), Click(False, (30, 40), 1), Click(True, (150.5, 260.25), 2),
+              Click(True, (95, 335), 3)]
+    fx = {"image_seed": np.asarray(11), "H": np.asarray(H), "W": np.asarray(W),
+          "clicks": np.asarray([[c.is_positive, c.coords[0], c.coords[1], c.indx] for c in clicks], np.float64)}
+    for name, kw in (("vpu", dict(target_size=(448, 448), skip_clicks=-1)), ("ritm", dict(target_size=400, skip_clicks=1))):
+        z = ZoomIn(**kw)
+        probs = [blob1 * 0.9, np.maximum(blob1, blob2) * 0.8, np.maximum(blob1, blob2) * 0.8]
+        for step in range(3):
+            cl = clicks[:step + 2]
+            img_t, tcl = z.transform(image_nd, [cl])
+            fx[f"{name}_{step}_roi"] = np.asarray(z._object_roi if z._object_roi is not None else (-1, -1, -1, -1))
+            fx[f"{name}_{step}_changed"] = np.asarray(z.image_changed)
+            fx[f"{name}_{step}_img_shape"] = np.asarray(img_t.shape)
+            fx[f"{name}_{step}_img_sub"] = img_t[:, :, ::13, ::11].numpy()
+            fx[f"{name}_{step}_tclicks"] = np.asarray([[c.coords[0], c.coords[1]] for c in tcl[0]], np.float64)
+            # the "network output": a smooth function at the transformed size
+            hh, ww = img_t.shape[2:]
+            ty, tx = torch.meshgrid(torch.linspace(0, 1, hh), torch.linspace(0, 1, ww), indexing="ij")
+            net_out = (torch.sin(3 * ty + step) * torch.cos(5 * tx) * 0.5 + 0.5)[None, None]
+            # what the model "predicted" in image space decides the next region: paste the blob through the inverse
+            back = z.inv_transform(net_out)
+            fx[f"{name}_{step}_back_shape"] = np.asarray(back.shape)
+            fx[f"{name}_{step}_back_sub"] = back[:, :, ::7, ::9].numpy()
+            z._prev_probs = probs[step][None, None]          # drive the region logic with the seeded blobs
+            fx[f"{name}_{step}_recalc"] = np.asarray(z.check_possible_recalculation())
+    lim = LimitLongestSide(max_size=256)
+    img_t, tcl = lim.transform(image_nd, [clicks[:2]])
+    fx["lim_roi"] = np.asarray(lim._object_roi)
+    fx["lim_img_shape"] = np.asarray(img_t.shape)
+    fx["lim_img_sub"] = img_t[:, :, ::13, ::11].numpy()
+    fx["lim_tclicks"] = np.asarray([[c.coords[0], c.coords[1]] for c in tcl[0]], np.float64)
+    np.savez_compressed(os.path.join(OUT, "zoom.npz"), **fx)
+    print("[zoom] written", {k: v.tolist() for k, v in fx.items() if k.endswith("_roi")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim"]
+    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom"]
+    if "zoom" in which:
+        zoom_fixtures()
     if "sim" in which:
         simulator_fixtures()
     if "pue" in which:

@@ -1,29 +1,37 @@
 """NoBRS predictor, API-compatible with the hot calls of isegm/inference/predictors/base.py:10-223:
-``set_input_image / get_prediction / get_vqu_prediction / get_points_nd / get_states / set_states``.  Supported
-transforms: sigmoid and horizontal-flip test-time augmentation (flip.py:8-37).  ZoomIn (zoom_in.py) is the next row
-(SURVEY.md section 8f): without it the model runs on the full image, which must have the constructed size."""
+``set_input_image / get_prediction / get_vqu_prediction / get_points_nd / apply_transforms / get_states / set_states``.
+Transform pipeline as in the reference (base.py:42-48): [ZoomIn] [LimitLongestSide] [SigmoidForPred] [AddHorizontalFlip],
+inverted in reverse order (so the flip average is taken on logits, before the sigmoid)."""
 import numpy as np
 import torch
 
 from ...engine.prompt_sim import get_next_promts
+from ..transforms import AddHorizontalFlip, LimitLongestSide, SigmoidForPred, get_roi_image_nd, resize_align_corners
 
 
 class BasePredictor:
     def __init__(self, model, device, net_clicks_limit=None, with_flip=False, with_sigmoid=True, zoom_in=None,
                  max_size=None, **kwargs):
-        if zoom_in is not None or max_size is not None:
-            raise NotImplementedError("ZoomIn / LimitLongestSide transforms are not built yet")
         self.net, self.device = model, device
         self.net_clicks_limit, self.with_flip, self.with_sigmoid = net_clicks_limit, with_flip, with_sigmoid
         self.original_image = None
         self.prev_prediction = None
-        self.zoom_in = None
+        self.zoom_in = zoom_in
+        self.transforms = [zoom_in] if zoom_in is not None else []
+        if max_size is not None:
+            self.transforms.append(LimitLongestSide(max_size=max_size))
+        if with_sigmoid:
+            self.transforms.append(SigmoidForPred())
+        if with_flip:
+            self.transforms.append(AddHorizontalFlip())
 
     def set_input_image(self, image):
         """image: HxWx3 uint8 / float numpy array (torchvision ToTensor semantics) or a [3,H,W] / [1,3,H,W] tensor."""
         if isinstance(image, np.ndarray):
             t = torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1).float()
             image = t / 255.0 if image.dtype == np.uint8 else t
+        for t in self.transforms:
+            t.reset()
         self.original_image = image.to(self.device)
         if self.original_image.dim() == 3:
             self.original_image = self.original_image.unsqueeze(0)
@@ -45,53 +53,67 @@ class BasePredictor:
             total.append(pos + (n - len(pos)) * [(-1, -1, -1)] + neg + (n - len(neg)) * [(-1, -1, -1)])
         return torch.tensor(total, device=self.device)
 
-    def _flip_inputs(self, image_nd, clicks_lists):
-        """AddHorizontalFlip.transform (flip.py:9-22): batch of [image, flipped image]; clicks mirrored in x."""
-        w = image_nd.shape[3]
-        image_nd = torch.cat([image_nd, torch.flip(image_nd, dims=[3])], dim=0)
-        flipped = [[c.copy(coords=(c.coords[0], w - c.coords[1] - 1)) for c in cl] for cl in clicks_lists]
-        return image_nd, clicks_lists + flipped
+    def apply_transforms(self, image_nd, clicks_lists):
+        is_image_changed = False
+        for t in self.transforms:
+            image_nd, clicks_lists = t.transform(image_nd, clicks_lists)
+            is_image_changed |= t.image_changed
+        return image_nd, clicks_lists, is_image_changed
 
     def _net_input(self, clicker, prev_mask):
         clicks_list = clicker.get_clicks()
         prev_mask = self.prev_prediction if prev_mask is None else prev_mask
         image_nd = torch.cat((self.original_image, prev_mask), dim=1) if self.net.with_prev_mask else self.original_image
-        clicks_lists = [clicks_list]
-        if self.with_flip:
-            image_nd, clicks_lists = self._flip_inputs(image_nd, clicks_lists)
+        image_nd, clicks_lists, _ = self.apply_transforms(image_nd, [clicks_list])
         return image_nd, clicks_lists, prev_mask
 
-    def _finish(self, logits):
-        pred = torch.sigmoid(logits) if self.with_sigmoid else logits
-        if self.with_flip:   # AddHorizontalFlip.inv_transform (flip.py:24-31)
-            half = pred.shape[0] // 2
-            pred = 0.5 * (pred[:half] + torch.flip(pred[half:], dims=[3]))
-        self.prev_prediction = pred
+    def _finish(self, logits, image_nd):
+        pred = logits
+        if tuple(pred.shape[2:]) != tuple(image_nd.shape[2:]):   # base.py:93-94 (a no-op at the model's own size)
+            pred = resize_align_corners(pred, image_nd.shape[2:])
+        for t in reversed(self.transforms):
+            pred = t.inv_transform(pred)
         return pred
 
     @torch.no_grad()
     def get_prediction(self, clicker, prev_mask=None):
         image_nd, clicks_lists, _ = self._net_input(clicker, prev_mask)
         logits = self.net(image_nd, self.get_points_nd(clicks_lists).float())['instances']   # base.py:102-104
-        return self._finish(logits).cpu().numpy()[0, 0]
+        pred = self._finish(logits, image_nd)
+        if self.zoom_in is not None and self.zoom_in.check_possible_recalculation():
+            return self.get_prediction(clicker)
+        self.prev_prediction = pred
+        return pred.cpu().numpy()[0, 0]
 
     @torch.no_grad()
     def get_vqu_prediction(self, clicker, prev_mask=None, on_cascade=False, gt_mask=None, as_prompt_type=0,
                            click_indx=0, as_multi_prompts=True):
-        """base.py:106-151,166-177: the model also receives the box prompt derived from (prev_mask, gt)."""
+        """base.py:106-151,166-177: the model also receives the box prompt derived from (prev_mask, gt), both cropped to
+        the ZoomIn region of interest."""
         image_nd, clicks_lists, prev = self._net_input(clicker, prev_mask)
         points_nd = self.get_points_nd(clicks_lists).float()
         gt = torch.from_numpy(np.asarray(gt_mask, dtype=np.float32))[None, None].to(self.device)
         if self.with_flip:
             gt = torch.cat([gt, torch.flip(gt, dims=[3])], dim=0)
             prev = torch.cat([prev, torch.flip(prev, dims=[3])], dim=0)
+        if self.zoom_in is not None and self.zoom_in._object_roi is not None:
+            gt = get_roi_image_nd(gt, self.zoom_in._object_roi, self.zoom_in.target_size)
+            prev = get_roi_image_nd(prev, self.zoom_in._object_roi, self.zoom_in.target_size)
         _, boxes = get_next_promts(prev, gt, points_nd, None, as_allmask=False, jitter_box=False)
         prompts = (points_nd, boxes, None)
         logits = self.net(image_nd, points_nd, prompts, as_prompt_type)['instances']
-        return self._finish(logits).cpu().numpy()[0, 0], prompts
+        pred = self._finish(logits, image_nd)
+        if self.zoom_in is not None and self.zoom_in.check_possible_recalculation():
+            return self.get_prediction(clicker), prompts
+        self.prev_prediction = pred
+        return pred.cpu().numpy()[0, 0], prompts
 
     def get_states(self):
-        return {'transform_states': [], 'prev_prediction': self.prev_prediction.clone()}
+        return {'transform_states': [t.get_state() for t in self.transforms],
+                'prev_prediction': self.prev_prediction.clone()}
 
     def set_states(self, states):
+        assert len(states['transform_states']) == len(self.transforms)
+        for st, t in zip(states['transform_states'], self.transforms):
+            t.set_state(st)
         self.prev_prediction = states['prev_prediction']

@@ -235,10 +235,12 @@ def test_train_step_multi_iteration_matches_oracle(golden_dir):
     assert not bad, bad[:8]
 
 
-def test_nobrs_click_loop_iou_parity(golden_dir):
+@pytest.mark.parametrize("zoom", [None, dict(skip_clicks=-1, target_size=(448, 448))])
+def test_nobrs_click_loop_iou_parity(golden_dir, zoom):
     """a18 / config 3: the NoBRS evaluation loop (oracle clicks from the Clicker, flip TTA, prev-mask feedback,
-    box prompt derived each click) driven through the predictor mirror on the HIP model vs the same loop on the CPU
-    oracle network: IoU-per-click series within +-0.1 (north star), click packing identical."""
+    box prompt derived each click; with and without the evaluation script's ZoomIn setting,
+    scripts/evaluate_vpumodel.py:187-192) driven through the predictor mirror on the HIP model vs the same loop on the
+    CPU oracle network: IoU-per-click series within +-0.1 (north star), click packing identical."""
     fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
     from pvpuformer_amd.isegm.inference.clicker import Clicker
     from pvpuformer_amd.isegm.inference.predictors import get_predictor
@@ -250,17 +252,18 @@ def test_nobrs_click_loop_iou_parity(golden_dir):
         def __call__(self, image, points, prompts=None, as_prompt_type=0):
             boxes = prompts[1].cpu() if prompts is not None else None
             with torch.no_grad():
-                return vo.vpu_forward(sd, cfg, image.cpu().float(), points.cpu().float(), boxes, as_prompt_type)
+                out = vo.vpu_forward(sd, cfg, image.cpu().float(), points.cpu().float(), boxes, as_prompt_type)
+            return {k: v.to(image.device) for k, v in out.items()}
 
     image = (batch["images"][0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
     gt = batch["instances"][0, 0].numpy().astype(np.int32)
     series = {}
-    for name, net, device in (("oracle", OracleNet(), "cpu"), ("hip_f32", model, "cuda"), ("hip_bf16", None, "cuda")):
+    for name, net, device in (("oracle", OracleNet(), "cuda"), ("hip_f32", model, "cuda"), ("hip_bf16", None, "cuda")):
         if name == "hip_bf16":
             model.set_compute_dtype("bf16")
             net = model
         model.weights_frozen = True
-        pred = get_predictor(net, "NoBRS", device, with_flip=True)
+        pred = get_predictor(net, "NoBRS", device, with_flip=True, zoom_in_params=zoom)
         pred.set_input_image(image)
         clicker = Clicker(gt_mask=gt)
         mask = np.zeros_like(gt, dtype=bool)
