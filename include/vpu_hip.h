@@ -228,6 +228,12 @@ int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, flo
  * seg_of (int32 [n/seg_gran]) is not used in v1 (uniform lr). */
 int vpu_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+/* The same step with per-tensor learning rate and weight decay (layer-wise lr decay isegm/utils/lr_decay.py:15-66,
+ * lr_mult isegm/engine/optimizer.py:15-17): segment s covers elements [seg_end[s-1], seg_end[s]) of the flat buffer
+ * (device arrays; segments start on 8-element boundaries); decoupled_wd 0 = torch.optim.Adam (L2), 1 = AdamW. */
+int vpu_adam_step_groups(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                         const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int32_t nseg, float beta1,
+                         float beta2, float eps, int32_t decoupled_wd, int32_t step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

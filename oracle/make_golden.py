@@ -382,14 +382,35 @@ def zoom_fixtures():
     print("[zoom] written", {k: v.tolist() for k, v in fx.items() if k.endswith("_roi")})
 
 
+def lrd_fixture(ref_vpu):
+    """Layer-wise lr decay groups of the reference (isegm/utils/lr_decay.py:15-69 as called by
+    isegm/engine/optimizer.py:29-35) on the tiny model: per tensor name its learning rate and weight decay."""
+    import isegm.utils.lr_decay as lrd
+    cfg = vo.make_cfg(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+    m, _ = build_reference(cfg, ref_vpu)
+    groups = lrd.param_groups_lrd(m, 5e-5, weight_decay=0.02, no_weight_decay_list=m.backbone.no_weight_decay(),
+                                  layer_decay=0.75)
+    by_id = {id(p): n for n, p in m.named_parameters()}
+    names, lrs, wds = [], [], []
+    for g in groups:
+        ps = g["params"] if isinstance(g["params"], (list, tuple)) else [g["params"]]
+        for p_ in ps:
+            names.append(by_id[id(p_)]); lrs.append(g.get("lr", 5e-5)); wds.append(g["weight_decay"])
+    np.savez_compressed(os.path.join(OUT, "lrd.npz"), names=np.asarray(names), lr=np.asarray(lrs, np.float64),
+                        wd=np.asarray(wds, np.float64), all_names=np.asarray([n for n, _ in m.named_parameters()]))
+    print("[lrd] written", len(names), "of", len(by_id), "tensors in groups")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom"]
+    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom", "lrd"]
     if "zoom" in which:
         zoom_fixtures()
+    if "lrd" in which:
+        lrd_fixture(ref_vpu)
     if "sim" in which:
         simulator_fixtures()
     if "pue" in which:

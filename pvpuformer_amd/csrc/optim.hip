@@ -7,11 +7,24 @@
 namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   bf16_t* __restrict__ shadow, int64_t n4, int64_t n, float lr, float b1,
-                                                   float b2, float eps, float wd, float bc1, float bc2s, float gs) {
+                                                   bf16_t* __restrict__ shadow, int64_t n4, int64_t n, float lr_in, float b1,
+                                                   float b2, float eps, float wd_in, float bc1, float bc2s, float gs,
+                                                   const int64_t* __restrict__ seg_end, const float* __restrict__ seg_lr,
+                                                   const float* __restrict__ seg_wd, int nseg, int decoupled) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float pv[4], gv[4], mv[4], vv[4];
         const int64_t base = i * 4;
+        // per-tensor learning rate / weight decay (layer-wise decay, lr_mult): the segment that holds element `base`
+        // (tensors start on 8-element boundaries, so four consecutive elements never straddle two of them)
+        float lr = lr_in, wd = wd_in;
+        if (nseg > 0) {
+            int lo = 0, hi = nseg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (seg_end[mid] > base) hi = mid; else lo = mid + 1;
+            }
+            lr = seg_lr[lo]; wd = seg_wd[lo];
+        }
         const bool full = base + 4 <= n;
         if (full) {
             const float4 a = *reinterpret_cast<const float4*>(p + base), b = *reinterpret_cast<const float4*>(g + base);
@@ -28,7 +41,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float gg = gv[j] * gs;
-            if (wd != 0.f) gg += wd * pv[j];
+            if (wd != 0.f) {
+                if (decoupled) pv[j] *= 1.f - lr * wd;     // AdamW
+                else gg += wd * pv[j];                     // Adam with L2 regularisation
+            }
             mv[j] = b1 * mv[j] + (1.f - b1) * gg;
             vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
             const float denom = sqrtf(vv[j]) / bc2s + eps;
@@ -59,6 +75,25 @@ extern "C" int vpu_adam_step(float* p, const float* g, float* m, float* v, void*
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     const int64_t n4 = (n + 3) / 4;
     adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        p, g, m, v, (bf16_t*)shadow_bf16, n4, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+        p, g, m, v, (bf16_t*)shadow_bf16, n4, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, nullptr,
+        nullptr, nullptr, 0, 0);
     return vpu_check_launch("vpu_adam_step");
+}
+
+extern "C" int vpu_adam_step_groups(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                                    const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int32_t nseg,
+                                    float beta1, float beta2, float eps, int32_t decoupled_wd, int32_t step,
+                                    float grad_scale, void* stream) {
+    vpu_clear_stale_error();
+    if (n <= 0 || step < 1 || nseg < 1 || !seg_end || !seg_lr || !seg_wd) {
+        vpu_set_error("adam_groups: n > 0, step >= 1, nseg >= 1, segment tables");
+        return VPU_ERR_ARG;
+    }
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    const int64_t n4 = (n + 3) / 4;
+    adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        p, g, m, v, (bf16_t*)shadow_bf16, n4, n, 0.f, beta1, beta2, eps, 0.f, bc1, bc2s, grad_scale, seg_end, seg_lr,
+        seg_wd, nseg, decoupled_wd);
+    return vpu_check_launch("vpu_adam_step_groups");
 }

@@ -256,6 +256,11 @@ def nfl_dice_fwd_bwd(logits, gt, sums, out, dlogits, w_nfl, w_dice, B, HW):
               _stream())
 
 
+def adam_step_groups(p, g, m, v, shadow, n, seg_end, seg_lr, seg_wd, nseg, b1, b2, eps, decoupled, step, grad_scale=1.0):
+    _lib.call("vpu_adam_step_groups", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, ptr(seg_end), ptr(seg_lr),
+              ptr(seg_wd), nseg, b1, b2, eps, int(decoupled), step, grad_scale, _stream())
+
+
 def adam_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
     _lib.call("vpu_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, lr, b1, b2, eps, wd, step, grad_scale,
               _stream())

@@ -1,18 +1,30 @@
-"""Fused Adam over the engine's flat parameter buffer (torch.optim.Adam semantics as configured by the reference at
-models/iSegNet/vpu_base448_cocolvis.py:149-154: lr 5e-5, betas (0.9, 0.999), eps 1e-8; isegm/engine/optimizer.py:6-27
-builds one param group PER TENSOR -> 349 tiny kernels per step; here it is ONE launch that also writes the bf16 shadow
-used by the MFMA GEMMs)."""
+"""Fused Adam / AdamW over the engine's flat parameter buffer (torch.optim.Adam semantics as configured by the
+reference at models/iSegNet/vpu_base448_cocolvis.py:149-154: lr 5e-5, betas (0.9, 0.999), eps 1e-8).
+isegm/engine/optimizer.py:6-27 builds one param group PER TENSOR -> 349 tiny kernels per step; here it is ONE launch that
+also writes the bf16 shadow used by the MFMA GEMMs.  Per-tensor learning rates / weight decay (``param.lr_mult``,
+layer-wise lr decay of isegm/utils/lr_decay.py) are a small segment table read by the same kernel."""
 import torch
 
 from . import ops
 
 
 class FusedAdam:
-    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled_weight_decay=False,
+                 per_param=None):
+        """``per_param``: optional {parameter name: (lr_scale, weight_decay)}; names missing from it use (1, weight_decay).
+        The effective learning rate of a tensor is ``self.lr * lr_scale`` (so a scheduler only touches ``self.lr``)."""
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.decoupled = decoupled_weight_decay
+        self.per_param = dict(per_param) if per_param else None
         self.step_count = 0
         self.m = self.v = None
+        self._seg = None
+
+    # torch.optim-like view used by schedulers / loggers
+    @property
+    def param_groups(self):
+        return [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}]
 
     def _state(self, eng):
         if self.m is None or self.m.numel() != eng.total or self.m.device != eng.flat.device:
@@ -20,16 +32,37 @@ class FusedAdam:
             self.v = torch.zeros_like(eng.flat)
         return self.m, self.v
 
+    def _segments(self, eng):
+        """(seg_end int64, lr_scale fp32, wd fp32) on the device, one segment per tensor of the flat buffer."""
+        if self._seg is None:
+            names = list(eng.names.items())
+            ends, scales, wds = [], [], []
+            for i, (n, (off, _, numel)) in enumerate(names):
+                end = names[i + 1][1][0] if i + 1 < len(names) else eng.total   # padding belongs to the tensor before it
+                sc, wd = self.per_param.get(n, (1.0, self.weight_decay))
+                ends.append(end); scales.append(float(sc)); wds.append(float(wd))
+            dev = eng.flat.device
+            self._seg = (torch.tensor(ends, dtype=torch.int64, device=dev), torch.tensor(scales, device=dev),
+                         torch.tensor(wds, device=dev), len(ends))
+        return self._seg
+
     def step(self, grad_scale=1.0):
         """``grad_scale`` multiplies the gradient first (1/world_size after a SUM all-reduce)."""
         eng = self.model._ensure_engine()
         m, v = self._state(eng)
         self.step_count += 1
-        ops.adam_step(eng.flat, eng.gflat, m, v, eng.shadow, eng.total, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.weight_decay, self.step_count, grad_scale)
+        if self.per_param is None and not self.decoupled:
+            ops.adam_step(eng.flat, eng.gflat, m, v, eng.shadow, eng.total, self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.weight_decay, self.step_count, grad_scale)
+        else:
+            if self.per_param is None:
+                self.per_param = {}
+            ends, scales, wds, nseg = self._segments(eng)
+            ops.adam_step_groups(eng.flat, eng.gflat, m, v, eng.shadow, eng.total, ends, scales * self.lr, wds, nseg,
+                                 self.betas[0], self.betas[1], self.eps, self.decoupled, self.step_count, grad_scale)
         eng.refresh_weights(shadow_is_fresh=True)
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=False):
         self.model._ensure_engine().zero_grad()
 
     def state_dict(self):
@@ -37,3 +70,25 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         self.step_count, self.m, self.v, self.lr = sd["step"], sd["m"], sd["v"], sd["lr"]
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR as the reference configures it (models/iSegNet/vpu_base448_cocolvis.py:
+    ``partial(MultiStepLR, milestones=[50, 55], gamma=0.1)``, stepped once per epoch, trainer.py:204-206)."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, last_epoch=-1):
+        self.optimizer, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
+        self.base_lr = optimizer.lr
+        self.last_epoch = last_epoch
+        self.step()
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+    def get_lr(self):
+        return self.get_last_lr()
+
+    def step(self):
+        self.last_epoch += 1
+        passed = sum(1 for m in self.milestones if m <= self.last_epoch)
+        self.optimizer.lr = self.base_lr * (self.gamma ** passed)

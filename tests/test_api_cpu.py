@@ -81,3 +81,36 @@ def test_fails_loudly_without_gpu():
         m(torch.zeros(1, 4, 448, 448), -torch.ones(1, 48, 3))
     assert m.backbone.no_weight_decay() == {"pos_embed", "cls_token", "dist_token"}
     assert m.backbone.patch_embed.grid_size == (28, 28) and m.with_prev_mask
+
+
+def test_layerwise_lr_decay_groups_match_reference(golden_dir):
+    """f3: the per-tensor (learning rate, weight decay) table of get_optimizer_with_layerwise_decay equals what the
+    reference's param_groups_lrd produced for the same model (tests/golden/lrd.npz); tensors the reference leaves out of
+    every group get learning-rate scale 0."""
+    import os
+    from pvpuformer_amd.isegm.utils import lr_decay as lrd
+    fx = np.load(os.path.join(golden_dir, "lrd.npz"))
+    m = make_model(vo.make_cfg(**TINY))
+    groups = lrd.param_groups_lrd(m, 5e-5, weight_decay=0.02, no_weight_decay_list=m.backbone.no_weight_decay(),
+                                  layer_decay=0.75)
+    table = lrd.per_param_table(groups, 5e-5)
+    ref = {str(n): (float(l), float(w)) for n, l, w in zip(fx["names"], fx["lr"], fx["wd"])}
+    assert set(table) == set(ref)
+    for n, (scale, wd) in table.items():
+        assert abs(scale * 5e-5 - ref[n][0]) <= 1e-18 + 1e-12 * ref[n][0] and wd == ref[n][1], n
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in fx["all_names"]]
+    assert lrd.get_layer_id_for_vit("blocks.3.attn.qkv.weight", 9) == 4 and lrd.get_layer_id_for_vit("fc_norm.weight", 9) == 9
+
+
+def test_multistep_lr():
+    from pvpuformer_amd.optim import MultiStepLR
+
+    class Opt:
+        lr = 5e-5
+    o = Opt()
+    s = MultiStepLR(o, milestones=[50, 55], gamma=0.1)
+    lrs = []
+    for _ in range(57):
+        lrs.append(o.lr)
+        s.step()
+    assert lrs[0] == 5e-5 and lrs[49] == 5e-5 and abs(lrs[50] - 5e-6) < 1e-18 and abs(lrs[55] - 5e-7) < 1e-18

@@ -280,3 +280,39 @@ def test_nobrs_click_loop_iou_parity(golden_dir, zoom):
             assert abs(a - b) <= (1e-3 if name == "hip_f32" else 0.1), (name, series[name][0], series["oracle"][0])
     for a, b in zip(series["hip_f32"][1], series["oracle"][1]):
         assert np.array_equal(a, b)
+
+
+def test_fused_adam_layerwise_decay_step(golden_dir):
+    """f3: one optimizer step through get_optimizer_with_layerwise_decay on the tiny model equals torch.optim.Adam with
+    the reference's param groups on a copy of the parameters and gradients (weight decay 0.02 on matrices of the
+    backbone / neck / head, lr * 0.75**(L - layer)); tensors in no group do not move."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    from pvpuformer_amd.isegm.engine.optimizer import get_optimizer_with_layerwise_decay
+    from pvpuformer_amd.isegm.utils import lr_decay as lrd
+    model.train()
+    out = _run(model, img4, batch, 0)
+    gt = batch["instances"].cuda()
+    total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+    model.zero_grad()
+    total.backward()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+    groups = lrd.param_groups_lrd(model, 5e-5, weight_decay=0.02, no_weight_decay_list=model.backbone.no_weight_decay(),
+                                  layer_decay=0.75)
+    table = lrd.per_param_table(groups, 5e-5)
+    ref_params = {n: torch.nn.Parameter(before[n].clone()) for n in table}
+    ropt = torch.optim.Adam([{"params": [ref_params[n]], "lr": 5e-5 * sc, "weight_decay": wd} for n, (sc, wd) in table.items()],
+                            lr=5e-5, betas=(0.9, 0.999), eps=1e-8)
+    for n in table:
+        ref_params[n].grad = grads[n].clone()
+    ropt.step()
+    opt = get_optimizer_with_layerwise_decay(model, "adam", dict(lr=5e-5, betas=(0.9, 0.999), eps=1e-8))
+    opt.step()
+    after = dict(model.named_parameters())
+    for n in before:
+        if n in table:
+            # (an Adam step moves a weight by <= lr = 5e-5; 5e-8 = 0.1 % of that: sqrt / divide rounding of gradients near eps)
+            d = (after[n].detach() - ref_params[n].detach()).abs().max().item()
+            assert d <= 5e-8 + 1e-6 * ref_params[n].detach().abs().max().item(), (n, d)
+        else:
+            assert torch.equal(after[n].detach(), before[n]), n

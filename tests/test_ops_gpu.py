@@ -510,6 +510,35 @@ def test_adam_matches_torch(ops):
     assert torch.equal(sh, p.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("decoupled", [0, 1])
+def test_adam_groups_matches_torch(ops, decoupled):
+    """Per-tensor learning rate / weight decay in ONE launch == torch.optim.Adam / AdamW with one param group per tensor
+    (three tensors at 8-element-aligned offsets of a flat buffer, the padding in between stays untouched)."""
+    sizes, offs = [1000, 37, 4096], [0, 1000, 1040]
+    total = 1040 + 4096
+    lrs, wds = [5e-5, 5e-5 * 0.75 ** 3, 0.0], [0.02, 0.0, 0.02]
+    flat0 = rnd(total, seed=52)
+    g = rnd(total, seed=53, scale=0.1)
+    p = dev(flat0.clone())
+    m, v = torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+    sh = torch.zeros(total, device="cuda", dtype=torch.bfloat16)
+    seg_end = torch.tensor([1000, 1040, total], dtype=torch.int64, device="cuda")
+    seg_lr, seg_wd = torch.tensor(lrs, device="cuda"), torch.tensor(wds, device="cuda")
+    params = [torch.nn.Parameter(flat0[o:o + n].clone()) for o, n in zip(offs, sizes)]
+    cls = torch.optim.AdamW if decoupled else torch.optim.Adam
+    opt = cls([{"params": [q], "lr": lr, "weight_decay": wd} for q, lr, wd in zip(params, lrs, wds)],
+              lr=5e-5, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(1, 4):
+        for q, o, n in zip(params, offs, sizes):
+            q.grad = g[o:o + n].clone() * step
+        opt.step()
+        ops.adam_step_groups(p, dev(g * step), m, v, sh, total, seg_end, seg_lr, seg_wd, 3, 0.9, 0.999, 1e-8, decoupled,
+                             step)
+    for q, o, n in zip(params, offs, sizes):
+        torch.testing.assert_close(p[o:o + n].cpu(), q.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(sh, p.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("tA,tB", [(1, 1), (0, 0), (0, 1)])
 def test_gemm_split_k_and_vector_epilogue(ops, tA, tB):
     """Long-K / few-tile shapes take the split-K path (fp32 slabs + ordered reduce); the result must equal the
