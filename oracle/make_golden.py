@@ -401,16 +401,50 @@ def lrd_fixture(ref_vpu):
     print("[lrd] written", len(names), "of", len(by_id), "tensors in groups")
 
 
+def scribble_fixture(ref_vpu):
+    """a9: the reference's _guassinvector_scribble (is_vpu_model.py:294-352) on seeded scribbles; its debug
+    ``draw_scribble`` (cv2.imwrite to a hard-coded path, ops.py:409-419) is replaced by a no-op."""
+    import random
+    import isegm.model.ops as ref_ops
+    ref_ops.draw_scribble = lambda *a, **k: None
+    cfg = vo.make_cfg(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+    m, _ = build_reference(cfg, ref_vpu)
+    rs = np.random.RandomState(7)
+    B, n, P = 3, 5, 60
+    pts = -np.ones((B, 2 * n, 3), np.float32)
+    pts[0, 0] = (100, 200, 0); pts[0, 1] = (50.7, 60.2, 1); pts[0, n] = (300, 10, 2)
+    pts[1, 0] = (5, 440, 0)
+    pts[2, n] = (10, 10, 0)                                   # no valid positive row: nothing is overwritten
+    t = np.linspace(0, 1, P)
+    scr = np.zeros((B, 1, P, 2), np.float64)
+    scr[0, 0] = np.stack([100 + 80 * t + rs.randint(-2, 3, P), 150 + 40 * np.sin(6 * t) + rs.randint(-2, 3, P)], 1)
+    scr[1, 0] = np.stack([300 + 20 * np.cos(5 * t), 200 + 100 * t], 1)
+    scr[2, 0] = np.stack([40 + 10 * t, 40 + 10 * t], 1)
+    rects = np.zeros((B, 1, 4), np.int64)
+    rects[0, 0] = (140, 150, 90, 90); rects[1, 0] = (300, 250, 50, 110); rects[2, 0] = (45, 45, 12, 12)
+    random.seed(123)
+    with torch.no_grad():
+        ref = m._guassinvector_scribble(torch.from_numpy(pts), [scr, rects]).numpy()
+    got = vo.pue_scribble(pts, scr.astype(np.int32), rects, random.Random(123), 24, cfg["img"])
+    err = np.abs(got - ref).max()
+    print(f"[scribble] oracle vs reference: max abs err {err:.3e}; non-zero entries {int((ref != 0).sum())}")
+    assert err == 0.0
+    np.savez_compressed(os.path.join(OUT, "scribble.npz"), points=pts, scribbles=scr.astype(np.int32), rects=rects,
+                        seed=np.asarray(123), pue=ref)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom", "lrd"]
+    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom", "lrd", "scribble"]
     if "zoom" in which:
         zoom_fixtures()
     if "lrd" in which:
         lrd_fixture(ref_vpu)
+    if "scribble" in which:
+        scribble_fixture(ref_vpu)
     if "sim" in which:
         simulator_fixtures()
     if "pue" in which:

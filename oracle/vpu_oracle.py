@@ -303,6 +303,55 @@ def pue_box(points, boxes, num_max_points=24, img=448):
 # ----------------------------------------------------------------------------------------------
 # a2/a3: click disk maps + box outline
 # ----------------------------------------------------------------------------------------------
+def scribble_vectors(scribble, rect, rng, img=448):
+    """GaussianVector_scribble.gen_guassian_vector (ops.py:244-296), sigma 3, scale 1.  ``scribble`` int [P,2] (x, y),
+    ``rect`` (x0, y0, w0, h0); ``rng`` is a ``random.Random`` (the reference draws from the global ``random`` module).
+    Quirks kept: the drawn index addresses the scribble array itself, not the list of matching points (ops.py:272-275,
+    :288-290); a chosen point is removed (all its duplicates) in the x pass only."""
+    vx, vy = np.zeros(img, np.float64), np.zeros(img, np.float64)
+    scribble = np.asarray(scribble).astype(np.int32)
+    rect = np.asarray(rect)
+    if np.sum(scribble) + np.sum(rect) == 0:
+        return vx, vy
+    scribble = (scribble * 4 / 4).astype("int32")
+    sigma = 3
+    x0, y0, w0, h0 = (int(min(int(v), img)) for v in rect)
+    w_box, h_box = x0 - w0 // 2, y0 - h0 // 2
+    for xi in range(w0):
+        idx = np.argwhere(scribble[:, 0] == xi)
+        if len(idx) != 0:
+            point = scribble[rng.randint(0, len(idx) - 1)]
+            xs, hs = int(point[0]), int(point[1])
+            vx[xi] = np.exp(-((hs - h_box) ** 2) / (2 * sigma ** 2))
+            scribble = np.delete(scribble, np.argwhere((scribble[:, 0] == xs) & (scribble[:, 1] == hs)), axis=0)
+    for yj in range(h0):
+        idx = np.argwhere(scribble[:, 1] == yj)
+        if len(idx) != 0:
+            point = scribble[rng.randint(0, len(idx) - 1)]
+            vy[yj] = np.exp(-((int(point[0]) - w_box) ** 2) / (2 * sigma ** 2))
+    return vx, vy
+
+
+def pue_scribble(points, scribbles, rects, rng, num_max_points=24, img=448):
+    """_guassinvector_scribble (is_vpu_model.py:294-352): click rows, then the LAST valid positive row of each sample is
+    overwritten by the scribble vector of that sample (label one-hot 0).  scribbles int [B,1,P,2], rects int [B,1,4].
+    a9 is never reached by the shipped trainer / evaluator; CPU restatement + seeded golden only."""
+    pts = np.asarray(points, dtype=np.float32)
+    B, N, _ = pts.shape
+    n = N // 2
+    E = 2 * img + 3
+    rows = pue_click(pts, n, img)  # un-padded [B, N, E]
+    vecs = [scribble_vectors(scribbles[b][0], rects[b][0], rng, img) for b in range(B)]   # all samples first, as the reference
+    for b in range(B):
+        valid = np.nonzero(pts[b, :n, 2] != -1)[0]
+        if len(valid):
+            i = int(valid[-1])
+            rows[b, i, :] = 0.0
+            rows[b, i, :img], rows[b, i, img:2 * img] = vecs[b]
+            rows[b, i, 2 * img] = 1.0
+    return _pad_slots(rows, n, num_max_points, E)
+
+
 def disk_maps(points, H, W, radius=5):
     """DistMaps.get_coord_features torch path, use_disks=True, spatial_scale=1 (ops.py:347-379).
     fp32 arithmetic with separately rounded sub/mul/add.  Returns float32 [B,2,H,W] in {0,1}."""

@@ -114,3 +114,28 @@ def test_multistep_lr():
         lrs.append(o.lr)
         s.step()
     assert lrs[0] == 5e-5 and lrs[49] == 5e-5 and abs(lrs[50] - 5e-6) < 1e-18 and abs(lrs[55] - 5e-7) < 1e-18
+
+
+def test_mae_checkpoint_import_interpolates_pos_embed(tmp_path):
+    """f4: backbone.init_weights_from_pretrained (models_vit.py:150-166 + pos_embed.py:75-96): an MAE-style checkpoint
+    ({'model': ...}, 14x14 position grid + cls token, extra decoder keys) is loaded non-strictly, its position embedding
+    bicubically re-gridded to the model's 28x28 grid with the cls token kept."""
+    import torch.nn.functional as F
+    cfg = vo.make_cfg(**TINY)
+    m = make_model(cfg)
+    D = cfg["embed_dim"]
+    g = torch.Generator().manual_seed(5)
+    mae = {"pos_embed": torch.randn(1, 1 + 14 * 14, D, generator=g), "cls_token": torch.randn(1, 1, D, generator=g),
+           "blocks.0.attn.qkv.weight": torch.randn(3 * D, D, generator=g), "decoder_embed.weight": torch.randn(8, D, generator=g)}
+    path = tmp_path / "mae.pth"
+    torch.save({"model": {k: v.clone() for k, v in mae.items()}}, path)
+    msg = m.backbone.init_weights_from_pretrained(str(path))
+    assert "decoder_embed.weight" in msg.unexpected_keys and "blocks.1.attn.qkv.weight" in msg.missing_keys
+    sd = m.backbone.state_dict()
+    assert torch.equal(sd["blocks.0.attn.qkv.weight"], mae["blocks.0.attn.qkv.weight"])
+    assert torch.equal(sd["cls_token"], mae["cls_token"])
+    grid = mae["pos_embed"][:, 1:].reshape(1, 14, 14, D).permute(0, 3, 1, 2)
+    want = F.interpolate(grid, size=(28, 28), mode="bicubic", align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)
+    assert torch.equal(sd["pos_embed"][:, :1], mae["pos_embed"][:, :1])
+    torch.testing.assert_close(sd["pos_embed"][:, 1:], want, rtol=0, atol=0)
+    assert m.backbone.init_weights_from_pretrained("") is None
