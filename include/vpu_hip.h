@@ -213,13 +213,17 @@ int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_t* slot_mas
                      float* loss_part, float* dprob, float grad_scale, int32_t B, int32_t S, int32_t H, int32_t W,
                      void* stream);
 /* The same loss taken on the LOW-resolution similarities: fuses the align_corners=True upsample (is_vpu_model.py:434-436),
- * the loss and both backward passes; sim_low fp32 [B][S][h][w], dsim_low (optional) its gradient.  loss_part as above. */
+ * the loss and both backward passes; sim_low fp32 [B][S][h][w], dsim_low (optional) its gradient.
+ * loss_part fp32 [B][S][vpu_p2cl_up_nband(h)]: un-normalised sums per (plane, band of low-resolution rows). */
+int vpu_p2cl_up_nband(int32_t h);
 int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const int32_t* slot_mask_idx, const float* override_masks,
                         float* loss_part, float* dsim_low, float grad_scale, int32_t B, int32_t S, int32_t h, int32_t w,
                         int32_t H, int32_t W, void* stream);
 /* NormalizedFocalLossSigmoid(alpha .5, gamma 2) + naive Dice on logits [B][HW] vs gt (losses.py:11-89,227-363).
  * sums fp64 [B][8] workspace; out fp32 [B][2] = (nfl_b, dice_b); dlogits = w_nfl*dNFL + w_dice*dDice (means over B
  * folded into w_*). */
+/* sums: scratch of vpu_nfl_dice_scratch_doubles(B) doubles (per-chunk partial sums; need not be initialised) */
+int vpu_nfl_dice_scratch_doubles(int32_t B);
 int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, float* out, float* dlogits, float w_nfl,
                          float w_dice, int32_t B, int64_t HW, void* stream);
 

@@ -195,9 +195,9 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
     for (int j = 0; j < 8; ++j) v[j] = (float)e[j];
 }
 // prefetch of the residual / aux values one lane will need in the epilogue: [pass][t] as laid out by the LDS staging
-__device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int mbase, int nbase,
-                                             int lane, uint4 (&pre)[2][4]) {
-    const bool is_res = (p.flags & VPU_EPI_RESID) != 0;
+__device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, const int flags, int64_t coff, int64_t roff,
+                                             int mbase, int nbase, int lane, uint4 (&pre)[2][4]) {
+    const bool is_res = (flags & VPU_EPI_RESID) != 0;
     const bf16_t* src = reinterpret_cast<const bf16_t*>(is_res ? p.resid : p.aux);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
@@ -222,9 +222,8 @@ struct EpiPre {
     uint4 pre;        // 8 bf16 of resid or aux for this position
     float bias[8];
 };
-__device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t coff, int64_t roff, int m, int n,
-                                                float (&v)[8], const EpiPre& e) {
-    const int flags = p.flags;
+__device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, const int flags, int64_t coff, int64_t roff,
+                                                int m, int n, float (&v)[8], const EpiPre& e) {
     const bool has_pre = e.has_pre;
     const uint4* pre = &e.pre;
 #pragma unroll
@@ -248,15 +247,17 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
         // |error| <= 1.5e-7, far below bf16 resolution) and pdf(x) = u/sqrt(2 pi).  (The fp32 parity path keeps erff.)
         float d[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 8; ++j) {   // explicit fmaf: the file is built with -ffp-contract=off
             const float x = v[j];
-            const float u = __expf(-0.5f * x * x);
-            const float z = fabsf(x) * 0.70710678118654752f;
-            const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-            const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-            const float erfa = 1.0f - poly * u;            // erf(|x|/sqrt2)
-            const float phi = 0.5f * (1.0f + (x < 0.f ? -erfa : erfa));
-            d[j] = phi + x * 0.3989422804014327f * u;
+            const float u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);       // exp(-x^2/2)
+            const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.23164188892868984f, 1.0f));
+            float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+            poly = __builtin_fmaf(t, poly, 1.421413741f);
+            poly = __builtin_fmaf(t, poly, -0.284496736f);
+            poly = __builtin_fmaf(t, poly, 0.254829592f);
+            const float erfa = __builtin_fmaf(-(poly * t), u, 1.0f);       // erf(|x|/sqrt2)
+            const float phi = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);
+            d[j] = __builtin_fmaf(x * 0.3989422804014327f, u, phi);
             v[j] = x * phi;
         }
         if (flags & VPU_EPI_SAVE_DGELU) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, d);
@@ -316,9 +317,13 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, int64_t 
 // DMA = true : LDS-DMA staging, two 32-KiB stages, one barrier per K-tile (kept selectable: VPU_GEMM_DMA=1).
 // CS: with the fused bias-gradient column sums (only instantiated for TA = 1); kept out of the plain kernels so that they
 // do not carry its 16 accumulators + ones fragment.  __launch_bounds__(256, 2): two workgroups per CU.
-template <int TA, int TB, bool DMA, bool CS>
+// FL >= 0: the epilogue flags are the compile-time constant FL (host guarantees: vector epilogue, no split-K, N % 8 == 0)
+// -- the generic epilogue tests a dozen flags per 8-element group at run time, ~15k lines of ISA for one kernel; the
+// specialised ones are straight-line code.  FL = -1: generic (run-time flags, scalar tails, split-K slabs, diagnostics).
+constexpr int FL_SLAB = 0x10000;
+template <int TA, int TB, bool DMA, bool CS, int FL>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
-                                                        const int kchunk, float* __restrict__ ws, const int vec,
+                                                        const int kchunk, float* __restrict__ ws, const int vec_in,
                                                         const int tiles_m_arg, const int nbatch) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 32 KiB (register staging) or 64 KiB (DMA)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -329,6 +334,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     // at K = 768 that bubble was 30-45 % of a tile's life (round-1 measurement: main loop 880 vs 600 TFLOP/s end to end).
     const int ntiles = tiles_n * tiles_m_arg;
     const int total_work = ntiles * splitk * nbatch;
+    const int vec = vec_in & 255;
+    constexpr bool GEN = FL < 0;
+    constexpr bool SLAB = FL == FL_SLAB;   // split-K slice: the raw fp32 tile goes to its workspace slab, nothing else
+    const int FLG = GEN ? p.flags : (SLAB ? 0 : FL);
+    if (vec_in >> 8) {   // diagnostic (VPU_GEMM_STAGGER=n): de-synchronise the resident workgroups by up to n x ~0.5 us
+        const int steps = (int)((blockIdx.x * 2654435761u) >> 16) % (vec_in >> 8);
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     for (int work = blockIdx.x; work < total_work; work += gridDim.x) {
     const int tile_lin = work % ntiles, rest = work / ntiles;
     const int split = rest % splitk, z = rest / splitk;
@@ -432,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
         __syncthreads();
     }
 
-    if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
+    if (GEN && vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -444,18 +457,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     // Everything the epilogue READS from global memory is requested here, before its first store: vmcnt counts stores
     // too on CDNA4, so a load issued after a store makes the wave wait for that store's round trip (the ISA of the first
     // version had 8 such serialised waits per tile: 12-30 us per GEMM).  A lane always handles the same 8 columns.
-    const bool use_pre = vec == 1 && splitk == 1 &&
-                         (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
-                         !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
+    const bool use_pre = (!GEN || (vec == 1 && splitk == 1)) &&
+                         (FLG & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
+                         !((FLG & VPU_EPI_RESID) && (FLG & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
     uint4 pre[2][4];
 #pragma unroll
     for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
         for (int b_ = 0; b_ < 4; ++b_) pre[a_][b_] = make_uint4(0, 0, 0, 0);
-    if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
+    if (use_pre) prefetch_epi(p, FLG, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int ncol = n0 + wn * 64 + (lane & 7) * 8;
-    const bool use_bias8 = vec == 1 && splitk == 1 && (p.flags & VPU_EPI_BIAS) && ncol + 8 <= p.N;
+    const bool use_bias8 = (!GEN || (vec == 1 && splitk == 1)) && (FLG & VPU_EPI_BIAS) && ncol + 8 <= p.N;
     if (use_bias8) load8(p.bias + ncol, bias8);
     // ---- epilogue: transpose the accumulators through LDS so that every lane owns 8 consecutive columns of one row
     // and all global accesses are 16-byte vectors.  Two passes of 32 rows per wave (8 KiB of fp32 per wave each).
@@ -489,14 +502,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                     const int row = ii * 16 + fq * 4 + r;
                     wl[row * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[pass * 2 + ii][j][r];
                 }
-        __syncthreads();
+        // `wl` is private to this wave and a wave's LDS operations complete in program order: a wave-local wait is all
+        // the transpose needs.  (A __syncthreads() here also waits vmcnt(0), i.e. for the HBM acknowledgement of every
+        // global store of the previous pass -- with all 512 resident workgroups storing in lockstep that exposed the
+        // full write burst twice per tile.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int u = lane + 64 * t;
             const int row = u >> 3, c8 = (u & 7) * 8;
             const int m = m0 + wm * 64 + pass * 32 + row;
             const int n = n0 + wn * 64 + c8;
-            if (m < p.M && n < p.N) {
+            if (SLAB) {
+                if (m < p.M && n < p.N) {
+                    float v[8];
+                    load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
+                    store8(wsz + (int64_t)m * p.N + n, v);
+                }
+            } else if (!GEN) {
+                if (m < p.M && n < p.N) {
+                    float v[8];
+                    load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
+                    EpiPre e;
+                    e.has_pre = use_pre; e.has_bias = use_bias8; e.pre = pre[pass][t];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e.bias[j] = bias8[j];
+                    epilogue_store8(p, FLG, coff, roff, m, n, v, e);
+                }
+            } else if (m < p.M && n < p.N) {
                 float v[8];
                 load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
                 if (splitk > 1) {
@@ -515,15 +548,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                         e.has_pre = use_pre; e.has_bias = use_bias8; e.pre = pre[pass][t];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) e.bias[j] = bias8[j];
-                        epilogue_store8(p, coff, roff, m, n, v, e);
+                        epilogue_store8(p, FLG, coff, roff, m, n, v, e);
                     }
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
                 }
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this pass's reads of `wl` are done before it is rewritten
     }
+    // every wave is done with its epilogue LDS before the next tile's DMA overwrites stage 0; the global stores stay in
+    // flight (raw barrier: no vmcnt wait) and drain under the next tile's first DMA
+    __builtin_amdgcn_s_barrier();
     }  // persistent work loop
 }
 
@@ -556,12 +592,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7FFFFFFF, 0x00020000);
 
+    const int FLG = p.flags;
     // (measured: requesting the tile up front costs more than it hides at 2-3 blocks per CU -- disabled)
     const bool use_pre = false && vec == 1 && splitk == 1 &&
                          (p.flags & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
                          !((p.flags & VPU_EPI_RESID) && (p.flags & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
     uint4 pre[2][4];
-    if (use_pre) prefetch_epi(p, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
+    if (use_pre) prefetch_epi(p, FLG, coff, roff, m0 + wm * 64, n0 + wn * 64, lane, pre);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -685,7 +722,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
                     {
                         EpiPre e;
                         e.has_pre = false; e.has_bias = false; e.pre = make_uint4(0, 0, 0, 0);
-                        epilogue_store8(p, coff, roff, m, n, v, e);
+                        epilogue_store8(p, FLG, coff, roff, m, n, v, e);
                     }
                 } else {
                     for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
@@ -698,11 +735,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc p, const int splitk,
-                                                            const float* __restrict__ ws) {
+                                                            const float* __restrict__ ws, const int vec8) {
     const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
     const int64_t coff = zo * p.sCo + zi * p.sCi, roff = zo * p.sRo + zi * p.sRi;
     const int64_t mn = (int64_t)p.M * p.N;
     const float* w = ws + (int64_t)z * splitk * mn;
+    if (vec8) {   // N % 8 == 0 and every epilogue operand 16/32-byte addressable: 8 columns of one row per thread
+        const int n8 = p.N >> 3;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (mn >> 3); i += (int64_t)gridDim.x * 256) {
+            const int m = (int)(i / n8), n = (int)(i % n8) * 8;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < splitk; ++s) {
+                float t[8];
+                load8(w + s * mn + i * 8, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t[j];
+            }
+            EpiPre e;
+            e.has_pre = false; e.has_bias = false; e.pre = make_uint4(0, 0, 0, 0);
+            epilogue_store8(p, p.flags, coff, roff, m, n, v, e);
+        }
+    } else
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < splitk; ++s) v += w[s * mn + i];
@@ -877,7 +930,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
         static const bool noepi = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
         static const bool nostore = [] { const char* e = getenv("VPU_GEMM_NOSTORE"); return e && e[0] == '1'; }();
-        const int vec_arg = noepi ? 9 : (nostore ? 8 : (vec ? 1 : 0));
+        static const int stagger = [] { const char* e = getenv("VPU_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+        const int vec_arg = (noepi ? 9 : (nostore ? 8 : (vec ? 1 : 0))) | (stagger << 8);
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
         // persistent launch of the 128x128 kernel: at most VPU_GEMM_PERSIST (default 2 per CU = 512) workgroups walk the
@@ -892,9 +946,39 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
-        if (use_dma) gemm_bf16_kernel<TA_, TB_, true, false><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch); \
-        else gemm_bf16_kernel<TA_, TB_, false, false><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
+        if (use_dma) gemm_bf16_kernel<TA_, TB_, true, false, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch); \
+        else gemm_bf16_kernel<TA_, TB_, false, false, -1><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
     } while (0)
+#define VPU_LAUNCH_FL(TA_, TB_, FL_) \
+    gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch)
+        // compile-time epilogues for the flag sets of the ViT blocks (engine.py: linear / mlp / _dgrad)
+        static const bool no_spec = [] { const char* e = getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
+        const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && vec_arg == 1;
+        bool launched = false;
+        if (spec_ok) {
+            launched = true;
+            constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
+                          F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
+            if (key == 0 && f == F_B) VPU_LAUNCH_FL(0, 0, F_B);
+            else if (key == 0 && f == F_BR) VPU_LAUNCH_FL(0, 0, F_BR);
+            else if (key == 0 && f == F_G) VPU_LAUNCH_FL(0, 0, F_G);
+            else if (key == 1 && f == 0) VPU_LAUNCH_FL(0, 1, 0);
+            else if (key == 1 && f == F_M) VPU_LAUNCH_FL(0, 1, F_M);
+            else if (key == 1 && f == VPU_EPI_ACCUM) VPU_LAUNCH_FL(0, 1, VPU_EPI_ACCUM);
+            else launched = false;
+        }
+        const bool slab_ok = use_dma && !no_spec && !big && splitk > 1 && d->N % 8 == 0 && vec_arg <= 1;
+        if (!launched && slab_ok) {
+            launched = true;
+            if (d->colsum && key == 3) gemm_bf16_kernel<1, 1, true, true, FL_SLAB><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+            else if (d->colsum) launched = false;
+            else if (key == 3) VPU_LAUNCH_FL(1, 1, FL_SLAB);
+            else if (key == 0) VPU_LAUNCH_FL(0, 0, FL_SLAB);
+            else if (key == 1) VPU_LAUNCH_FL(0, 1, FL_SLAB);
+            else launched = false;
+        }
+        if (launched) {
+        } else
         if (big) {
             static bool attr_done = false;
             if (!attr_done) {
@@ -914,8 +998,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         } else {
             if (d->colsum) {  // weight-gradient GEMM with the fused bias gradient (always transA = transB = 1 in the engine)
-                if (key == 3) gemm_bf16_kernel<1, 1, true, true><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
-                else gemm_bf16_kernel<1, 0, true, true><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+                if (key == 3) gemm_bf16_kernel<1, 1, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+                else gemm_bf16_kernel<1, 0, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
             } else
             switch (key) {
                 case 0: VPU_LAUNCH(0, 0); break;
@@ -925,10 +1009,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         }
 #undef VPU_LAUNCH
+#undef VPU_LAUNCH_FL
         if (splitk > 1) {
             const int64_t mn = (int64_t)d->M * d->N;
-            dim3 rgrid((unsigned)vpu_grid_for(mn, 256, 4096), 1, (unsigned)d->batch);
-            splitk_reduce_kernel<bf16_t><<<rgrid, block, 0, s>>>(*d, splitk, ws);
+            const int vec8 = vec && d->N % 8 == 0 ? 1 : 0;
+            dim3 rgrid((unsigned)vpu_grid_for(vec8 ? mn / 8 : mn, 256, 4096), 1, (unsigned)d->batch);
+            splitk_reduce_kernel<bf16_t><<<rgrid, block, 0, s>>>(*d, splitk, ws, vec8);
         }
     } else {
         dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)d->batch), block(256);

@@ -61,134 +61,181 @@ __device__ __forceinline__ int ac_i0(int dst, float scale, int in_size) {
     int i0 = (int)(scale * (float)dst);
     return i0 > in_size - 1 ? in_size - 1 : i0;
 }
+// One block per (plane, band of P2_BAND low-resolution anchor rows) + one halo row above: 1 thread per low-resolution
+// cell.  A pixel whose bilinear anchor is cell (y0, x0) contributes to the 4 corners (y0|y0+1, x0|x0+1); the block owns
+// the gradient rows [r0, r1) of its band, so it also evaluates the anchor row r0-1 (whose lower corners land on row r0)
+// and drops the lower corners of its last anchor row (the next band's halo recomputes them).  Losses are counted for
+// the band's own anchor rows only.  The corner sums are added to the LDS gradient band in four barrier-separated
+// phases: in each phase every LDS word has exactly one writer -> bitwise reproducible, no atomics.
+constexpr int P2_BAND = 8;
+
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
                                                        const int* __restrict__ slot_idx,
                                                        const float* __restrict__ override_masks,
                                                        float* __restrict__ loss_part, float* __restrict__ dlow,
-                                                       float grad_scale, int S, int h, int w, int H, int W) {
-    extern __shared__ float sm[];          // [h*w] values, [h*w] gradients
+                                                       float grad_scale, int S, int h, int w, int H, int W, int nband) {
+    extern __shared__ float sm[];          // [(P2_BAND + 2) * w] values (rows r0-1 .. r1), [P2_BAND * w] gradients
     __shared__ double red[16];
-    float* sv = sm;
-    float* sg = sm + h * w;
-    const int plane = blockIdx.x, b = plane / S, s = plane % S;
+    const int plane = blockIdx.x / nband, band = blockIdx.x % nband;
+    const int b = plane / S, s = plane % S;
+    const int r0 = band * P2_BAND, r1 = (r0 + P2_BAND < h) ? r0 + P2_BAND : h;
+    float* sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
+    float* sg = sm + (P2_BAND + 2) * w;    // sg[(y - r0) * w + x]
     const int ov = slot_idx ? slot_idx[plane] : -1;
     const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
     const bool invert = ov < 0 && s >= S / 2;
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const float fh = sh > 0.f ? 1.f / sh : 0.f, fw = sw > 0.f ? 1.f / sw : 0.f;
-    for (int i = threadIdx.x; i < h * w; i += blockDim.x) { sv[i] = low[(int64_t)plane * h * w + i]; sg[i] = 0.f; }
+    for (int i = threadIdx.x; i < (P2_BAND + 2) * w; i += blockDim.x) {
+        const int y = r0 - 1 + i / w;
+        sv[i] = (y >= 0 && y < h) ? low[(int64_t)plane * h * w + (int64_t)y * w + (i % w)] : 0.f;
+    }
+    for (int i = threadIdx.x; i < P2_BAND * w; i += blockDim.x) sg[i] = 0.f;
     __syncthreads();
-    double acc = 0.0;
-    const int ncell = h * w;
-    const int iters = (ncell + blockDim.x - 1) / blockDim.x;
-    for (int it = 0; it < iters; ++it) {
-        const int cell = it * blockDim.x + threadIdx.x;
-        const bool live = cell < ncell;
-        const int y0 = live ? cell / w : 0, x0 = live ? cell % w : 0;
-        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-        float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f, part = 0.f;
-        if (live) {
-            const float v00 = sv[y0 * w + x0], v01 = sv[y0 * w + x1], v10 = sv[y1 * w + x0], v11 = sv[y1 * w + x1];
-            int Ya = (int)floorf(fh * (float)y0) - 1, Yb = (int)ceilf(fh * (float)(y0 + 1)) + 1;
-            int Xa = (int)floorf(fw * (float)x0) - 1, Xb = (int)ceilf(fw * (float)(x0 + 1)) + 1;
-            Ya = Ya < 0 ? 0 : Ya; Xa = Xa < 0 ? 0 : Xa;
-            Yb = Yb > H - 1 ? H - 1 : Yb; Xb = Xb > W - 1 ? W - 1 : Xb;
-            for (int Y = Ya; Y <= Yb; ++Y) {
-                if (ac_i0(Y, sh, h) != y0) continue;
-                const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
-                for (int X = Xa; X <= Xb; ++X) {
-                    if (ac_i0(X, sw, w) != x0) continue;
-                    const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
-                    const float p = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-                    float y = lab[(int64_t)Y * W + X];
-                    const bool valid = y != -1.0f;
-                    if (invert) y = (y != 0.f) ? 0.f : 1.f;
-                    if (!valid) y = 0.f;
-                    const float a = p + 1e-12f, c = 1.f - p + 1e-12f;
-                    if (valid) {
-                        part += -(logf(a) * y + logf(c) * (1.f - y));
-                        const float g = grad_scale * (-(y / a) + (1.f - y) / c);
-                        g00 += g * hy * hx; g01 += g * hy * lx; g10 += g * ly * hx; g11 += g * ly * lx;
+    // thread -> cell (y0, x0) with y0 in [r0-1, r1)
+    const int ly_ = threadIdx.x / w, x0 = threadIdx.x % w;
+    const int y0 = r0 - 1 + ly_;
+    const bool live = ly_ <= (r1 - r0) && y0 >= 0 && y0 < h;
+    const bool own = live && y0 >= r0;     // the loss of this anchor row is counted here
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f, part = 0.f;
+    if (live) {
+        const float v00 = sv[(y0 - r0 + 1) * w + x0], v01 = sv[(y0 - r0 + 1) * w + x1];
+        const float v10 = sv[(y1 - r0 + 1) * w + x0], v11 = sv[(y1 - r0 + 1) * w + x1];
+        // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone)
+        int Ya = (int)(fh * (float)y0) - 1; Ya = Ya < 0 ? 0 : Ya;
+        while (Ya < H && ac_i0(Ya, sh, h) < y0) ++Ya;
+        int Yb = Ya; while (Yb < H && ac_i0(Yb, sh, h) == y0) ++Yb;
+        int Xa = (int)(fw * (float)x0) - 1; Xa = Xa < 0 ? 0 : Xa;
+        while (Xa < W && ac_i0(Xa, sw, w) < x0) ++Xa;
+        int Xb = Xa; while (Xb < W && ac_i0(Xb, sw, w) == x0) ++Xb;
+        for (int Y = Ya; Y < Yb; ++Y) {
+            const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+            for (int X = Xa; X < Xb; ++X) {
+                const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
+                const float pr = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                float y = lab[(int64_t)Y * W + X];
+                const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
+                if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
+                if (valid) {
+                    const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                    float l, g;
+                    if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
+                        const float q = y != 0.f ? a : c;
+                        l = -__logf(q);
+                        const float rq = __builtin_amdgcn_rcpf(q);
+                        g = y != 0.f ? -rq : rq;
+                    } else {
+                        l = -(__logf(a) * y + __logf(c) * (1.f - y));
+                        g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
                     }
+                    part += l;
+                    g *= grad_scale;
+                    g00 += g * hy * hx; g01 += g * hy * lx; g10 += g * ly * hx; g11 += g * ly * lx;
                 }
             }
         }
-        acc += part;
-        if (dlow) {   // four phases: one writer per LDS word in each
-            // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
-            // corner terms into the cell's own word and skip the write
-            const bool bx = x1 != x0, by = y1 != y0;
-            if (!bx) { g00 += g01; g10 += g11; }
-            if (!by) { g00 += g10; if (bx) g01 += g11; }
-            if (live) sg[y0 * w + x0] += g00;
-            __syncthreads();
-            if (live && bx) sg[y0 * w + x1] += g01;
-            __syncthreads();
-            if (live && by) sg[y1 * w + x0] += g10;
-            __syncthreads();
-            if (live && bx && by) sg[y1 * w + x1] += g11;
-            __syncthreads();
+    }
+    const double t = block_sum_d(own ? (double)part : 0.0, red);
+    if (threadIdx.x == 0) loss_part[(int64_t)plane * nband + band] = (float)t;
+    if (dlow) {
+        // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
+        // corner terms into the cell's own word and skip the write
+        const bool bx = x1 != x0, by = y1 != y0;
+        if (!bx) { g00 += g01; g10 += g11; }
+        if (!by) { g00 += g10; if (bx) g01 += g11; }
+        const bool up = live && y0 >= r0;              // upper corners land on row y0 (inside the band unless halo)
+        const bool dn = live && by && y1 < r1;         // lower corners land on row y1 (dropped for the last anchor row)
+        if (up) sg[(y0 - r0) * w + x0] += g00;
+        __syncthreads();
+        if (up && bx) sg[(y0 - r0) * w + x1] += g01;
+        __syncthreads();
+        if (dn) sg[(y1 - r0) * w + x0] += g10;
+        __syncthreads();
+        if (dn && bx) sg[(y1 - r0) * w + x1] += g11;
+        __syncthreads();
+        for (int i = threadIdx.x; i < (r1 - r0) * w; i += blockDim.x)
+            dlow[(int64_t)plane * h * w + (int64_t)r0 * w + i] = sg[i];
+    }
+}
+
+// NFL + Dice in three launches over (sample, chunk) blocks: per-chunk partial sums -> gradients + per-chunk loss partials
+// (every block re-reduces the NFL_NBLK partial rows of its sample in a fixed order) -> per-sample losses.
+// scratch layout (double): sums[b][1 + chunk][0..4] = sum w, sum beta, sum p*t, sum p, sum t ; [5] = NFL loss partial.
+constexpr int NFL_NBLK = 32;
+
+__global__ __launch_bounds__(256) void nfl_dice_sums_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ gt, double* __restrict__ sums,
+                                                            int64_t HW) {
+    __shared__ double red[16];
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int64_t n4 = HW / 4, per = (n4 + NFL_NBLK - 1) / NFL_NBLK;
+    const int64_t lo = blk * per, hi = lo + per < n4 ? lo + per : n4;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t i4 = lo + threadIdx.x; i4 < hi; i4 += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(logits + (int64_t)b * HW + i4 * 4);
+        const float4 tv = *reinterpret_cast<const float4*>(gt + (int64_t)b * HW + i4 * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = xs[j], t = ts[j];
+            const float p = 1.f / (1.f + expf(-x));
+            const float w = t != -1.0f ? 1.f : 0.f;
+            const float pt = w > 0.f ? 1.f - fabsf(t - p) : 1.f;
+            const float beta = (1.f - pt) * (1.f - pt);
+            a[0] += w; a[1] += beta; a[2] += p * t; a[3] += p; a[4] += t;
         }
     }
-    const double t = block_sum_d(acc, red);
-    if (threadIdx.x == 0) loss_part[plane] = (float)t;
-    if (dlow) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < h * w; i += blockDim.x) dlow[(int64_t)plane * h * w + i] = sg[i];
-    }
-}
-
-// sums[b][0..4] = sum w, sum beta, sum p*t, sum p, sum t
-__global__ __launch_bounds__(1024) void nfl_dice_sums_kernel(const float* __restrict__ logits,
-                                                             const float* __restrict__ gt, double* __restrict__ sums,
-                                                             int64_t HW) {
-    __shared__ double red[16];
-    const int b = blockIdx.x;
-    double a[5] = {0, 0, 0, 0, 0};
-    for (int64_t i = threadIdx.x; i < HW; i += 1024) {
-        const float x = logits[(int64_t)b * HW + i], t = gt[(int64_t)b * HW + i];
-        const float p = 1.f / (1.f + expf(-x));
-        const float w = t != -1.0f ? 1.f : 0.f;
-        const float pt = w > 0.f ? 1.f - fabsf(t - p) : 1.f;
-        const float beta = (1.f - pt) * (1.f - pt);
-        a[0] += w; a[1] += beta; a[2] += p * t; a[3] += p; a[4] += t;
-    }
     for (int k = 0; k < 5; ++k) {
-        const double v = block_sum_d(a[k], red);
-        if (threadIdx.x == 0) sums[b * 8 + k] = v;
+        const double v = block_sum_d((double)a[k], red);
+        if (threadIdx.x == 0) sums[((int64_t)b * (NFL_NBLK + 1) + 1 + blk) * 8 + k] = v;
     }
 }
 
-__global__ __launch_bounds__(1024) void nfl_dice_grad_kernel(const float* __restrict__ logits,
-                                                             const float* __restrict__ gt,
-                                                             const double* __restrict__ sums, float* __restrict__ out,
-                                                             float* __restrict__ dlogits, float w_nfl, float w_dice,
-                                                             int64_t HW) {
+__device__ __forceinline__ void nfl_sample_sums(const double* __restrict__ sums, int b, float (&o)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double t = 0.0;
+        for (int c = 0; c < NFL_NBLK; ++c) t += sums[((int64_t)b * (NFL_NBLK + 1) + 1 + c) * 8 + k];
+        o[k] = (float)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void nfl_dice_grad_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ gt, double* __restrict__ sums,
+                                                            float* __restrict__ dlogits, float w_nfl, float w_dice,
+                                                            int64_t HW) {
     __shared__ double red[16];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, blk = blockIdx.x;
     const float eps = 1e-12f;
-    const float sw = (float)sums[b * 8 + 0], bs = (float)sums[b * 8 + 1];
-    const float A = (float)sums[b * 8 + 2], Bp = (float)sums[b * 8 + 3], Ct = (float)sums[b * 8 + 4];
+    float sm[5];
+    nfl_sample_sums(sums, b, sm);
+    const float sw = sm[0], bs = sm[1], A = sm[2], Bp = sm[3], Ct = sm[4];
     const float mult = sw / (bs + eps);          // detached (losses.py:57-59)
     const float inv_bsum = 1.f / (sw + eps);     // size_average (losses.py:80-82)
     const float deps = 1e-3f;
     const float den = Bp + Ct + deps;
-    const float dice = (2.f * A + deps) / den;
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < HW; i += 1024) {
-        const float x = logits[(int64_t)b * HW + i], t = gt[(int64_t)b * HW + i];
-        const float p = 1.f / (1.f + expf(-x));
-        const float w = t != -1.0f ? 1.f : 0.f;
-        const bool pos = t > 0.5f;
-        const float alpha = 0.5f * w;  // alpha = 1-alpha = 0.5
-        const float pt = w > 0.f ? 1.f - fabsf(t - p) : 1.f;
-        const float om = 1.f - pt;
-        const float beta = om * om * mult;
-        const float arg = fminf(pt + eps, 1.f);
-        const float lg = logf(arg);
-        acc += (double)(-alpha * beta * lg * w);
-        if (dlogits) {
+    const int64_t n4 = HW / 4, per = (n4 + NFL_NBLK - 1) / NFL_NBLK;
+    const int64_t lo = blk * per, hi = lo + per < n4 ? lo + per : n4;
+    float acc = 0.f;
+    for (int64_t i4 = lo + threadIdx.x; i4 < hi; i4 += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(logits + (int64_t)b * HW + i4 * 4);
+        const float4 tv = *reinterpret_cast<const float4*>(gt + (int64_t)b * HW + i4 * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = xs[j], t = ts[j];
+            const float p = 1.f / (1.f + expf(-x));
+            const float w = t != -1.0f ? 1.f : 0.f;
+            const float alpha = 0.5f * w;  // alpha = 1-alpha = 0.5
+            const float pt = w > 0.f ? 1.f - fabsf(t - p) : 1.f;
+            const float om = 1.f - pt;
+            const float beta = om * om * mult;
+            const float arg = fminf(pt + eps, 1.f);
+            const float lg = logf(arg);
+            acc += -alpha * beta * lg * w;
             // d/dpt of (1-pt)^2 * log(min(pt+eps,1))
             const float dfd = -2.f * om * lg + om * om * ((pt + eps < 1.f) ? 1.f / (pt + eps) : 0.f);
             const float dptdp = (t - p) > 0.f ? 1.f : ((t - p) < 0.f ? -1.f : 0.f);
@@ -196,15 +243,24 @@ __global__ __launch_bounds__(1024) void nfl_dice_grad_kernel(const float* __rest
             const float g_nfl = -alpha * mult * w * dfd * dptdp * dp_dx * inv_bsum;
             const float dd_dp = (2.f * t * den - (2.f * A + deps)) / (den * den);
             const float g_dice = -dd_dp * dp_dx;
-            dlogits[(int64_t)b * HW + i] = w_nfl * g_nfl + w_dice * g_dice;
+            g[j] = w_nfl * g_nfl + w_dice * g_dice;
         }
-        (void)pos;
+        if (dlogits) *reinterpret_cast<float4*>(dlogits + (int64_t)b * HW + i4 * 4) = make_float4(g[0], g[1], g[2], g[3]);
     }
-    const double L = block_sum_d(acc, red);
-    if (threadIdx.x == 0) {
-        out[b * 2 + 0] = (float)L * inv_bsum;
-        out[b * 2 + 1] = 1.f - dice;
-    }
+    const double L = block_sum_d((double)acc, red);
+    if (threadIdx.x == 0) sums[((int64_t)b * (NFL_NBLK + 1) + 1 + blk) * 8 + 5] = L;
+}
+
+__global__ void nfl_dice_final_kernel(const double* __restrict__ sums, float* __restrict__ out, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float sm[5];
+    nfl_sample_sums(sums, b, sm);
+    double L = 0.0;
+    for (int c = 0; c < NFL_NBLK; ++c) L += sums[((int64_t)b * (NFL_NBLK + 1) + 1 + c) * 8 + 5];
+    const float deps = 1e-3f;
+    out[b * 2 + 0] = (float)L * (1.f / (sm[0] + 1e-12f));
+    out[b * 2 + 1] = 1.f - (2.f * sm[2] + deps) / (sm[3] + sm[4] + deps);
 }
 
 }  // namespace
@@ -220,27 +276,32 @@ extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_
     return vpu_check_launch("vpu_p2cl_fwd_bwd");
 }
 
+extern "C" int vpu_p2cl_up_nband(int32_t h) { return (h + P2_BAND - 1) / P2_BAND; }
+
 extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const int32_t* slot_mask_idx,
                                    const float* override_masks, float* loss_part, float* dsim_low, float grad_scale,
                                    int32_t B, int32_t S, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
-    const size_t shmem = (size_t)2 * h * w * sizeof(float);
-    if (S % 2 || shmem > 150 * 1024) { vpu_set_error("p2cl_up: S % 2, low-res plane must fit LDS twice"); return VPU_ERR_ARG; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  150 * 1024);
-        attr_set = true;
+    if (S % 2 || (P2_BAND + 1) * w > 1024) {
+        vpu_set_error("p2cl_up: S % 2, (band + 1) * w <= 1024 (w <= 113)");
+        return VPU_ERR_ARG;
     }
-    p2cl_up_kernel<<<(unsigned)(B * S), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part, dsim_low,
-                                                         grad_scale, S, h, w, H, W);
+    const int nband = (h + P2_BAND - 1) / P2_BAND;
+    const size_t shmem = (size_t)(2 * P2_BAND + 2) * w * sizeof(float);
+    p2cl_up_kernel<<<(unsigned)(B * S * nband), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
+                                                                  dsim_low, grad_scale, S, h, w, H, W, nband);
     return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
 }
+
+extern "C" int vpu_nfl_dice_scratch_doubles(int32_t B) { return B * (NFL_NBLK + 1) * 8; }
 
 extern "C" int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, float* out, float* dlogits,
                                     float w_nfl, float w_dice, int32_t B, int64_t HW, void* stream) {
     vpu_clear_stale_error();
-    nfl_dice_sums_kernel<<<B, 1024, 0, ST>>>(logits, gt, sums, HW);
-    nfl_dice_grad_kernel<<<B, 1024, 0, ST>>>(logits, gt, sums, out, dlogits, w_nfl, w_dice, HW);
+    if (HW % 4) { vpu_set_error("nfl_dice: H*W % 4"); return VPU_ERR_ARG; }
+    dim3 grid(NFL_NBLK, B);
+    nfl_dice_sums_kernel<<<grid, 256, 0, ST>>>(logits, gt, sums, HW);
+    nfl_dice_grad_kernel<<<grid, 256, 0, ST>>>(logits, gt, sums, dlogits, w_nfl, w_dice, HW);
+    nfl_dice_final_kernel<<<(B + 63) / 64, 64, 0, ST>>>(sums, out, B);
     return vpu_check_launch("vpu_nfl_dice_fwd_bwd");
 }

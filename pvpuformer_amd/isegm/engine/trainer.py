@@ -20,10 +20,9 @@ def vpu_step_losses(inst, aux, gt, slot_idx=None, override=None, iter_weight=1.0
     B, S = (aux.shape[:2] if aux is not None else sim_low.shape[:2])
     dev = inst.device
     gt = gt.contiguous().float()
-    sums = torch.zeros(B, 8, device=dev, dtype=torch.float64)
     out = torch.empty(B, 2, device=dev)
     d_inst = torch.empty_like(inst) if want_grads else None
-    ops.nfl_dice_fwd_bwd(inst, gt, sums, out, d_inst, w_nfl * iter_weight / B, w_dice * iter_weight / B, B, H * W)
+    ops.nfl_dice_fwd_bwd(inst, gt, None, out, d_inst, w_nfl * iter_weight / B, w_dice * iter_weight / B, B, H * W)
     part = torch.empty(B, S, device=dev)
     gs = w_pcl * iter_weight / (B * S * H * W)
     if aux is not None:

@@ -247,11 +247,18 @@ def p2cl_fwd_bwd(prob, gt, slot_idx, override, loss_part, dprob, grad_scale, B, 
 
 
 def p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, loss_part, dsim_low, grad_scale, B, S, h, w, H, W):
-    _lib.call("vpu_p2cl_up_fwd_bwd", ptr(sim_low), ptr(gt), ptr(slot_idx), ptr(override), ptr(loss_part), ptr(dsim_low),
+    """loss_part fp32 [B, S]: per-plane sums (the kernel's per-band partials are summed here)."""
+    nband = _lib.load().vpu_p2cl_up_nband(h)
+    bands = torch.empty(B * S, nband, device=sim_low.device, dtype=torch.float32)
+    _lib.call("vpu_p2cl_up_fwd_bwd", ptr(sim_low), ptr(gt), ptr(slot_idx), ptr(override), ptr(bands), ptr(dsim_low),
               grad_scale, B, S, h, w, H, W, _stream())
+    torch.sum(bands, dim=1, out=loss_part.view(B * S))
 
 
 def nfl_dice_fwd_bwd(logits, gt, sums, out, dlogits, w_nfl, w_dice, B, HW):
+    """``sums``: float64 scratch of vpu_nfl_dice_scratch_doubles(B) elements, or None to allocate it here."""
+    if sums is None:
+        sums = torch.empty(_lib.load().vpu_nfl_dice_scratch_doubles(B), device=logits.device, dtype=torch.float64)
     _lib.call("vpu_nfl_dice_fwd_bwd", ptr(logits), ptr(gt), ptr(sums), ptr(out), ptr(dlogits), w_nfl, w_dice, B, HW,
               _stream())
 

@@ -485,10 +485,9 @@ def test_upsample_and_losses(ops):
     logits = dev(rnd(B, 1, H, H, seed=47, scale=4.0)).requires_grad_(True)
     l_n, l_d = vo.nfl_loss(logits, gt).mean(), vo.dice_loss_naive(logits, gt)
     (1.5 * l_n + 0.7 * l_d).backward()
-    sums = torch.zeros(B, 8, device="cuda", dtype=torch.float64)
     out = torch.empty(B, 2, device="cuda")
     dl = torch.empty(B, H * H, device="cuda")
-    ops.nfl_dice_fwd_bwd(logits.detach(), gt, sums, out, dl, 1.5 / B, 0.7 / B, B, H * H)
+    ops.nfl_dice_fwd_bwd(logits.detach(), gt, None, out, dl, 1.5 / B, 0.7 / B, B, H * H)
     torch.testing.assert_close(out[:, 0].mean(), l_n.detach(), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(out[:, 1].mean(), l_d.detach(), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(dl.view_as(logits), logits.grad, rtol=2e-4, atol=1e-9)

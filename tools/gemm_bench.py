@@ -45,7 +45,10 @@ def main():
     dev = "cuda"
     tot_t, tot_f = 0.0, 0.0
     with_torch = os.environ.get("GEMM_BENCH_TORCH", "0") == "1"
+    only = [t for t in os.environ.get("GEMM_BENCH_ONLY", "").split(",") if t]
     for name, tA, tB, m, n, k, flags in SHAPES + NECK:
+        if only and not any(t in name for t in only):
+            continue
         A = (torch.rand((k, m) if tA else (m, k), device=dev) - 0.5).to(torch.bfloat16)
         Bm = (torch.rand((k, n) if tB else (n, k), device=dev) - 0.5).to(torch.bfloat16)
         out_f32 = bool(flags & ops.EPI_OUT_F32)
