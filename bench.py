@@ -182,6 +182,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0   # host time to ENQUEUE the steps (diagnostic: close to dt means launch-bound)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -220,6 +221,7 @@ def main():
                            "flop_per_image_fwd_bwd": FLOP_PER_IMG[args.model],
                            "mfma_roofline_frac_end_to_end":
                                round(value / world * FLOP_PER_IMG[args.model] / (BF16_PEAK_TFLOPS * 1e12), 4),
+                           "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
                            "final_loss": round(loss_val, 5)},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -154,8 +154,9 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, 
     if (TRANS == 0) {
         const int row = x16 + (lane & 15);
         const int chunk = ks * 4 + (lane >> 4);
-        const uint4 v = *reinterpret_cast<const uint4*>(lds + kc_off(row, chunk));
-        return __builtin_bit_cast(bf16x8_t, v);
+        // (an ext-vector load: through HIP's uint4 struct the load carries TBAA info, and SIInsertWaitcnts then puts
+        // s_waitcnt vmcnt(0) in front of every such ds_read while an LDS-DMA is pending -- the ring would never overlap)
+        return *reinterpret_cast<const bf16x8_t*>(lds + kc_off(row, chunk));
     } else {
         const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
         const int k = ks * 32 + 8 * g + q;
@@ -320,8 +321,44 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, const in
 // FL >= 0: the epilogue flags are the compile-time constant FL (host guarantees: vector epilogue, no split-K, N % 8 == 0)
 // -- the generic epilogue tests a dozen flags per 8-element group at run time, ~15k lines of ISA for one kernel; the
 // specialised ones are straight-line code.  FL = -1: generic (run-time flags, scalar tails, split-K slabs, diagnostics).
+// One K-tile of the ring loop: DMA of a later K-tile into stage `wr`, fragments of the current one from stage `rd`.
+// The two stages are __restrict__ parameters of an inlined function on purpose: the scoped no-alias information this
+// leaves on the LDS-DMA and on the ds_reads is what stops SIInsertWaitcnts from putting s_waitcnt vmcnt(0) in front of
+// the reads while a DMA is pending (it cannot tell the stages of one LDS array apart otherwise).
+template <int TA, int TB, bool CS>
+__device__ __forceinline__ void ring_step(__amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rB, int lda, int ldb, int m0,
+                                          int M, int n0, int N, int k0, int kend, char* __restrict__ wr,
+                                          const char* __restrict__ rd, int wave, int lane, int wm, int wn, bool do_cs,
+                                          bf16x8_t ones, f32x4_t (&acc)[4][4], f32x4_t (&acc_cs)[4]) {
+    stage_tile<TA>(rA, lda, m0, M, k0, kend, wr, wave, lane);
+    stage_tile<TB>(rB, ldb, n0, N, k0, kend, wr + TILE_BYTES, wave, lane);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(rd, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(rd + TILE_BYTES, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (CS && TA == 1 && do_cs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+        }
+    }
+}
+
+// RING = S > 0: S LDS stages of 32 KiB in a ring, the DMA of K-tile kt+S-1 is issued while tile kt is computed, a COUNTED
+// s_waitcnt vmcnt(8*(S-2)) (a stage = 8 DMA instructions per wave; past the end of K the pieces are requested out of
+// range, which costs no memory traffic and keeps the count uniform) + one raw s_barrier per K-tile.  For the small
+// problems of the DMA neck (one tile per workgroup, <= 24 K-tiles): the two-stage loop pays one full L2/HBM round trip
+// per K-tile there (~1.2 us), which split-K + a reduce launch used to paper over.
 constexpr int FL_SLAB = 0x10000;
-template <int TA, int TB, bool DMA, bool CS, int FL>
+template <int TA, int TB, bool DMA, bool CS, int FL, int RING = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
                                                         const int kchunk, float* __restrict__ ws, const int vec_in,
                                                         const int tiles_m_arg, const int nbatch) {
@@ -374,6 +411,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    if constexpr (RING > 0) {
+        static_assert(RING == 3 || RING == 4, "ring depth");
+#pragma unroll
+        for (int st = 0; st < RING - 1; ++st) {   // k0 >= kend: every piece is requested out of range (zeros, no traffic)
+            stage_tile<TA>(rA, p.lda, m0, p.M, kbeg + st * BK, kend, lds + st * 2 * TILE_BYTES, wave, lane);
+            stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg + st * BK, kend, lds + st * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (RING == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // tile kt has landed for every wave; everyone is done reading tile kt-1
+            ring_step<TA, TB, CS>(rA, rB, p.lda, p.ldb, m0, p.M, n0, p.N, kbeg + (kt + RING - 1) * BK, kend,
+                                  lds + ((kt + RING - 1) % RING) * 2 * TILE_BYTES, lds + (kt % RING) * 2 * TILE_BYTES, wave,
+                                  lane, wm, wn, do_cs, ones, acc, acc_cs);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail pieces still write (zeros) into LDS
+        __syncthreads();
+    } else {
     if (DMA) {
         stage_tile<TA>(rA, p.lda, m0, p.M, kbeg, kend, lds, wave, lane);
         stage_tile<TB>(rB, p.ldb, n0, p.N, kbeg, kend, lds + TILE_BYTES, wave, lane);
@@ -444,6 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
         }
         __syncthreads();
     }
+    }  // RING == 0
 
     if (GEN && vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
         float t = 0.f;
@@ -916,7 +972,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // split-K: few output tiles and a long reduction (weight gradients, cosine-logit gradients)
         const int64_t tiles = (int64_t)tiles_m * tiles_n * d->batch;
         int splitk = 1, kchunk = (d->K + BK - 1) / BK * BK;
-        if (d->workspace && tiles < 192 && d->K >= 8 * BK) {
+        // one-wave problems (96..256 tiles, e.g. the DMA neck's 9408 x 384 x 768 projections): one tile per workgroup, no
+        // split-K, the three-stage ring hides the per-K-tile round trip.  (Measured: with fewer tiles -- the 576-row token
+        // GEMMs, 15-30 tiles -- too few bytes are in flight and split-K + reduce stays faster: 13+5 us vs 17-21 us.)
+        static const int ring_env = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 1; }();   // 0 off, 2 everywhere
+        const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= 96 && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
+        if (!ring && d->workspace && tiles < 192 && d->K >= 8 * BK) {
             int64_t want = (384 + tiles - 1) / tiles;
             const int64_t max_by_k = d->K / (4 * BK);
             const int64_t max_by_ws = d->workspace_bytes / ((int64_t)d->batch * d->M * (d->N + 1) * 4);
@@ -955,7 +1016,27 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         static const bool no_spec = [] { const char* e = getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
         const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && vec_arg == 1;
         bool launched = false;
-        if (spec_ok) {
+#define VPU_LAUNCH_RING(TA_, TB_, CS_, FL_)                                                                            \
+    do {                                                                                                             \
+        static bool attr_ = false;                                                                                   \
+        auto kern_ = gemm_bf16_kernel<TA_, TB_, true, CS_, FL_, 3>;                                                   \
+        if (!attr_) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
+            attr_ = true;                                                                                            \
+        }                                                                                                            \
+        kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
+    } while (0)
+        if (ring && use_dma && vec_arg <= 1) {
+            launched = true;
+            if (d->colsum && key == 3) VPU_LAUNCH_RING(1, 1, true, -1);
+            else if (d->colsum) launched = false;
+            else if (key == 0) VPU_LAUNCH_RING(0, 0, false, -1);
+            else if (key == 1) VPU_LAUNCH_RING(0, 1, false, -1);
+            else if (key == 2) VPU_LAUNCH_RING(1, 0, false, -1);
+            else VPU_LAUNCH_RING(1, 1, false, -1);
+        }
+#undef VPU_LAUNCH_RING
+        if (!launched && spec_ok) {
             launched = true;
             constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
                           F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;

@@ -68,6 +68,7 @@ __device__ __forceinline__ int ac_i0(int dst, float scale, int in_size) {
 // the band's own anchor rows only.  The corner sums are added to the LDS gradient band in four barrier-separated
 // phases: in each phase every LDS word has exactly one writer -> bitwise reproducible, no atomics.
 constexpr int P2_BAND = 8;
+constexpr int P2_SPAN = 5;   // most full-resolution pixels per low-resolution cell and axis
 
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
                                                        const int* __restrict__ slot_idx,
@@ -110,30 +111,43 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         int Xa = (int)(fw * (float)x0) - 1; Xa = Xa < 0 ? 0 : Xa;
         while (Xa < W && ac_i0(Xa, sw, w) < x0) ++Xa;
         int Xb = Xa; while (Xb < W && ac_i0(Xb, sw, w) == x0) ++Xb;
-        for (int Y = Ya; Y < Yb; ++Y) {
+        // all label pixels of the cell are requested up front (at most P2_SPAN x P2_SPAN, host-checked): 25 independent
+        // loads in flight instead of one dependent L2 round trip per pixel
+        float labv[P2_SPAN][P2_SPAN];
+#pragma unroll
+        for (int iy = 0; iy < P2_SPAN; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < P2_SPAN; ++ix) {
+                const int Y = Ya + iy, X = Xa + ix;
+                labv[iy][ix] = (Y < Yb && X < Xb) ? lab[(int64_t)Y * W + X] : -1.0f;
+            }
+#pragma unroll
+        for (int iy = 0; iy < P2_SPAN; ++iy) {
+            const int Y = Ya + iy;
             const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
-            for (int X = Xa; X < Xb; ++X) {
+#pragma unroll
+            for (int ix = 0; ix < P2_SPAN; ++ix) {
+                const int X = Xa + ix;
                 const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
                 const float pr = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-                float y = lab[(int64_t)Y * W + X];
-                const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
+                float y = labv[iy][ix];
+                const bool valid = y != -1.0f;   // outside the cell, or ignore_label (never set by ed_mask_label)
                 if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
-                if (valid) {
-                    const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-                    float l, g;
-                    if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
-                        const float q = y != 0.f ? a : c;
-                        l = -__logf(q);
-                        const float rq = __builtin_amdgcn_rcpf(q);
-                        g = y != 0.f ? -rq : rq;
-                    } else {
-                        l = -(__logf(a) * y + __logf(c) * (1.f - y));
-                        g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
-                    }
-                    part += l;
-                    g *= grad_scale;
-                    g00 += g * hy * hx; g01 += g * hy * lx; g10 += g * ly * hx; g11 += g * ly * lx;
+                const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                float l, g;
+                if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
+                    const float q = y != 0.f ? a : c;
+                    l = -__logf(q);
+                    const float rq = __builtin_amdgcn_rcpf(q);
+                    g = y != 0.f ? -rq : rq;
+                } else {
+                    l = -(__logf(a) * y + __logf(c) * (1.f - y));
+                    g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
                 }
+                l = valid ? l : 0.f;
+                g = valid ? g * grad_scale : 0.f;
+                part += l;
+                g00 += g * hy * hx; g01 += g * hy * lx; g10 += g * ly * hx; g11 += g * ly * lx;
             }
         }
     }
@@ -282,8 +296,9 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
                                    const float* override_masks, float* loss_part, float* dsim_low, float grad_scale,
                                    int32_t B, int32_t S, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
-    if (S % 2 || (P2_BAND + 1) * w > 1024) {
-        vpu_set_error("p2cl_up: S % 2, (band + 1) * w <= 1024 (w <= 113)");
+    if (S % 2 || (P2_BAND + 1) * w > 1024 || h < 2 || w < 2 || (int64_t)(H - 1) >= (int64_t)(P2_SPAN - 1) * (h - 1) + (h - 1) ||
+        (int64_t)(W - 1) >= (int64_t)(P2_SPAN - 1) * (w - 1) + (w - 1)) {
+        vpu_set_error("p2cl_up: S % 2, (band + 1) * w <= 1024 (w <= 113), upsampling factor (H-1)/(h-1) < 5");
         return VPU_ERR_ARG;
     }
     const int nband = (h + P2_BAND - 1) / P2_BAND;
