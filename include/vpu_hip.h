@@ -238,6 +238,13 @@ int vpu_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf1
 int vpu_adam_step_groups(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
                          const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int32_t nseg, float beta1,
                          float beta2, float eps, int32_t decoupled_wd, int32_t step, float grad_scale, void* stream);
+/* The same update with the step-dependent scalars read from DEVICE memory, so that the launch can be captured in a
+ * hipGraph and replayed: hyper fp32 [4] = {lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale}, uploaded by the host before
+ * each replay.  nseg > 0: per-tensor lr = hyper[0] * seg_scale[s], weight decay seg_wd[s]; nseg == 0: weight_decay. */
+int vpu_adam_step_hyper(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* hyper,
+                        const int64_t* seg_end, const float* seg_scale, const float* seg_wd, int32_t nseg, float beta1,
+                        float beta2, float eps, float weight_decay, int32_t decoupled_wd, void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -972,11 +972,14 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // split-K: few output tiles and a long reduction (weight gradients, cosine-logit gradients)
         const int64_t tiles = (int64_t)tiles_m * tiles_n * d->batch;
         int splitk = 1, kchunk = (d->K + BK - 1) / BK * BK;
-        // one-wave problems (96..256 tiles, e.g. the DMA neck's 9408 x 384 x 768 projections): one tile per workgroup, no
-        // split-K, the three-stage ring hides the per-K-tile round trip.  (Measured: with fewer tiles -- the 576-row token
-        // GEMMs, 15-30 tiles -- too few bytes are in flight and split-K + reduce stays faster: 13+5 us vs 17-21 us.)
-        static const int ring_env = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 1; }();   // 0 off, 2 everywhere
-        const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= 96 && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
+        // VPU_GEMM_RING=1: one-wave problems (96..256 tiles, e.g. the DMA neck's 9408 x 384 x 768 projections) run one tile
+        // per workgroup, no split-K, on the three-stage ring.  Off by default -- measured from a hipGraph replay
+        // (tools/gemm_bench.py, GEMM_BENCH_GRAPH=1): 9408x384x768 18.9 us (ring, generic epilogue) vs 16.1 us (two-stage,
+        // specialised epilogue); the 576-row token GEMMs (15-30 tiles) 15.4 us vs 12.4 us for split-K + reduce: too few
+        // bytes in flight per CU.  The ring pays at one workgroup per CU with long K; kept for the next tile shapes.
+        static const int ring_env = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 0; }();   // 0 off (default), 1 one-wave problems, 2 everywhere
+        static const int ring_min = [] { const char* e = getenv("VPU_GEMM_RING_MIN"); return e ? atoi(e) : 96; }();
+        const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= ring_min && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
         if (!ring && d->workspace && tiles < 192 && d->K >= 8 * BK) {
             int64_t want = (384 + tiles - 1) / tiles;
             const int64_t max_by_k = d->K / (4 * BK);
@@ -1043,6 +1046,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             if (key == 0 && f == F_B) VPU_LAUNCH_FL(0, 0, F_B);
             else if (key == 0 && f == F_BR) VPU_LAUNCH_FL(0, 0, F_BR);
             else if (key == 0 && f == F_G) VPU_LAUNCH_FL(0, 0, F_G);
+            else if (key == 0 && f == (VPU_EPI_BIAS | VPU_EPI_RELU)) VPU_LAUNCH_FL(0, 0, VPU_EPI_BIAS | VPU_EPI_RELU);
+            else if (key == 0 && f == 0) VPU_LAUNCH_FL(0, 0, 0);
+            else if (key == 1 && f == VPU_EPI_DRELU) VPU_LAUNCH_FL(0, 1, VPU_EPI_DRELU);
             else if (key == 1 && f == 0) VPU_LAUNCH_FL(0, 1, 0);
             else if (key == 1 && f == F_M) VPU_LAUNCH_FL(0, 1, F_M);
             else if (key == 1 && f == VPU_EPI_ACCUM) VPU_LAUNCH_FL(0, 1, VPU_EPI_ACCUM);

@@ -61,12 +61,15 @@ __device__ __forceinline__ int ac_i0(int dst, float scale, int in_size) {
     int i0 = (int)(scale * (float)dst);
     return i0 > in_size - 1 ? in_size - 1 : i0;
 }
-// One block per (plane, band of P2_BAND low-resolution anchor rows) + one halo row above: 1 thread per low-resolution
-// cell.  A pixel whose bilinear anchor is cell (y0, x0) contributes to the 4 corners (y0|y0+1, x0|x0+1); the block owns
-// the gradient rows [r0, r1) of its band, so it also evaluates the anchor row r0-1 (whose lower corners land on row r0)
-// and drops the lower corners of its last anchor row (the next band's halo recomputes them).  Losses are counted for
-// the band's own anchor rows only.  The corner sums are added to the LDS gradient band in four barrier-separated
-// phases: in each phase every LDS word has exactly one writer -> bitwise reproducible, no atomics.
+// One block per (plane, band of P2_BAND low-resolution anchor rows) plus one halo row above.  Two passes:
+//  1. pixel pass -- every full-resolution pixel anchored in the band (and in the halo row) is evaluated ONCE by one lane
+//     (4 consecutive pixels per thread, 16-byte label loads): interpolated probability, loss term, d loss / d prob -> LDS;
+//  2. cell pass -- one thread per low-resolution cell gathers the gradients of its <= P2_SPAN x P2_SPAN pixels from LDS,
+//     weighted per corner; the corner sums are added to the LDS gradient band in four barrier-separated phases (in each
+//     phase every LDS word has exactly one writer -> bitwise reproducible, no atomics).
+// The block owns the gradient rows [r0, r1) of its band: the halo row r0-1 contributes its lower corners (row r0), the
+// lower corners of the last anchor row are dropped (the next band's halo recomputes them); losses are counted for the
+// band's own anchor rows only.
 constexpr int P2_BAND = 8;
 constexpr int P2_SPAN = 5;   // most full-resolution pixels per low-resolution cell and axis
 
@@ -74,14 +77,16 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
                                                        const int* __restrict__ slot_idx,
                                                        const float* __restrict__ override_masks,
                                                        float* __restrict__ loss_part, float* __restrict__ dlow,
-                                                       float grad_scale, int S, int h, int w, int H, int W, int nband) {
-    extern __shared__ float sm[];          // [(P2_BAND + 2) * w] values (rows r0-1 .. r1), [P2_BAND * w] gradients
+                                                       float grad_scale, int S, int h, int w, int H, int W, int nband,
+                                                       int max_rows) {
+    extern __shared__ float sm[];   // [(P2_BAND + 2) * w] values (rows r0-1 .. r1) | [P2_BAND * w] gradients | [max_rows * W] d loss / d prob
     __shared__ double red[16];
     const int plane = blockIdx.x / nband, band = blockIdx.x % nband;
     const int b = plane / S, s = plane % S;
     const int r0 = band * P2_BAND, r1 = (r0 + P2_BAND < h) ? r0 + P2_BAND : h;
     float* sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
     float* sg = sm + (P2_BAND + 2) * w;    // sg[(y - r0) * w + x]
+    float* gp = sg + P2_BAND * w;          // gp[(Y - Y0) * W + X]
     const int ov = slot_idx ? slot_idx[plane] : -1;
     const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
     const bool invert = ov < 0 && s >= S / 2;
@@ -93,17 +98,65 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         sv[i] = (y >= 0 && y < h) ? low[(int64_t)plane * h * w + (int64_t)y * w + (i % w)] : 0.f;
     }
     for (int i = threadIdx.x; i < P2_BAND * w; i += blockDim.x) sg[i] = 0.f;
+    // pixel rows of the block: the first row anchored at max(r0-1, 0) .. the last row anchored at r1-1
+    const int ya = r0 > 0 ? r0 - 1 : 0;
+    int Y0 = (int)(fh * (float)ya) - 1; Y0 = Y0 < 0 ? 0 : Y0;
+    while (Y0 < H && ac_i0(Y0, sh, h) < ya) ++Y0;
+    int Y1 = (int)(fh * (float)r1) - 1; Y1 = Y1 < Y0 ? Y0 : (Y1 > H ? H : Y1);
+    while (Y1 < H && ac_i0(Y1, sh, h) < r1) ++Y1;          // one past the last row anchored below r1
+    if (Y1 - Y0 > max_rows) Y1 = Y0 + max_rows;            // (cannot happen: host-side bound)
     __syncthreads();
-    // thread -> cell (y0, x0) with y0 in [r0-1, r1)
+    // ---- pass 1: pixels
+    float part = 0.f;
+    const int W4 = W >> 2;
+    const int npx4 = (Y1 - Y0) * W4;
+    for (int i = threadIdx.x; i < npx4; i += blockDim.x) {
+        const int Yl = i / W4, X4 = (i - Yl * W4) * 4, Y = Y0 + Yl;
+        const int y0 = ac_i0(Y, sh, h);
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+        const bool own = y0 >= r0;
+        const float4 lv = *reinterpret_cast<const float4*>(lab + (int64_t)Y * W + X4);
+        const float ls[4] = {lv.x, lv.y, lv.z, lv.w};
+        const float* row0 = sv + (y0 - r0 + 1) * w;
+        const float* row1 = sv + (y1 - r0 + 1) * w;
+        float gout[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int X = X4 + k;
+            const int x0 = ac_i0(X, sw, w);
+            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
+            const float pr = hy * (hx * row0[x0] + lx * row0[x1]) + ly * (hx * row1[x0] + lx * row1[x1]);
+            float y = ls[k];
+            const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
+            if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
+            const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+            float l, g;
+            if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
+                const float q = y != 0.f ? a : c;
+                l = -__logf(q);
+                const float rq = __builtin_amdgcn_rcpf(q);
+                g = y != 0.f ? -rq : rq;
+            } else {
+                l = -(__logf(a) * y + __logf(c) * (1.f - y));
+                g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+            }
+            part += (valid && own) ? l : 0.f;
+            gout[k] = valid ? g * grad_scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(gp + Yl * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+    }
+    const double t = block_sum_d((double)part, red);   // (its barriers also publish gp)
+    if (threadIdx.x == 0) loss_part[(int64_t)plane * nband + band] = (float)t;
+    if (!dlow) return;
+    // ---- pass 2: thread -> cell (y0, x0) with y0 in [r0-1, r1)
     const int ly_ = threadIdx.x / w, x0 = threadIdx.x % w;
     const int y0 = r0 - 1 + ly_;
     const bool live = ly_ <= (r1 - r0) && y0 >= 0 && y0 < h;
-    const bool own = live && y0 >= r0;     // the loss of this anchor row is counted here
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f, part = 0.f;
+    float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
     if (live) {
-        const float v00 = sv[(y0 - r0 + 1) * w + x0], v01 = sv[(y0 - r0 + 1) * w + x1];
-        const float v10 = sv[(y1 - r0 + 1) * w + x0], v11 = sv[(y1 - r0 + 1) * w + x1];
         // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone)
         int Ya = (int)(fh * (float)y0) - 1; Ya = Ya < 0 ? 0 : Ya;
         while (Ya < H && ac_i0(Ya, sh, h) < y0) ++Ya;
@@ -111,67 +164,42 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         int Xa = (int)(fw * (float)x0) - 1; Xa = Xa < 0 ? 0 : Xa;
         while (Xa < W && ac_i0(Xa, sw, w) < x0) ++Xa;
         int Xb = Xa; while (Xb < W && ac_i0(Xb, sw, w) == x0) ++Xb;
-        // all label pixels of the cell are requested up front (at most P2_SPAN x P2_SPAN, host-checked): 25 independent
-        // loads in flight instead of one dependent L2 round trip per pixel
-        float labv[P2_SPAN][P2_SPAN];
-#pragma unroll
-        for (int iy = 0; iy < P2_SPAN; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < P2_SPAN; ++ix) {
-                const int Y = Ya + iy, X = Xa + ix;
-                labv[iy][ix] = (Y < Yb && X < Xb) ? lab[(int64_t)Y * W + X] : -1.0f;
-            }
 #pragma unroll
         for (int iy = 0; iy < P2_SPAN; ++iy) {
             const int Y = Ya + iy;
-            const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+            if (Y < Yb) {
+                const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+                float rx0 = 0.f, rx1 = 0.f;   // this row's gradient split over the left / right corner columns
 #pragma unroll
-            for (int ix = 0; ix < P2_SPAN; ++ix) {
-                const int X = Xa + ix;
-                const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
-                const float pr = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-                float y = labv[iy][ix];
-                const bool valid = y != -1.0f;   // outside the cell, or ignore_label (never set by ed_mask_label)
-                if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
-                const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-                float l, g;
-                if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
-                    const float q = y != 0.f ? a : c;
-                    l = -__logf(q);
-                    const float rq = __builtin_amdgcn_rcpf(q);
-                    g = y != 0.f ? -rq : rq;
-                } else {
-                    l = -(__logf(a) * y + __logf(c) * (1.f - y));
-                    g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+                for (int ix = 0; ix < P2_SPAN; ++ix) {
+                    const int X = Xa + ix;
+                    if (X < Xb) {
+                        const float lx = sw * (float)X - (float)x0;
+                        const float g = gp[(Y - Y0) * W + X];
+                        rx0 += g * (1.f - lx); rx1 += g * lx;
+                    }
                 }
-                l = valid ? l : 0.f;
-                g = valid ? g * grad_scale : 0.f;
-                part += l;
-                g00 += g * hy * hx; g01 += g * hy * lx; g10 += g * ly * hx; g11 += g * ly * lx;
+                g00 += hy * rx0; g01 += hy * rx1; g10 += ly * rx0; g11 += ly * rx1;
             }
         }
     }
-    const double t = block_sum_d(own ? (double)part : 0.0, red);
-    if (threadIdx.x == 0) loss_part[(int64_t)plane * nband + band] = (float)t;
-    if (dlow) {
-        // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
-        // corner terms into the cell's own word and skip the write
-        const bool bx = x1 != x0, by = y1 != y0;
-        if (!bx) { g00 += g01; g10 += g11; }
-        if (!by) { g00 += g10; if (bx) g01 += g11; }
-        const bool up = live && y0 >= r0;              // upper corners land on row y0 (inside the band unless halo)
-        const bool dn = live && by && y1 < r1;         // lower corners land on row y1 (dropped for the last anchor row)
-        if (up) sg[(y0 - r0) * w + x0] += g00;
-        __syncthreads();
-        if (up && bx) sg[(y0 - r0) * w + x1] += g01;
-        __syncthreads();
-        if (dn) sg[(y1 - r0) * w + x0] += g10;
-        __syncthreads();
-        if (dn && bx) sg[(y1 - r0) * w + x1] += g11;
-        __syncthreads();
-        for (int i = threadIdx.x; i < (r1 - r0) * w; i += blockDim.x)
-            dlow[(int64_t)plane * h * w + (int64_t)r0 * w + i] = sg[i];
-    }
+    // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
+    // corner terms into the cell's own word and skip the write
+    const bool bx = x1 != x0, by = y1 != y0;
+    if (!bx) { g00 += g01; g10 += g11; }
+    if (!by) { g00 += g10; if (bx) g01 += g11; }
+    const bool up = live && y0 >= r0;              // upper corners land on row y0 (inside the band unless halo)
+    const bool dn = live && by && y1 < r1;         // lower corners land on row y1 (dropped for the last anchor row)
+    if (up) sg[(y0 - r0) * w + x0] += g00;
+    __syncthreads();
+    if (up && bx) sg[(y0 - r0) * w + x1] += g01;
+    __syncthreads();
+    if (dn) sg[(y1 - r0) * w + x0] += g10;
+    __syncthreads();
+    if (dn && bx) sg[(y1 - r0) * w + x1] += g11;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (r1 - r0) * w; i += blockDim.x)
+        dlow[(int64_t)plane * h * w + (int64_t)r0 * w + i] = sg[i];
 }
 
 // NFL + Dice in three launches over (sample, chunk) blocks: per-chunk partial sums -> gradients + per-chunk loss partials
@@ -296,15 +324,24 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
                                    const float* override_masks, float* loss_part, float* dsim_low, float grad_scale,
                                    int32_t B, int32_t S, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
-    if (S % 2 || (P2_BAND + 1) * w > 1024 || h < 2 || w < 2 || (int64_t)(H - 1) >= (int64_t)(P2_SPAN - 1) * (h - 1) + (h - 1) ||
-        (int64_t)(W - 1) >= (int64_t)(P2_SPAN - 1) * (w - 1) + (w - 1)) {
-        vpu_set_error("p2cl_up: S % 2, (band + 1) * w <= 1024 (w <= 113), upsampling factor (H-1)/(h-1) < 5");
+    if (S % 2 || (P2_BAND + 1) * w > 1024 || h < 2 || w < 2 || W % 4 || (int64_t)(H - 1) >= (int64_t)P2_SPAN * (h - 1) ||
+        (int64_t)(W - 1) >= (int64_t)P2_SPAN * (w - 1)) {
+        vpu_set_error("p2cl_up: S % 2, W % 4, (band + 1) * w <= 1024 (w <= 113), upsampling factor (H-1)/(h-1) < 5");
         return VPU_ERR_ARG;
     }
     const int nband = (h + P2_BAND - 1) / P2_BAND;
-    const size_t shmem = (size_t)(2 * P2_BAND + 2) * w * sizeof(float);
+    // pixel rows one block can own: (P2_BAND + 1) anchor rows x (H-1)/(h-1) rows per anchor row, + 2 for rounding
+    const int max_rows = (int)(((int64_t)(P2_BAND + 1) * (H - 1)) / (h - 1)) + 2;
+    const size_t shmem = ((size_t)(2 * P2_BAND + 2) * w + (size_t)max_rows * W) * sizeof(float);
+    if (shmem > 160 * 1024 - 256) { vpu_set_error("p2cl_up: band does not fit LDS"); return VPU_ERR_ARG; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set = true;
+    }
     p2cl_up_kernel<<<(unsigned)(B * S * nband), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
-                                                                  dsim_low, grad_scale, S, h, w, H, W, nband);
+                                                                  dsim_low, grad_scale, S, h, w, H, W, nband, max_rows);
     return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
 }
 

@@ -8,22 +8,27 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, int64_t n4, int64_t n, float lr_in, float b1,
-                                                   float b2, float eps, float wd_in, float bc1, float bc2s, float gs,
+                                                   float b2, float eps, float wd_in, float bc1_in, float bc2s_in, float gs_in,
                                                    const int64_t* __restrict__ seg_end, const float* __restrict__ seg_lr,
-                                                   const float* __restrict__ seg_wd, int nseg, int decoupled) {
+                                                   const float* __restrict__ seg_wd, int nseg, int decoupled,
+                                                   const float* __restrict__ hyper) {
+    float bc1 = bc1_in, bc2s = bc2s_in, gs = gs_in, lr_scalar = lr_in;
+    if (hyper) {   // step-dependent scalars from device memory: the launch can be replayed from a hipGraph
+        lr_scalar = hyper[0]; bc1 = hyper[1]; bc2s = hyper[2]; gs = hyper[3];
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float pv[4], gv[4], mv[4], vv[4];
         const int64_t base = i * 4;
         // per-tensor learning rate / weight decay (layer-wise decay, lr_mult): the segment that holds element `base`
         // (tensors start on 8-element boundaries, so four consecutive elements never straddle two of them)
-        float lr = lr_in, wd = wd_in;
+        float lr = lr_scalar, wd = wd_in;
         if (nseg > 0) {
             int lo = 0, hi = nseg - 1;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (seg_end[mid] > base) hi = mid; else lo = mid + 1;
             }
-            lr = seg_lr[lo]; wd = seg_wd[lo];
+            lr = hyper ? lr_scalar * seg_lr[lo] : seg_lr[lo]; wd = seg_wd[lo];
         }
         const bool full = base + 4 <= n;
         if (full) {
@@ -76,7 +81,7 @@ extern "C" int vpu_adam_step(float* p, const float* g, float* m, float* v, void*
     const int64_t n4 = (n + 3) / 4;
     adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         p, g, m, v, (bf16_t*)shadow_bf16, n4, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, nullptr,
-        nullptr, nullptr, 0, 0);
+        nullptr, nullptr, 0, 0, nullptr);
     return vpu_check_launch("vpu_adam_step");
 }
 
@@ -94,6 +99,22 @@ extern "C" int vpu_adam_step_groups(float* p, const float* g, float* m, float* v
     const int64_t n4 = (n + 3) / 4;
     adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         p, g, m, v, (bf16_t*)shadow_bf16, n4, n, 0.f, beta1, beta2, eps, 0.f, bc1, bc2s, grad_scale, seg_end, seg_lr,
-        seg_wd, nseg, decoupled_wd);
+        seg_wd, nseg, decoupled_wd, nullptr);
     return vpu_check_launch("vpu_adam_step_groups");
+}
+
+extern "C" int vpu_adam_step_hyper(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                                   const float* hyper, const int64_t* seg_end, const float* seg_scale,
+                                   const float* seg_wd, int32_t nseg, float beta1, float beta2, float eps,
+                                   float weight_decay, int32_t decoupled_wd, void* stream) {
+    vpu_clear_stale_error();
+    if (n <= 0 || !hyper || (nseg > 0 && (!seg_end || !seg_scale || !seg_wd))) {
+        vpu_set_error("adam_hyper: n > 0, hyper, segment tables when nseg > 0");
+        return VPU_ERR_ARG;
+    }
+    const int64_t n4 = (n + 3) / 4;
+    adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        p, g, m, v, (bf16_t*)shadow_bf16, n4, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, seg_end, seg_scale,
+        seg_wd, nseg > 0 ? nseg : 0, decoupled_wd, hyper);
+    return vpu_check_launch("vpu_adam_step_hyper");
 }

@@ -79,31 +79,46 @@ __global__ __launch_bounds__(256) void window_permute_kernel(const T* __restrict
 // ------------------------------------------------------------------------------ pixel shuffle (2x2)
 // dir 0: in [B*h*w][C*4] (col = c*4+di*2+dj) -> out [B][2h][2w][C] (+bias[c])
 // dir 1: x [B][2h][2w][C] -> in-layout [B*h*w][C*4]
+// One thread moves 8 channels x the 4 sub-pixels of one coarse cell: 32 consecutive elements of the coarse row
+// (64 B as 4 x 16-byte accesses; column = c*4 + dd) <-> one 16-byte vector in each of the 4 fine pixels -- the transpose
+// happens in registers.  (The first version gathered 2-byte elements at stride 4: 100 us for the 2x 112^2 x 192 map.)
 template <typename T>
 __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* __restrict__ src, T* __restrict__ dst,
                                                              const float* __restrict__ bias, int B, int h, int w, int C,
                                                              int dir) {
     const int chunks = C / 8;
-    const int H2 = 2 * h, W2 = 2 * w;
-    const int64_t total = (int64_t)B * H2 * W2 * chunks;
+    const int W2 = 2 * w;
+    const int64_t total = (int64_t)B * h * w * chunks;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ck = (int)(i % chunks);
-        const int64_t pix = i / chunks;
-        const int X = (int)(pix % W2), Y = (int)((pix / W2) % H2), b = (int)(pix / ((int64_t)W2 * H2));
-        const int64_t m = ((int64_t)b * h + (Y >> 1)) * w + (X >> 1);
-        const int dd = (Y & 1) * 2 + (X & 1);
-        const int64_t fine = pix * C + ck * 8;           // channels-last fine-resolution element
-        const int64_t coarse = m * (C * 4) + (ck * 8) * 4 + dd;  // stride-4 gather
+        const int64_t m = i / chunks;                     // coarse cell (b, y, x)
+        const int x = (int)(m % w), y = (int)((m / w) % h);
+        const int64_t b = m / ((int64_t)w * h);
+        const int64_t coarse = m * (C * 4) + (int64_t)ck * 32;
+        const int64_t fine0 = (((b * 2 * h) + 2 * y) * W2 + 2 * x) * C + ck * 8;   // sub-pixel (0, 0)
+        float v[4][8];   // [column group of 8][k]: coarse element g*8+k = channel (g*8+k)/4, sub-pixel (g*8+k)%4
         if (dir == 0) {
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = to_f32(src[coarse + j * 4]) + (bias ? bias[ck * 8 + j] : 0.f);
-            store8(dst + fine, v);
+            for (int g = 0; g < 4; ++g) load8(src + coarse + g * 8, v[g]);
+            float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (bias) load8(bias + ck * 8, bb);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = v[(j * 4 + dd) >> 3][(j * 4 + dd) & 7] + bb[j];
+                store8(dst + fine0 + ((int64_t)(dd >> 1) * W2 + (dd & 1)) * C, o);
+            }
         } else {
-            float v[8];
-            load8(src + fine, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dst[coarse + j * 4] = from_f32<T>(v[j]);
+            for (int dd = 0; dd < 4; ++dd) {
+                float o[8];
+                load8(src + fine0 + ((int64_t)(dd >> 1) * W2 + (dd & 1)) * C, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[(j * 4 + dd) >> 3][(j * 4 + dd) & 7] = o[j];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) store8(dst + coarse + g * 8, v[g]);
         }
     }
 }
@@ -404,6 +419,57 @@ __global__ __launch_bounds__(256) void bilinear_cl_bwd_kernel(const T* __restric
     }
 }
 
+// Integer up-sampling ratio R (H = R*h, W = R*w): the outputs that touch input pixel x are exactly the 2R columns
+// [R*x - R/2, R*x + 3R/2) (clipped), so the gather walks (2R)^2 taps with the column weights computed once per thread
+// (the generic kernel above scans a (2R+4)^2 candidate window and re-derives both indices per candidate).
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bilinear_cl_bwd_int_kernel(const T* __restrict__ dout, int ld_out,
+                                                                  T* __restrict__ din, int ld_in, int B, int h, int w,
+                                                                  int C) {
+    const int H = R * h, W = R * w;
+    const int chunks = C / 8;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int64_t total = (int64_t)B * h * w * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t pix = i / chunks;
+        const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
+        const int Xs = R * x - R / 2, Ys = R * y - R / 2;
+        float wx[2 * R];
+#pragma unroll
+        for (int u = 0; u < 2 * R; ++u) {
+            const int X = Xs + u;
+            int x0, x1; float lx;
+            src_index_half(X < 0 ? 0 : X, sw, w, x0, x1, lx);
+            const float wgt = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            wx[u] = (X >= 0 && X < W) ? wgt : 0.f;
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int v = 0; v < 2 * R; ++v) {
+            const int Y = Ys + v;
+            if (Y < 0 || Y >= H) continue;
+            int y0, y1; float ly;
+            src_index_half(Y, sh, h, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            const T* rowp = dout + (((int64_t)b * H + Y) * W) * ld_out + ck * 8;
+#pragma unroll
+            for (int u = 0; u < 2 * R; ++u) {
+                const int X = Xs + u;
+                if (X >= 0 && X < W) {
+                    float g[8];
+                    load8(rowp + (int64_t)X * ld_out, g);
+                    const float ww = wy * wx[u];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += ww * g[j];
+                }
+            }
+        }
+        store8(din + pix * ld_in + ck * 8, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------ DMA gates
 template <typename T>
 __global__ __launch_bounds__(256) void gate_colmax_kernel(const T* __restrict__ Q, float* __restrict__ cg,
@@ -608,6 +674,62 @@ __global__ __launch_bounds__(256) void convseg_bwd_kernel(const float* __restric
     if (threadIdx.x == 0) part_b[blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
 }
 
+// 16-byte form of convseg_bwd for bf16 maps with C in {64, 128, 256, 512}: a lane owns 8 consecutive channels, a wave
+// covers 512 / C rows per pass (the scalar form above moves 2 B per lane: 265 us for the 77 MB map, this one is HBM-bound).
+__global__ __launch_bounds__(256) void convseg_bwd_vec_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                              const float* __restrict__ w, const float* __restrict__ mask,
+                                                              bf16_t* __restrict__ dx, int accum, float* __restrict__ part,
+                                                              float* __restrict__ part_b, int64_t rows, int64_t HW, int C,
+                                                              int nblk) {
+    __shared__ float red[4][512];
+    __shared__ float redb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lpr = C >> 3;            // lanes per row
+    const int rpp = 64 / lpr;          // rows per wave pass
+    const int sub = lane / lpr, c8 = (lane % lpr) * 8;
+    float wv[8];
+    load8(w + c8, wv);
+    float dwa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dba = 0.f;
+    const int64_t per = (rows + nblk - 1) / nblk;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    for (int64_t rb = r0 + (int64_t)wave * rpp; rb < r1; rb += 4 * rpp) {
+        const int64_t row = rb + sub;
+        if (row < r1) {
+            const float d = dout[row];
+            const int64_t b = row / HW;
+            if (c8 == 0) dba += d;
+            float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (mask) load8(mask + b * C + c8, mk);
+            float xv[8], o[8];
+            load8(x + row * C + c8, xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dwa[j] += d * xv[j] * mk[j]; o[j] = d * wv[j] * mk[j]; }
+            if (accum) {
+                float old[8];
+                load8(dx + row * C + c8, old);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += old[j];
+            }
+            store8(dx + row * C + c8, o);
+        }
+    }
+    // lanes with the same c8 (different sub-rows) -> one value per channel per wave, then over the 4 waves
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int o = lpr; o < 64; o <<= 1) dwa[j] += __shfl_xor(dwa[j], o, 64);
+    dba = wave_sum(dba);
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][c8 + j] = dwa[j];
+    }
+    if (lane == 0) redb[wave] = dba;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        part[(int64_t)blockIdx.x * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (threadIdx.x == 0) part_b[blockIdx.x] = redb[0] + redb[1] + redb[2] + redb[3];
+}
+
 // ------------------------------------------------------------------------------ align_corners=True upsample (planes)
 __device__ __forceinline__ void src_index_ac(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
     const float s = scale * (float)dst;
@@ -692,7 +814,7 @@ extern "C" int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, 
                                   int32_t C, int32_t dir, int32_t dtype, void* stream) {
     vpu_clear_stale_error();
     if (C % 8) { vpu_set_error("pixel_shuffle2: C % 8"); return VPU_ERR_ARG; }
-    const int64_t total = (int64_t)B * 4 * h * w * (C / 8);
+    const int64_t total = (int64_t)B * h * w * (C / 8);
     DISPATCH_T(dtype, pixel_shuffle2_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)in, (T*)out,
                                                                                                bias, B, h, w, C, dir);)
     return vpu_check_launch("vpu_pixel_shuffle2");
@@ -736,6 +858,17 @@ extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, 
     vpu_clear_stale_error();
     if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl_bwd: C, ld % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * h * w * (C / 8);
+    const int R = (h > 0 && w > 0 && H % h == 0 && W % w == 0 && H / h == W / w) ? H / h : 0;
+    if (R == 2 || R == 4 || R == 8) {
+        DISPATCH_T(dtype,
+                   if (R == 2) bilinear_cl_bwd_int_kernel<T, 2><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+                       (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, C);
+                   else if (R == 4) bilinear_cl_bwd_int_kernel<T, 4><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+                       (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, C);
+                   else bilinear_cl_bwd_int_kernel<T, 8><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+                       (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, C);)
+        return vpu_check_launch("vpu_bilinear_cl_bwd");
+    }
     DISPATCH_T(dtype, bilinear_cl_bwd_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
         (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, H, W, C);)
     return vpu_check_launch("vpu_bilinear_cl_bwd");
@@ -789,6 +922,13 @@ extern "C" int vpu_convseg_bwd(const float* dout, const void* x, const float* w,
     vpu_clear_stale_error();
     if (C > 512) { vpu_set_error("convseg_bwd: C <= 512"); return VPU_ERR_ARG; }
     const int nblk = vpu_convseg_bwd_nblk(rows);
+    if (dtype == VPU_BF16 && (C == 64 || C == 128 || C == 256 || C == 512) &&
+        (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) % 16 == 0 &&
+        (reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mask)) % 32 == 0) {
+        convseg_bwd_vec_kernel<<<nblk, 256, 0, ST>>>(dout, (const bf16_t*)x, w, mask, (bf16_t*)dx, accum, part, part_b, rows,
+                                                    HW, C, nblk);
+        return vpu_check_launch("vpu_convseg_bwd");
+    }
     DISPATCH_T(dtype, convseg_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dout, (const T*)x, w, mask, (T*)dx, accum, part,
                                                                  part_b, rows, HW, C, nblk);)
     return vpu_check_launch("vpu_convseg_bwd");

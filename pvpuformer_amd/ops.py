@@ -268,6 +268,11 @@ def adam_step_groups(p, g, m, v, shadow, n, seg_end, seg_lr, seg_wd, nseg, b1, b
               ptr(seg_wd), nseg, b1, b2, eps, int(decoupled), step, grad_scale, _stream())
 
 
+def adam_step_hyper(p, g, m, v, shadow, n, hyper, seg_end, seg_scale, seg_wd, nseg, b1, b2, eps, wd, decoupled):
+    _lib.call("vpu_adam_step_hyper", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, ptr(hyper), ptr(seg_end),
+              ptr(seg_scale), ptr(seg_wd), nseg, b1, b2, eps, wd, int(decoupled), _stream())
+
+
 def adam_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
     _lib.call("vpu_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, lr, b1, b2, eps, wd, step, grad_scale,
               _stream())

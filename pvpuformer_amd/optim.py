@@ -10,10 +10,15 @@ from . import ops
 
 class FusedAdam:
     def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled_weight_decay=False,
-                 per_param=None):
+                 per_param=None, capturable=False):
         """``per_param``: optional {parameter name: (lr_scale, weight_decay)}; names missing from it use (1, weight_decay).
-        The effective learning rate of a tensor is ``self.lr * lr_scale`` (so a scheduler only touches ``self.lr``)."""
+        The effective learning rate of a tensor is ``self.lr * lr_scale`` (so a scheduler only touches ``self.lr``).
+        ``capturable``: the step-dependent scalars (lr, bias corrections, grad_scale) live in device memory: call
+        ``prepare_step(grad_scale)`` on the host before every ``step()`` -- ``step()`` itself can then be captured in a
+        hipGraph and replayed (it no longer advances the step count)."""
         self.model = model
+        self.capturable = capturable
+        self._hyper = None
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.decoupled = decoupled_weight_decay
         self.per_param = dict(per_param) if per_param else None
@@ -46,10 +51,34 @@ class FusedAdam:
                          torch.tensor(wds, device=dev), len(ends))
         return self._seg
 
+    def prepare_step(self, grad_scale=1.0):
+        """capturable mode: advance the step count and upload {lr, 1-b1^t, sqrt(1-b2^t), grad_scale} (pinned, async)."""
+        eng = self.model._ensure_engine()
+        if self._hyper is None:
+            self._hyper = (torch.empty(4, dtype=torch.float32).pin_memory(), torch.empty(4, device=eng.flat.device))
+        self.step_count += 1
+        host, dev = self._hyper
+        host[0], host[1] = self.lr, 1.0 - self.betas[0] ** self.step_count
+        host[2], host[3] = (1.0 - self.betas[1] ** self.step_count) ** 0.5, grad_scale
+        dev.copy_(host, non_blocking=True)
+
     def step(self, grad_scale=1.0):
         """``grad_scale`` multiplies the gradient first (1/world_size after a SUM all-reduce)."""
         eng = self.model._ensure_engine()
         m, v = self._state(eng)
+        if self.capturable:
+            assert self._hyper is not None, "capturable FusedAdam: call prepare_step() before step()"
+            if self.per_param is None and not self.decoupled:
+                ops.adam_step_hyper(eng.flat, eng.gflat, m, v, eng.shadow, eng.total, self._hyper[1], None, None, None, 0,
+                                    self.betas[0], self.betas[1], self.eps, self.weight_decay, False)
+            else:
+                if self.per_param is None:
+                    self.per_param = {}
+                ends, scales, wds, nseg = self._segments(eng)
+                ops.adam_step_hyper(eng.flat, eng.gflat, m, v, eng.shadow, eng.total, self._hyper[1], ends, scales, wds,
+                                    nseg, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.decoupled)
+            eng.refresh_weights(shadow_is_fresh=True)
+            return
         self.step_count += 1
         if self.per_param is None and not self.decoupled:
             ops.adam_step(eng.flat, eng.gflat, m, v, eng.shadow, eng.total, self.lr, self.betas[0], self.betas[1],

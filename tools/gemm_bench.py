@@ -62,10 +62,22 @@ def main():
         for _ in range(3):
             ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
-        e1.record()
+        if os.environ.get("GEMM_BENCH_GRAPH", "0") == "1":   # replay a captured hipGraph: GPU time without the host launch cost
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(reps):
+                    ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
+            graph.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            graph.replay()
+            e1.record()
+        else:
+            e0.record()
+            for _ in range(reps):
+                ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
+            e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
         fl = 2.0 * m * n * k
