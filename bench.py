@@ -75,6 +75,24 @@ def cpu_baseline(batch_size):
                       f"{'after 1 warm-up ' if len(times) > 1 else '(no warm-up: budget spent) '}({t:.2f} s/step)"}
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of the dominant GEMM variant from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, separate passes: tools/run_pmc_bench.sh + tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json).  Counters
+    cannot be read from inside this process, so the number is the one measured for the default workload; any other
+    workload reports null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or args.model != "vitb" or args.batch != 12 or args.dtype != "bf16":
+        return None
+    key = kernel.replace(",", ", ").rstrip(">") + ","     # "gemm_bf16_kernel<1, 1," : every epilogue variant of the form
+    tab = json.load(open(path))
+    n = sum(v["launches"] for k, v in tab.items() if k.startswith(key))
+    if not n:
+        return None
+    tot = sum(v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) for k, v in tab.items()
+              if k.startswith(key))
+    return round(tot / n)
+
+
 class GemmProbe:
     """HIP-event timing of every GEMM launch of ONE extra (untimed) step, grouped by kernel variant."""
 
@@ -150,10 +168,11 @@ def main():
     eng = model._ensure_engine()
     broadcast_parameters(eng.flat)
     eng.refresh_weights()
-    # single-GPU runs replay the whole step (zero-grad, forward, losses, backward, Adam: ~800 kernel launches) from ONE
-    # captured hipGraph; VPU_BENCH_GRAPH=0 (and every multi-GPU run, whose RCCL collectives are launched from the tape)
-    # enqueues the same launches eagerly
-    use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
+    # VPU_BENCH_GRAPH=1 (single GPU only): the whole step (zero-grad, forward, losses, backward, Adam: ~890 kernel launches)
+    # is captured once and replayed as ONE hipGraph.  Off by default: the step is GPU-bound (the host enqueues it in
+    # ~13 ms) and the replay measured 20.8 ms against 20.4 ms eager on ROCm 7.2 (round 1); multi-GPU runs launch their
+    # RCCL collectives from the backward tape and always run eagerly
+    use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "0") == "1"
     opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, capturable=use_graph)
     red = GradReducer(eng.gflat)
     eng.grad_ready_hook = red.ready if red.enabled else None
@@ -233,7 +252,7 @@ def main():
         name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
         roof = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4), "traffic": pmc_traffic(name, args),
                 "launches_per_step": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "all_gemm_variants": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3),
                                            "launches": v[2]} for k, v in sorted(agg.items())}}

@@ -69,6 +69,10 @@ int vpu_abi_version(void);
  * bf16: requires lda, ldb (and column offsets) to be multiples of 8 elements, 16-byte aligned bases; K padded with
  * zeros to a multiple of 8 by the producer of a K-contiguous operand.  f32: multiples of 4 / 16 bytes. */
 int vpu_gemm(const vpu_gemm_desc* d, void* stream);
+/* Kernel-selection knobs of vpu_gemm (tuning / tests; the defaults are the measured-fastest choices).
+ * "ring": main loop of the 128x128 bf16 kernel = three LDS stages in a ring with a counted vmcnt instead of two stages:
+ * -1 environment default (VPU_GEMM_RING, 0 if unset), 0 off, 1 one-wave problems (96..256 tiles, K <= 1536), 2 always. */
+int vpu_gemm_set_option(const char* name, int32_t value);
 
 /* ---- row-wise ops ---- */
 /* nn.LayerNorm over the last dim (models_vit.py:126 eps 1e-6; transformer.py:417-426 eps 1e-5). */

@@ -12,6 +12,8 @@
 // (isegm/model/modeling/models_vit.py:38-52,16-27,91; transformer.py:484-517; is_vpu_model.py:55-86;
 // swin_transformer.py:680-756).
 #include <stdlib.h>
+#include <string.h>
+#include <atomic>
 #include "vpu_common.h"
 #include "../../include/vpu_hip.h"
 
@@ -913,6 +915,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const vpu_gemm_desc p, co
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// ring-pipeline selection: 0 off (default), 1 one-wave problems, 2 everywhere; VPU_GEMM_RING at start-up,
+// vpu_gemm_set_option("ring", v) at run time (tests)
+std::atomic<int> g_opt_ring{-1};
+inline int ring_env0() {
+    static const int v = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
@@ -977,7 +987,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // (tools/gemm_bench.py, GEMM_BENCH_GRAPH=1): 9408x384x768 18.9 us (ring, generic epilogue) vs 16.1 us (two-stage,
         // specialised epilogue); the 576-row token GEMMs (15-30 tiles) 15.4 us vs 12.4 us for split-K + reduce: too few
         // bytes in flight per CU.  The ring pays at one workgroup per CU with long K; kept for the next tile shapes.
-        static const int ring_env = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 0; }();   // 0 off (default), 1 one-wave problems, 2 everywhere
+        const int ring_env = g_opt_ring.load(std::memory_order_relaxed) >= 0 ? g_opt_ring.load(std::memory_order_relaxed) : ring_env0();
         static const int ring_min = [] { const char* e = getenv("VPU_GEMM_RING_MIN"); return e ? atoi(e) : 96; }();
         const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= ring_min && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
         if (!ring && d->workspace && tiles < 192 && d->K >= 8 * BK) {
@@ -1113,4 +1123,14 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
     }
     return vpu_check_launch("vpu_gemm");
+}
+
+extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
+    vpu_clear_stale_error();
+    if (name && !strcmp(name, "ring") && value >= -1 && value <= 2) {
+        g_opt_ring.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
+    vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere)");
+    return VPU_ERR_ARG;
 }

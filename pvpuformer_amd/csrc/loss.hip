@@ -79,25 +79,21 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
                                                        float* __restrict__ loss_part, float* __restrict__ dlow,
                                                        float grad_scale, int S, int h, int w, int H, int W, int nband,
                                                        int max_rows) {
-    extern __shared__ float sm[];   // [(P2_BAND + 2) * w] values (rows r0-1 .. r1) | [P2_BAND * w] gradients | [max_rows * W] d loss / d prob
+    extern __shared__ float sm[];   // [(P2_BAND+2)*w] values (rows r0-1..r1) | [P2_BAND*w] gradients | [(P2_BAND+2)*W] hr | [max_rows*W] d loss / d prob
     __shared__ double red[16];
     const int plane = blockIdx.x / nband, band = blockIdx.x % nband;
     const int b = plane / S, s = plane % S;
     const int r0 = band * P2_BAND, r1 = (r0 + P2_BAND < h) ? r0 + P2_BAND : h;
     float* sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
     float* sg = sm + (P2_BAND + 2) * w;    // sg[(y - r0) * w + x]
-    float* gp = sg + P2_BAND * w;          // gp[(Y - Y0) * W + X]
+    float* hr = sg + P2_BAND * w;          // hr[(y - (r0 - 1)) * W + X]: rows of sv interpolated along x
+    float* gp = hr + (P2_BAND + 2) * W;    // gp[(Y - Y0) * W + X]
     const int ov = slot_idx ? slot_idx[plane] : -1;
     const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
     const bool invert = ov < 0 && s >= S / 2;
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const float fh = sh > 0.f ? 1.f / sh : 0.f, fw = sw > 0.f ? 1.f / sw : 0.f;
-    for (int i = threadIdx.x; i < (P2_BAND + 2) * w; i += blockDim.x) {
-        const int y = r0 - 1 + i / w;
-        sv[i] = (y >= 0 && y < h) ? low[(int64_t)plane * h * w + (int64_t)y * w + (i % w)] : 0.f;
-    }
-    for (int i = threadIdx.x; i < P2_BAND * w; i += blockDim.x) sg[i] = 0.f;
     // pixel rows of the block: the first row anchored at max(r0-1, 0) .. the last row anchored at r1-1
     const int ya = r0 > 0 ? r0 - 1 : 0;
     int Y0 = (int)(fh * (float)ya) - 1; Y0 = Y0 < 0 ? 0 : Y0;
@@ -105,47 +101,79 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     int Y1 = (int)(fh * (float)r1) - 1; Y1 = Y1 < Y0 ? Y0 : (Y1 > H ? H : Y1);
     while (Y1 < H && ac_i0(Y1, sh, h) < r1) ++Y1;          // one past the last row anchored below r1
     if (Y1 - Y0 > max_rows) Y1 = Y0 + max_rows;            // (cannot happen: host-side bound)
+    const int W4 = W >> 2;
+    // pixel-pass mapping: thread -> (anchor row yq = r0-1+g, 4-pixel column group X4); it walks the <= P2_SPAN pixel
+    // rows anchored at yq.  Every label vector it needs is requested before anything else (independent 16-byte loads
+    // in flight together with the low-resolution rows below).
+    const int pg = threadIdx.x / W4, X4 = (threadIdx.x - pg * W4) * 4;
+    const int yq = r0 - 1 + pg;
+    const bool plive = pg <= (r1 - r0) && yq >= 0 && yq < h;
+    int Ya = 0, Yb = 0;
+    if (plive) {
+        Ya = (int)(fh * (float)yq) - 1; Ya = Ya < 0 ? 0 : Ya;
+        while (Ya < H && ac_i0(Ya, sh, h) < yq) ++Ya;
+        Yb = Ya; while (Yb < H && ac_i0(Yb, sh, h) == yq) ++Yb;
+    }
+    float4 lv[P2_SPAN];
+#pragma unroll
+    for (int k = 0; k < P2_SPAN; ++k) {
+        lv[k] = make_float4(-1.f, -1.f, -1.f, -1.f);
+        if (Ya + k < Yb) lv[k] = *reinterpret_cast<const float4*>(lab + (int64_t)(Ya + k) * W + X4);
+    }
+    for (int i = threadIdx.x; i < (P2_BAND + 2) * w; i += blockDim.x) {
+        const int y = r0 - 1 + i / w;
+        sv[i] = (y >= 0 && y < h) ? low[(int64_t)plane * h * w + (int64_t)y * w + (i % w)] : 0.f;
+    }
+    for (int i = threadIdx.x; i < P2_BAND * w; i += blockDim.x) sg[i] = 0.f;
+    __syncthreads();
+    // ---- pass 0: horizontal interpolation of the band's low-resolution rows, hr[row][X] = hx*v[x0] + lx*v[x1]
+    // (the inner sums of the align_corners=True formula  hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11), same rounding)
+    for (int i = threadIdx.x; i < (P2_BAND + 2) * W; i += blockDim.x) {
+        const int rr = i / W, X = i - rr * W;
+        const int x0 = ac_i0(X, sw, w);
+        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
+        hr[i] = hx * sv[rr * w + x0] + lx * sv[rr * w + x1];
+    }
     __syncthreads();
     // ---- pass 1: pixels
     float part = 0.f;
-    const int W4 = W >> 2;
-    const int npx4 = (Y1 - Y0) * W4;
-    for (int i = threadIdx.x; i < npx4; i += blockDim.x) {
-        const int Yl = i / W4, X4 = (i - Yl * W4) * 4, Y = Y0 + Yl;
-        const int y0 = ac_i0(Y, sh, h);
-        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-        const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
-        const bool own = y0 >= r0;
-        const float4 lv = *reinterpret_cast<const float4*>(lab + (int64_t)Y * W + X4);
-        const float ls[4] = {lv.x, lv.y, lv.z, lv.w};
-        const float* row0 = sv + (y0 - r0 + 1) * w;
-        const float* row1 = sv + (y1 - r0 + 1) * w;
-        float gout[4];
+    if (plive) {
+        const bool own = yq >= r0;
+        const int yq1 = yq + (yq < h - 1 ? 1 : 0);
+        const float4 t0 = *reinterpret_cast<const float4*>(hr + (yq - r0 + 1) * W + X4);
+        const float4 t1 = *reinterpret_cast<const float4*>(hr + (yq1 - r0 + 1) * W + X4);
+        const float top[4] = {t0.x, t0.y, t0.z, t0.w}, bot[4] = {t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int X = X4 + k;
-            const int x0 = ac_i0(X, sw, w);
-            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-            const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
-            const float pr = hy * (hx * row0[x0] + lx * row0[x1]) + ly * (hx * row1[x0] + lx * row1[x1]);
-            float y = ls[k];
-            const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
-            if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
-            const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-            float l, g;
-            if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
-                const float q = y != 0.f ? a : c;
-                l = -__logf(q);
-                const float rq = __builtin_amdgcn_rcpf(q);
-                g = y != 0.f ? -rq : rq;
-            } else {
-                l = -(__logf(a) * y + __logf(c) * (1.f - y));
-                g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+        for (int k = 0; k < P2_SPAN; ++k) {
+            const int Y = Ya + k;
+            if (Y < Yb) {
+                const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
+                const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
+                float gout[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float pr = hy * top[q4] + ly * bot[q4];
+                    float y = ls[q4];
+                    const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
+                    if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
+                    const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                    float l, g;
+                    if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
+                        const float q = y != 0.f ? a : c;
+                        l = -__logf(q);
+                        const float rq = __builtin_amdgcn_rcpf(q);
+                        g = y != 0.f ? -rq : rq;
+                    } else {
+                        l = -(__logf(a) * y + __logf(c) * (1.f - y));
+                        g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+                    }
+                    part += (valid && own) ? l : 0.f;
+                    gout[q4] = valid ? g * grad_scale : 0.f;
+                }
+                *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
             }
-            part += (valid && own) ? l : 0.f;
-            gout[k] = valid ? g * grad_scale : 0.f;
         }
-        *reinterpret_cast<float4*>(gp + Yl * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
     }
     const double t = block_sum_d((double)part, red);   // (its barriers also publish gp)
     if (threadIdx.x == 0) loss_part[(int64_t)plane * nband + band] = (float)t;
@@ -332,8 +360,11 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
     const int nband = (h + P2_BAND - 1) / P2_BAND;
     // pixel rows one block can own: (P2_BAND + 1) anchor rows x (H-1)/(h-1) rows per anchor row, + 2 for rounding
     const int max_rows = (int)(((int64_t)(P2_BAND + 1) * (H - 1)) / (h - 1)) + 2;
-    const size_t shmem = ((size_t)(2 * P2_BAND + 2) * w + (size_t)max_rows * W) * sizeof(float);
-    if (shmem > 160 * 1024 - 256) { vpu_set_error("p2cl_up: band does not fit LDS"); return VPU_ERR_ARG; }
+    const size_t shmem = ((size_t)(2 * P2_BAND + 2) * w + (size_t)(P2_BAND + 2 + max_rows) * W) * sizeof(float);
+    if (shmem > 160 * 1024 - 256 || (int64_t)(P2_BAND + 1) * (W / 4) > 1024) {
+        vpu_set_error("p2cl_up: band does not fit LDS / one block ((band + 1) * W/4 <= 1024)");
+        return VPU_ERR_ARG;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

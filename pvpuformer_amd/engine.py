@@ -87,9 +87,10 @@ class Engine:
         self._const_ready = False
         import os
         self.use_flash = os.environ.get("VPU_FLASH_ATTN", "1") != "0"   # 0: unfused S/P path (also used for fp32 / other head dims)
-        # weight gradients are only consumed by the optimizer: run them on a second HIP stream so that their under-filled
-        # grids (few output tiles, split-K) overlap the dgrad / LayerNorm / attention chain on the main stream
-        self.use_side = os.environ.get("VPU_WGRAD_STREAM", "1") != "0"
+        # weight gradients are only consumed by the optimizer: VPU_WGRAD_STREAM=1 runs them on a second HIP stream.  Off by
+        # default: since the GEMM launches became persistent (every launch fills the chip) the two streams only share the
+        # CUs, and the fork/join events cost host time (measured: 19.45 ms/step on one stream, 19.9 ms on two)
+        self.use_side = os.environ.get("VPU_WGRAD_STREAM", "0") == "1"
         self.side = None
         self._frozen = set()   # data_ptr of gradient buffers a queued side-stream GEMM still reads: no in-place writes
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)

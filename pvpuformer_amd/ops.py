@@ -77,6 +77,10 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, 
     _lib.call("vpu_gemm", C.byref(d), _stream())
 
 
+def gemm_set_option(name, value):
+    _lib.call("vpu_gemm_set_option", name.encode(), int(value))
+
+
 def layernorm_fwd(x, w, b, y, mean, rstd, rows, Cdim, eps):
     _lib.call("vpu_layernorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, Cdim, eps, code_of(x),
               _stream())

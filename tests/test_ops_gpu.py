@@ -59,6 +59,43 @@ def test_gemm_exact_integers(ops, dtype, tA, tB):
     assert torch.all(out[:, N:] == 7.0), "wrote outside the N range"
 
 
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("K", [72, 200, 648])
+def test_gemm_ring_pipeline_exact(ops, tA, tB, K):
+    """The three-stage LDS-DMA ring main loop (vpu_gemm_set_option("ring", 2)): exact-integer operands must give the
+    fp32 matmul bit for bit for every operand layout, ragged M / N, K shorter than / equal to / longer than the ring
+    (2, 4 and 11 K-tiles: the out-of-range tail stages are requested as zeros), plus the fused bias-gradient column sums
+    of the weight-gradient form."""
+    M, N = 200, 136
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = A @ Bm.t()
+    lda = 208 if tA else (K + 8)
+    ldb = 144 if tB else (K + 8)
+    Am = torch.zeros((K, lda) if tA else (M, lda))
+    Bs = torch.zeros((K, ldb) if tB else (N, ldb))
+    if tA: Am[:, :M] = A.t()
+    else: Am[:, :K] = A
+    if tB: Bs[:, :N] = Bm.t()
+    else: Bs[:, :K] = Bm
+    Ad, Bd = dev(Am).to(torch.bfloat16), dev(Bs).to(torch.bfloat16)
+    Cd = torch.full((M, 152), 7.0, device="cuda", dtype=torch.float32)
+    cs = torch.zeros(M, device="cuda") if (tA and tB) else None
+    ops.gemm_set_option("ring", 2)
+    try:
+        ops.gemm(Ad, Bd, Cd, M, N, K, lda, ldb, 152, 0, transA=bool(tA), transB=bool(tB), flags=ops.EPI_OUT_F32,
+                 workspace=None, colsum=cs)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_set_option("ring", -1)
+    out = Cd.cpu()
+    assert torch.equal(out[:, :N], ref), f"max diff {(out[:, :N] - ref).abs().max()}"
+    assert torch.all(out[:, N:] == 7.0), "wrote outside the N range"
+    if cs is not None:
+        assert torch.equal(cs.cpu(), A.sum(1))
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 300, 192, 128
@@ -535,6 +572,56 @@ def test_adam_groups_matches_torch(ops, decoupled):
                              step)
     for q, o, n in zip(params, offs, sizes):
         torch.testing.assert_close(p[o:o + n].cpu(), q.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(sh, p.to(torch.bfloat16))
+
+
+def test_adam_hyper_replayed_from_a_graph_matches_torch(ops):
+    """vpu_adam_step_hyper reads {lr, 1-b1^t, sqrt(1-b2^t), grad_scale} from device memory: ONE captured launch, replayed
+    with the scalars (and the gradient buffer) refreshed before every replay, must equal torch.optim.Adam with a
+    per-tensor lr scale / weight decay table -- the capturable path of pvpuformer_amd.optim.FusedAdam."""
+    sizes, offs = [1000, 37, 4096], [0, 1000, 1040]
+    total = 1040 + 4096
+    scales, wds, base_lr = [1.0, 0.75 ** 3, 0.5], [0.02, 0.0, 0.02], 5e-5
+    flat0 = rnd(total, seed=54)
+    g = rnd(total, seed=55, scale=0.1)
+    p = dev(flat0.clone())
+    gbuf = torch.zeros(total, device="cuda")
+    m, v = torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+    sh = torch.zeros(total, device="cuda", dtype=torch.bfloat16)
+    seg_end = torch.tensor([1000, 1040, total], dtype=torch.int64, device="cuda")
+    seg_sc, seg_wd = torch.tensor(scales, device="cuda"), torch.tensor(wds, device="cuda")
+    hyper = torch.zeros(4, device="cuda")
+    params = [torch.nn.Parameter(flat0[o:o + n].clone()) for o, n in zip(offs, sizes)]
+    opt = torch.optim.Adam([{"params": [q], "lr": base_lr * sc, "weight_decay": wd} for q, sc, wd in zip(params, scales, wds)],
+                           lr=base_lr, betas=(0.9, 0.999), eps=1e-8)
+
+    def launch():
+        ops.adam_step_hyper(p, gbuf, m, v, sh, total, hyper, seg_end, seg_sc, seg_wd, 3, 0.9, 0.999, 1e-8, 0.0, False)
+
+    graph = None
+    for step in range(1, 5):
+        for q, o, n in zip(params, offs, sizes):
+            q.grad = g[o:o + n].clone() * step
+        opt.step()
+        # the summed gradient of "2 ranks": grad_scale 0.5 undoes it
+        gbuf.copy_(dev(g * step * 2.0))
+        hyper.copy_(torch.tensor([base_lr, 1 - 0.9 ** step, (1 - 0.999 ** step) ** 0.5, 0.5]))
+        if step == 1:
+            launch()                      # eager first: nothing to replay yet
+        elif graph is None:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            keep = [t.clone() for t in (p, m, v)]
+            with torch.cuda.graph(graph):
+                launch()
+            for t, k in zip((p, m, v), keep):   # capture enqueues nothing; state unchanged
+                assert torch.equal(t, k)
+            graph.replay()
+        else:
+            graph.replay()
+    torch.cuda.synchronize()
+    for q, o, n in zip(params, offs, sizes):
+        torch.testing.assert_close(p[o:o + n].cpu(), q.detach(), rtol=2e-6, atol=1e-7)
     assert torch.equal(sh, p.to(torch.bfloat16))
 
 

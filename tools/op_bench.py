@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the non-GEMM kernels at the ViT-B bs=12 shapes (HIP-event timing, random data).
+usage: python tools/op_bench.py [name-substring ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pvpuformer_amd import ops  # noqa: E402
+
+dev = "cuda"
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    only = sys.argv[1:]
+    B, S, h, H = 12, 48, 112, 448
+    cases = {}
+    low = torch.sigmoid(torch.randn(B, S, h, h, device=dev))
+    gt = (torch.rand(B, 1, H, H, device=dev) > 0.5).float()
+    part, dlow = torch.empty(B, S, device=dev), torch.empty_like(low)
+    cases["p2cl_up"] = (lambda: ops.p2cl_up_fwd_bwd(low, gt, None, None, part, dlow, 1e-6, B, S, h, h, H, H),
+                        low.numel() * 8 + gt.numel() * 4)
+    logits = torch.randn(B, 1, H, H, device=dev)
+    out, dl = torch.empty(B, 2, device=dev), torch.empty(B, H * H, device=dev)
+    cases["nfl_dice"] = (lambda: ops.nfl_dice_fwd_bwd(logits, gt, None, out, dl, 1.0, 1.0, B, H * H), logits.numel() * 20)
+    for r, hh in ((8, 14), (4, 28), (2, 56)):
+        C = 256
+        dcat = torch.randn(B * 112 * 112, 4 * C, device=dev).to(torch.bfloat16)
+        din = torch.empty(B * hh * hh, C, device=dev, dtype=torch.bfloat16)
+        cases[f"bilinear_bwd_r{r}"] = (lambda dcat=dcat, din=din, hh=hh: ops.bilinear_cl_bwd((dcat, C), 4 * C, din, C, B, hh, hh, 112, 112, C, 0),
+                                       B * 112 * 112 * C * 2)
+        cases[f"bilinear_fwd_r{r}"] = (lambda dcat=dcat, din=din, hh=hh: ops.bilinear_cl_fwd(din, C, (dcat, C), 4 * C, B, hh, hh, 112, 112, C, 0),
+                                       B * 112 * 112 * C * 2)
+    for name, (fn, nbytes) in cases.items():
+        if only and not any(t in name for t in only):
+            continue
+        us = timeit(fn)
+        print(f"{name:22s} {us:9.1f} us   {nbytes / us / 1e6:8.2f} TB/s (algorithmic bytes)")
+
+
+if __name__ == "__main__":
+    main()
