@@ -54,8 +54,10 @@ typedef struct vpu_gemm_desc {
     int32_t dtype, flags;
     int32_t resid_period; /* > 0: resid row = m % period and no batch stride (broadcast pos_embed) */
     float alpha, post_mul, post_add;
-    void* workspace;         /* optional fp32 scratch for split-K partial tiles (bf16 path); NULL disables split-K */
-    int64_t workspace_bytes; /* split-K needs batch * slices * M * (N + 1) * 4 bytes */
+    void* workspace;         /* optional fp32 scratch for split-K partial tiles (bf16 path); NULL disables split-K.
+                                ZERO it once after allocation: its last 256 KiB are tile-arrival counters of the in-launch
+                                split-K combine, which every launch leaves zeroed; one workspace per stream */
+    int64_t workspace_bytes; /* split-K needs batch * slices * M * (N + 1) * 4 bytes + 256 KiB */
     float* colsum;           /* optional (bf16, transA=1, batch=1): colsum[m] += sum_k op(A)[m][k] -- the bias gradient
                                 fused into the weight-gradient GEMM whose A operand is dY */
 } vpu_gemm_desc;
@@ -71,7 +73,10 @@ int vpu_abi_version(void);
 int vpu_gemm(const vpu_gemm_desc* d, void* stream);
 /* Kernel-selection knobs of vpu_gemm (tuning / tests; the defaults are the measured-fastest choices).
  * "ring": main loop of the 128x128 bf16 kernel = three LDS stages in a ring with a counted vmcnt instead of two stages:
- * -1 environment default (VPU_GEMM_RING, 0 if unset), 0 off, 1 one-wave problems (96..256 tiles, K <= 1536), 2 always. */
+ * -1 environment default (VPU_GEMM_RING, 0 if unset), 0 off, 1 one-wave problems (96..256 tiles, K <= 1536), 2 always.
+ * "splitk_inlaunch": 0 (default; VPU_GEMM_INLAUNCH) a separate reduce launch sums the split-K slices; 1 they are summed,
+ * in slice order, by the slice that arrives last at the tile's counter, inside the GEMM launch; n > 1: that, but only
+ * when the slabs of the launch total at most n MiB.  Same results bit for bit; the default is the measured-faster one. */
 int vpu_gemm_set_option(const char* name, int32_t value);
 
 /* ---- row-wise ops ---- */

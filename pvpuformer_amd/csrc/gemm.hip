@@ -359,11 +359,24 @@ __device__ __forceinline__ void ring_step(__amdgpu_buffer_rsrc_t rA, __amdgpu_bu
 // range, which costs no memory traffic and keeps the count uniform) + one raw s_barrier per K-tile.  For the small
 // problems of the DMA neck (one tile per workgroup, <= 24 K-tiles): the two-stage loop pays one full L2/HBM round trip
 // per K-tile there (~1.2 us), which split-K + a reduce launch used to paper over.
+// 8 floats written through to memory (sc1): a slab that another workgroup of the same launch will read needs no release
+// fence when every byte of it is stored this way and drained (s_waitcnt vmcnt(0)) before the arrival counter is bumped
+// (cdna guide, Guideline 16, rule R1)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store8_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, const float (&v)[8]) {
+    u32x4_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = __builtin_bit_cast(unsigned, v[j]); b[j] = __builtin_bit_cast(unsigned, v[4 + j]); }
+    __builtin_amdgcn_raw_buffer_store_b128(a, r, byte_off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(b, r, byte_off + 16, 0, 16);
+}
+
 constexpr int FL_SLAB = 0x10000;
 template <int TA, int TB, bool DMA, bool CS, int FL, int RING = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
                                                         const int kchunk, float* __restrict__ ws, const int vec_in,
-                                                        const int tiles_m_arg, const int nbatch) {
+                                                        const int tiles_m_arg, const int nbatch,
+                                                        unsigned* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 32 KiB (register staging) or 64 KiB (DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -544,11 +557,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
         __syncthreads();
         if (tid < 128 && m0 + tid < p.M) {
             const float t = red[tid];
-            if (splitk > 1) ws[(int64_t)nbatch * splitk * p.M * p.N + ((int64_t)z * splitk + split) * p.M + m0 + tid] = t;
-            else p.colsum[m0 + tid] += t;
+            if (splitk > 1) {
+                float* cp = ws + (int64_t)nbatch * splitk * p.M * p.N + ((int64_t)z * splitk + split) * p.M + m0 + tid;
+                if (SLAB && cnt) __hip_atomic_store(cp, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 store
+                else *cp = t;
+            } else p.colsum[m0 + tid] += t;
         }
         __syncthreads();
     }
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(wsz, 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -575,7 +592,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
                 if (m < p.M && n < p.N) {
                     float v[8];
                     load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
-                    store8(wsz + (int64_t)m * p.N + n, v);
+                    if (cnt) store8_sc1(rws, (m * p.N + n) * 4, v);
+                    else store8(wsz + (int64_t)m * p.N + n, v);
                 }
             } else if (!GEN) {
                 if (m < p.M && n < p.N) {
@@ -614,6 +632,70 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this pass's reads of `wl` are done before it is rewritten
+    }
+    if constexpr (SLAB) {
+        if (cnt) {
+            // ---- split-K combined inside the launch: the slice that arrives LAST at the tile's counter sums all slabs
+            // in slice order (deterministic whatever the arrival order) and applies the epilogue -- no reduce launch.
+            // Publish: every storing wave drains its write-through (sc1) slab stores, the workgroup meets, ONE lane
+            // bumps the agent-scope counter.  Consume: the last arriver reads every slab byte with sc1 loads.
+            // (cdna guide, Guideline 16 and "Projection GEMM", item 2.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(lds);
+            unsigned* tc = cnt + (int64_t)z * ntiles + tile_lin;
+            if (tid == 0) *flag = __hip_atomic_fetch_add(tc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == (unsigned)(splitk - 1);   // block-uniform
+            if (last) {
+                // (no agent-scope acquire: buffer_inv sc1 drops this XCD's whole L2, i.e. the A / B panels the remaining
+                // tiles of the persistent loop still share -- measured +4.4 ms per training step.  Instead EVERY load of a
+                // handed-off byte below is an sc1 load, which bypasses the caches that could hold a stale copy.)
+                if (tid == 0) __hip_atomic_store(tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
+                const int64_t mn = (int64_t)p.M * p.N;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int u = lane + 64 * t;
+                        const int row = u >> 3, c8 = (u & 7) * 8;
+                        const int m = m0 + wm * 64 + pass * 32 + row;
+                        const int n = n0 + wn * 64 + c8;
+                        if (m < p.M && n < p.N) {
+                            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            for (int sl = 0; sl < splitk; ++sl) {
+                                // four 8-byte relaxed agent-scope atomic loads = global_load_dwordx2 ... sc1
+                                // (__builtin_amdgcn_raw_buffer_load_b128 with aux = sc1 is mis-lowered to ONE dword
+                                // load by ROCm 7.2's hipcc; checked in the ISA)
+                                const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(
+                                    ws + ((int64_t)z * splitk + sl) * mn + (int64_t)m * p.N + n);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const unsigned long long q = __hip_atomic_load(sp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    v[2 * j] += __builtin_bit_cast(float, (unsigned)(q & 0xFFFFFFFFull));
+                                    v[2 * j + 1] += __builtin_bit_cast(float, (unsigned)(q >> 32));
+                                }
+                            }
+                            if (vec) {
+                                EpiPre e;
+                                e.has_pre = false; e.has_bias = false; e.pre = make_uint4(0, 0, 0, 0);
+                                epilogue_store8(p, p.flags, coff, roff, m, n, v, e);
+                            } else {
+                                for (int j = 0; j < 8; ++j) epilogue_store<bf16_t>(p, coff, roff, m, n + j, v[j]);
+                            }
+                        }
+                    }
+                if (CS && TA == 1 && p.colsum != nullptr && tile_n == 0 && tid < 128 && m0 + tid < p.M) {
+                    const float* wb = ws + (int64_t)nbatch * splitk * mn + (int64_t)z * splitk * p.M + m0 + tid;
+                    float t = 0.f;
+                    for (int sl = 0; sl < splitk; ++sl)
+                        t += __hip_atomic_load(wb + (int64_t)sl * p.M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 load
+                    p.colsum[m0 + tid] += t;
+                }
+            }
+            __syncthreads();   // `flag` lives in stage 0
+        }
     }
     // every wave is done with its epilogue LDS before the next tile's DMA overwrites stage 0; the global stores stay in
     // flight (raw barrier: no vmcnt wait) and drain under the next tile's first DMA
@@ -918,6 +1000,18 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 // ring-pipeline selection: 0 off (default), 1 one-wave problems, 2 everywhere; VPU_GEMM_RING at start-up,
 // vpu_gemm_set_option("ring", v) at run time (tests)
 std::atomic<int> g_opt_ring{-1};
+// split-K slices combined by a separate reduce launch (0, default) or by the last-arriving workgroup of the same launch
+// (1: always, n > 1: only when all slabs of the launch total <= n MiB): VPU_GEMM_INLAUNCH at start-up,
+// vpu_gemm_set_option("splitk_inlaunch", v) at run time.  Measured on the training step (round 1, bs 12): off 19.5 ms,
+// slabs <= 2 MiB 19.8 ms, <= 8 MiB 21.5 ms, always 27.4 ms (24.1 ms with an agent-scope acquire + plain loads instead of
+// sc1 loads: the acquire drops the XCD's L2) -- the write-through slab stores and sc1 loads cost more than the reduce
+// launch they save, at every slab size of this model.  Kept (and tested) for shapes where a launch boundary is dearer.
+std::atomic<int> g_opt_inlaunch{-1};
+inline int inlaunch_env0() {
+    static const int v = [] { const char* e = getenv("VPU_GEMM_INLAUNCH"); return e ? atoi(e) : 0; }();
+    return v;
+}
+constexpr int64_t CNT_BYTES = 256 << 10;   // tile arrival counters at the end of the split-K workspace
 inline int ring_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 0; }();
     return v;
@@ -993,7 +1087,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         if (!ring && d->workspace && tiles < 192 && d->K >= 8 * BK) {
             int64_t want = (384 + tiles - 1) / tiles;
             const int64_t max_by_k = d->K / (4 * BK);
-            const int64_t max_by_ws = d->workspace_bytes / ((int64_t)d->batch * d->M * (d->N + 1) * 4);
+            const int64_t max_by_ws = (d->workspace_bytes - CNT_BYTES) / ((int64_t)d->batch * d->M * (d->N + 1) * 4);
             if (want > max_by_k) want = max_by_k;
             if (want > max_by_ws) want = max_by_ws;
             if (want > 128) want = 128;
@@ -1020,15 +1114,16 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
-        if (use_dma) gemm_bf16_kernel<TA_, TB_, true, false, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch); \
-        else gemm_bf16_kernel<TA_, TB_, false, false, -1><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
+        if (use_dma) gemm_bf16_kernel<TA_, TB_, true, false, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg); \
+        else gemm_bf16_kernel<TA_, TB_, false, false, -1><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
     } while (0)
 #define VPU_LAUNCH_FL(TA_, TB_, FL_) \
-    gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch)
+    gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg)
         // compile-time epilogues for the flag sets of the ViT blocks (engine.py: linear / mlp / _dgrad)
         static const bool no_spec = [] { const char* e = getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
         const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && vec_arg == 1;
-        bool launched = false;
+        bool launched = false, inlaunch = false;
+        unsigned* cnt_arg = nullptr;
 #define VPU_LAUNCH_RING(TA_, TB_, CS_, FL_)                                                                            \
     do {                                                                                                             \
         static bool attr_ = false;                                                                                   \
@@ -1037,7 +1132,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
             attr_ = true;                                                                                            \
         }                                                                                                            \
-        kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);       \
+        kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
     } while (0)
         if (ring && use_dma && vec_arg <= 1) {
             launched = true;
@@ -1067,7 +1162,15 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool slab_ok = use_dma && !no_spec && !big && splitk > 1 && d->N % 8 == 0 && vec_arg <= 1;
         if (!launched && slab_ok) {
             launched = true;
-            if (d->colsum && key == 3) gemm_bf16_kernel<1, 1, true, true, FL_SLAB><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+            // in-launch combine: tile counters in the last CNT_BYTES of the workspace (zero at first use, left zero)
+            const int inl = g_opt_inlaunch.load(std::memory_order_relaxed) >= 0 ? g_opt_inlaunch.load(std::memory_order_relaxed) : inlaunch_env0();
+            const int64_t slab_bytes = (int64_t)d->batch * splitk * d->M * d->N * 4;
+            if (inl && (inl == 1 || slab_bytes <= ((int64_t)inl << 20)) && tiles <= CNT_BYTES / 4 &&
+                (int64_t)d->M * d->N * 4 < 0x7FFFFFF0LL && d->workspace_bytes > 2 * CNT_BYTES) {
+                cnt_arg = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d->workspace) + d->workspace_bytes - CNT_BYTES);
+                inlaunch = true;
+            }
+            if (d->colsum && key == 3) gemm_bf16_kernel<1, 1, true, true, FL_SLAB><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
             else if (d->colsum) launched = false;
             else if (key == 3) VPU_LAUNCH_FL(1, 1, FL_SLAB);
             else if (key == 0) VPU_LAUNCH_FL(0, 0, FL_SLAB);
@@ -1095,8 +1198,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         } else {
             if (d->colsum) {  // weight-gradient GEMM with the fused bias gradient (always transA = transB = 1 in the engine)
-                if (key == 3) gemm_bf16_kernel<1, 1, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
-                else gemm_bf16_kernel<1, 0, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch);
+                if (key == 3) gemm_bf16_kernel<1, 1, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
+                else gemm_bf16_kernel<1, 0, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
             } else
             switch (key) {
                 case 0: VPU_LAUNCH(0, 0); break;
@@ -1107,7 +1210,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
 #undef VPU_LAUNCH
 #undef VPU_LAUNCH_FL
-        if (splitk > 1) {
+        if (splitk > 1 && !inlaunch) {
             const int64_t mn = (int64_t)d->M * d->N;
             const int vec8 = vec && d->N % 8 == 0 ? 1 : 0;
             dim3 rgrid((unsigned)vpu_grid_for(vec8 ? mn / 8 : mn, 256, 4096), 1, (unsigned)d->batch);
@@ -1131,6 +1234,11 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_ring.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
-    vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere)");
+    if (name && !strcmp(name, "splitk_inlaunch") && value >= -1 && value <= 4096) {
+        g_opt_inlaunch.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
+    vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere), "
+                  "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine)");
     return VPU_ERR_ARG;
 }

@@ -44,7 +44,7 @@ def split_k_workspace(device, nbytes=128 << 20):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)   # one scratch buffer per stream
     ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        ws = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)   # (zeroed: its tail holds tile counters)
         _WORKSPACE[key] = ws
     return ws
 

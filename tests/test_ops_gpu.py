@@ -655,6 +655,39 @@ def test_gemm_split_k_and_vector_epilogue(ops, tA, tB):
     torch.testing.assert_close(outs[0], outs[1], atol=0.13, rtol=1e-2)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 768, 768, 9408), (1, 1, 384, 768, 2048), (0, 0, 576, 768, 768), (0, 1, 576, 384, 1024)])
+def test_gemm_split_k_inlaunch_combine_stress(ops, shape):
+    """Split-K combined inside the launch (the last-arriving slice of a tile sums the write-through slabs after an
+    agent-scope acquire) against the separate reduce launch: 25 back-to-back launches on FRESH exact-integer operands
+    that reuse the same workspace (so a stale cached slab line would show), every result bit-identical to the fp32
+    matmul, including the fused bias-gradient column sums of the weight-gradient form."""
+    tA, tB, M, N, K = shape
+    g = torch.Generator().manual_seed(11)
+    for it in range(25):
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+        ref = A @ Bm.t()
+        Ad = dev(A.t().contiguous() if tA else A).to(torch.bfloat16)
+        Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+        lda, ldb = (M if tA else K), (N if tB else K)
+        outs = []
+        for mode in (1, 0):
+            ops.gemm_set_option("splitk_inlaunch", mode)
+            try:
+                C32 = torch.full((M, N), float(it), device="cuda")
+                cs = torch.full((M,), 2.0, device="cuda") if (tA and tB) else None
+                ops.gemm(Ad, Bd, C32, M, N, K, lda, ldb, N, 0, transA=bool(tA), transB=bool(tB),
+                         flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)
+            finally:
+                ops.gemm_set_option("splitk_inlaunch", -1)
+            outs.append((C32, cs))
+        torch.cuda.synchronize()
+        for C32, cs in outs:
+            assert torch.equal(C32.cpu(), ref + float(it)), (it, (C32.cpu() - ref - it).abs().max())
+            if cs is not None:
+                assert torch.equal(cs.cpu(), A.sum(1) + 2.0), it
+
+
 @pytest.mark.parametrize("K", [512, 8192])
 def test_gemm_fused_bias_gradient(ops, K):
     """wgrad GEMM with the bias-gradient column sums fused in (split-K for the long K, direct for the short one)."""
