@@ -223,8 +223,8 @@ int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_t* slot_mas
                      void* stream);
 /* The same loss taken on the LOW-resolution similarities: fuses the align_corners=True upsample (is_vpu_model.py:434-436),
  * the loss and both backward passes; sim_low fp32 [B][S][h][w], dsim_low (optional) its gradient.
- * loss_part fp32 [B][S][vpu_p2cl_up_nband(h)]: un-normalised sums per (plane, band of low-resolution rows). */
-int vpu_p2cl_up_nband(int32_t h);
+ * loss_part fp32 [B][S][vpu_p2cl_up_nband(h, w)]: un-normalised sums per (plane, band of low-resolution rows). */
+int vpu_p2cl_up_nband(int32_t h, int32_t w);
 int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const int32_t* slot_mask_idx, const float* override_masks,
                         float* loss_part, float* dsim_low, float grad_scale, int32_t B, int32_t S, int32_t h, int32_t w,
                         int32_t H, int32_t W, void* stream);

@@ -75,7 +75,7 @@ SIGNATURES = {
     "vpu_upsample_ac_fwd": [_P, _P, _L, _I, _I, _I, _I, _P],
     "vpu_upsample_ac_bwd": [_P, _P, _L, _I, _I, _I, _I, _P],
     "vpu_p2cl_fwd_bwd": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
-    "vpu_p2cl_up_nband": [_I],
+    "vpu_p2cl_up_nband": [_I, _I],
     "vpu_p2cl_up_fwd_bwd": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P],
     "vpu_nfl_dice_scratch_doubles": [_I],
     "vpu_nfl_dice_fwd_bwd": [_P, _P, _P, _P, _P, _F, _F, _I, _L, _P],

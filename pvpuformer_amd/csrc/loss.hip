@@ -70,7 +70,7 @@ __device__ __forceinline__ int ac_i0(int dst, float scale, int in_size) {
 // The block owns the gradient rows [r0, r1) of its band: the halo row r0-1 contributes its lower corners (row r0), the
 // lower corners of the last anchor row are dropped (the next band's halo recomputes them); losses are counted for the
 // band's own anchor rows only.
-constexpr int P2_BAND = 8;
+constexpr int P2_BAND_MAX = 8;   // anchor rows per block: min(8, 1024 / w - 1) so that (band + 1) * w threads fit one block
 constexpr int P2_SPAN = 5;   // most full-resolution pixels per low-resolution cell and axis
 
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
@@ -78,16 +78,16 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
                                                        const float* __restrict__ override_masks,
                                                        float* __restrict__ loss_part, float* __restrict__ dlow,
                                                        float grad_scale, int S, int h, int w, int H, int W, int nband,
-                                                       int max_rows) {
-    extern __shared__ float sm[];   // [(P2_BAND+2)*w] values (rows r0-1..r1) | [P2_BAND*w] gradients | [(P2_BAND+2)*W] hr | [max_rows*W] d loss / d prob
+                                                       int max_rows, int BAND) {
+    extern __shared__ float sm[];   // [(BAND+2)*w] values (rows r0-1..r1) | [BAND*w] gradients | [(BAND+2)*W] hr | [max_rows*W] d loss / d prob
     __shared__ double red[16];
     const int plane = blockIdx.x / nband, band = blockIdx.x % nband;
     const int b = plane / S, s = plane % S;
-    const int r0 = band * P2_BAND, r1 = (r0 + P2_BAND < h) ? r0 + P2_BAND : h;
+    const int r0 = band * BAND, r1 = (r0 + BAND < h) ? r0 + BAND : h;
     float* sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
-    float* sg = sm + (P2_BAND + 2) * w;    // sg[(y - r0) * w + x]
-    float* hr = sg + P2_BAND * w;          // hr[(y - (r0 - 1)) * W + X]: rows of sv interpolated along x
-    float* gp = hr + (P2_BAND + 2) * W;    // gp[(Y - Y0) * W + X]
+    float* sg = sm + (BAND + 2) * w;    // sg[(y - r0) * w + x]
+    float* hr = sg + BAND * w;          // hr[(y - (r0 - 1)) * W + X]: rows of sv interpolated along x
+    float* gp = hr + (BAND + 2) * W;    // gp[(Y - Y0) * W + X]
     const int ov = slot_idx ? slot_idx[plane] : -1;
     const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
     const bool invert = ov < 0 && s >= S / 2;
@@ -120,15 +120,15 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         lv[k] = make_float4(-1.f, -1.f, -1.f, -1.f);
         if (Ya + k < Yb) lv[k] = *reinterpret_cast<const float4*>(lab + (int64_t)(Ya + k) * W + X4);
     }
-    for (int i = threadIdx.x; i < (P2_BAND + 2) * w; i += blockDim.x) {
+    for (int i = threadIdx.x; i < (BAND + 2) * w; i += blockDim.x) {
         const int y = r0 - 1 + i / w;
         sv[i] = (y >= 0 && y < h) ? low[(int64_t)plane * h * w + (int64_t)y * w + (i % w)] : 0.f;
     }
-    for (int i = threadIdx.x; i < P2_BAND * w; i += blockDim.x) sg[i] = 0.f;
+    for (int i = threadIdx.x; i < BAND * w; i += blockDim.x) sg[i] = 0.f;
     __syncthreads();
     // ---- pass 0: horizontal interpolation of the band's low-resolution rows, hr[row][X] = hx*v[x0] + lx*v[x1]
     // (the inner sums of the align_corners=True formula  hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11), same rounding)
-    for (int i = threadIdx.x; i < (P2_BAND + 2) * W; i += blockDim.x) {
+    for (int i = threadIdx.x; i < (BAND + 2) * W; i += blockDim.x) {
         const int rr = i / W, X = i - rr * W;
         const int x0 = ac_i0(X, sw, w);
         const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
@@ -346,22 +346,30 @@ extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_
     return vpu_check_launch("vpu_p2cl_fwd_bwd");
 }
 
-extern "C" int vpu_p2cl_up_nband(int32_t h) { return (h + P2_BAND - 1) / P2_BAND; }
+static inline int p2cl_band(int w) {
+    int b = 1024 / (w > 0 ? w : 1) - 1;
+    return b > P2_BAND_MAX ? P2_BAND_MAX : b;
+}
+extern "C" int vpu_p2cl_up_nband(int32_t h, int32_t w) {
+    const int band = p2cl_band(w);
+    return band < 1 ? 0 : (h + band - 1) / band;
+}
 
 extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const int32_t* slot_mask_idx,
                                    const float* override_masks, float* loss_part, float* dsim_low, float grad_scale,
                                    int32_t B, int32_t S, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
-    if (S % 2 || (P2_BAND + 1) * w > 1024 || h < 2 || w < 2 || W % 4 || (int64_t)(H - 1) >= (int64_t)P2_SPAN * (h - 1) ||
+    const int band = p2cl_band(w);
+    if (S % 2 || band < 1 || h < 2 || w < 2 || W % 4 || (int64_t)(H - 1) >= (int64_t)P2_SPAN * (h - 1) ||
         (int64_t)(W - 1) >= (int64_t)P2_SPAN * (w - 1)) {
-        vpu_set_error("p2cl_up: S % 2, W % 4, (band + 1) * w <= 1024 (w <= 113), upsampling factor (H-1)/(h-1) < 5");
+        vpu_set_error("p2cl_up: S % 2, W % 4, 2 <= w <= 512, upsampling factor (H-1)/(h-1) < 5");
         return VPU_ERR_ARG;
     }
-    const int nband = (h + P2_BAND - 1) / P2_BAND;
-    // pixel rows one block can own: (P2_BAND + 1) anchor rows x (H-1)/(h-1) rows per anchor row, + 2 for rounding
-    const int max_rows = (int)(((int64_t)(P2_BAND + 1) * (H - 1)) / (h - 1)) + 2;
-    const size_t shmem = ((size_t)(2 * P2_BAND + 2) * w + (size_t)(P2_BAND + 2 + max_rows) * W) * sizeof(float);
-    if (shmem > 160 * 1024 - 256 || (int64_t)(P2_BAND + 1) * (W / 4) > 1024) {
+    const int nband = (h + band - 1) / band;
+    // pixel rows one block can own: (band + 1) anchor rows x (H-1)/(h-1) rows per anchor row, + 2 for rounding
+    const int max_rows = (int)(((int64_t)(band + 1) * (H - 1)) / (h - 1)) + 2;
+    const size_t shmem = ((size_t)(2 * band + 2) * w + (size_t)(band + 2 + max_rows) * W) * sizeof(float);
+    if (shmem > 160 * 1024 - 256 || (int64_t)(band + 1) * (W / 4) > 1024) {
         vpu_set_error("p2cl_up: band does not fit LDS / one block ((band + 1) * W/4 <= 1024)");
         return VPU_ERR_ARG;
     }
@@ -372,7 +380,7 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
         attr_set = true;
     }
     p2cl_up_kernel<<<(unsigned)(B * S * nband), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
-                                                                  dsim_low, grad_scale, S, h, w, H, W, nband, max_rows);
+                                                                  dsim_low, grad_scale, S, h, w, H, W, nband, max_rows, band);
     return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
 }
 

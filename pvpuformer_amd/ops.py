@@ -252,7 +252,7 @@ def p2cl_fwd_bwd(prob, gt, slot_idx, override, loss_part, dprob, grad_scale, B, 
 
 def p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, loss_part, dsim_low, grad_scale, B, S, h, w, H, W):
     """loss_part fp32 [B, S]: per-plane sums (the kernel's per-band partials are summed here)."""
-    nband = _lib.load().vpu_p2cl_up_nband(h)
+    nband = _lib.load().vpu_p2cl_up_nband(h, w)
     bands = torch.empty(B * S, nband, device=sim_low.device, dtype=torch.float32)
     _lib.call("vpu_p2cl_up_fwd_bwd", ptr(sim_low), ptr(gt), ptr(slot_idx), ptr(override), ptr(bands), ptr(dsim_low),
               grad_scale, B, S, h, w, H, W, _stream())
