@@ -37,32 +37,33 @@ template <int HD> __device__ __forceinline__ int tr_off(int row, int unit) {
     return row * (HD * 2) + ((unit ^ ((((row >> 1) & 3) << 2) & (HD / 4 - 1))) << 3);
 }
 
-// rows [r0, r0+CH) x HD columns of a [*, ld] matrix: fetch_rows pulls this thread's 16-B chunks into registers (rows >= n
-// and columns >= hd as zeros), put_rows writes them into an LDS image.  The loops below fetch chunk i+1 right after
-// chunk i has been put, so that its global-memory latency is covered by the MFMA work on chunk i (with 96 workgroups on
-// 256 CUs -- the neck's 48-token side -- nothing else hides it).
-template <int HD> struct RowChunk { uint4 v[(CH * HD / 8 + 255) / 256]; };
-template <int HD>
+// rows [r0, r0 + NS*CH) x HD columns of a [*, ld] matrix: fetch_rows pulls this thread's 16-B chunks into registers (rows
+// >= n and columns >= hd as zeros), put_rows writes them into an LDS image.  A staged block is NS sub-chunks of CH rows:
+// the kernels walk the sub-chunks of a block without any barrier, and fetch block i+1 right after block i has been put.
+// (The swizzles depend on the row modulo 16 only, so a sub-chunk is just a byte offset into the image.  NS > 1 trades
+// occupancy for fewer barrier pairs / round trips; the launchers use NS = 1, see the measurement there.)
+template <int HD, int NS> struct RowChunk { uint4 v[(NS * CH * HD / 8 + 255) / 256]; };
+template <int HD, int NS>
 __device__ __forceinline__ void fetch_rows(const bf16_t* __restrict__ base, int ld, int r0, int n, int tid, int hd,
-                                           RowChunk<HD>& rc) {
+                                           RowChunk<HD, NS>& rc) {
     constexpr int CPR = HD / 8;  // 16-B chunks per row
 #pragma unroll
-    for (int i = 0; i < (CH * CPR + 255) / 256; ++i) {
+    for (int i = 0; i < (NS * CH * CPR + 255) / 256; ++i) {
         const int c = tid + i * 256;
         const int row = c / CPR, ch = c % CPR;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < CH * CPR && r0 + row < n && ch * 8 < hd)
+        if (c < NS * CH * CPR && r0 + row < n && ch * 8 < hd)
             v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
         rc.v[i] = v;
     }
 }
-template <int HD, bool TR>
-__device__ __forceinline__ void put_rows(char* lds, int tid, const RowChunk<HD>& rc) {
+template <int HD, int NS, bool TR>
+__device__ __forceinline__ void put_rows(char* lds, int tid, const RowChunk<HD, NS>& rc) {
     constexpr int CPR = HD / 8;
 #pragma unroll
-    for (int i = 0; i < (CH * CPR + 255) / 256; ++i) {
+    for (int i = 0; i < (NS * CH * CPR + 255) / 256; ++i) {
         const int c = tid + i * 256;
-        if (c < CH * CPR) {
+        if (c < NS * CH * CPR) {
             const int row = c / CPR, ch = c % CPR;
             const int off = TR ? tr_off<HD>(row, ch * 2) : rc_off<HD>(row, ch);
             *reinterpret_cast<uint4*>(lds + off) = rc.v[i];
@@ -118,10 +119,10 @@ struct AttnArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int HD>
+template <int HD, int NS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char ldsK[CH * HD * 2];
-    __shared__ __attribute__((aligned(16))) char ldsV[CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsK[NS * CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsV[NS * CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
@@ -135,18 +136,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     f32x4_t acc[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    RowChunk<HD> pk, pv;
-    fetch_rows<HD>(k, a.ldk, 0, nk, tid, hd, pk);
-    fetch_rows<HD>(v, a.ldk, 0, nk, tid, hd, pv);
-    for (int kc = 0; kc < nk; kc += CH) {
+    RowChunk<HD, NS> pk, pv;
+    fetch_rows<HD, NS>(k, a.ldk, 0, nk, tid, hd, pk);
+    fetch_rows<HD, NS>(v, a.ldk, 0, nk, tid, hd, pv);
+    for (int kb = 0; kb < nk; kb += NS * CH) {
         __syncthreads();
-        put_rows<HD, false>(ldsK, tid, pk);
-        put_rows<HD, true>(ldsV, tid, pv);
+        put_rows<HD, NS, false>(ldsK, tid, pk);
+        put_rows<HD, NS, true>(ldsV, tid, pv);
         __syncthreads();
-        if (kc + CH < nk) {
-            fetch_rows<HD>(k, a.ldk, kc + CH, nk, tid, hd, pk);
-            fetch_rows<HD>(v, a.ldk, kc + CH, nk, tid, hd, pv);
+        if (kb + NS * CH < nk) {
+            fetch_rows<HD, NS>(k, a.ldk, kb + NS * CH, nk, tid, hd, pk);
+            fetch_rows<HD, NS>(v, a.ldk, kb + NS * CH, nk, tid, hd, pv);
         }
+        for (int sub = 0; sub < NS && kb + sub * CH < nk; ++sub) {
+        const int kc = kb + sub * CH;
+        const char* sK = ldsK + sub * (CH * HD * 2);
+        const char* sV = ldsV + sub * (CH * HD * 2);
         f32x4_t s[2];
         float mx = m;
 #pragma unroll
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
             s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsK, 16 * t, ks, lane), qf[ks], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(sK, 16 * t, ks, lane), qf[ks], s[t], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = (kc + 16 * t + 4 * g + r < nk) ? s[t][r] * a.scale : -INFINITY;
@@ -182,7 +187,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         for (int dt = 0; dt < HD / 16; ++dt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[dt][r] *= ar[r];
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(ldsV, dt, lane), acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(sV, dt, lane), acc[dt], 0, 0, 0);
+        }
         }
     }
     const float il = 1.0f / l;
@@ -222,10 +228,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a, int64
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int HD>
+template <int HD, int NS>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char ldsQr[CH * HD * 2], ldsQt[CH * HD * 2];
-    __shared__ __attribute__((aligned(16))) char ldsOr[CH * HD * 2], ldsOt[CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsQr[NS * CH * HD * 2], ldsQt[NS * CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsOr[NS * CH * HD * 2], ldsOt[NS * CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
@@ -243,28 +249,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
     f32x4_t adk[HD / 16], adv[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
-    RowChunk<HD> pq, po;
-    fetch_rows<HD>(q, a.ldq, 0, nq, tid, hd, pq);
-    fetch_rows<HD>(d_o, a.ldo, 0, nq, tid, hd, po);
-    for (int qc = 0; qc < nq; qc += CH) {
+    RowChunk<HD, NS> pq, po;
+    fetch_rows<HD, NS>(q, a.ldq, 0, nq, tid, hd, pq);
+    fetch_rows<HD, NS>(d_o, a.ldo, 0, nq, tid, hd, po);
+    for (int qb = 0; qb < nq; qb += NS * CH) {
         __syncthreads();
-        put_rows<HD, false>(ldsQr, tid, pq);
-        put_rows<HD, true>(ldsQt, tid, pq);
-        put_rows<HD, false>(ldsOr, tid, po);
-        put_rows<HD, true>(ldsOt, tid, po);
+        put_rows<HD, NS, false>(ldsQr, tid, pq);
+        put_rows<HD, NS, true>(ldsQt, tid, pq);
+        put_rows<HD, NS, false>(ldsOr, tid, po);
+        put_rows<HD, NS, true>(ldsOt, tid, po);
         __syncthreads();
-        if (qc + CH < nq) {
-            fetch_rows<HD>(q, a.ldq, qc + CH, nq, tid, hd, pq);
-            fetch_rows<HD>(d_o, a.ldo, qc + CH, nq, tid, hd, po);
+        if (qb + NS * CH < nq) {
+            fetch_rows<HD, NS>(q, a.ldq, qb + NS * CH, nq, tid, hd, pq);
+            fetch_rows<HD, NS>(d_o, a.ldo, qb + NS * CH, nq, tid, hd, po);
         }
+        for (int sub = 0; sub < NS && qb + sub * CH < nq; ++sub) {
+        const int qc = qb + sub * CH;
+        const int so = sub * (CH * HD * 2);
         f32x4_t P[2], dS[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsQr, 16 * t, ks, lane), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsOr, 16 * t, ks, lane), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsQr + so, 16 * t, ks, lane), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsOr + so, 16 * t, ks, lane), vf[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {   // element [query = qc+16t+4g+r][key = key0+c]
@@ -280,8 +289,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
         const bf16x8_t pf = pack_pair(P[0], P[1]), dsf = pack_pair(dS[0], dS[1]);
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
-            adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(ldsOt, dt, lane), adv[dt], 0, 0, 0);
-            adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(ldsQt, dt, lane), adk[dt], 0, 0, 0);
+            adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(ldsOt + so, dt, lane), adv[dt], 0, 0, 0);
+            adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(ldsQt + so, dt, lane), adk[dt], 0, 0, 0);
+        }
         }
     }
 #pragma unroll
@@ -301,9 +311,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int HD>
+template <int HD, int NS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char ldsKr[CH * HD * 2], ldsKt[CH * HD * 2], ldsVr[CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsKr[NS * CH * HD * 2], ldsKt[NS * CH * HD * 2], ldsVr[NS * CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
@@ -321,27 +331,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     f32x4_t adq[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    RowChunk<HD> pk, pv;
-    fetch_rows<HD>(k, a.ldk, 0, nk, tid, hd, pk);
-    fetch_rows<HD>(v, a.ldk, 0, nk, tid, hd, pv);
-    for (int kc = 0; kc < nk; kc += CH) {
+    RowChunk<HD, NS> pk, pv;
+    fetch_rows<HD, NS>(k, a.ldk, 0, nk, tid, hd, pk);
+    fetch_rows<HD, NS>(v, a.ldk, 0, nk, tid, hd, pv);
+    for (int kb = 0; kb < nk; kb += NS * CH) {
         __syncthreads();
-        put_rows<HD, false>(ldsKr, tid, pk);
-        put_rows<HD, true>(ldsKt, tid, pk);
-        put_rows<HD, false>(ldsVr, tid, pv);
+        put_rows<HD, NS, false>(ldsKr, tid, pk);
+        put_rows<HD, NS, true>(ldsKt, tid, pk);
+        put_rows<HD, NS, false>(ldsVr, tid, pv);
         __syncthreads();
-        if (kc + CH < nk) {
-            fetch_rows<HD>(k, a.ldk, kc + CH, nk, tid, hd, pk);
-            fetch_rows<HD>(v, a.ldk, kc + CH, nk, tid, hd, pv);
+        if (kb + NS * CH < nk) {
+            fetch_rows<HD, NS>(k, a.ldk, kb + NS * CH, nk, tid, hd, pk);
+            fetch_rows<HD, NS>(v, a.ldk, kb + NS * CH, nk, tid, hd, pv);
         }
+        for (int sub = 0; sub < NS && kb + sub * CH < nk; ++sub) {
+        const int kc = kb + sub * CH;
+        const int so = sub * (CH * HD * 2);
         f32x4_t dS[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsKr, 16 * t, ks, lane), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsVr, 16 * t, ks, lane), dof[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsKr + so, 16 * t, ks, lane), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(ldsVr + so, 16 * t, ks, lane), dof[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {   // element [key = kc+16t+4g+r][query = q0+c]
@@ -354,7 +367,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
         const bf16x8_t dsf = pack_pair(dS[0], dS[1]);
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt)
-            adq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(ldsKt, dt, lane), adq[dt], 0, 0, 0);
+            adq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(ldsKt + so, dt, lane), adq[dt], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -389,9 +403,13 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     dim3 grid((nq + 63) / 64, nb * H);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (hd_image(hd)) {
-        case 32: attn_fwd_kernel<32><<<grid, 256, 0, s>>>(a); break;
-        case 64: attn_fwd_kernel<64><<<grid, 256, 0, s>>>(a); break;
-        default: attn_fwd_kernel<128><<<grid, 256, 0, s>>>(a); break;
+        // staged block = NS x 32 keys.  NS = 1 everywhere: measured (tools/op_bench.py attn, round 1) window forward 35.8 us
+        // at NS = 1, 36.2 at NS = 2, 41.8 at NS = 7 (a whole 196-token window resident, one barrier pair); backward 111.7 /
+        // 119.2 / 144.3 us -- the loop is bound by its softmax dependency chain, and the 8-KiB blocks' occupancy (8 per CU)
+        // hides more of it than fewer round trips save
+        case 32: attn_fwd_kernel<32, 1><<<grid, 256, 0, s>>>(a); break;
+        case 64: attn_fwd_kernel<64, 1><<<grid, 256, 0, s>>>(a); break;
+        default: attn_fwd_kernel<128, 1><<<grid, 256, 0, s>>>(a); break;
     }
     return vpu_check_launch("vpu_xattn_fwd");
 }
@@ -419,18 +437,18 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     switch (hd_image(hd)) {
         case 32:
             attn_delta_kernel<32><<<dgrid, 256, 0, s>>>(a, total);
-            attn_bwd_dkdv_kernel<32><<<gk, 256, 0, s>>>(a);
-            attn_bwd_dq_kernel<32><<<gq, 256, 0, s>>>(a);
+            attn_bwd_dkdv_kernel<32, 1><<<gk, 256, 0, s>>>(a);
+            attn_bwd_dq_kernel<32, 1><<<gq, 256, 0, s>>>(a);
             break;
         case 64:
             attn_delta_kernel<64><<<dgrid, 256, 0, s>>>(a, total);
-            attn_bwd_dkdv_kernel<64><<<gk, 256, 0, s>>>(a);
-            attn_bwd_dq_kernel<64><<<gq, 256, 0, s>>>(a);
+            attn_bwd_dkdv_kernel<64, 1><<<gk, 256, 0, s>>>(a);
+            attn_bwd_dq_kernel<64, 1><<<gq, 256, 0, s>>>(a);
             break;
         default:
             attn_delta_kernel<128><<<dgrid, 256, 0, s>>>(a, total);
-            attn_bwd_dkdv_kernel<128><<<gk, 256, 0, s>>>(a);
-            attn_bwd_dq_kernel<128><<<gq, 256, 0, s>>>(a);
+            attn_bwd_dkdv_kernel<128, 1><<<gk, 256, 0, s>>>(a);
+            attn_bwd_dq_kernel<128, 1><<<gq, 256, 0, s>>>(a);
             break;
     }
     return vpu_check_launch("vpu_xattn_bwd");

@@ -390,9 +390,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     constexpr bool GEN = FL < 0;
     constexpr bool SLAB = FL == FL_SLAB;   // split-K slice: the raw fp32 tile goes to its workspace slab, nothing else
     const int FLG = GEN ? p.flags : (SLAB ? 0 : FL);
-    if (vec_in >> 8) {   // diagnostic (VPU_GEMM_STAGGER=n): de-synchronise the resident workgroups by up to n x ~0.5 us
-        const int steps = (int)((blockIdx.x * 2654435761u) >> 16) % (vec_in >> 8);
-        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
+    if (vec_in >> 8) {
+        // diagnostic, VPU_GEMM_STAGGER=c: the workgroups that own one work item FEWER than the others (total_work %
+        // gridDim != 0) start about half a tile late (c cycles per K-tile), so that their epilogue (HBM stores) falls into
+        // the main loop (L2 -> LDS traffic) of the workgroup they share the CU with.  Measured round 1 on the six ViT-B
+        // forward / dgrad shapes with c = 300..1300: no effect beyond noise (fc1 82.9 -> 81.1..85.6 us) -- kept off.
+        const int rem = total_work % (int)gridDim.x;
+        if (rem != 0 && (int)blockIdx.x >= rem && total_work > (int)gridDim.x) {
+            const int nk_all = (p.K / splitk + BK - 1) / BK;
+            const int steps = (nk_all * (vec_in >> 8)) >> 10;   // s_sleep(16) ~ 1024 cycles
+            for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
+        }
     }
     for (int work = blockIdx.x; work < total_work; work += gridDim.x) {
     const int tile_lin = work % ntiles, rest = work / ntiles;
@@ -1121,7 +1129,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg)
         // compile-time epilogues for the flag sets of the ViT blocks (engine.py: linear / mlp / _dgrad)
         static const bool no_spec = [] { const char* e = getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
-        const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && vec_arg == 1;
+        const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && (vec_arg & 255) == 1;
         bool launched = false, inlaunch = false;
         unsigned* cnt_arg = nullptr;
 #define VPU_LAUNCH_RING(TA_, TB_, CS_, FL_)                                                                            \

@@ -45,11 +45,22 @@ def main():
                                        B * 112 * 112 * C * 2)
         cases[f"bilinear_fwd_r{r}"] = (lambda dcat=dcat, din=din, hh=hh: ops.bilinear_cl_fwd(din, C, (dcat, C), 4 * C, B, hh, hh, 112, 112, C, 0),
                                        B * 112 * 112 * C * 2)
+    D, Hh = 768, 12
+    for tag, nb, n in (("window", 48, 196), ("global", 12, 784)):
+        qkv = torch.randn(nb * n, 3 * D, device=dev).to(torch.bfloat16)
+        o, do = torch.empty(nb * n, D, device=dev, dtype=torch.bfloat16), torch.randn(nb * n, D, device=dev).to(torch.bfloat16)
+        lse, delta = torch.empty(nb * Hh, n, device=dev), torch.empty(nb * Hh, n, device=dev)
+        dqkv = torch.empty_like(qkv)
+        fl = 4.0 * n * n * 64 * nb * Hh
+        cases[f"attn_fwd_{tag}"] = (lambda qkv=qkv, o=o, lse=lse, nb=nb, n=n: ops.attn_fwd((qkv, 0), (qkv, D), (qkv, 2 * D), o, lse, nb, Hh, n, 64, 3 * D, D, 0.125), fl)
+        cases[f"attn_bwd_{tag}"] = (lambda qkv=qkv, o=o, do=do, lse=lse, delta=delta, dqkv=dqkv, nb=nb, n=n: ops.attn_bwd(
+            (qkv, 0), (qkv, D), (qkv, 2 * D), o, do, lse, delta, (dqkv, 0), (dqkv, D), (dqkv, 2 * D), nb, Hh, n, 64, 3 * D, D, 3 * D, 0.125), 2.5 * fl)
     for name, (fn, nbytes) in cases.items():
         if only and not any(t in name for t in only):
             continue
         us = timeit(fn)
-        print(f"{name:22s} {us:9.1f} us   {nbytes / us / 1e6:8.2f} TB/s (algorithmic bytes)")
+        unit = "TFLOP/s" if name.startswith("attn") else "TB/s (algorithmic bytes)"
+        print(f"{name:22s} {us:9.1f} us   {nbytes / us / 1e6:8.2f} {unit}")
 
 
 if __name__ == "__main__":
