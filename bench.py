@@ -97,7 +97,7 @@ class GemmProbe:
     """HIP-event timing of every GEMM launch of ONE extra (untimed) step, grouped by kernel variant."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.rec, self.shapes = ops, ops.gemm, [], []
+        self.ops, self.orig, self.orig_grouped, self.rec, self.shapes = ops, ops.gemm, ops.gemm_grouped, [], []
 
     def __enter__(self):
         def wrapped(A, B, C, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, **kw):
@@ -108,11 +108,23 @@ class GemmProbe:
             self.rec.append((f"gemm_{'bf16' if dtype == 0 else 'f32'}_kernel<{int(transA)},{int(transB)}>",
                              2.0 * M * N * K * kw.get("batch", 1), e0, e1))
             self.shapes.append((int(transA), int(transB), M, N, K, kw.get("batch", 1), kw.get("flags", 0)))
+        def wrapped_grouped(problems):   # one launch for several problems (the queued weight gradients)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_grouped(problems)
+            e1.record()
+            (a0, k0) = problems[0]
+            fl = sum(2.0 * a[3] * a[4] * a[5] for a, _ in problems)
+            self.rec.append((f"gemm_bf16_grouped_kernel<{int(k0.get('transA', False))},{int(k0.get('transB', False))}>",
+                             fl, e0, e1))
+            self.shapes.append(("grouped", len(problems), sum(a[3] for a, _ in problems), a0[4], a0[5], 1, 0))
         self.ops.gemm = wrapped
+        self.ops.gemm_grouped = wrapped_grouped
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
+        self.ops.gemm_grouped = self.orig_grouped
 
     def summary(self):
         torch.cuda.synchronize()

@@ -62,6 +62,15 @@ typedef struct vpu_gemm_desc {
                                 fused into the weight-gradient GEMM whose A operand is dY */
 } vpu_gemm_desc;
 
+/* Up to VPU_GEMM_GROUP_MAX independent bf16 problems run by ONE launch of vpu_gemm_grouped: start[i] = first tile of
+ * problem i in the concatenated list of 128x128 output tiles, start[n] = total. */
+#define VPU_GEMM_GROUP_MAX 8
+typedef struct vpu_gemm_group {
+    int32_t n;
+    int32_t start[VPU_GEMM_GROUP_MAX + 1];
+    vpu_gemm_desc d[VPU_GEMM_GROUP_MAX];
+} vpu_gemm_group;
+
 const char* vpu_last_error(void);
 int vpu_abi_version(void);
 
@@ -78,6 +87,12 @@ int vpu_gemm(const vpu_gemm_desc* d, void* stream);
  * in slice order, by the slice that arrives last at the tile's counter, inside the GEMM launch; n > 1: that, but only
  * when the slabs of the launch total at most n MiB.  Same results bit for bit; the default is the measured-faster one. */
 int vpu_gemm_set_option(const char* name, int32_t value);
+/* n (1..VPU_GEMM_GROUP_MAX) independent bf16 GEMMs in one persistent launch, every problem un-split over its whole K:
+ * meant for sets whose tiles together fill the chip (the four weight gradients of a ViT block: models_vit.py:38-40,16-18
+ * backward) or whose K is short (the DMA neck's 576-row problems), where separate launches each pay split-K slabs + a
+ * reduce launch.  All descriptors: dtype bf16, batch 1, the same transA / transB; epilogue flags, bias, colsum etc. are
+ * per problem as in vpu_gemm; workspace is ignored. */
+int vpu_gemm_grouped(const vpu_gemm_desc* d, int32_t n, void* stream);
 
 /* ---- row-wise ops ---- */
 /* nn.LayerNorm over the last dim (models_vit.py:126 eps 1e-6; transformer.py:417-426 eps 1e-5). */

@@ -372,11 +372,14 @@ __device__ __forceinline__ void store8_sc1(__amdgpu_buffer_rsrc_t r, int byte_of
 }
 
 constexpr int FL_SLAB = 0x10000;
-template <int TA, int TB, bool DMA, bool CS, int FL, int RING = 0>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
-                                                        const int kchunk, float* __restrict__ ws, const int vec_in,
-                                                        const int tiles_m_arg, const int nbatch,
-                                                        unsigned* __restrict__ cnt) {
+// GRP: the work list is the concatenation of the tiles of up to VPU_GEMM_GROUP_MAX independent problems (same operand
+// layouts, no split-K, batch 1), descriptors read from the kernel-argument segment -- one launch for e.g. the four weight
+// gradients of a ViT block (432 full-K tiles: one round of the 512 persistent workgroups, no slabs, no reduce launches).
+template <int TA, int TB, bool DMA, bool CS, int FL, int RING, bool GRP>
+__device__ __forceinline__ void gemm_bf16_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
+                                               const int tiles_n_arg, const int splitk, const int kchunk_arg,
+                                               float* __restrict__ ws, const int vec_in, const int tiles_m_arg,
+                                               const int nbatch, unsigned* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 32 KiB (register staging) or 64 KiB (DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -384,26 +387,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     // PERSISTENT tile loop: at most two workgroups per CU walk the (tile, split-K slice, batch) work list.  A workgroup
     // that exits holds its CU slot until its stores are acknowledged and its successor pays launch + first-tile latency;
     // at K = 768 that bubble was 30-45 % of a tile's life (round-1 measurement: main loop 880 vs 600 TFLOP/s end to end).
-    const int ntiles = tiles_n * tiles_m_arg;
-    const int total_work = ntiles * splitk * nbatch;
+    const int ntiles0 = tiles_n_arg * tiles_m_arg;
+    const int total_work = GRP ? ga->start[ga->n] : ntiles0 * splitk * nbatch;
     const int vec = vec_in & 255;
     constexpr bool GEN = FL < 0;
     constexpr bool SLAB = FL == FL_SLAB;   // split-K slice: the raw fp32 tile goes to its workspace slab, nothing else
-    const int FLG = GEN ? p.flags : (SLAB ? 0 : FL);
-    if (vec_in >> 8) {
+    if (!GRP && (vec_in >> 8)) {
         // diagnostic, VPU_GEMM_STAGGER=c: the workgroups that own one work item FEWER than the others (total_work %
         // gridDim != 0) start about half a tile late (c cycles per K-tile), so that their epilogue (HBM stores) falls into
         // the main loop (L2 -> LDS traffic) of the workgroup they share the CU with.  Measured round 1 on the six ViT-B
         // forward / dgrad shapes with c = 300..1300: no effect beyond noise (fc1 82.9 -> 81.1..85.6 us) -- kept off.
         const int rem = total_work % (int)gridDim.x;
         if (rem != 0 && (int)blockIdx.x >= rem && total_work > (int)gridDim.x) {
-            const int nk_all = (p.K / splitk + BK - 1) / BK;
+            const int nk_all = (p_arg.K / splitk + BK - 1) / BK;
             const int steps = (nk_all * (vec_in >> 8)) >> 10;   // s_sleep(16) ~ 1024 cycles
             for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
         }
     }
     for (int work = blockIdx.x; work < total_work; work += gridDim.x) {
-    const int tile_lin = work % ntiles, rest = work / ntiles;
+    int grp = 0;
+    if constexpr (GRP) {
+        while (grp + 1 < ga->n && work >= ga->start[grp + 1]) ++grp;
+    }
+    const vpu_gemm_desc& p = GRP ? ga->d[grp] : p_arg;
+    const int tiles_n = GRP ? (p.N + BN - 1) / BN : tiles_n_arg;
+    const int ntiles = GRP ? ga->start[grp + 1] - ga->start[grp] : ntiles0;
+    const int kchunk = GRP ? (p.K + BK - 1) / BK * BK : kchunk_arg;
+    const int FLG = GEN ? p.flags : (SLAB ? 0 : FL);
+    const int tile_lin = GRP ? work - ga->start[grp] : work % ntiles, rest = GRP ? 0 : work / ntiles;
     const int split = rest % splitk, z = rest / splitk;
     int tile_m, tile_n;
     tile_coords(tile_lin, ntiles, tiles_n, tile_m, tile_n);
@@ -709,6 +720,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p
     // flight (raw barrier: no vmcnt wait) and drain under the next tile's first DMA
     __builtin_amdgcn_s_barrier();
     }  // persistent work loop
+}
+
+template <int TA, int TB, bool DMA, bool CS, int FL, int RING = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const vpu_gemm_desc p, const int tiles_n, const int splitk,
+                                                        const int kchunk, float* __restrict__ ws, const int vec_in,
+                                                        const int tiles_m_arg, const int nbatch,
+                                                        unsigned* __restrict__ cnt) {
+    gemm_bf16_body<TA, TB, DMA, CS, FL, RING, false>(p, nullptr, tiles_n, splitk, kchunk, ws, vec_in, tiles_m_arg, nbatch, cnt);
+}
+template <int TA, int TB, bool CS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const vpu_gemm_group ga, const int vec_in) {
+    gemm_bf16_body<TA, TB, true, CS, -1, 0, true>(ga.d[0], &ga, 0, 1, 0, nullptr, vec_in, 0, 1, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1249,4 +1272,64 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere), "
                   "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine)");
     return VPU_ERR_ARG;
+}
+
+extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* stream) {
+    vpu_clear_stale_error();
+    if (!descs || n < 1 || n > VPU_GEMM_GROUP_MAX) { vpu_set_error("vpu_gemm_grouped: 1 <= n <= VPU_GEMM_GROUP_MAX"); return VPU_ERR_ARG; }
+    vpu_gemm_group ga;
+    ga.n = n;
+    int total = 0;
+    bool vec = true;
+    const int key = (descs[0].transA ? 2 : 0) | (descs[0].transB ? 1 : 0);
+    for (int i = 0; i < n; ++i) {
+        const vpu_gemm_desc* d = descs + i;
+        if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch != 1 || d->inner != 1 ||
+            d->dtype != VPU_BF16 || ((d->transA ? 2 : 0) | (d->transB ? 1 : 0)) != key) {
+            vpu_set_error("vpu_gemm_grouped: every problem bf16, batch 1, non-null operands, the same transA / transB");
+            return VPU_ERR_ARG;
+        }
+        const int f = d->flags;
+        if (((f & VPU_EPI_BIAS) && !d->bias) || ((f & VPU_EPI_RESID) && !d->resid) ||
+            ((f & (VPU_EPI_DGELU | VPU_EPI_DRELU | VPU_EPI_MULAUX)) && !d->aux) ||
+            ((f & (VPU_EPI_PREACT | VPU_EPI_SAVE_DGELU)) && !d->preact) ||
+            ((f & VPU_EPI_SAVE_DGELU) && (!(f & VPU_EPI_GELU) || (f & VPU_EPI_PREACT))) || (d->colsum && key != 3)) {
+            vpu_set_error("vpu_gemm_grouped: epilogue flag set but its pointer is null (colsum: transA = transB = 1 only)");
+            return VPU_ERR_ARG;
+        }
+        if (d->lda % 8 || d->ldb % 8 || !aligned_to(d->A, 16) || !aligned_to(d->B, 16)) {
+            vpu_set_error("vpu_gemm_grouped: A/B base and leading dimensions must be 16-byte multiples");
+            return VPU_ERR_ALIGN;
+        }
+        const int64_t ea = d->transA ? (int64_t)d->K * d->lda : (int64_t)d->M * d->lda;
+        const int64_t eb = d->transB ? (int64_t)d->K * d->ldb : (int64_t)d->N * d->ldb;
+        if (ea * 2 >= 0x7FFFFFF0LL || eb * 2 >= 0x7FFFFFF0LL) {
+            vpu_set_error("vpu_gemm_grouped: an operand spans more than 2 GiB");
+            return VPU_ERR_ARG;
+        }
+        const size_t cbytes = (f & VPU_EPI_OUT_F32) ? 32 : 16;
+        bool v = d->ldc % 8 == 0 && aligned_to(d->C, cbytes);
+        if (f & VPU_EPI_BIAS) v = v && aligned_to(d->bias, 32);
+        if (f & (VPU_EPI_PREACT | VPU_EPI_SAVE_DGELU)) v = v && aligned_to(d->preact, 16);
+        if (f & (VPU_EPI_DGELU | VPU_EPI_DRELU | VPU_EPI_MULAUX)) v = v && d->ldaux % 8 == 0 && aligned_to(d->aux, 16);
+        if (f & VPU_EPI_RESID) v = v && d->ldr % 8 == 0 && aligned_to(d->resid, 16);
+        vec = vec && v;
+        ga.start[i] = total;
+        ga.d[i] = *d;
+        const int64_t t = (int64_t)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+        if (t + total > 0x3FFFFFFF) { vpu_set_error("vpu_gemm_grouped: too many tiles"); return VPU_ERR_ARG; }
+        total += (int)t;
+    }
+    for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) ga.start[i] = total;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const int persist_cap = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 512; }();
+    dim3 grid((unsigned)(total < persist_cap ? total : persist_cap)), block(256);
+    const int vec_arg = vec ? 1 : 0;
+    switch (key) {
+        case 0: gemm_bf16_grouped_kernel<0, 0, false><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;
+        case 1: gemm_bf16_grouped_kernel<0, 1, false><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;
+        case 2: gemm_bf16_grouped_kernel<1, 0, false><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;
+        default: gemm_bf16_grouped_kernel<1, 1, true><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;
+    }
+    return vpu_check_launch("vpu_gemm_grouped");
 }

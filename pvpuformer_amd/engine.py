@@ -92,7 +92,12 @@ class Engine:
         # CUs, and the fork/join events cost host time (measured: 19.45 ms/step on one stream, 19.9 ms on two)
         self.use_side = os.environ.get("VPU_WGRAD_STREAM", "0") == "1"
         self.side = None
-        self._frozen = set()   # data_ptr of gradient buffers a queued side-stream GEMM still reads: no in-place writes
+        # weight-gradient GEMMs are queued and launched in groups (ops.gemm_grouped): the four of a ViT block are 432
+        # full-K tiles -- one round of the persistent grid, no split-K slabs, no reduce launches --, the neck's 576-row
+        # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
+        self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
+        self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
+        self._frozen = set()   # data_ptr of buffers a queued / side-stream GEMM still reads: no in-place writes
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -192,6 +197,17 @@ class Engine:
         """G[N,K] += dy[M,N]^T x[M,K];  optionally G[bias][N] += column sums of dy, fused into the same launch (bf16
         path; the fp32 parity path uses the stand-alone column-sum kernel)."""
         fuse = bias is not None and self.dt == BF16
+        if self.group_wgrad and self.dt == BF16 and not self.use_side:
+            ldc_ = K if ldc is None else ldc
+            args = (dy, x, self.G(gname), N, K, M, ld_dy, ld_x, ldc_, self.dt)
+            kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
+            self._wq.append((args, kw, ((N + 127) // 128) * ((K + 127) // 128), M))   # (the queue keeps dy and x alive)
+            for t in (dy, x):
+                tt = t[0] if isinstance(t, tuple) else t
+                self._frozen.add(tt.data_ptr())
+            if len(self._wq) >= 8:
+                self.flush_wgrads()
+            return
         if not self.use_side:
             ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
                      transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
@@ -751,13 +767,35 @@ class Engine:
         hi = self.total if next_name is None else self.names[next_name][0]
 
         def marker():
+            self.flush_wgrads()
             if self.grad_ready_hook is not None:
                 self.join_side()
                 self.grad_ready_hook(lo, hi)
         self.tape.append(marker)
 
+    def flush_wgrads(self):
+        """Launches the queued weight gradients: those with a short reduction (<= 2048 rows) all in one grouped launch; long
+        ones grouped per reduction length when their tiles together fill the chip (>= 200), otherwise one by one (split-K)."""
+        q, self._wq = self._wq, []
+        if not q:
+            return
+        parts = {}   # reduction length -> entries; every short reduction goes into one part
+        for e in q:
+            parts.setdefault(0 if e[3] <= 2048 else e[3], []).append(e)
+        for red, part in parts.items():
+            # un-split tiles of one launch should take equally long: long reductions are grouped only with their own
+            # length, and only when the tiles fill the chip (a 2-tile problem over 150528 rows needs its split-K)
+            if len(part) >= 2 and (red == 0 or sum(e[2] for e in part) >= 200):
+                ops.gemm_grouped([(e[0], e[1]) for e in part])
+            else:
+                for args, kw, _, _ in part:
+                    ops.gemm(*args, **kw)
+        if not self.use_side:
+            self._frozen.clear()
+
     def join_side(self):
-        """main stream waits for every weight-gradient GEMM queued on the side stream."""
+        """Launches the queued weight gradients; the main stream then waits for the side stream (if one is in use)."""
+        self.flush_wgrads()
         if self.side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
         self._frozen.clear()

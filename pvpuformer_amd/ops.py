@@ -49,12 +49,9 @@ def split_k_workspace(device, nbytes=128 << 20):
     return ws
 
 
-def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, flags=0, bias=None, resid=None,
-         ldr=0, aux=None, ldaux=0, preact=None, alpha=1.0, post_mul=1.0, post_add=0.0, batch=1, inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto", colsum=None):
-    """C = epilogue(alpha * op(A) op(B)); see include/vpu_hip.h.  A/B/C/resid/aux/preact may be tensors or
-    (tensor, element_offset) tuples."""
-    d = GemmDesc()
+def _fill_desc(d, A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, flags=0, bias=None, resid=None,
+               ldr=0, aux=None, ldaux=0, preact=None, alpha=1.0, post_mul=1.0, post_add=0.0, batch=1, inner=1,
+               sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto", colsum=None):
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
     d.bias, d.resid, d.aux, d.preact = ptr(bias), ptr(resid), ptr(aux), ptr(preact)
     d.M, d.N, d.K = M, N, K
@@ -74,7 +71,27 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, 
         workspace = split_k_workspace(c0.device)
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, dtype, **kw):
+    """C = epilogue(alpha * op(A) op(B)); see include/vpu_hip.h.  A/B/C/resid/aux/preact may be tensors or
+    (tensor, element_offset) tuples.  Keywords: transA, transB, flags, bias, resid, ldr, aux, ldaux, preact, alpha,
+    post_mul, post_add, batch, inner, sA, sB, sC, sR, resid_period, workspace ("auto" | tensor | None), colsum."""
+    d = GemmDesc()
+    _fill_desc(d, A, B, Cout, M, N, K, lda, ldb, ldc, dtype, **kw)
     _lib.call("vpu_gemm", C.byref(d), _stream())
+
+
+def gemm_grouped(problems):
+    """ONE launch for up to 8 independent bf16 GEMMs (vpu_gemm_grouped): ``problems`` is a list of (args, kwargs) of
+    ``gemm`` -- same transA / transB for all, batch 1, no split-K (every problem runs over its whole K)."""
+    n = len(problems)
+    arr = (GemmDesc * n)()
+    for d, (args, kw) in zip(arr, problems):
+        kw = dict(kw)
+        kw["workspace"] = None
+        _fill_desc(d, *args, **kw)
+    _lib.call("vpu_gemm_grouped", arr, n, _stream())
 
 
 def gemm_set_option(name, value):

@@ -688,6 +688,38 @@ def test_gemm_split_k_inlaunch_combine_stress(ops, shape):
                 assert torch.equal(cs.cpu(), A.sum(1) + 2.0), it
 
 
+@pytest.mark.parametrize("tA,tB", [(1, 1), (0, 0), (0, 1)])
+def test_gemm_grouped_matches_single_launches(ops, tA, tB):
+    """vpu_gemm_grouped: several independent problems (different M, N, K, ragged edges, long and short K) in ONE
+    persistent launch, each un-split over its whole K == the fp32 matmul bit for bit on exact-integer operands, incl.
+    accumulation into a pre-filled fp32 output and the fused bias-gradient column sums of the weight-gradient form."""
+    g = torch.Generator().manual_seed(21)
+    shapes = [(768, 768, 1152), (200, 136, 72), (384, 256, 4608), (130, 520, 640)]
+    problems, checks = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+        lda, ldb = ((M + 7) // 8 * 8 if tA else K), ((N + 7) // 8 * 8 if tB else K)
+        Ah = torch.zeros((K, lda) if tA else (M, lda)); Bh = torch.zeros((K, ldb) if tB else (N, ldb))
+        if tA: Ah[:, :M] = A.t()
+        else: Ah[:, :K] = A
+        if tB: Bh[:, :N] = Bm.t()
+        else: Bh[:, :K] = Bm
+        Ad, Bd = dev(Ah).to(torch.bfloat16), dev(Bh).to(torch.bfloat16)
+        ldc = (N + 7) // 8 * 8
+        Cd = torch.full((M, ldc), float(i + 1), device="cuda")
+        cs = torch.full((M,), 5.0, device="cuda") if (tA and tB and i != 1) else None
+        problems.append(((Ad, Bd, Cd, M, N, K, lda, ldb, ldc, 0),
+                         dict(transA=bool(tA), transB=bool(tB), flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)))
+        checks.append((Cd, cs, A @ Bm.t() + float(i + 1), A.sum(1) + 5.0, N))
+    ops.gemm_grouped(problems)
+    torch.cuda.synchronize()
+    for Cd, cs, ref, csref, N in checks:
+        assert torch.equal(Cd.cpu()[:, :N], ref), (Cd.cpu()[:, :N] - ref).abs().max()
+        if cs is not None:
+            assert torch.equal(cs.cpu(), csref)
+
+
 @pytest.mark.parametrize("K", [512, 8192])
 def test_gemm_fused_bias_gradient(ops, K):
     """wgrad GEMM with the bias-gradient column sums fused in (split-K for the long K, direct for the short one)."""
