@@ -911,7 +911,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc 
     const int64_t coff = zo * p.sCo + zi * p.sCi, roff = zo * p.sRo + zi * p.sRi;
     const int64_t mn = (int64_t)p.M * p.N;
     const float* w = ws + (int64_t)z * splitk * mn;
-    if (vec8) {   // N % 8 == 0 and every epilogue operand 16/32-byte addressable: 8 columns of one row per thread
+    if (vec8 == 2) {
+        // many slices, few elements (weight gradients over 150528 rows: 128 slices of a 256 x 128 output): 8 lanes share one
+        // group of 8 columns, lane j sums the slices j, j+8, ... and the eight partial sums are added in lane order through
+        // LDS (fixed tree: deterministic).  One thread per group walked 128 slabs back to back: 63 us for 16 MB.
+        __shared__ float red[8][32][8];
+        const int eg = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const int n8 = p.N >> 3;
+        const int64_t i = (int64_t)blockIdx.x * 32 + eg;
+        const bool live = i < (mn >> 3);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll 4
+            for (int s = sl; s < splitk; s += 8) {
+                float t[8];
+                load8(w + s * mn + i * 8, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[sl][eg][j] = v[j];
+        __syncthreads();
+        if (sl == 0 && live) {
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += red[q][eg][j];
+            EpiPre e;
+            e.has_pre = false; e.has_bias = false; e.pre = make_uint4(0, 0, 0, 0);
+            epilogue_store8(p, p.flags, coff, roff, (int)(i / n8), (int)(i % n8) * 8, v, e);
+        }
+    } else if (vec8) {   // N % 8 == 0 and every epilogue operand 16/32-byte addressable: 8 columns of one row per thread
         const int n8 = p.N >> 3;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (mn >> 3); i += (int64_t)gridDim.x * 256) {
             const int m = (int)(i / n8), n = (int)(i % n8) * 8;
@@ -1243,8 +1274,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
 #undef VPU_LAUNCH_FL
         if (splitk > 1 && !inlaunch) {
             const int64_t mn = (int64_t)d->M * d->N;
-            const int vec8 = vec && d->N % 8 == 0 ? 1 : 0;
-            dim3 rgrid((unsigned)vpu_grid_for(vec8 ? mn / 8 : mn, 256, 4096), 1, (unsigned)d->batch);
+            int vec8 = vec && d->N % 8 == 0 ? 1 : 0;
+            if (vec8 && splitk >= 16 && mn / 8 <= 32 * 65535) vec8 = 2;   // slice-parallel form
+            dim3 rgrid((unsigned)(vec8 == 2 ? (mn / 8 + 31) / 32 : vpu_grid_for(vec8 ? mn / 8 : mn, 256, 4096)), 1,
+                       (unsigned)d->batch);
             splitk_reduce_kernel<bf16_t><<<rgrid, block, 0, s>>>(*d, splitk, ws, vec8);
         }
     } else {
