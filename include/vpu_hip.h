@@ -104,6 +104,13 @@ int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, fl
 int vpu_layernorm_bwd_nblk(int64_t rows);
 int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype, void* stream);
+/* n (<= VPU_COLSUM_BATCH_MAX) independent fp32 column sums in one launch: out_j[c] += sum_r in_j[r * ncols_j + c].
+ * Used for the partial weight / bias gradient rows of every LayerNorm / GroupNorm backward of a step
+ * (models_vit.py:72-75, transformer.py:417-426, is_vpu_model.py:55-86 backward). */
+#define VPU_COLSUM_BATCH_MAX 64
+typedef struct vpu_colsum_job { const float* in; float* out; int32_t nrows, ncols; } vpu_colsum_job;
+typedef struct vpu_colsum_batch { vpu_colsum_job job[VPU_COLSUM_BATCH_MAX]; } vpu_colsum_batch;
+int vpu_colsum_batched(const vpu_colsum_job* jobs, int32_t n, void* stream);
 /* out[c] = beta*out[c] + sum_r in[r][c]  (fp32 in) */
 int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream);
 /* out[c] = beta*out[c] + sum_r in[r*ld + c]  (activation dtype in; bias gradients) ; part = workspace [64][C] */

@@ -35,11 +35,16 @@ class GemmDesc(C.Structure):
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (every function returns int unless listed in _RET)
+class ColsumJob(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32)]
+
+
 SIGNATURES = {
     "vpu_gemm": [C.POINTER(GemmDesc), _P],
     "vpu_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "vpu_layernorm_bwd_nblk": [_L],
     "vpu_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "vpu_colsum_batched": [C.POINTER(ColsumJob), _I, _P],
     "vpu_colsum_f32": [_P, _P, _L, _I, _F, _P],
     "vpu_colsum": [_P, _I, _P, _P, _L, _I, _F, _I, _P],
     "vpu_softmax_fwd": [_P, _I, _P, _I, _L, _I, _I, _P],

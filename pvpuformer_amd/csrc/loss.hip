@@ -158,14 +158,15 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
                     const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
                     if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
                     const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-                    float l, g;
-                    if (y == 0.f || y == 1.f) {   // hard labels: one log, one reciprocal
-                        const float q = y != 0.f ? a : c;
-                        l = -__logf(q);
-                        const float rq = __builtin_amdgcn_rcpf(q);
-                        g = y != 0.f ? -rq : rq;
-                    } else {
-                        l = -(__logf(a) * y + __logf(c) * (1.f - y));
+                    // hard labels (every mask this loss sees): one raw v_log_f32 (log2; the arguments are >= 1e-12, far from
+                    // the denormals that logf's ~14-instruction wrapper guards) and one reciprocal, no branch
+                    const bool yb = y != 0.f;
+                    const float q = yb ? a : c;
+                    float l = -0.69314718056f * __builtin_amdgcn_logf(q);
+                    const float rq = __builtin_amdgcn_rcpf(q);
+                    float g = yb ? -rq : rq;
+                    if (__builtin_expect(valid && yb && y != 1.f, 0)) {   // soft label: the general form
+                        l = -0.69314718056f * (__builtin_amdgcn_logf(a) * y + __builtin_amdgcn_logf(c) * (1.f - y));
                         g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
                     }
                     part += (valid && own) ? l : 0.f;

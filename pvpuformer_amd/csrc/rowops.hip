@@ -171,6 +171,36 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     }
 }
 
+// Batched form: blockIdx.y = job; out_j[c] += sum_r in_j[r*C_j + c].  The partial parameter-gradient rows that every
+// LayerNorm / GroupNorm backward leaves behind (50 per training step) are reduced by ONE launch at the end of backward
+// instead of one launch each.
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const vpu_colsum_batch jb) {
+    __shared__ float red[8][33];
+    const vpu_colsum_job& j = jb.job[blockIdx.y];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int C = j.ncols;
+    const int64_t rows = j.nrows;
+    const float* __restrict__ in = j.in;
+    for (int c0 = blockIdx.x * 32; c0 < C; c0 += gridDim.x * 32) {   // block-uniform trip count
+        const int c = c0 + cl;
+        float s0 = 0.f, s1 = 0.f;
+        if (c < C) {
+            int64_t r = grp;
+            for (; r + 8 < rows; r += 16) { s0 += in[r * C + c]; s1 += in[(r + 8) * C + c]; }
+            if (r < rows) s0 += in[r * C + c];
+        }
+        __syncthreads();
+        red[grp][cl] = s0 + s1;
+        __syncthreads();
+        if (grp == 0 && c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += red[g][cl];
+            j.out[c] += t;
+        }
+    }
+}
+
 // few rows (<= 64): one pass, no partials.  out[c] = beta*out[c] + sum_r in[r*ld + c]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ in, int64_t ld, float* __restrict__ out,
@@ -438,6 +468,23 @@ extern "C" int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t
     vpu_clear_stale_error();
     colsum_f32_kernel<<<(C + 31) / 32, 256, 0, ST>>>(in, out, rows, C, beta);
     return vpu_check_launch("vpu_colsum_f32");
+}
+extern "C" int vpu_colsum_batched(const vpu_colsum_job* jobs, int32_t n, void* stream) {
+    vpu_clear_stale_error();
+    if (!jobs || n < 1 || n > VPU_COLSUM_BATCH_MAX) { vpu_set_error("colsum_batched: 1 <= n <= VPU_COLSUM_BATCH_MAX"); return VPU_ERR_ARG; }
+    vpu_colsum_batch jb;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!jobs[i].in || !jobs[i].out || jobs[i].nrows < 1 || jobs[i].ncols < 1) {
+            vpu_set_error("colsum_batched: null pointer or empty job");
+            return VPU_ERR_ARG;
+        }
+        jb.job[i] = jobs[i];
+        cmax = jobs[i].ncols > cmax ? jobs[i].ncols : cmax;
+    }
+    dim3 grid((cmax + 31) / 32, n);
+    colsum_batched_kernel<<<grid, 256, 0, ST>>>(jb);
+    return vpu_check_launch("vpu_colsum_batched");
 }
 extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, int64_t rows, int32_t C, float beta,
                           int32_t dtype, void* stream) {

@@ -97,6 +97,7 @@ class Engine:
         # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
+        self._csq = []         # queued column sums of norm-layer gradient partials: (part, out, rows, cols)
         self._frozen = set()   # data_ptr of buffers a queued / side-stream GEMM still reads: no in-place writes
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
@@ -184,7 +185,8 @@ class Engine:
         gradients are adjacent in the flat buffer (always the case for the norm layers: C % 8 == 0)."""
         ow, ob = self.names[prefix + ".weight"][0], self.names[prefix + ".bias"][0]
         if ob == ow + Cdim:
-            ops.colsum_f32(part, self.G(prefix + ".weight"), nrows, 2 * Cdim, beta=1.0)
+            # queued: one batched launch reduces the partial rows of every norm layer (flush_colsums)
+            self._csq.append((part, self.G(prefix + ".weight"), nrows, 2 * Cdim))
         else:
             ops.colsum_f32(part.view(nrows, 2 * Cdim)[:, :Cdim].contiguous(), self.G(prefix + ".weight"), nrows, Cdim, beta=1.0)
             ops.colsum_f32(part.view(nrows, 2 * Cdim)[:, Cdim:].contiguous(), self.G(prefix + ".bias"), nrows, Cdim, beta=1.0)
@@ -769,6 +771,7 @@ class Engine:
         def marker():
             self.flush_wgrads()
             if self.grad_ready_hook is not None:
+                self.flush_colsums()       # the range must be final before it is handed to the reducer
                 self.join_side()
                 self.grad_ready_hook(lo, hi)
         self.tape.append(marker)
@@ -793,6 +796,11 @@ class Engine:
         if not self.use_side:
             self._frozen.clear()
 
+    def flush_colsums(self):
+        q, self._csq = self._csq, []
+        if q:
+            ops.colsum_batched(q)
+
     def join_side(self):
         """Launches the queued weight gradients; the main stream then waits for the side stream (if one is in use)."""
         self.flush_wgrads()
@@ -814,6 +822,7 @@ class Engine:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.flush_colsums()
         self.join_side()
         if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0
             self.grad_ready_hook(0, self.names["backbone.blocks.0.norm1.weight"][0])

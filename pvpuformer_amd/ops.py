@@ -112,6 +112,17 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, Cdim):
               Cdim, code_of(x), _stream())
 
 
+def colsum_batched(jobs):
+    """jobs: list of (in fp32 [rows, C], out fp32 [C] (tensor or (tensor, offset)), rows, C): out += column sums, 64 per
+    launch."""
+    for i in range(0, len(jobs), 64):
+        chunk = jobs[i:i + 64]
+        arr = (_lib.ColsumJob * len(chunk))()
+        for j, (inp, out, rows, Cdim) in zip(arr, chunk):
+            j.inp, j.out, j.nrows, j.ncols = ptr(inp), ptr(out), rows, Cdim
+        _lib.call("vpu_colsum_batched", arr, len(chunk), _stream())
+
+
 def colsum_f32(inp, out, rows, Cdim, beta=0.0):
     _lib.call("vpu_colsum_f32", ptr(inp), ptr(out), rows, Cdim, beta, _stream())
 

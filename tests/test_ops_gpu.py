@@ -31,6 +31,23 @@ TD = {0: torch.bfloat16, 1: torch.float32}
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+def test_colsum_batched(ops):
+    """70 independent column sums (more than one launch's 64) of different shapes accumulate into slices of one flat
+    buffer exactly like per-job fp32 sums (integer data: exact)."""
+    g = torch.Generator().manual_seed(5)
+    flat = torch.arange(0, 70 * 4096, dtype=torch.float32).remainder(7).cuda()
+    ref = flat.clone().cpu()
+    jobs = []
+    for i in range(70):
+        rows, C = 1 + (i * 37) % 300, 8 * (1 + (i * 13) % 400)
+        part = torch.randint(-4, 5, (rows, C), generator=g).float()
+        jobs.append((dev(part), (flat, i * 4096), rows, C))
+        ref[i * 4096:i * 4096 + C] += part.sum(0)
+    ops.colsum_batched(jobs)
+    torch.cuda.synchronize()
+    assert torch.equal(flat.cpu(), ref)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_exact_integers(ops, dtype, tA, tB):
