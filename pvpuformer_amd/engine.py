@@ -207,8 +207,10 @@ class Engine:
             for t in (dy, x):
                 tt = t[0] if isinstance(t, tuple) else t
                 self._frozen.add(tt.data_ptr())
-            if len(self._wq) >= 8:
-                self.flush_wgrads()
+            # a full group of one kind (short reductions / this reduction length) is launched at once; the other kinds stay
+            kind = 0 if M <= 2048 else M
+            if sum(1 for e in self._wq if (0 if e[3] <= 2048 else e[3]) == kind) >= 8:
+                self.flush_wgrads(kind)
             return
         if not self.use_side:
             ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
@@ -776,25 +778,33 @@ class Engine:
                 self.grad_ready_hook(lo, hi)
         self.tape.append(marker)
 
-    def flush_wgrads(self):
-        """Launches the queued weight gradients: those with a short reduction (<= 2048 rows) all in one grouped launch; long
-        ones grouped per reduction length when their tiles together fill the chip (>= 200), otherwise one by one (split-K)."""
-        q, self._wq = self._wq, []
+    def flush_wgrads(self, only_kind=None):
+        """Launches the queued weight gradients (``only_kind``: just the entries of that kind, 0 = short reductions, else a
+        reduction length).  Short reductions (<= 2048 rows) go into one grouped launch; long ones are grouped per reduction
+        length when that beats one split-K launch + reduce each, otherwise they are launched one by one."""
+        kind_of = lambda e: 0 if e[3] <= 2048 else e[3]
+        q = [e for e in self._wq if only_kind is None or kind_of(e) == only_kind]
         if not q:
             return
-        parts = {}   # reduction length -> entries; every short reduction goes into one part
+        self._wq = [e for e in self._wq if not (only_kind is None or kind_of(e) == only_kind)]
+        parts = {}   # kind -> entries
         for e in q:
-            parts.setdefault(0 if e[3] <= 2048 else e[3], []).append(e)
+            parts.setdefault(kind_of(e), []).append(e)
         for red, part in parts.items():
-            # un-split tiles of one launch should take equally long: long reductions are grouped only with their own
-            # length, and only when the tiles fill the chip (a 2-tile problem over 150528 rows needs its split-K)
-            if len(part) >= 2 and (red == 0 or sum(e[2] for e in part) >= 200):
+            # un-split tiles of one launch take nk K-tiles each (~0.6 us per K-tile on a CU of their own): worth it when
+            # the tiles fill the chip (the four of a ViT block: 432) or when the alternative -- a split-K launch + reduce
+            # per problem, ~35 us -- costs more (three or more over 9408 rows; never for a 2-tile problem over 150528)
+            nk = (red + 63) // 64
+            if len(part) >= 2 and (red == 0 or sum(e[2] for e in part) >= 200 or nk * 0.6 < len(part) * 35.0):
                 ops.gemm_grouped([(e[0], e[1]) for e in part])
             else:
                 for args, kw, _, _ in part:
                     ops.gemm(*args, **kw)
         if not self.use_side:
-            self._frozen.clear()
+            self._frozen = set()
+            for args, _, _, _ in self._wq:   # operands of the entries still queued stay frozen
+                for t in (args[0], args[1]):
+                    self._frozen.add((t[0] if isinstance(t, tuple) else t).data_ptr())
 
     def flush_colsums(self):
         q, self._csq = self._csq, []

@@ -197,6 +197,59 @@ def test_vitb_bf16_backward_grad_norms(golden_dir):
     assert worst[0][1] < 0.1, worst
 
 
+def test_vitb_bf16_grouped_weight_gradients_equal_ungrouped(golden_dir):
+    """The engine queues the weight-gradient GEMMs and launches them in groups (one un-split launch for the four of a
+    ViT block, the neck's short ones eight at a time), with the queued operands frozen against in-place reuse.  The
+    operands of every GEMM are the same as without queueing, so each parameter gradient may differ only by its fp32
+    summation order (split-K slices vs one pass): compared tensor by tensor at 1e-4 of the tensor's largest entry."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    eng = model._ensure_engine()
+    gt = batch["instances"].cuda()
+    grads = []
+    for grouped in (True, False):
+        eng.group_wgrad = grouped
+        model.zero_grad()
+        out = _run(model, img4, batch, 1)          # box prompts: also the outline rasteriser path
+        total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+        total.backward()
+        torch.cuda.synchronize()
+        grads.append(eng.gflat.clone())
+    eng.group_wgrad = True
+    bad = []
+    for n, (off, shape, numel) in eng.names.items():
+        a, b = grads[0][off:off + numel], grads[1][off:off + numel]
+        scale = float(b.abs().max())
+        if scale > 0 and float((a - b).abs().max()) > 1e-4 * scale:
+            bad.append((n, float((a - b).abs().max()) / scale))
+    assert not bad, sorted(bad, key=lambda kv: -kv[1])[:5]
+
+
+@pytest.mark.parametrize("fixture", ["tiny.npz", "vitb.npz"])
+def test_grad_ready_ranges_are_final_when_reported(golden_dir, fixture):
+    """Data-parallel contract of Engine.grad_ready_hook: every reported range [lo, hi) of the flat gradient buffer is
+    FINAL at the moment it is reported (the reducer launches its all-reduce right there), although weight gradients are
+    queued for grouped launches and the norm layers' parameter-gradient partials are reduced in batches; the ranges
+    arrive tail-first, are disjoint and cover the whole buffer."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
+    eng = model._ensure_engine()
+    seen = []
+    eng.grad_ready_hook = lambda lo, hi: seen.append((lo, hi, eng.gflat[lo:hi].clone()))
+    try:
+        model.zero_grad()
+        out = _run(model, img4, batch, 0)
+        gt = batch["instances"].cuda()
+        total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        eng.grad_ready_hook = None
+    assert seen and seen[0][1] == eng.total and seen[-1][0] == 0
+    for (lo, hi, _), (lo2, hi2, _) in zip(seen, seen[1:]):
+        assert hi2 == lo, "ranges must arrive tail-first and contiguous"
+    for lo, hi, snap in seen:
+        assert torch.equal(snap, eng.gflat[lo:hi]), f"gradient range [{lo}, {hi}) changed after it was reported"
+
+
 def test_train_step_multi_iteration_matches_oracle(golden_dir):
     """a16: three click iterations (click / box prompts, iteration weights 1,2,3, per-slot error-mask labels, prev mask
     fed back) through VPUTrainStep == the oracle replaying the same prompts, loss summed and back-propagated once."""
