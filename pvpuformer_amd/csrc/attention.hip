@@ -119,7 +119,9 @@ struct AttnArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int HD, int NS>
+// QT query tiles of 16 per wave (QT = 2: the two tiles share every K / V fragment read and give the scheduler two
+// independent softmax dependency chains to interleave; a workgroup covers 64 * QT queries).
+template <int HD, int NS, int QT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char ldsK[NS * CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsV[NS * CH * HD * 2];
@@ -129,13 +131,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
-    const int q0 = blockIdx.x * 64 + wave * 16;
-    bf16x8_t qf[HD / 32];
-    load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
-    float m = -INFINITY, l = 0.f;
-    f32x4_t acc[HD / 16];
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const float sc2 = a.scale * 1.44269504089f;
+    bf16x8_t qf[QT][HD / 32];
+    float m[QT], l[QT];
+    f32x4_t acc[QT][HD / 16];
 #pragma unroll
-    for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < QT; ++u) {
+        load_rows_as_b<HD>(q, a.ldq, q0 + 16 * u, nq, lane, qf[u], hd);
+        m[u] = -INFINITY; l[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
     RowChunk<HD, NS> pk, pv;
     fetch_rows<HD, NS>(k, a.ldk, 0, nk, tid, hd, pk);
     fetch_rows<HD, NS>(v, a.ldk, 0, nk, tid, hd, pv);
@@ -152,56 +159,80 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         const int kc = kb + sub * CH;
         const char* sK = ldsK + sub * (CH * HD * 2);
         const char* sV = ldsV + sub * (CH * HD * 2);
-        f32x4_t s[2];
-        float mx = m;
+        f32x4_t s[QT][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < QT; ++u)
 #pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rc<HD>(sK, 16 * t, ks, lane), qf[ks], s[t], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = (kc + 16 * t + 4 * g + r < nk) ? s[t][r] * a.scale : -INFINITY;
-                s[t][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float alpha = __expf(m - mx);
-        float ps = 0.f;
+            for (int t = 0; t < 2; ++t) s[u][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - mx); ps += s[t][r]; }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        l = l * alpha + ps;
-        m = mx;
-        float ar[4];
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const bf16x8_t kfr = frag_rc<HD>(sK, 16 * t, ks, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);
-        const bf16x8_t pf = pack_pair(s[0], s[1]);
+                for (int u = 0; u < QT; ++u)
+                    s[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][ks], s[u][t], 0, 0, 0);
+            }
+        bf16x8_t pf[QT];
+        float ar[QT][4];
+        const bool tail = kc + CH > nk;   // only the last chunk has keys to mask (block-uniform)
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            // scores in the log2 domain: x = s * (scale * log2 e), p = exp2(x - max): one multiply, one subtract and one
+            // v_exp_f32 per element (the running max / log-sum-exp are converted back to natural units at the end)
+            float mx = m[u];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[u][t][r] * sc2;
+                    if (tail) x = (kc + 16 * t + 4 * g + r < nk) ? x : -INFINITY;
+                    s[u][t][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float alpha = __builtin_amdgcn_exp2f(m[u] - mx);
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[u][t][r] = __builtin_amdgcn_exp2f(s[u][t][r] - mx); ps += s[u][t][r]; }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l[u] = l[u] * alpha + ps;
+            m[u] = mx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[u][r] = __shfl(alpha, 4 * g + r, 64);
+            pf[u] = pack_pair(s[u][0], s[u][1]);
+        }
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
+            const bf16x8_t vfr = frag_tr_perm<HD>(sV, dt, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[dt][r] *= ar[r];
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(sV, dt, lane), acc[dt], 0, 0, 0);
+            for (int u = 0; u < QT; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[u][dt][r] *= ar[u][r];
+                acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], vfr, acc[u][dt], 0, 0, 0);
+            }
         }
         }
     }
-    const float il = 1.0f / l;
-    if (g == 0 && q0 + c < nq) a.lse[(int64_t)bh * nq + q0 + c] = m + __logf(l);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float s1 = __shfl(il, 4 * g + r, 64);
-        const int qq = q0 + 4 * g + r;
-        if (qq < nq) {
-            bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
+    for (int u = 0; u < QT; ++u) {
+        const int qu = q0 + 16 * u;
+        const float il = 1.0f / l[u];
+        if (g == 0 && qu + c < nq) a.lse[(int64_t)bh * nq + qu + c] = (m[u] + __builtin_amdgcn_logf(l[u])) * 0.69314718056f;
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt)
-                if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[dt][r] * s1);
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = __shfl(il, 4 * g + r, 64);
+            const int qq = qu + 4 * g + r;
+            if (qq < nq) {
+                bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+                    if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[u][dt][r] * s1);
+            }
         }
     }
 }
@@ -400,16 +431,27 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale;
-    dim3 grid((nq + 63) / 64, nb * H);
+    static const int qt2 = [] { const char* e = getenv("VPU_ATTN_QT"); return e ? atoi(e) : 2; }();
+    // two query tiles per wave (128 queries per workgroup) for the 196-token windows: 33.9 vs 35.4 us (bs 12, round 1);
+    // for the global blocks one tile per wave stays ahead (84.1 vs 86.0 us).  Time grows linearly with the number of
+    // (window, head) problems from ~300 workgroups on (tools/attn_scale.py): the kernel is issue-bound on the softmax's
+    // dependent VALU / cross-lane chain (~160 instructions per 32-key step for 8 MFMAs), not on latency or LDS traffic.
+    const bool two = qt2 == 2 && nq > 64 && nk <= 256 && hd_image(hd) <= 64;
+    dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (two) {
+        if (hd_image(hd) == 32) attn_fwd_kernel<32, 1, 2><<<grid, 256, 0, s>>>(a);
+        else attn_fwd_kernel<64, 1, 2><<<grid, 256, 0, s>>>(a);
+        return vpu_check_launch("vpu_xattn_fwd");
+    }
     switch (hd_image(hd)) {
         // staged block = NS x 32 keys.  NS = 1 everywhere: measured (tools/op_bench.py attn, round 1) window forward 35.8 us
         // at NS = 1, 36.2 at NS = 2, 41.8 at NS = 7 (a whole 196-token window resident, one barrier pair); backward 111.7 /
         // 119.2 / 144.3 us -- the loop is bound by its softmax dependency chain, and the 8-KiB blocks' occupancy (8 per CU)
         // hides more of it than fewer round trips save
-        case 32: attn_fwd_kernel<32, 1><<<grid, 256, 0, s>>>(a); break;
-        case 64: attn_fwd_kernel<64, 1><<<grid, 256, 0, s>>>(a); break;
-        default: attn_fwd_kernel<128, 1><<<grid, 256, 0, s>>>(a); break;
+        case 32: attn_fwd_kernel<32, 1, 1><<<grid, 256, 0, s>>>(a); break;
+        case 64: attn_fwd_kernel<64, 1, 1><<<grid, 256, 0, s>>>(a); break;
+        default: attn_fwd_kernel<128, 1, 1><<<grid, 256, 0, s>>>(a); break;
     }
     return vpu_check_launch("vpu_xattn_fwd");
 }
