@@ -237,27 +237,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
 }
 
-// delta[bh][q] = sum_d dO[q][d] * O[q][d]
-template <int HD>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int qq = (int)(i % a.nq);
-    const int bh = (int)(i / a.nq), bw = bh / a.H, h = bh % a.H;
-    const int64_t off = ((int64_t)bw * a.nq + qq) * a.ldo + h * a.hd;
-    float s = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < HD / 8; ++ch) {
-        if (ch * 8 >= a.hd) break;
-        float x[8], y[8];
-        load8(a.d_o + off + ch * 8, x);
-        load8(a.o + off + ch * 8, y);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += x[j] * y[j];
-    }
-    a.delta[i] = s;
-}
-
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int HD, int NS>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
@@ -355,10 +334,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int q0 = blockIdx.x * 64 + wave * 16;
     const bool q_ok = q0 + c < nq;
     const float lse_q = q_ok ? a.lse[(int64_t)bh * nq + q0 + c] : 0.f;
-    const float dl_q = q_ok ? a.delta[(int64_t)bh * nq + q0 + c] : 0.f;
     bf16x8_t qf[HD / 32], dof[HD / 32];
     load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
     load_rows_as_b<HD>(d_o, a.ldo, q0, nq, lane, dof, hd);
+    // delta[q] = sum_d dO[q][d] * O[q][d], computed here from the dO fragments the wave holds anyway (lane c + 16 g has
+    // columns 8 g .. 8 g + 7 of every 32-column group of row q0 + c) and published for the dK/dV kernel, which is
+    // launched after this one -- the separate delta pass (19 launches per step, a second read of dO and O) is gone.
+    float dl_q = 0.f;
+    {
+        bf16x8_t of[HD / 32];
+        load_rows_as_b<HD>(a.o + rbq * a.ldo + h * hd, a.ldo, q0, nq, lane, of, hd);
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl_q += (float)dof[ks][j] * (float)of[ks][j];
+        dl_q += __shfl_xor(dl_q, 16, 64);
+        dl_q += __shfl_xor(dl_q, 32, 64);
+        if (blockIdx.x * 64 + wave * 16 + c < nq && g == 0) a.delta[(int64_t)bh * nq + q0 + c] = dl_q;
+    }
     f32x4_t adq[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -473,24 +466,19 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int64_t total = (int64_t)nb * H * nq;
-    const unsigned dgrid = (unsigned)((total + 255) / 256);
     dim3 gk((nk + 63) / 64, nb * H), gq((nq + 63) / 64, nb * H);
     switch (hd_image(hd)) {
         case 32:
-            attn_delta_kernel<32><<<dgrid, 256, 0, s>>>(a, total);
+            attn_bwd_dq_kernel<32, 1><<<gq, 256, 0, s>>>(a);     // also writes delta
             attn_bwd_dkdv_kernel<32, 1><<<gk, 256, 0, s>>>(a);
-            attn_bwd_dq_kernel<32, 1><<<gq, 256, 0, s>>>(a);
             break;
         case 64:
-            attn_delta_kernel<64><<<dgrid, 256, 0, s>>>(a, total);
+            attn_bwd_dq_kernel<64, 1><<<gq, 256, 0, s>>>(a);     // also writes delta
             attn_bwd_dkdv_kernel<64, 1><<<gk, 256, 0, s>>>(a);
-            attn_bwd_dq_kernel<64, 1><<<gq, 256, 0, s>>>(a);
             break;
         default:
-            attn_delta_kernel<128><<<dgrid, 256, 0, s>>>(a, total);
+            attn_bwd_dq_kernel<128, 1><<<gq, 256, 0, s>>>(a);     // also writes delta
             attn_bwd_dkdv_kernel<128, 1><<<gk, 256, 0, s>>>(a);
-            attn_bwd_dq_kernel<128, 1><<<gq, 256, 0, s>>>(a);
             break;
     }
     return vpu_check_launch("vpu_xattn_bwd");
