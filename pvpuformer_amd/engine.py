@@ -98,6 +98,8 @@ class Engine:
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
         self._csq = []         # queued column sums of norm-layer gradient partials: (part, out, rows, cols)
+        self._gq = []          # deferred small GEMMs of one group (an attention's q / k / v projections or their dgrads)
+        self._gq_out = set()   # data_ptr of the outputs the queued GEMMs will write
         self._frozen = set()   # data_ptr of buffers a queued / side-stream GEMM still reads: no in-place writes
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
@@ -232,18 +234,41 @@ class Engine:
             if bias is not None and not fuse:
                 self._colsum_to(dy, ld_dy, bias, M, N)
 
-    def _dgrad(self, dy, ld_dy, w, ldw, xvar, M, K, N, flags=0, aux=None, ldaux=0):
-        """x.g (+)= dy[M,N] W[N,K]"""
+    def _dgrad(self, dy, ld_dy, w, ldw, xvar, M, K, N, flags=0, aux=None, ldaux=0, defer=False):
+        """x.g (+)= dy[M,N] W[N,K].  ``defer``: queued for the group launch of flush_group (the caller's tape runs it)."""
         f = flags
         if xvar.g is None:
             xvar.g = torch.empty_like(xvar.t)
         else:
             self._writable(xvar.g)
             f |= EPI_ACCUM
-        ops.gemm(dy, w, xvar.g, M, K, N, ld_dy, ldw, K, self.dt, transB=True, flags=f, aux=aux, ldaux=ldaux)
+        args = (dy, w, xvar.g, M, K, N, ld_dy, ldw, K, self.dt)
+        kw = dict(transB=True, flags=f, aux=aux, ldaux=ldaux)
+        if defer:
+            self._gemm_deferred(xvar.g.data_ptr(), args, kw)
+        else:
+            ops.gemm(*args, **kw)
+
+    def _gemm_deferred(self, out_ptr, args, kw):
+        """Queues one GEMM of a group of independent ones (flush_group launches them: the small ones -- <= 64 output tiles,
+        K <= 2048 -- in ONE grouped launch).  A GEMM that accumulates into an output already in the queue runs after it."""
+        if out_ptr in self._gq_out:
+            self.flush_group()
+        self._gq.append((args, kw))
+        self._gq_out.add(out_ptr)
+
+    def flush_group(self):
+        q, self._gq = self._gq, []
+        self._gq_out = set()
+        is_small = [((a[3] + 127) // 128) * ((a[4] + 127) // 128) <= 64 and a[5] <= 2048 for a, _ in q]
+        if sum(is_small) >= 2:
+            ops.gemm_grouped([e for e, sm in zip(q, is_small) if sm])
+            q = [e for e, sm in zip(q, is_small) if not sm]
+        for args, kw in q:
+            ops.gemm(*args, **kw)
 
     # ------------------------------------------------------------------------------------------ ops with backward
-    def linear(self, x, wname, bname, M, N, K, act=None, resid=None, out=None, x_grad=True):
+    def linear(self, x, wname, bname, M, N, K, act=None, resid=None, out=None, x_grad=True, group=False):
         """y = act(x W^T + b) [+ resid].  ``out`` = (Var, col_offset, ld) writes into a column slice of a wider map."""
         assert not (act and resid is not None)
         if out is None:
@@ -253,8 +278,13 @@ class Engine:
             y, yoff, ldc = out
             yt = y.t
         flags = EPI_BIAS | (EPI_RELU if act == "relu" else 0) | (EPI_RESID if resid is not None else 0)
-        ops.gemm(x.t, self.W(wname), (yt, yoff), M, N, K, K, K, ldc, self.dt, flags=flags, bias=self.Pm(bname),
-                 resid=None if resid is None else resid.t, ldr=N)
+        group = group and self.dt == BF16 and act is None and resid is None and out is None
+        g_args = (x.t, self.W(wname), (yt, yoff), M, N, K, K, K, ldc, self.dt)
+        g_kw = dict(flags=flags, bias=self.Pm(bname), resid=None if resid is None else resid.t, ldr=N)
+        if group:     # the caller flushes the group (flush_group) before anything reads y
+            self._gemm_deferred(yt.data_ptr(), g_args, g_kw)
+        else:
+            ops.gemm(*g_args, **g_kw)
         if self.training:
             def bwd():
                 if y.g is None:
@@ -271,7 +301,7 @@ class Engine:
                     ld = ldc
                 self._wgrad(dy, ld, x.t, K, wname, N, K, M, bias=bname)
                 if x_grad:
-                    self._dgrad(dy, ld, self.W(wname), K, x, M, K, N)
+                    self._dgrad(dy, ld, self.W(wname), K, x, M, K, N, defer=group)
             self.tape.append(bwd)
         return y
 
@@ -415,9 +445,14 @@ class Engine:
         """transformer.py Attention.forward (:499-521) + optional residual of the caller."""
         D, H = self.D, 8
         hd = internal // H
-        Qp = self.linear(xq, prefix + ".q_proj.weight", prefix + ".q_proj.bias", B * nq, internal, D)
-        Kp = self.linear(xk, prefix + ".k_proj.weight", prefix + ".k_proj.bias", B * nk, internal, D)
-        Vp = self.linear(xv, prefix + ".v_proj.weight", prefix + ".v_proj.bias", B * nk, internal, D)
+        # the three projections are independent: their forward GEMMs -- and, in backward, their dgrads -- are queued and
+        # launched together (the 576-row ones in ONE grouped launch instead of a split-K GEMM + reduce each)
+        if self.training:
+            self.tape.append(self.flush_group)       # runs AFTER the three backward closures below
+        Qp = self.linear(xq, prefix + ".q_proj.weight", prefix + ".q_proj.bias", B * nq, internal, D, group=True)
+        Kp = self.linear(xk, prefix + ".k_proj.weight", prefix + ".k_proj.bias", B * nk, internal, D, group=True)
+        Vp = self.linear(xv, prefix + ".v_proj.weight", prefix + ".v_proj.bias", B * nk, internal, D, group=True)
+        self.flush_group()
         O = Var(self._new(B * nq, internal))
         if self.dt == BF16 and self.use_flash and hd % 16 == 0 and hd <= 128:
             self.cross_attention(Qp, Kp, Vp, O, B, H, nq, nk, hd, internal, 1.0 / math.sqrt(hd))
