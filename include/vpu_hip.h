@@ -173,6 +173,13 @@ int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64_t ld_aux, 
  * out64 (optional, may be NULL) receives the float64 rows exactly as the reference returns them. */
 int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
                    int32_t B, int32_t n, int32_t num_max, int32_t img, int32_t ld, int32_t dtype, void* stream);
+/* Exact Euclidean distance transform of B masks: dist[b][y][x] = distance of a non-zero pixel to the nearest zero pixel
+ * (0 at zero pixels; +inf when there is none), float32(sqrt(float64)) of the exact integer squared distance -- the map
+ * whose arg-max the click simulators take (clicker.py:29-56, trainer.py:628-629, 673-674, 736-737).  zero_border != 0:
+ * the image is treated as surrounded by zero pixels (the reference pads the mask by one pixel first).
+ * scratch: int32 [B][H][W]. */
+int vpu_edt(const uint8_t* mask, int32_t* scratch, float* dist, int32_t B, int32_t H, int32_t W, int32_t zero_border,
+            void* stream);
 /* DistMaps disks (ops.py:347-379, use_disks, spatial_scale 1) + optional draw_box outline (is_model.py:97-121).
  * out fp32 [B][2][H][W] in {0,1}. */
 int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H, int32_t W,

@@ -24,6 +24,21 @@ def distance_transform(mask_u8):
     return ndimage.distance_transform_edt(mask_u8).astype(np.float32)
 
 
+def distance_transform_batch(masks, device=None):
+    """Exact Euclidean distance transforms of N masks [N,H,W] (bool / uint8), each treated as surrounded by zero pixels
+    (the reference pads by one pixel first, trainer.py:626-629) -> float32 [N,H,W].  On a CUDA ``device`` the HIP kernel
+    (ops.edt: bit-identical to the float64 transform cast to float32, tests/test_ops_gpu.py) does all N at once --
+    4.4 ms per 448x448 mask on the host was most of a NoBRS click --; without one, scipy on the host."""
+    masks = np.ascontiguousarray(masks).astype(np.uint8)
+    if device is not None and torch.device(device).type == "cuda":
+        from pvpuformer_amd import ops
+        return ops.edt(torch.from_numpy(masks).to(device), zero_border=True).cpu().numpy()
+    out = np.empty(masks.shape, np.float32)
+    for i, m in enumerate(masks):
+        out[i] = ndimage.distance_transform_edt(np.pad(m, 1, "constant")).astype(np.float32)[1:-1, 1:-1]
+    return out
+
+
 def max_connected_regions(mask):
     """trainer.py:1175-1190 incl. its quirk: every component larger than 10 % of the foreground is merged into the
     largest-so-far label while scanning labels in ascending order."""
@@ -85,20 +100,19 @@ def cal_box(gt_mask, fn_mask, fp_mask, points, as_allmask=True, jitter_box=True,
     return out
 
 
-def next_click(pred, gt, points, pred_thresh=0.49, np_rng=np.random):
+def next_click(pred, gt, points, pred_thresh=0.49, np_rng=np.random, device=None):
     """The shared body of get_next_points / get_next_promts (trainer.py:615-654, 733-764): for each sample the new
     click (or None), its slot, and whether it is positive.  pred: float [B,H,W]; gt: bool [B,H,W]; points float
     [B,2n,3] (modified copy is returned).  Also returns the false-negative / false-positive masks."""
     fn = np.logical_and(gt, pred < pred_thresh)
     fp = np.logical_and(np.logical_not(gt), pred > pred_thresh)
-    fn_p = np.pad(fn, ((0, 0), (1, 1), (1, 1)), "constant").astype(np.uint8)
-    fp_p = np.pad(fp, ((0, 0), (1, 1), (1, 1)), "constant").astype(np.uint8)
+    dts = distance_transform_batch(np.concatenate([fn, fp], 0), device)   # zero border = the reference's np.pad(.., 1)
     n = points.shape[1] // 2
     points = points.copy()
     picks = []
-    for b in range(gt.shape[0]):
-        fn_dt = distance_transform(fn_p[b])[1:-1, 1:-1]
-        fp_dt = distance_transform(fp_p[b])[1:-1, 1:-1]
+    B = gt.shape[0]
+    for b in range(B):
+        fn_dt, fp_dt = dts[b], dts[B + b]
         fn_max, fp_max = float(np.max(fn_dt)), float(np.max(fp_dt))
         is_pos = fn_max > fp_max
         dt = fn_dt if is_pos else fp_dt
@@ -152,7 +166,8 @@ def get_next_promts(pred, gt, points, state=None, pred_thresh=0.49, as_allmask=F
     fn0 = np.logical_and(gt_np, pred_np < pred_thresh)
     fp0 = np.logical_and(np.logical_not(gt_np), pred_np > pred_thresh)
     boxes = cal_box(gt_np, fn0, fp0, pts_np, as_allmask=as_allmask, jitter_box=jitter_box, rng=rng)
-    new_pts, picks, fn, fp = next_click(pred_np, gt_np, pts_np, pred_thresh, np_rng)
+    new_pts, picks, fn, fp = next_click(pred_np, gt_np, pts_np, pred_thresh, np_rng,
+                                        device=pred.device if pred.is_cuda else None)
     if state is not None:
         for b, pk in enumerate(picks):
             if pk is not None:

@@ -1,6 +1,6 @@
 """Oracle click simulation of the NoBRS evaluation loop, API-compatible with isegm/inference/clicker.py:7-118.
-``cv2.distanceTransform(DIST_L2, 0)`` (precise) is replaced by the exact Euclidean transform of scipy (same
-definition; cv2 is not installable here)."""
+``cv2.distanceTransform(DIST_L2, 0)`` (precise) is replaced by the exact Euclidean transform (same definition; cv2 is
+not installable here): the HIP kernel ``vpu_edt`` on a GPU, scipy on the host -- bit-identical values."""
 from copy import deepcopy
 
 import numpy as np
@@ -23,7 +23,13 @@ class Click:
 
 
 class Clicker:
-    def __init__(self, gt_mask=None, init_clicks=None, ignore_label=-1, click_indx_offset=0):
+    def __init__(self, gt_mask=None, init_clicks=None, ignore_label=-1, click_indx_offset=0, device="auto"):
+        """``device`` (not in the reference): where the two distance transforms of a click run -- "auto": the HIP kernel
+        when a GPU is present, else scipy on the host; None: always the host.  Same values either way."""
+        if device == "auto":
+            import torch
+            device = "cuda" if torch.cuda.is_available() else None
+        self.device = device
         self.click_indx_offset = click_indx_offset
         if gt_mask is not None:
             self.gt_mask = gt_mask == 1
@@ -44,12 +50,16 @@ class Clicker:
     def _get_next_click(self, pred_mask, padding=True):
         fn = np.logical_and(np.logical_and(self.gt_mask, np.logical_not(pred_mask)), self.not_ignore_mask)
         fp = np.logical_and(np.logical_and(np.logical_not(self.gt_mask), pred_mask), self.not_ignore_mask)
-        if padding:
-            fn, fp = np.pad(fn, ((1, 1), (1, 1)), "constant"), np.pad(fp, ((1, 1), (1, 1)), "constant")
-        fn_dt = ndimage.distance_transform_edt(fn).astype(np.float32)
-        fp_dt = ndimage.distance_transform_edt(fp).astype(np.float32)
-        if padding:
-            fn_dt, fp_dt = fn_dt[1:-1, 1:-1], fp_dt[1:-1, 1:-1]
+        if padding and self.device is not None:      # both transforms in one launch of the HIP kernel
+            from pvpuformer_amd.isegm.engine.prompt_sim import distance_transform_batch
+            fn_dt, fp_dt = distance_transform_batch(np.stack([fn, fp]), self.device)
+        else:
+            if padding:
+                fn, fp = np.pad(fn, ((1, 1), (1, 1)), "constant"), np.pad(fp, ((1, 1), (1, 1)), "constant")
+            fn_dt = ndimage.distance_transform_edt(fn).astype(np.float32)
+            fp_dt = ndimage.distance_transform_edt(fp).astype(np.float32)
+            if padding:
+                fn_dt, fp_dt = fn_dt[1:-1, 1:-1], fp_dt[1:-1, 1:-1]
         fn_dt, fp_dt = fn_dt * self.not_clicked_map, fp_dt * self.not_clicked_map
         fn_max, fp_max = np.max(fn_dt), np.max(fp_dt)
         is_positive = fn_max > fp_max

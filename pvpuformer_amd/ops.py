@@ -112,6 +112,16 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, Cdim):
               Cdim, code_of(x), _stream())
 
 
+def edt(mask_u8, zero_border=True):
+    """Exact Euclidean distance transform of uint8 masks [B, H, W] on the GPU (vpu_edt) -> float32 [B, H, W]."""
+    B, H, W = mask_u8.shape
+    mask_u8 = mask_u8.contiguous()
+    scratch = torch.empty(B, H, W, device=mask_u8.device, dtype=torch.int32)
+    dist = torch.empty(B, H, W, device=mask_u8.device, dtype=torch.float32)
+    _lib.call("vpu_edt", ptr(mask_u8), ptr(scratch), ptr(dist), B, H, W, int(zero_border), _stream())
+    return dist
+
+
 def colsum_batched(jobs):
     """jobs: list of (in fp32 [rows, C], out fp32 [C] (tensor or (tensor, offset)), rows, C): out += column sums, 64 per
     launch."""

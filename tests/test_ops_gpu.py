@@ -31,6 +31,36 @@ TD = {0: torch.bfloat16, 1: torch.float32}
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("shape", [(3, 448, 448), (2, 97, 131), (1, 5, 1)])
+@pytest.mark.parametrize("border", [True, False])
+def test_edt_bit_exact_vs_scipy(ops, shape, border):
+    """vpu_edt == float32(scipy.ndimage.distance_transform_edt) bit for bit: blobs, thin lines, an all-ones mask (only
+    the zero border -- or nothing: +inf -- to measure against), an all-zero mask; with the implicit zero border it
+    equals the transform of the mask padded by one pixel (the reference's np.pad + [1:-1, 1:-1])."""
+    from scipy import ndimage
+    g = np.random.RandomState(7)
+    B, H, W = shape
+    masks = np.zeros(shape, np.uint8)
+    for b in range(B):
+        m = g.rand(H, W) > (0.02 if b == 0 else 0.5)
+        if H > 20:
+            m[H // 4:H // 2, W // 3:W // 3 + 2] = False
+        masks[b] = m
+    if B > 1:
+        masks[1] = 1
+    if B > 2:
+        masks[2] = 0
+    got = ops.edt(dev(torch.from_numpy(masks)), zero_border=border).cpu().numpy()
+    for b in range(B):
+        if border:
+            ref = ndimage.distance_transform_edt(np.pad(masks[b], 1, "constant")).astype(np.float32)[1:-1, 1:-1]
+        elif masks[b].all():
+            ref = np.full((H, W), np.inf, np.float32)
+        else:
+            ref = ndimage.distance_transform_edt(masks[b]).astype(np.float32)
+        assert np.array_equal(got[b], ref), (b, np.abs(got[b] - ref).max())
+
+
 def test_colsum_batched(ops):
     """70 independent column sums (more than one launch's 64) of different shapes accumulate into slices of one flat
     buffer exactly like per-job fp32 sums (integer data: exact)."""
