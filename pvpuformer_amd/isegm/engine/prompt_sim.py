@@ -43,19 +43,23 @@ def max_connected_regions(mask):
     """trainer.py:1175-1190 incl. its quirk: every component larger than 10 % of the foreground is merged into the
     largest-so-far label while scanning labels in ascending order."""
     labels, n = ndimage.label(mask, structure=_EIGHT)
-    labels = labels.astype(np.int64)
     if n == 0:
-        return labels
+        return labels.astype(np.int64)
+    # the reference relabels the image once per component (O(n * H * W)); the same scan on the component sizes: a label
+    # is evaluated before anything can be merged into it, so its size at that moment is its original size
+    counts = np.bincount(labels.ravel(), minlength=n + 1)
+    total = int(counts[1:].sum())
+    target = np.arange(n + 1)
     max_num, max_pixel = 0, 0
     for j in range(1, n + 1):
-        cnt = int(np.sum(labels == j))
+        cnt = int(counts[j])
         if cnt > max_num:
             max_num, max_pixel = cnt, j
-        if cnt > 0.1 * np.sum(labels != 0):
-            labels[labels == j] = max_pixel
-    labels[labels != max_pixel] = 0
-    labels[labels == max_pixel] = 1
-    return labels.astype(np.int8)
+        if cnt > 0.1 * total:
+            target[j] = max_pixel
+    keep = target == max_pixel
+    keep[0] = False
+    return keep[labels].astype(np.int8)
 
 
 def _first_free(points_b, lo, hi, default):

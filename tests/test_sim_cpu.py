@@ -68,3 +68,35 @@ def test_max_connected_regions_and_cal_box():
     pts = -np.ones((1, 48, 3), np.float32)
     box = ps.cal_box(m, m, np.zeros_like(m), pts, as_allmask=False, jitter_box=False)
     assert box.tolist() == [[int(0.5 * (5 + 29)), int(0.5 * (5 + 19)), 24, 14, 23]]
+
+
+def test_max_connected_regions_equals_reference_scan():
+    """max_connected_regions scans the component SIZES; the reference (trainer.py:1175-1190) relabels the image once per
+    component.  Same result on 200 random masks, including the quirk that large components are merged into the
+    largest-so-far label, which can change later."""
+    from scipy import ndimage
+    from pvpuformer_amd.isegm.engine.prompt_sim import _EIGHT, max_connected_regions
+
+    def reference_scan(mask):
+        labels, n = ndimage.label(mask, structure=_EIGHT)
+        labels = labels.astype(np.int64)
+        if n == 0:
+            return labels
+        max_num, max_pixel = 0, 0
+        for j in range(1, n + 1):
+            cnt = int(np.sum(labels == j))
+            if cnt > max_num:
+                max_num, max_pixel = cnt, j
+            if cnt > 0.1 * np.sum(labels != 0):
+                labels[labels == j] = max_pixel
+        labels[labels != max_pixel] = 0
+        labels[labels == max_pixel] = 1
+        return labels
+
+    g = np.random.RandomState(0)
+    for t in range(200):
+        H, W = g.randint(5, 60), g.randint(5, 60)
+        m = g.rand(H, W) > g.uniform(0.3, 0.9)
+        if t % 2:
+            m = ndimage.binary_opening(m)
+        assert np.array_equal(max_connected_regions(m).astype(np.int64), reference_scan(m)), t
