@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""The reference-faithful training step ("also report the mixed 1-3-iteration step"):
+``VPUTrainStep.batch_forward`` = ISTrainer.batch_forward (isegm/engine/trainer.py:310-491) with num_iters ~ randint(1, 3),
+click / box prompt type per iteration, the next click and the error-mask label simulated between the iterations
+(host bookkeeping, distance transforms on the GPU), each iteration back-propagated, one fused Adam step.
+Prints optimizer steps/s and images/s (images = batch size per step, as the reference counts them) next to the
+single-iteration rate of bench.py.   usage: python tools/bench_trainstep.py [steps] [batch]"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pvpuformer_amd.isegm.engine.trainer import VPUTrainStep                      # noqa: E402
+from pvpuformer_amd.isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model   # noqa: E402
+from pvpuformer_amd.optim import FusedAdam                                        # noqa: E402
+from pvpuformer_amd.synth import synth_batch, vitb_model_kwargs                   # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    torch.manual_seed(0)
+    model = VitMultiGaussianVector_ed_Model(**vitb_model_kwargs()).cuda()
+    model.set_compute_dtype("bf16")
+    model.train()
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    step = VPUTrainStep(model, optimizer=FusedAdam(model, lr=5e-5))
+    batch = synth_batch(B, 448, seed=3, device="cuda")
+    rng, np_rng = random.Random(0), np.random.RandomState(0)
+    for fixed in (1, None):
+        iters = 0
+        for i in range(steps + 2):
+            if i == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter(); iters = 0
+            logged, _ = step.batch_forward(batch, num_iters=fixed, rng=rng, np_rng=np_rng)
+            iters += logged["num_iters"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{'num_iters = 1' if fixed else 'num_iters ~ randint(1,3)'}: {steps / dt:6.2f} steps/s = {steps * B / dt:7.1f} images/s "
+              f"({dt / steps * 1e3:6.1f} ms/step, {iters / steps:.2f} forward+backward passes per step)")
+
+
+if __name__ == "__main__":
+    main()
