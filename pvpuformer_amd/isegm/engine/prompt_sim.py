@@ -42,6 +42,16 @@ def distance_transform_batch(masks, device=None):
 def max_connected_regions(mask):
     """trainer.py:1175-1190 incl. its quirk: every component larger than 10 % of the foreground is merged into the
     largest-so-far label while scanning labels in ascending order."""
+    mask = np.asarray(mask)
+    rows, cols = np.flatnonzero(mask.any(1)), np.flatnonzero(mask.any(0))
+    if len(rows) == 0:
+        return np.zeros(mask.shape, np.int64)
+    if (rows[-1] - rows[0] + 1) * (cols[-1] - cols[0] + 1) * 2 < mask.size:
+        # label only the bounding box of the foreground (same components, same raster order of their first pixels)
+        out = np.zeros(mask.shape, np.int8)
+        sl = (slice(rows[0], rows[-1] + 1), slice(cols[0], cols[-1] + 1))
+        out[sl] = max_connected_regions(np.ascontiguousarray(mask[sl]))
+        return out
     labels, n = ndimage.label(mask, structure=_EIGHT)
     if n == 0:
         return labels.astype(np.int64)
@@ -146,6 +156,12 @@ class PromptState:
         self.slot_idx[b, slot] = self.used
         self.used += 1
 
+    def assign_device(self, b, slot, mask_t):
+        """assign() for a mask that already lives on the device."""
+        self.override[self.used].copy_(mask_t.to(torch.float32))
+        self.slot_idx[b, slot] = self.used
+        self.used += 1
+
     def dense(self, gt):
         """Materialises ed_mask_label [B,S,H,W] (tests only)."""
         B, S = self.slot_idx.shape
@@ -164,6 +180,8 @@ def get_next_promts(pred, gt, points, state=None, pred_thresh=0.49, as_allmask=F
     (points, boxes int32 [B,5]) as tensors on points' device and updates ``state`` (the slot that received the click now
     predicts the false-negative / false-positive mask of this round)."""
     dev = points.device
+    if pred.is_cuda:
+        return _get_next_promts_gpu(pred, gt, points, state, pred_thresh, as_allmask, jitter_box, np_rng, rng)
     pred_np = pred.detach().float().cpu().numpy()[:, 0]
     gt_np = gt.detach().cpu().numpy()[:, 0] > 0.5
     pts_np = points.detach().float().cpu().numpy()
@@ -183,3 +201,79 @@ def get_iou(pred, gt, pred_thresh=0.49):
     """trainer.py:1045-1051."""
     pm, gm = pred > pred_thresh, gt > 0.5
     return (pm & gm).sum() / (pm | gm).sum()
+
+
+def _get_next_promts_gpu(pred, gt, points, state, pred_thresh, as_allmask, jitter_box, np_rng, rng):
+    """get_next_promts with the masks, distance transforms, maxima and the k-th-candidate lookup on the GPU: what crosses
+    to the host per call is one uint8 mask per sample (for the connected-component labelling of cal_box), a few scalars
+    per sample and the chosen coordinates -- not 2B float distance maps.  Same random draws in the same order, same
+    results as the host path (tests/test_ops_gpu.py::test_get_next_promts_gpu_equals_host)."""
+    from pvpuformer_amd import ops
+    dev = points.device
+    B, _, H, W = pred.shape
+    p = pred.detach().float()[:, 0]
+    g = gt.detach()[:, 0] > 0.5
+    fn = g & (p < pred_thresh)
+    fp = (~g) & (p > pred_thresh)
+    pts_np = points.detach().float().cpu().numpy()
+    n = pts_np.shape[1] // 2
+    # ---- cal_box (trainer.py:1061-1131): the mask whose bounding box is taken, per sample, goes to the host
+    if as_allmask:
+        chosen_np, use_fn = g.to(torch.uint8).cpu().numpy(), None
+    else:
+        cnt = torch.stack([fn.flatten(1).sum(1), fp.flatten(1).sum(1)]).cpu().numpy()     # [2, B]
+        use_fn = cnt[0] > cnt[1]
+        sel = torch.from_numpy(use_fn).to(pred.device)
+        chosen_np = torch.where(sel[:, None, None], fn, fp).to(torch.uint8).cpu().numpy()
+    boxes = np.zeros((B, 5), np.int32)
+    set_offset = 10
+    for b in range(B):
+        if as_allmask:
+            region, loc = chosen_np[b] > 0, _first_free(pts_np[b], 0, n, n - 1)
+        else:
+            region = max_connected_regions(chosen_np[b] > 0) == 1
+            loc = n - 1 if use_fn[b] else _first_free(pts_np[b], n, 2 * n, 2 * n - 1)
+        rows, cols = np.flatnonzero(region.any(1)), np.flatnonzero(region.any(0))
+        if len(rows) == 0:
+            continue
+        y0, y1, x0, x1 = rows[0], rows[-1], cols[0], cols[-1]
+        if jitter_box:
+            off = rng.randint(-set_offset, 0)
+            bx = min(max(x0 + off, 0), W - set_offset)
+            off = rng.randint(0, set_offset)
+            ex = max(min(x1 + off, W), bx + set_offset)
+            off = rng.randint(-set_offset, 0)
+            by = min(max(y0 + off, 0), H - set_offset)
+            off = rng.randint(0, set_offset)
+            ey = max(min(y1 + off, H), by + set_offset)
+            y0, y1, x0, x1 = by, ey, bx, ex
+        xc, yc, bw, bh = int(0.5 * (x0 + x1)), int(0.5 * (y0 + y1)), int(x1 - x0), int(y1 - y0)
+        if xc >= 1 and yc >= 1 and bw >= 1 and bh >= 1:
+            boxes[b] = (xc, yc, bw, bh, loc)
+    # ---- next_click (trainer.py:615-654, 733-764)
+    dts = ops.edt(torch.cat([fn, fp], 0).to(torch.uint8), zero_border=True)                # [2B, H, W]
+    mx = dts.flatten(1).amax(1).cpu().numpy()                                              # fn maxima, then fp maxima
+    is_pos = mx[:B] > mx[B:]
+    pick_t = torch.from_numpy(np.where(is_pos, np.arange(B), np.arange(B) + B)).to(pred.device)
+    dt = dts[pick_t]                                                                       # the map each sample draws from
+    thr = torch.from_numpy((np.maximum(mx[:B], mx[B:]) / 2.0).astype(np.float32)).to(pred.device)
+    inner = (dt > thr[:, None, None]).flatten(1)
+    counts = inner.sum(1).cpu().numpy()
+    ks = np.full(B, -1, np.int64)
+    for b in range(B):                                   # the draws of the host path, in its order
+        if counts[b] > 0:
+            ks[b] = np_rng.randint(0, counts[b])
+    # k-th candidate in raster order = first position where the running count reaches k + 1
+    cs = inner.cumsum(1)
+    kt = torch.from_numpy(ks).to(pred.device)
+    pos = ((cs == (kt[:, None] + 1)) & inner).to(torch.uint8).argmax(1).cpu().numpy()
+    new_pts = pts_np.copy()
+    for b in range(B):
+        if ks[b] < 0:
+            continue
+        order = max(float(new_pts[b, :, 2].max()), 0.0) + 1
+        loc = _first_free(new_pts[b], 0, n, n - 1) if is_pos[b] else _first_free(new_pts[b], n, 2 * n, 2 * n - 1)
+        new_pts[b, loc] = (float(pos[b] // W), float(pos[b] % W), float(order))
+        if state is not None:
+            state.assign_device(b, loc, (fn if is_pos[b] else fp)[b])
+    return torch.from_numpy(new_pts).to(dev), torch.from_numpy(boxes).to(dev)

@@ -61,6 +61,43 @@ def test_edt_bit_exact_vs_scipy(ops, shape, border):
         assert np.array_equal(got[b], ref), (b, np.abs(got[b] - ref).max())
 
 
+@pytest.mark.parametrize("as_allmask", [False, True])
+def test_get_next_promts_gpu_equals_host(ops, as_allmask):
+    """The device path of get_next_promts (masks, distance transforms, maxima and the k-th-candidate lookup on the GPU)
+    against the host path (numpy + scipy) on the same inputs and the same random streams, three rounds deep: identical
+    points (click coordinates, slots, orders), boxes, P2CL slot table and override masks."""
+    import random
+    from pvpuformer_amd.isegm.engine.prompt_sim import PromptState, get_next_promts
+    B, H, n = 5, 96, 24
+    g = torch.Generator().manual_seed(9)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing="ij")
+    gt = torch.zeros(B, 1, H, H)
+    for b in range(B):
+        cy, cx, r = (torch.rand(3, generator=g) * torch.tensor([H * 0.6, H * 0.6, H * 0.25]) + torch.tensor([H * 0.2, H * 0.2, 6.0])).tolist()
+        gt[b, 0] = ((yy - cy) ** 2 + (xx - cx) ** 2 < r * r).float()
+    gt[4] = 0                                             # an empty object: no click, no box
+    points0 = -torch.ones(B, 2 * n, 3)
+    points0[:, 0] = torch.tensor([10.0, 12.0, 0.0])
+    results = []
+    for device in ("cpu", "cuda"):
+        rng, np_rng = random.Random(3), np.random.RandomState(3)
+        pts = points0.clone().to(device)
+        state = PromptState(B, 2 * n, H, H, device, max_rounds=3)
+        gg = torch.Generator().manual_seed(10)
+        trace = []
+        for rnd in range(3):
+            noise = torch.rand(B, 1, H, H, generator=gg)
+            pred = (0.75 * gt + 0.25 * noise if rnd else torch.zeros(B, 1, H, H)).to(device)
+            pts, boxes = get_next_promts(pred, gt.to(device), pts, state, as_allmask=as_allmask, np_rng=np_rng, rng=rng)
+            trace.append((pts.cpu().clone(), boxes.cpu().clone()))
+        results.append((trace, state.slot_idx.cpu().clone(), state.override.cpu().clone(), state.used))
+    (ta, sa, oa, ua), (tb, sb, ob, ub) = results
+    assert ua == ub and ua > 0
+    for (pa, ba), (pb, bb) in zip(ta, tb):
+        assert torch.equal(pa, pb) and torch.equal(ba, bb)
+    assert torch.equal(sa, sb) and torch.equal(oa, ob)
+
+
 def test_colsum_batched(ops):
     """70 independent column sums (more than one launch's 64) of different shapes accumulate into slices of one flat
     buffer exactly like per-job fp32 sums (integer data: exact)."""
