@@ -881,15 +881,16 @@ def test_cross_attention_fwd_bwd(ops, hd, nq, nk, nb):
         assert (got - ref_g).abs().max().item() < tol, (name, (got - ref_g).abs().max().item(), tol)
 
 
-def test_fused_upsample_p2cl_matches_unfused(ops):
+@pytest.mark.parametrize("B,S,h,H", [(2, 8, 28, 112), (1, 4, 128, 448), (1, 2, 112, 448), (2, 2, 9, 32)])
+def test_fused_upsample_p2cl_matches_unfused(ops, B, S, h, H):
     """p2cl_up (upsample + loss + both backward passes, one kernel) == upsample_ac_fwd -> p2cl -> upsample_ac_bwd,
-    with per-slot override masks, and it is bitwise reproducible."""
-    B, S, h, H = 2, 8, 28, 112
+    with per-slot override masks, and it is bitwise reproducible.  Shapes: the test size, ViT-H's 128-wide head map
+    (7-row bands), ViT-B's 112 -> 448, and a non-integer ratio with a short last band."""
     low = dev(torch.sigmoid(rnd(B, S, h, h, seed=70, scale=3.0)))
     gt = dev((rnd(B, 1, H, H, seed=71) > 0.2).float())
     ov = dev((rnd(2, H, H, seed=72) > 0.5).float())
     idx = -torch.ones(B, S, dtype=torch.int32)
-    idx[0, 1] = 0; idx[1, 6] = 1
+    idx[0, 1] = 0; idx[B - 1, S - 2] = 1
     idx = dev(idx)
     gs = 2.0 / (B * S * H * H)
     up = torch.empty(B, S, H, H, device="cuda")
