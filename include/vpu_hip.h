@@ -180,6 +180,12 @@ int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, 
  * scratch: int32 [B][H][W]. */
 int vpu_edt(const uint8_t* mask, int32_t* scratch, float* dist, int32_t B, int32_t H, int32_t W, int32_t zero_border,
             void* stream);
+/* 8-connected components of B masks [B][H][W]: roots[i] = smallest linear index (within the whole [B][H][W] array) of the
+ * component of non-zero pixel i, -1 on zero pixels.  Sorted by root, the components are in the raster order of their first
+ * pixel -- the label order of the reference's skimage.measure.label(connectivity=2) in max_connected_regions
+ * (trainer.py:1175-1190). */
+int vpu_cc_roots(const uint8_t* mask, int32_t* roots, int32_t B, int32_t H, int32_t W, void* stream);
+
 /* DistMaps disks (ops.py:347-379, use_disks, spatial_scale 1) + optional draw_box outline (is_model.py:97-121).
  * out fp32 [B][2][H][W] in {0,1}. */
 int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H, int32_t W,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vpu_sigmoid_to_channel": [_P, _P, _I, _L, _I, _I, _P],
     "vpu_act_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
     "vpu_pue_encode": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_cc_roots": [_P, _P, _I, _I, _I, _P],
     "vpu_edt": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_disk_maps": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpu_patch_im2col": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -177,6 +177,83 @@ __global__ __launch_bounds__(256) void edt_rows_kernel(const uint8_t* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 8-connected component labelling of B masks by union-find on the pixel grid: root[i] = smallest linear index of the
+// component of foreground pixel i (-1 on background).  Components ordered by their root are in the raster order of their
+// first pixel, i.e. the label order of scipy.ndimage.label / skimage.measure.label that max_connected_regions
+// (isegm/engine/trainer.py:1175-1190) scans.  The result does not depend on the order in which the unions happen.
+__device__ __forceinline__ int cc_find(int* __restrict__ lab, int i) {
+    // path halving: every visited node is re-pointed to its grandparent (parents only ever decrease towards the root,
+    // so a concurrent writer can at worst install another valid ancestor)
+    int r = i;
+    while (true) {
+        const int p = __hip_atomic_load(lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == r) return r;
+        const int gp = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) __hip_atomic_store(lab + r, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = p;
+    }
+}
+__device__ __forceinline__ void cc_union(int* __restrict__ lab, int a, int b) {
+    while (true) {
+        a = cc_find(lab, a);
+        b = cc_find(lab, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang the larger root under the smaller
+        const int old = atomicMin(lab + a, b);
+        if (old == a) return;                                  // a was still a root: linked
+        a = old;                                               // somebody re-parented a meanwhile: merge that parent with b
+    }
+}
+// one block per image row: every foreground pixel starts as a child of the FIRST pixel of its horizontal run (inclusive
+// max-scan of "index after the last background pixel"), so the union step only has to join runs of adjacent rows
+__global__ __launch_bounds__(256) void cc_init_kernel(const uint8_t* __restrict__ mask, int* __restrict__ lab, int H, int W) {
+    __shared__ int sc[256];
+    const int64_t row = ((int64_t)blockIdx.y * H + blockIdx.x) * W;
+    int carry = 0;                                             // run start candidate carried over from the previous chunk
+    for (int x0 = 0; x0 < W; x0 += 256) {
+        const int x = x0 + threadIdx.x;
+        const bool fg = x < W && mask[row + x];
+        int v = (x < W && !fg) ? x + 1 : 0;                    // a background pixel at x: later runs start at >= x + 1
+        sc[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+            __syncthreads();
+            v = v > t ? v : t;
+            sc[threadIdx.x] = v;
+            __syncthreads();
+        }
+        v = v > carry ? v : carry;
+        if (x < W) lab[row + x] = fg ? (int)(row + v) : -1;
+        carry = sc[255] > carry ? sc[255] : carry;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t* __restrict__ mask, int* __restrict__ lab, int H, int W) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W || y == 0) return;
+    const int64_t base = (int64_t)b * H * W;
+    const int i = (int)(base + (int64_t)y * W + x);
+    if (!mask[i]) return;
+    // join this pixel's run with the runs of the row above it touches (N, NW, NE); a run of the row above is joined once
+    // per run of this row: skip a neighbour whose left neighbour (same upper run) was already seen from this run
+    const bool left_fg = x > 0 && mask[i - 1];
+    const bool n = mask[i - W], nw = x > 0 && mask[i - W - 1], ne = x + 1 < W && mask[i - W + 1];
+    if (n && !(left_fg && nw)) cc_union(lab, i, i - W);
+    else if (!n && nw && !left_fg) cc_union(lab, i, i - W - 1);
+    if (ne && !n) cc_union(lab, i, i - W + 1);
+}
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int* __restrict__ lab, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && lab[i] >= 0) {
+        int r = (int)i;
+        while (lab[r] != r) r = lab[r];     // (read-only walk: the unions are complete)
+        lab[i] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
@@ -213,4 +290,19 @@ extern "C" int vpu_edt(const uint8_t* mask, int32_t* scratch, float* dist, int32
     edt_cols_kernel<<<dim3((W + 255) / 256, B), 256, 0, s>>>(mask, scratch, H, W, zero_border);
     edt_rows_kernel<<<dim3(H, B), 256, (size_t)W * sizeof(int), s>>>(mask, scratch, dist, H, W, zero_border);
     return vpu_check_launch("vpu_edt");
+}
+
+extern "C" int vpu_cc_roots(const uint8_t* mask, int32_t* roots, int32_t B, int32_t H, int32_t W, void* stream) {
+    vpu_clear_stale_error();
+    const int64_t n = (int64_t)B * H * W;
+    if (!mask || !roots || B < 1 || H < 1 || W < 1 || n >= 0x7FFFFFFFLL) {
+        vpu_set_error("cc_roots: null pointer or B*H*W >= 2^31");
+        return VPU_ERR_ARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = (unsigned)((n + 255) / 256);
+    cc_init_kernel<<<dim3(H, B), 256, 0, s>>>(mask, roots, H, W);
+    cc_merge_kernel<<<dim3((W + 255) / 256, H, B), 256, 0, s>>>(mask, roots, H, W);
+    cc_flatten_kernel<<<g, 256, 0, s>>>(roots, n);
+    return vpu_check_launch("vpu_cc_roots");
 }

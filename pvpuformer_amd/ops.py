@@ -122,6 +122,16 @@ def edt(mask_u8, zero_border=True):
     return dist
 
 
+def cc_roots(mask_u8):
+    """8-connected components of uint8 masks [B, H, W] (vpu_cc_roots) -> int32 [B, H, W]: smallest linear index of the
+    pixel's component, -1 on background."""
+    B, H, W = mask_u8.shape
+    mask_u8 = mask_u8.contiguous()
+    roots = torch.empty(B, H, W, device=mask_u8.device, dtype=torch.int32)
+    _lib.call("vpu_cc_roots", ptr(mask_u8), ptr(roots), B, H, W, _stream())
+    return roots
+
+
 def colsum_batched(jobs):
     """jobs: list of (in fp32 [rows, C], out fp32 [C] (tensor or (tensor, offset)), rows, C): out += column sums, 64 per
     launch."""

@@ -61,13 +61,15 @@ def test_edt_bit_exact_vs_scipy(ops, shape, border):
         assert np.array_equal(got[b], ref), (b, np.abs(got[b] - ref).max())
 
 
-@pytest.mark.parametrize("as_allmask", [False, True])
-def test_get_next_promts_gpu_equals_host(ops, as_allmask):
+@pytest.mark.parametrize("as_allmask,gpu_cc", [(False, False), (False, True), (True, False)])
+def test_get_next_promts_gpu_equals_host(ops, as_allmask, gpu_cc, monkeypatch):
     """The device path of get_next_promts (masks, distance transforms, maxima and the k-th-candidate lookup on the GPU)
     against the host path (numpy + scipy) on the same inputs and the same random streams, three rounds deep: identical
     points (click coordinates, slots, orders), boxes, P2CL slot table and override masks."""
     import random
+    from pvpuformer_amd.isegm.engine import prompt_sim
     from pvpuformer_amd.isegm.engine.prompt_sim import PromptState, get_next_promts
+    monkeypatch.setattr(prompt_sim, "GPU_CC", gpu_cc)     # connected components of cal_box on the host / on the GPU
     B, H, n = 5, 96, 24
     g = torch.Generator().manual_seed(9)
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing="ij")
@@ -96,6 +98,42 @@ def test_get_next_promts_gpu_equals_host(ops, as_allmask):
     for (pa, ba), (pb, bb) in zip(ta, tb):
         assert torch.equal(pa, pb) and torch.equal(ba, bb)
     assert torch.equal(sa, sb) and torch.equal(oa, ob)
+
+
+def test_cc_roots_equal_scipy_components(ops):
+    """vpu_cc_roots: the partition into 8-connected components and their order (by smallest pixel index) equal
+    scipy.ndimage.label with the 3x3 structure, on noise at several densities, blobs, a spiral, a full and an empty
+    mask; root = smallest linear index of the component."""
+    from scipy import ndimage
+    g = np.random.RandomState(11)
+    H, W = 97, 131
+    masks = []
+    for dens in (0.1, 0.45, 0.6, 0.9):
+        masks.append(g.rand(H, W) < dens)
+    masks.append(ndimage.binary_opening(g.rand(H, W) < 0.6, iterations=2))
+    sp = np.zeros((H, W), bool)                      # a spiral: one long thin component
+    y0, y1, x0, x1 = 0, H - 1, 0, W - 1
+    while y1 - y0 > 3 and x1 - x0 > 3:
+        sp[y0, x0:x1 + 1] = True; sp[y0:y1 + 1, x1] = True; sp[y1, x0 + 2:x1 + 1] = True; sp[y0 + 2:y1 + 1, x0 + 2] = True
+        y0, y1, x0, x1 = y0 + 2, y1 - 2, x0 + 2, x1 - 2   # (touching rings: 8-connectivity joins them)
+    masks += [sp, np.ones((H, W), bool), np.zeros((H, W), bool)]
+    m = np.stack(masks).astype(np.uint8)
+    roots = ops.cc_roots(dev(torch.from_numpy(m))).cpu().numpy()
+    for b in range(len(masks)):
+        lab, n = ndimage.label(masks[b], structure=np.ones((3, 3), bool))
+        r = roots[b]
+        assert ((r >= 0) == masks[b]).all()
+        if n == 0:
+            continue
+        rr = r[masks[b]] - b * H * W
+        uniq = np.unique(rr)
+        assert len(uniq) == n
+        # ascending roots <-> scipy labels 1..n, and every root is the smallest index of its component
+        flat = np.flatnonzero(masks[b].ravel())
+        for k, u in enumerate(uniq):
+            members = flat[rr == u]
+            assert members.min() == u
+            assert (lab.ravel()[members] == k + 1).all()
 
 
 def test_colsum_batched(ops):
