@@ -64,7 +64,7 @@ typedef struct vpu_gemm_desc {
 
 /* Up to VPU_GEMM_GROUP_MAX independent bf16 problems run by ONE launch of vpu_gemm_grouped: start[i] = first tile of
  * problem i in the concatenated list of 128x128 output tiles, start[n] = total. */
-#define VPU_GEMM_GROUP_MAX 8
+#define VPU_GEMM_GROUP_MAX 16   /* 16 descriptors = 3.5 KB of the 4-KB kernel-argument segment */
 typedef struct vpu_gemm_group {
     int32_t n;
     int32_t start[VPU_GEMM_GROUP_MAX + 1];
@@ -222,6 +222,12 @@ int vpu_bilinear_cl_fwd(const void* in, int32_t ld_in, void* out, int32_t ld_out
                         int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_in, int32_t B, int32_t h, int32_t w,
                         int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* Head fusion without the channel concat (swin_transformer.py:744-756: 1x1 fusion_conv over cat(resize(convs_i(x_i)))):
+ * by linearity io[B][H][W][C] = relu(io + sum_{i<n} resize(z_i)), z_i [B][h_i][w_i][C] = convs_i output times its column
+ * block of the fusion weight at low resolution, io = the full-resolution level's product + bias; bilinear,
+ * align_corners False (wrappers.py:8-28); in place; n <= 3. */
+int vpu_upsum_relu(void* io, const void* const* z, const int32_t* h, const int32_t* w, int32_t n, int32_t B, int32_t H,
+                   int32_t W, int32_t C, int32_t dtype, void* stream);
 /* DMA gates (is_vpu_model.py:106-121): cg[b][c] = sigmoid(max_q Q[b][q][c]), sg[b][n] = sigmoid(max_c K[b][n][c]),
  * out = x*(1+cg+sg). arg* record the arg-max for backward. */
 int vpu_gate_stats(const void* Q, const void* Kt, float* cg, int32_t* argq, float* sg, int32_t* argc, int32_t B,

@@ -375,6 +375,50 @@ __global__ __launch_bounds__(256) void bilinear_cl_fwd_kernel(const T* __restric
     }
 }
 
+// Head fusion by linearity (swin_transformer.py:744-756): a 1x1 convolution over the channel concat of bilinearly resized
+// maps equals the sum of the resized per-map 1x1 convolutions (both are linear, the resize acts per channel), so the
+// [B*H*W, 4C] concat buffer (308 MB per step at ViT-B bs 12) and three quarters of the fusion GEMM never exist:
+//     io[p] = relu(io[p] + sum_i resize(z_i)[p]),   io = pre-activation of the full-resolution level (+ bias), in place.
+struct UpsumArgs {
+    const void* z[3];
+    int h[3], w[3];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void upsum_relu_kernel(T* __restrict__ io, const UpsumArgs a, int B, int H, int W, int C) {
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)B * H * W * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t pix = i / chunks;
+        const int X = (int)(pix % W), Y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        float o[8];
+        load8(io + pix * C + ck * 8, o);
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            if (m < a.n) {
+                const int h = a.h[m], w = a.w[m];
+                const T* __restrict__ in = reinterpret_cast<const T*>(a.z[m]);
+                int y0, y1, x0, x1;
+                float ly, lx;
+                src_index_half(Y, (float)h / (float)H, h, y0, y1, ly);
+                src_index_half(X, (float)w / (float)W, w, x0, x1, lx);
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                float p[8], q[8], r[8], s[8];
+                const int64_t base = (int64_t)b * h * w;
+                load8(in + (base + (int64_t)y0 * w + x0) * C + ck * 8, p);
+                load8(in + (base + (int64_t)y0 * w + x1) * C + ck * 8, q);
+                load8(in + (base + (int64_t)y1 * w + x0) * C + ck * 8, r);
+                load8(in + (base + (int64_t)y1 * w + x1) * C + ck * 8, s);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += hy * (hx * p[j] + lx * q[j]) + ly * (hx * r[j] + lx * s[j]);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
+        store8(io + pix * C + ck * 8, o);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_cl_bwd_kernel(const T* __restrict__ dout, int ld_out,
                                                               T* __restrict__ din, int ld_in, int B, int h, int w, int H,
@@ -852,6 +896,23 @@ extern "C" int vpu_bilinear_cl_fwd(const void* in, int32_t ld_in, void* out, int
     DISPATCH_T(dtype, bilinear_cl_fwd_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
         (const T*)in, ld_in, (T*)out, ld_out, B, h, w, H, W, C);)
     return vpu_check_launch("vpu_bilinear_cl_fwd");
+}
+extern "C" int vpu_upsum_relu(void* io, const void* const* z, const int32_t* h, const int32_t* w, int32_t n, int32_t B,
+                             int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (!io || !z || !h || !w || n < 0 || n > 3 || C % 8 || B < 1 || H < 1 || W < 1) {
+        vpu_set_error("upsum_relu: 0 <= n <= 3 maps, C % 8 == 0, non-null pointers");
+        return VPU_ERR_ARG;
+    }
+    UpsumArgs a;
+    a.n = n;
+    for (int i = 0; i < 3; ++i) {
+        a.z[i] = i < n ? z[i] : nullptr; a.h[i] = i < n ? h[i] : 1; a.w[i] = i < n ? w[i] : 1;
+        if (i < n && (!z[i] || h[i] < 1 || w[i] < 1)) { vpu_set_error("upsum_relu: null / empty map"); return VPU_ERR_ARG; }
+    }
+    const int64_t total = (int64_t)B * H * W * (C / 8);
+    DISPATCH_T(dtype, upsum_relu_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((T*)io, a, B, H, W, C);)
+    return vpu_check_launch("vpu_upsum_relu");
 }
 extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_in, int32_t B, int32_t h,
                                    int32_t w, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {

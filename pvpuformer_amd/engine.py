@@ -96,6 +96,7 @@ class Engine:
         # full-K tiles -- one round of the persistent grid, no split-K slabs, no reduce launches --, the neck's 576-row
         # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
+        self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
         self._csq = []         # queued column sums of norm-layer gradient partials: (part, out, rows, cols)
         self._gq = []          # deferred small GEMMs of one group (an attention's q / k / v projections or their dgrads)
@@ -201,9 +202,10 @@ class Engine:
         """G[N,K] += dy[M,N]^T x[M,K];  optionally G[bias][N] += column sums of dy, fused into the same launch (bf16
         path; the fp32 parity path uses the stand-alone column-sum kernel)."""
         fuse = bias is not None and self.dt == BF16
+        gout = self.G(gname) if isinstance(gname, str) else gname      # (flat gradient buffer, element offset)
         if self.group_wgrad and self.dt == BF16 and not self.use_side:
             ldc_ = K if ldc is None else ldc
-            args = (dy, x, self.G(gname), N, K, M, ld_dy, ld_x, ldc_, self.dt)
+            args = (dy, x, gout, N, K, M, ld_dy, ld_x, ldc_, self.dt)
             kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
             self._wq.append((args, kw, ((N + 127) // 128) * ((K + 127) // 128), M))   # (the queue keeps dy and x alive)
             for t in (dy, x):
@@ -215,7 +217,7 @@ class Engine:
                 self.flush_wgrads(kind)
             return
         if not self.use_side:
-            ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
+            ops.gemm(dy, x, gout, N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
                      transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
             if bias is not None and not fuse:
                 self._colsum_to(dy, ld_dy, bias, M, N)
@@ -229,7 +231,7 @@ class Engine:
             tt.record_stream(self.side)                  # the allocator must not recycle them under the side stream
             self._frozen.add(tt.data_ptr())
         with torch.cuda.stream(self.side):
-            ops.gemm(dy, x, self.G(gname), N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
+            ops.gemm(dy, x, gout, N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
                      transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
             if bias is not None and not fuse:
                 self._colsum_to(dy, ld_dy, bias, M, N)
@@ -717,24 +719,40 @@ class Engine:
         Cc = self.C
         Hs = 4 * g
         HW4 = Hs * Hs
-        cat = Var(self._new(B * HW4, 4 * Cc))
-        self.linear(feats[0][0], "head.convs.0.conv.weight", "head.convs.0.conv.bias", B * HW4, Cc, o[0], act="relu",
-                    out=(cat, 0, 4 * Cc))
-        for i in (1, 2, 3):
+        # fusion_conv over the concat of the four resized maps, by linearity: each level's column block of the fusion weight
+        # is applied at that level's own resolution, the low-resolution products are resized and summed into the
+        # full-resolution one (vpu_upsum_relu) -- no [B*112^2, 1024] concat, a third of the fusion FLOPs
+        wf, ldf = self.W("head.fusion_conv.conv.weight"), 4 * Cc
+        gf = self.G("head.fusion_conv.conv.weight")
+        ys, zs = [], []
+        for i in range(4):
             f, s = feats[i]
-            ci = self.linear(f, f"head.convs.{i}.conv.weight", f"head.convs.{i}.conv.bias", B * s * s, Cc, o[i],
-                             act="relu")
-            ops.bilinear_cl_fwd(ci.t, Cc, (cat.t, i * Cc), 4 * Cc, B, s, s, Hs, Hs, Cc, self.dt)
-            if training:
-                def bwd_resize(ci=ci, i=i, s=s):
-                    if cat.g is None:
-                        return
-                    assert ci.g is None
-                    ci.g = torch.empty_like(ci.t)
-                    ops.bilinear_cl_bwd((cat.g, i * Cc), 4 * Cc, ci.g, Cc, B, s, s, Hs, Hs, Cc, self.dt)
-                self.tape.append(bwd_resize)
-        fused = self.linear(cat, "head.fusion_conv.conv.weight", "head.fusion_conv.conv.bias", B * HW4, Cc, 4 * Cc,
-                            act="relu")
+            ys.append(self.linear(f, f"head.convs.{i}.conv.weight", f"head.convs.{i}.conv.bias", B * s * s, Cc, o[i],
+                                  act="relu"))
+        fused = Var(self._new(B * HW4, Cc))
+        ops.gemm(ys[0].t, wf, fused.t, B * HW4, Cc, Cc, Cc, ldf, Cc, self.dt, flags=EPI_BIAS,
+                 bias=self.Pm("head.fusion_conv.conv.bias"))
+        for i in (1, 2, 3):
+            s = feats[i][1]
+            z = self._new(B * s * s, Cc)
+            ops.gemm(ys[i].t, (wf[0], wf[1] + i * Cc), z, B * s * s, Cc, Cc, Cc, ldf, Cc, self.dt)
+            zs.append((z, s, s))
+        ops.upsum_relu(fused.t, zs, B, Hs, Hs, Cc, self.dt)
+        if training:
+            def bwd_fusion():
+                if fused.g is None:
+                    return
+                dt_ = self._new(B * HW4, Cc)
+                ops.act_bwd(fused.g, Cc, fused.t, Cc, dt_, Cc, B * HW4, Cc, 0, self.dt)
+                self._wgrad(dt_, Cc, ys[0].t, Cc, gf, Cc, Cc, B * HW4, ldc=ldf, bias="head.fusion_conv.conv.bias")
+                self._dgrad(dt_, Cc, wf, ldf, ys[0], B * HW4, Cc, Cc)
+                for i in (1, 2, 3):
+                    s = feats[i][1]
+                    dz = self._new(B * s * s, Cc)
+                    ops.bilinear_cl_bwd(dt_, Cc, dz, Cc, B, s, s, Hs, Hs, Cc, self.dt)
+                    self._wgrad(dz, Cc, ys[i].t, Cc, (gf[0], gf[1] + i * Cc), Cc, Cc, B * s * s, ldc=ldf)
+                    self._dgrad(dz, Cc, (wf[0], wf[1] + i * Cc), ldf, ys[i], B * s * s, Cc, Cc)
+            self.tape.append(bwd_fusion)
         seg = self._new(B * HW4, dtype=torch.float32)
         ops.convseg_fwd(fused.t, self.Pm("head.conv_seg.weight"), self.Pm("head.conv_seg.bias"), drop_mask, seg,
                         B * HW4, HW4, Cc)
@@ -830,7 +848,18 @@ class Engine:
             # the tiles fill the chip (the four of a ViT block: 432) or when the alternative -- a split-K launch + reduce
             # per problem, ~35 us -- costs more (three or more over 9408 rows; never for a 2-tile problem over 150528)
             nk = (red + 63) // 64
-            if len(part) >= 2 and (red == 0 or sum(e[2] for e in part) >= 200 or nk * 0.6 < len(part) * 35.0):
+            tiles = sum(e[2] for e in part)
+            # (reductions beyond ~16k rows -- the head / FPN maps -- keep the per-problem split-K launch with up to 128
+            # slices: measured 18.5 vs 17.9 ms per step when they were cut into 8 slices here)
+            elig = [e for e in part if e[0][8] == e[0][4]]     # slabs are summed into contiguous gradients only
+            etiles = sum(e[2] for e in elig)
+            if self.split_wgrad and 2048 < red <= 16384 and len(elig) >= 2 and etiles < 200:
+                self._wgrad_sliced(elig, red, etiles)
+                part = [e for e in part if e[0][8] != e[0][4]]
+                tiles -= etiles
+            if not part:
+                pass
+            elif len(part) >= 2 and (red == 0 or tiles >= 200 or nk * 0.6 < len(part) * 35.0):
                 ops.gemm_grouped([(e[0], e[1]) for e in part])
             else:
                 for args, kw, _, _ in part:
@@ -840,6 +869,36 @@ class Engine:
             for args, _, _, _ in self._wq:   # operands of the entries still queued stay frozen
                 for t in (args[0], args[1]):
                     self._frozen.add((t[0] if isinstance(t, tuple) else t).data_ptr())
+
+    def _wgrad_sliced(self, part, red, tiles):
+        """Few output tiles over a long reduction (the DMA neck's 768 x 384 projections over the 9408 image tokens: 72
+        tiles walking 147 K-tiles each on 72 of the 256 CUs, 150 us): every problem is cut into S reduction slices that
+        run as independent problems of the grouped launch, each writing its raw fp32 slab (and its slice of the bias
+        column sums); one batched column-sum launch adds the slabs to the gradients in slice order (deterministic)."""
+        S = max(2, min(8, 288 // tiles, 16 // len(part)))   # (one launch holds 16 descriptors)
+        kchunk = ((red + S - 1) // S + 63) // 64 * 64
+        S = (red + kchunk - 1) // kchunk
+        slab = self._new(sum(S * e[0][3] * e[0][4] for e in part), dtype=torch.float32)
+        nb = sum(S * e[0][3] for e in part if e[1].get("colsum") is not None)
+        bslab = torch.zeros(max(nb, 1), device=self.dev, dtype=torch.float32)   # the fused column sums accumulate
+        sub, jobs, so, bo = [], [], 0, 0
+        adv = lambda t, n: (t[0], t[1] + n) if isinstance(t, tuple) else (t, n)
+        for args, kw, _, _ in part:
+            dy, x, g, N, K, M, ld_dy, ld_x, ldc, dt = args
+            cs = kw.get("colsum")
+            for s in range(S):
+                k0 = s * kchunk
+                k1 = min(red, k0 + kchunk)
+                kw_s = dict(kw, flags=EPI_OUT_F32, colsum=None if cs is None else (bslab, bo + s * N))
+                sub.append(((adv(dy, k0 * ld_dy), adv(x, k0 * ld_x), (slab, so + s * N * K), N, K, k1 - k0, ld_dy, ld_x, K, dt), kw_s))
+            jobs.append(((slab, so), g, S, N * K))
+            so += S * N * K
+            if cs is not None:
+                jobs.append(((bslab, bo), cs, S, N))
+                bo += S * N
+        for i in range(0, len(sub), 16):
+            ops.gemm_grouped(sub[i:i + 16])
+        ops.colsum_batched(jobs)
 
     def flush_colsums(self):
         q, self._csq = self._csq, []

@@ -107,6 +107,8 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         self._compute_dtype = os.environ.get("VPU_COMPUTE_DTYPE", "bf16")
         self._anchor = None
         self.weights_frozen = False
+        self.graph_inference = os.environ.get("VPU_INFER_GRAPH", "0") == "1"   # see _graph_forward
+        self._graphs = {}
 
     # ---------------------------------------------------------------------------------------------- engine plumbing
     def engine_cfg(self):
@@ -180,9 +182,37 @@ class VitMultiGaussianVector_ed_Model(ISModel):
             drop_mask = torch.bernoulli(torch.full((image.shape[0], self.head.channels), keep, device=image.device)) / keep
         if torch.is_grad_enabled():
             inst, aux = _VPUFunction.apply(self._anchor, self, image, points, boxes, as_prompt_type, drop_mask)
+        elif self.graph_inference and self.weights_frozen and drop_mask is None and image.is_cuda:
+            inst, aux = self._graph_forward(eng, image, points, boxes, as_prompt_type)
         else:
             inst, aux = eng.forward(image, points, boxes, as_prompt_type, drop_mask, training=False)
         return {'instances': inst, 'instances_aux': aux if self.with_aux_output else None}
+
+    def _graph_forward(self, eng, image, points, boxes, ptype):
+        """No-grad forward replayed from a captured hipGraph (``graph_inference``; env VPU_INFER_GRAPH=1 turns it on at
+        construction): the ~230 launches of a batch-2 NoBRS forward are launch-bound when enqueued one by one.  One graph
+        per (image shape, prompt rows, prompt type, dtype); inputs are copied into the graph's static buffers, the
+        returned tensors are the graph's output buffers (valid until the next call with the same key, which is how the
+        predictor uses them).  Needs ``weights_frozen`` (the compute-dtype operands are not rebuilt per call)."""
+        points = points.to(image.device).float().contiguous()
+        key = (tuple(image.shape), tuple(points.shape), int(ptype), eng.dt)
+        ent = self._graphs.get(key)
+        if ent is None:
+            s_img, s_pts = image.clone(), points.clone()
+            s_box = None if boxes is None else boxes.to(device=image.device, dtype=torch.int32).contiguous().clone()
+            eng.forward(s_img, s_pts, s_box, ptype, None, training=False)          # eager once: lazily created state
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                inst, aux = eng.forward(s_img, s_pts, s_box, ptype, None, training=False)
+            ent = self._graphs[key] = (g, s_img, s_pts, s_box, inst, aux)
+        g, s_img, s_pts, s_box, inst, aux = ent
+        s_img.copy_(image)
+        s_pts.copy_(points)
+        if s_box is not None:
+            s_box.copy_(boxes.to(device=image.device, dtype=torch.int32))
+        g.replay()
+        return inst, aux
 
     def backbone_forward(self, *a, **k):
         raise NotImplementedError("use forward(); the stages are fused inside the engine")

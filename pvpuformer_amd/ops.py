@@ -258,6 +258,15 @@ def bilinear_cl_bwd(dout, ld_out, din, ld_in, B, h, w, H, W, Cdim, dtype):
     _lib.call("vpu_bilinear_cl_bwd", ptr(dout), ld_out, ptr(din), ld_in, B, h, w, H, W, Cdim, dtype, _stream())
 
 
+def upsum_relu(io, maps, B, H, W, Cdim, dtype):
+    """io[B,H,W,C] = relu(io + sum_i bilinear(z_i)), in place; maps = [(z_i [B,h,w,C], h, w), ...] (at most 3)."""
+    n = len(maps)
+    zp = (C.c_void_p * 3)(*[ptr(m[0]) for m in maps])
+    hs = (C.c_int32 * 3)(*[m[1] for m in maps])
+    ws = (C.c_int32 * 3)(*[m[2] for m in maps])
+    _lib.call("vpu_upsum_relu", ptr(io), zp, hs, ws, n, B, H, W, Cdim, dtype, _stream())
+
+
 def gate_stats(Q, Kt, cg, argq, sg, argc, B, nq, N, Cdim):
     _lib.call("vpu_gate_stats", ptr(Q), ptr(Kt), ptr(cg), ptr(argq), ptr(sg), ptr(argc), B, nq, N, Cdim, code_of(Q),
               _stream())

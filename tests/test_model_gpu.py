@@ -224,6 +224,59 @@ def test_vitb_bf16_grouped_weight_gradients_equal_ungrouped(golden_dir):
     assert not bad, sorted(bad, key=lambda kv: -kv[1])[:5]
 
 
+def test_vitb_bf16_sliced_weight_gradients_equal_unsliced(golden_dir):
+    """Engine._wgrad_sliced (the neck's 768 x 384 projections over the 9408 image tokens run as reduction slices of a
+    grouped launch + one batched slab sum) against the un-sliced grouped launch: same operands, fp32 summation order
+    differs only; weight and fused bias gradients compared tensor by tensor at 1e-4 of the tensor's largest entry."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    eng = model._ensure_engine()
+    gt = batch["instances"].cuda()
+    grads, calls = [], []
+    orig = eng._wgrad_sliced
+    eng._wgrad_sliced = lambda *a: (calls.append(len(a[0])), orig(*a))
+    try:
+        for sliced in (True, False):
+            eng.split_wgrad = sliced
+            model.zero_grad()
+            out = _run(model, img4, batch, 0)
+            total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+            total.backward()
+            torch.cuda.synchronize()
+            grads.append(eng.gflat.clone())
+    finally:
+        eng.split_wgrad = True
+        eng._wgrad_sliced = orig
+    assert calls, "the sliced path was never taken"
+    bad = []
+    for n, (off, shape, numel) in eng.names.items():
+        a, b = grads[0][off:off + numel], grads[1][off:off + numel]
+        scale = float(b.abs().max())
+        if scale > 0 and float((a - b).abs().max()) > 1e-4 * scale:
+            bad.append((n, float((a - b).abs().max()) / scale))
+    assert not bad, sorted(bad, key=lambda kv: -kv[1])[:5]
+
+
+def test_graph_inference_equals_eager(golden_dir):
+    """graph_inference: the no-grad forward replayed from a captured hipGraph returns bit-identical outputs to the eager
+    launches, for new inputs copied into the captured buffers and for a second prompt-row count (second graph)."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "bf16")
+    model.eval()
+    model.weights_frozen = True
+    pts = batch["points"].cuda().float()
+    img4 = img4.cuda()
+    with torch.no_grad():
+        for trial, (img, p) in enumerate(((img4, pts), (img4.flip(3).contiguous(), pts), (img4, pts[:, :40].contiguous()))):
+            model.graph_inference = False
+            ref = {k: v.clone() for k, v in model(img, p).items() if v is not None}
+            model.graph_inference = True
+            got = model(img, p)
+            torch.cuda.synchronize()
+            for k, v in ref.items():
+                assert torch.equal(v, got[k]), (trial, k, float((v.float() - got[k].float()).abs().max()))
+    model.graph_inference = False
+    assert len(model._graphs) == 2
+
+
 @pytest.mark.parametrize("fixture", ["tiny.npz", "vitb.npz"])
 def test_grad_ready_ranges_are_final_when_reported(golden_dir, fixture):
     """Data-parallel contract of Engine.grad_ready_hook: every reported range [lo, hi) of the flat gradient buffer is

@@ -570,6 +570,40 @@ def test_bilinear_channels_last(ops, dtype, h):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n", [0, 2, 3])
+def test_upsum_relu_equals_fusion_over_concat(ops, dtype, n):
+    """vpu_upsum_relu (head fusion by linearity): relu(t0 + sum_i resize(z_i)) in place == the same sum built from
+    F.interpolate(align_corners=False), and -- the identity the engine relies on -- a 1x1 convolution over the channel
+    concat of resized maps == the sum of the resized per-map products (fp32: to rounding)."""
+    td = TD[dtype]
+    B, C, H = 2, 32, 112
+    sizes = [56, 28, 14][:n]
+    t0 = dev(rnd(B, H, H, C, seed=40)).to(td)
+    zs = [dev(rnd(B, s, s, C, seed=41 + i)).to(td) for i, s in enumerate(sizes)]
+    ref = t0.float()
+    for z in zs:
+        ref = ref + F.interpolate(z.float().permute(0, 3, 1, 2), size=(H, H), mode="bilinear",
+                                  align_corners=False).permute(0, 2, 3, 1)
+    ref = torch.relu(ref)
+    io = t0.clone()
+    ops.upsum_relu(io, [(z, s, s) for z, s in zip(zs, sizes)], B, H, H, C, dtype)
+    tol = dict(atol=3e-2, rtol=2e-2) if dtype == 0 else dict(atol=2e-6, rtol=1e-6)
+    torch.testing.assert_close(io.float(), ref, **tol)
+    if dtype == 1 and n == 3:
+        g = torch.Generator().manual_seed(50)
+        ys = [dev(rnd(B, s, s, 16, seed=60 + i)) for i, s in enumerate([112] + sizes)]
+        Wf = dev(torch.randn(C, 64, generator=g) * 0.2)
+        bias = dev(torch.randn(C, generator=g))
+        cat = torch.cat([F.interpolate(y.permute(0, 3, 1, 2), size=(H, H), mode="bilinear", align_corners=False)
+                         for y in ys], 1)
+        want = torch.relu(F.conv2d(cat, Wf[:, :, None, None], bias)).permute(0, 2, 3, 1)
+        io = (ys[0] @ Wf[:, :16].t() + bias).contiguous()
+        lows = [(ys[i] @ Wf[:, 16 * i:16 * (i + 1)].t()).contiguous() for i in (1, 2, 3)]
+        ops.upsum_relu(io, [(z, s, s) for z, s in zip(lows, sizes)], B, H, H, C, dtype)
+        torch.testing.assert_close(io, want, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 def test_gates_and_convseg(ops, dtype):
     td = TD[dtype]
     B, nq, N, C = 2, 48, 784, 64
