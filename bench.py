@@ -152,11 +152,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
+    # rehearsal on a one-GPU box (never used by the driver): VPU_DIST_SHARE_GPU=1 puts every rank on cuda:0 and
+    # VPU_DIST_BACKEND=gloo exchanges the gradients through the host -- RCCL refuses two ranks on one device
+    if os.environ.get("VPU_DIST_SHARE_GPU", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VPU_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import __graft_entry__ as ge
