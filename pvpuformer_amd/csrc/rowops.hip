@@ -11,60 +11,82 @@
 namespace {
 
 constexpr int LN_MAXCH = 4;  // 8-element chunks per lane -> C <= 2048
-constexpr int LN_BWD_WAVES = 16;
+constexpr int LN_BWD_WAVES = 8;   // part rows: rows / 16, at most 512
 
 // ---------------------------------------------------------------------------------- LayerNorm fwd
-template <typename T>
+// One row per wave and trip; a wave walks rows with the grid stride and requests the NEXT row before it reduces the
+// current one (the reductions are two dependent cross-lane chains: without the prefetch every row pays a full HBM round
+// trip with nothing in flight).  NCH: 512-column chunks per row.
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const T* xr = x + row * C;
-    float v[LN_MAXCH][8];
-    float s = 0.f;
+    float ww[NCH][8], bb[NCH][8];
+    Raw8<T> cur[NCH], nxt[NCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = (lane + i * 64) * 8;
-        if (c < C) {
-            load8(xr + c, v[i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[i][j];
-        }
+        if (c < C) { load8(w + c, ww[i]); load8(b + c, bb[i]); cur[i].load(x + row * C + c); }
     }
-    const float mu = wave_sum(s) / C;
-    float q = 0.f;
+    const float invC = 1.0f / (float)C;
+    for (; row < rows; row += stride) {
+        const int64_t nr = row + stride;
+        if (nr < rows) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        const int c = (lane + i * 64) * 8;
-        if (c < C) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + i * 64) * 8;
+                if (c < C) nxt[i].load(x + nr * C + c);
+            }
         }
-    }
-    const float rs = rsqrtf(wave_sum(q) / C + eps);
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    T* yr = y + row * C;
+        float v[NCH][8];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        const int c = (lane + i * 64) * 8;
-        if (c < C) {
-            float ww[8], bb[8], o[8];
-            load8(w + c, ww);
-            load8(b + c, bb);
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                cur[i].get(v[i]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * ww[j] + bb[j];
-            store8(yr + c, o);
+                for (int j = 0; j < 8; ++j) s += v[i][j];
+            }
         }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / C + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        T* yr = y + row * C;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * ww[i][j] + bb[i][j];
+                store8(yr + c, o);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) cur[i] = nxt[i];
     }
+    (void)invC;
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm bwd
 // NCH: 512-column chunks per row (C <= 512*NCH); NW waves per workgroup, one row per wave and trip: 16 rows in
 // flight per CU (one 1024-thread workgroup per CU) instead of 4 -- the kernel is a latency-bound stream of 3 KB rows.
-template <typename T, int NCH, int NW>
+template <typename T, int NCH, int NW, bool PF>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ mean,
@@ -84,8 +106,50 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
         const int c = (lane + i * 64) * 8;
         if (c < C) load8(w + c, ww[i]);
     }
-    for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < rows; row += (int64_t)nblk * NW) {
-        const float mu = mean[row], rs = rstd[row];
+    // the next row's x / dy / residual gradient / statistics are requested before the current row's two cross-lane
+    // reductions (raw registers, converted only when consumed)
+    const int64_t stride = (int64_t)nblk * NW;
+    int64_t row = (int64_t)blockIdx.x * NW + wave;
+    Raw8<T> cx[NCH], cd[NCH], cr[NCH], nx[NCH], nd[NCH], nres[NCH];
+    float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
+    if (PF && row < rows) {
+        mu = mean[row]; rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                cx[i].load(x + row * C + c);
+                cd[i].load(dy + row * C + c);
+                if (dres) cr[i].load(dres + row * C + c);
+            }
+        }
+    }
+    for (; row < rows; row += stride) {
+        const int64_t nr = row + stride;
+        if (PF && nr < rows) {
+            nmu = mean[nr]; nrs = rstd[nr];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + i * 64) * 8;
+                if (c < C) {
+                    nx[i].load(x + nr * C + c);
+                    nd[i].load(dy + nr * C + c);
+                    if (dres) nres[i].load(dres + nr * C + c);
+                }
+            }
+        }
+        if (!PF) {   // 4 chunks per lane: no registers for a second row in flight
+            mu = mean[row]; rs = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + i * 64) * 8;
+                if (c < C) {
+                    cx[i].load(x + row * C + c);
+                    cd[i].load(dy + row * C + c);
+                    if (dres) cr[i].load(dres + row * C + c);
+                }
+            }
+        }
         float xh[NCH][8], g[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -93,8 +157,8 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
             const int c = (lane + i * 64) * 8;
             if (c < C) {
                 float xv[8], dv[8];
-                load8(x + row * C + c, xv);
-                load8(dy + row * C + c, dv);
+                cx[i].get(xv);
+                cd[i].get(dv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -113,7 +177,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
             const int c = (lane + i * 64) * 8;
             if (c < C) {
                 float o[8];
-                if (dres) load8(dres + row * C + c, o);
+                if (dres) cr[i].get(o);
                 else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = 0.f;
@@ -122,6 +186,11 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
                 for (int j = 0; j < 8; ++j) o[j] += rs * (g[i][j] - s1 - xh[i][j] * s2);
                 store8(dx + row * C + c, o);
             }
+        }
+        if (PF) {
+            mu = nmu; rs = nrs;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nres[i]; }
         }
     }
     // reduce the waves' dw / db and write this block's partial row
@@ -441,14 +510,18 @@ extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, 
                                  int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
     vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm: C % 8 == 0, C <= 2048"); return VPU_ERR_ARG; }
-    DISPATCH_T(dtype, layernorm_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(
-        (const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps);)
+    // balanced persistent grid: at most 2048 workgroups (8 per CU), every wave the same number of rows (+-1)
+    const int64_t nb = (rows + 3) / 4, trips = (nb + 2047) / 2048;
+    const unsigned grid = (unsigned)((nb + trips - 1) / trips);
+#define VPU_LN_FWD(NCH_) DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps);)
+    if (C <= 512) { VPU_LN_FWD(1) } else if (C <= 1024) { VPU_LN_FWD(2) } else { VPU_LN_FWD(4) }
+#undef VPU_LN_FWD
     return vpu_check_launch("vpu_layernorm_fwd");
 }
 extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
     int64_t n = rows / (2 * LN_BWD_WAVES);
-    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));   // two workgroups per CU
 }
 extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                                  const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype,
@@ -457,10 +530,11 @@ extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, 
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
     const int nblk = vpu_layernorm_bwd_nblk(rows);
 #define VPU_LN_BWD(NCH_, NW_)                                                                                         \
-    DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_><<<nblk, 64 * NW_, 0, ST>>>(                                 \
+    DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2)><<<nblk, 64 * NW_, 0, ST>>>(                    \
                           (const T*)dy, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);)
     // (C > 1024 keeps 8 waves: its 4 chunks per lane need the 256-register budget)
-    if (C <= 512) { VPU_LN_BWD(1, 16) } else if (C <= 1024) { VPU_LN_BWD(2, 16) } else { VPU_LN_BWD(4, 8) }
+    // (<= 2 chunks: 4-wave workgroups, ~170 VGPRs with the prefetched row -> three per CU; 4 chunks: no prefetch)
+    if (C <= 512) { VPU_LN_BWD(1, 4) } else if (C <= 1024) { VPU_LN_BWD(2, 4) } else { VPU_LN_BWD(4, 8) }
 #undef VPU_LN_BWD
     return vpu_check_launch("vpu_layernorm_bwd");
 }

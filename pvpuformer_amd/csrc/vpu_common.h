@@ -105,6 +105,29 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<bf16x8_t*>(p) = a;
 }
 
+// 8 contiguous elements kept RAW (unconverted) in registers: a software prefetch must not touch the loaded value before
+// the iteration that consumes it, or the wave waits for the load right where it was issued.
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    bf16x8_t r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const bf16x8_t*>(p); }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+    }
+};
+template <> struct Raw8<float> {
+    f32x4_t a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4_t*>(p);
+        b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+};
+
 static inline int vpu_grid_for(long long n_items, int per_block, int cap = 1 << 20) {
     long long g = (n_items + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -55,6 +55,15 @@ def main():
         cases[f"attn_fwd_{tag}"] = (lambda qkv=qkv, o=o, lse=lse, nb=nb, n=n: ops.attn_fwd((qkv, 0), (qkv, D), (qkv, 2 * D), o, lse, nb, Hh, n, 64, 3 * D, D, 0.125), fl)
         cases[f"attn_bwd_{tag}"] = (lambda qkv=qkv, o=o, do=do, lse=lse, delta=delta, dqkv=dqkv, nb=nb, n=n: ops.attn_bwd(
             (qkv, 0), (qkv, D), (qkv, 2 * D), o, do, lse, delta, (dqkv, 0), (dqkv, D), (dqkv, 2 * D), nb, Hh, n, 64, 3 * D, D, 3 * D, 0.125), 2.5 * fl)
+    rows, Cd = 9408, 768
+    xl = torch.randn(rows, Cd, device=dev).to(torch.bfloat16)
+    dyl, drl = torch.randn_like(xl), torch.randn_like(xl)
+    yl, dxl = torch.empty_like(xl), torch.empty_like(xl)
+    wl, bl = torch.rand(Cd, device=dev), torch.rand(Cd, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    partl = torch.empty(ops.layernorm_bwd_nblk(rows), 2, Cd, device=dev)
+    cases["layernorm_fwd"] = (lambda: ops.layernorm_fwd(xl, wl, bl, yl, mean, rstd, rows, Cd, 1e-6), rows * Cd * 4)
+    cases["layernorm_bwd"] = (lambda: ops.layernorm_bwd(dyl, xl, wl, mean, rstd, drl, dxl, partl, rows, Cd), rows * Cd * 8)
     for name, (fn, nbytes) in cases.items():
         if only and not any(t in name for t in only):
             continue
