@@ -178,10 +178,21 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, 
 //     (~1.8 MB for fc1 at bs 12) stay resident in the XCD's L2 while each B (weight) tile is fetched once per chunk.
 //     With the N-fastest order every row-panel re-streamed the whole weight (4.7 MB > L2): L2 hit rate 65 %,
 //     fabric fetch 160 MB for 19 MB of unique inputs (rocprofv3 TCC_HIT/MISS, FETCH_SIZE, round 1).
+// (3) chunk along the LONGER tile dimension: a weight gradient with few row-panels and many column tiles (fc2: 6 x 24)
+//     chunked by rows gives every XCD three quarters of the wide operand (PMC round 1: ~360 MB fetched for 72 MB of
+//     distinct bytes); chunked by columns an XCD's 18 tiles are 3 column strips x all 6 row strips.
 __device__ __forceinline__ void tile_coords(int bid, int nwg, int tiles_n, int& tile_m, int& tile_n) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tiles_m = nwg / tiles_n;
+    if (tiles_n > tiles_m) {
+        const int cn = (tiles_n + 7) >> 3;
+        const int chunk = v / (cn * tiles_m), rem = v - chunk * (cn * tiles_m);
+        const int ncount = (tiles_n - chunk * cn) < cn ? (tiles_n - chunk * cn) : cn;
+        tile_m = rem / ncount;
+        tile_n = chunk * cn + (rem - tile_m * ncount);
+        return;
+    }
     const int cm = (tiles_m + 7) >> 3;
     const int chunk = v / (cm * tiles_n), rem = v - chunk * (cm * tiles_n);
     const int mcount = (tiles_m - chunk * cm) < cm ? (tiles_m - chunk * cm) : cm;

@@ -250,6 +250,17 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const vpu_colsum_ba
     const int C = j.ncols;
     const int64_t rows = j.nrows;
     const float* __restrict__ in = j.in;
+    if (rows <= 16 && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(j.out)) & 15) == 0) {
+        // few rows over many columns (the split-K style slabs of Engine._wgrad_sliced: 2-8 rows x ~300k columns): one
+        // lane per 4 columns, 16-byte accesses, rows in order (deterministic); block-uniform branch, no barrier below
+        const int C4 = C >> 2;
+        for (int c4 = blockIdx.x * 256 + threadIdx.x; c4 < C4; c4 += gridDim.x * 256) {
+            f32x4_t a = *reinterpret_cast<const f32x4_t*>(j.out + 4 * (int64_t)c4);
+            for (int64_t r = 0; r < rows; ++r) a += *reinterpret_cast<const f32x4_t*>(in + r * C + 4 * (int64_t)c4);
+            *reinterpret_cast<f32x4_t*>(j.out + 4 * (int64_t)c4) = a;
+        }
+        return;
+    }
     for (int c0 = blockIdx.x * 32; c0 < C; c0 += gridDim.x * 32) {   // block-uniform trip count
         const int c = c0 + cl;
         float s0 = 0.f, s1 = 0.f;

@@ -419,6 +419,71 @@ __global__ __launch_bounds__(256) void upsum_relu_kernel(T* __restrict__ io, con
     }
 }
 
+// 2 x 2 output pixels per lane (integer ratios >= 2, even H / W): the four pixels share a 3 x 3 (ratio 2) or 2 x 2 (ratio
+// >= 4) neighbourhood of each low-resolution map, 9 / 4 tap loads instead of 16 -- the one-pixel form moves 12 x the bytes
+// of the output through L2 (82 us at ViT-B bs 12).  Same association as above (horizontal, then vertical): identical bits.
+template <typename T>
+__global__ __launch_bounds__(256) void upsum_relu2_kernel(T* __restrict__ io, const UpsumArgs a, int B, int H, int W, int C) {
+    const int chunks = C / 8, H2 = H >> 1, W2 = W >> 1;
+    const int64_t total = (int64_t)B * H2 * W2 * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t blk = i / chunks;
+        const int X = 2 * (int)(blk % W2), Y = 2 * (int)((blk / W2) % H2), b = (int)(blk / ((int64_t)W2 * H2));
+        float o[2][2][8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) load8(io + (((int64_t)b * H + Y + dy) * W + X + dx) * C + ck * 8, o[dy][dx]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            if (m < a.n) {
+                const int h = a.h[m], w = a.w[m];
+                const T* __restrict__ in = reinterpret_cast<const T*>(a.z[m]) + (int64_t)b * h * w * C + ck * 8;
+                int y0a, y1a, y0b, y1b, x0a, x1a, x0b, x1b;
+                float lya, lyb, lxa, lxb;
+                src_index_half(Y, (float)h / (float)H, h, y0a, y1a, lya);
+                src_index_half(Y + 1, (float)h / (float)H, h, y0b, y1b, lyb);
+                src_index_half(X, (float)w / (float)W, w, x0a, x1a, lxa);
+                src_index_half(X + 1, (float)w / (float)W, w, x0b, x1b, lxb);
+                const bool sy = y0b != y0a, sx = x0b != x0a;   // second pixel moved on to the taps (1, 2) of the triple
+                const int ry[3] = {y0a, y1a, y1b}, rx[3] = {x0a, x1a, x1b};
+                float ha[3][8], hb[3][8];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (r == 2 && !sy) continue;
+                    float t0[8], t1[8], t2[8];
+                    load8(in + ((int64_t)ry[r] * w + rx[0]) * C, t0);
+                    load8(in + ((int64_t)ry[r] * w + rx[1]) * C, t1);
+                    if (sx) load8(in + ((int64_t)ry[r] * w + rx[2]) * C, t2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        ha[r][j] = (1.f - lxa) * t0[j] + lxa * t1[j];
+                        const float u0 = sx ? t1[j] : t0[j], u1 = sx ? t2[j] : t1[j];
+                        hb[r][j] = (1.f - lxb) * u0 + lxb * u1;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o[0][0][j] += (1.f - lya) * ha[0][j] + lya * ha[1][j];
+                    o[0][1][j] += (1.f - lya) * hb[0][j] + lya * hb[1][j];
+                    const float a0 = sy ? ha[1][j] : ha[0][j], a1 = sy ? ha[2][j] : ha[1][j];
+                    const float b0 = sy ? hb[1][j] : hb[0][j], b1 = sy ? hb[2][j] : hb[1][j];
+                    o[1][0][j] += (1.f - lyb) * a0 + lyb * a1;
+                    o[1][1][j] += (1.f - lyb) * b0 + lyb * b1;
+                }
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[dy][dx][j] = fmaxf(o[dy][dx][j], 0.f);
+                store8(io + (((int64_t)b * H + Y + dy) * W + X + dx) * C + ck * 8, o[dy][dx]);
+            }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_cl_bwd_kernel(const T* __restrict__ dout, int ld_out,
                                                               T* __restrict__ din, int ld_in, int B, int h, int w, int H,
@@ -911,7 +976,13 @@ extern "C" int vpu_upsum_relu(void* io, const void* const* z, const int32_t* h, 
         if (i < n && (!z[i] || h[i] < 1 || w[i] < 1)) { vpu_set_error("upsum_relu: null / empty map"); return VPU_ERR_ARG; }
     }
     const int64_t total = (int64_t)B * H * W * (C / 8);
-    DISPATCH_T(dtype, upsum_relu_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((T*)io, a, B, H, W, C);)
+    bool quad = n > 0 && H % 2 == 0 && W % 2 == 0;
+    for (int i = 0; i < n; ++i) quad = quad && H % h[i] == 0 && W % w[i] == 0 && H / h[i] >= 2 && W / w[i] >= 2;
+    if (quad) {
+        DISPATCH_T(dtype, upsum_relu2_kernel<T><<<vpu_grid_for(total / 4, 256, 16384), 256, 0, ST>>>((T*)io, a, B, H, W, C);)
+    } else {
+        DISPATCH_T(dtype, upsum_relu_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((T*)io, a, B, H, W, C);)
+    }
     return vpu_check_launch("vpu_upsum_relu");
 }
 extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_in, int32_t B, int32_t h,

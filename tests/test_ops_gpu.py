@@ -570,14 +570,14 @@ def test_bilinear_channels_last(ops, dtype, h):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("n", [0, 2, 3])
+@pytest.mark.parametrize("n", [0, 1, 2, 3])
 def test_upsum_relu_equals_fusion_over_concat(ops, dtype, n):
     """vpu_upsum_relu (head fusion by linearity): relu(t0 + sum_i resize(z_i)) in place == the same sum built from
     F.interpolate(align_corners=False), and -- the identity the engine relies on -- a 1x1 convolution over the channel
     concat of resized maps == the sum of the resized per-map products (fp32: to rounding)."""
     td = TD[dtype]
     B, C, H = 2, 32, 112
-    sizes = [56, 28, 14][:n]
+    sizes = [48] if n == 1 else [56, 28, 14][:n]    # 112 / 48: not an integer ratio -> the one-pixel-per-lane kernel
     t0 = dev(rnd(B, H, H, C, seed=40)).to(td)
     zs = [dev(rnd(B, s, s, C, seed=41 + i)).to(td) for i, s in enumerate(sizes)]
     ref = t0.float()
