@@ -196,6 +196,15 @@ def main():
     opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, capturable=use_graph)
     red = GradReducer(eng.gflat)
     eng.grad_ready_hook = red.ready if red.enabled else None
+    # VPU_ADAM_OVERLAP=1: the optimizer step runs range by range on a second stream while backward continues
+    # (OverlappedAdam; also zeroes the gradients it has consumed).  Off by default: bit-identical results, but measured
+    # slower on one GPU (17.3-17.5 ms per step against 17.0 with one Adam launch after backward, whatever the Adam grid:
+    # the HBM-bound stream takes more from the GEMMs it runs beside than its own 0.65 ms)
+    overlap = None
+    if not use_graph and os.environ.get("VPU_ADAM_OVERLAP", "0") == "1":
+        from pvpuformer_amd.optim import OverlappedAdam
+        overlap = OverlappedAdam(opt, eng, red)
+        eng.zero_grad()
 
     B = args.batch
     batch = synth_batch(B, 448, seed=100 + rank, device=dev)   # each rank its own shard of the global batch
@@ -204,14 +213,22 @@ def main():
     keep = 1.0 - model.head.dropout_ratio
     last = {}
 
+    mode = {"overlap": overlap is not None}
+
     def step_body():
-        eng.zero_grad()
+        if not mode["overlap"]:
+            eng.zero_grad()
         mask = torch.bernoulli(torch.full((B, model.head.channels), keep, device=dev)) / keep
         inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
         losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
-        red.begin()
-        eng.backward(d_inst, None, d_sim_low=d_sim)
-        opt.step(grad_scale=red.finish())
+        if mode["overlap"]:
+            overlap.begin()
+            eng.backward(d_inst, None, d_sim_low=d_sim)
+            overlap.finish()
+        else:
+            red.begin()
+            eng.backward(d_inst, None, d_sim_low=d_sim)
+            opt.step(grad_scale=red.finish())
         last["loss"] = losses["total"]
 
     graph = [None]
@@ -263,10 +280,16 @@ def main():
     # spans the wait for the other stream).
     side_was = eng.use_side
     eng.use_side = False
+    hook_was = eng.grad_ready_hook
+    if overlap is not None:            # the instrumented step runs the optimizer after backward: nothing beside the GEMMs
+        mode["overlap"] = False
+        eng.grad_ready_hook = red.ready if red.enabled else None
+        red.on_bucket = None
     with GemmProbe(ops) as probe:
         graph[0] = None                # the instrumented step is enqueued eagerly (HIP events around every GEMM launch)
         step()
     eng.use_side = side_was
+    eng.grad_ready_hook = hook_was
     agg = probe.summary()
     if agg:
         name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
@@ -288,6 +311,8 @@ def main():
                            "mfma_roofline_frac_end_to_end":
                                round(value / world * FLOP_PER_IMG[args.model] / (BF16_PEAK_TFLOPS * 1e12), 4),
                            "launch": "hipGraph replay of the captured step" if use_graph else "eager",
+                           "optimizer": "Adam per finished gradient range on a second stream, overlapped with backward"
+                                        if overlap is not None else "one Adam launch after backward",
                            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
                            "final_loss": round(loss_val, 5)},
                 "roofline": roof}

@@ -2,6 +2,7 @@
 // models/iSegNet/vpu_base448_cocolvis.py:149-154), writing the bf16 shadow used by the MFMA GEMMs in the same pass.
 // HBM-bound: 16 B reads of p,g,m,v and writes of p,m,v (+2 B shadow) per element.
 #include "vpu_common.h"
+#include <stdlib.h>
 #include "../../include/vpu_hip.h"
 
 namespace {
@@ -79,7 +80,8 @@ extern "C" int vpu_adam_step(float* p, const float* g, float* m, float* v, void*
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     const int64_t n4 = (n + 3) / 4;
-    adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    static const int grid_cap = [] { const char* e = getenv("VPU_ADAM_GRID"); return e ? atoi(e) : 8192; }();
+    adam_kernel<<<vpu_grid_for(n4, 256, grid_cap), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         p, g, m, v, (bf16_t*)shadow_bf16, n4, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, nullptr,
         nullptr, nullptr, 0, 0, nullptr);
     return vpu_check_launch("vpu_adam_step");

@@ -25,6 +25,7 @@ class GradReducer:
         self._pending_lo = None
         self._works = []
         self.launched = []        # (lo, hi) of every collective of the current step (for tests / logging)
+        self.on_bucket = None     # optional callable(lo, hi, work): called right after a bucket's collective is launched
 
     def begin(self):
         self._pending_hi = self._pending_lo = None
@@ -48,8 +49,11 @@ class GradReducer:
             return
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
-        self._works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        work = dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(work)
         self.launched.append((lo, hi))
+        if self.on_bucket is not None:
+            self.on_bucket(lo, hi, work)
 
     def finish(self):
         """Launches the last partial bucket and makes the current stream wait for every collective.  Returns the factor

@@ -256,6 +256,45 @@ def test_vitb_bf16_sliced_weight_gradients_equal_unsliced(golden_dir):
     assert not bad, sorted(bad, key=lambda kv: -kv[1])[:5]
 
 
+def test_overlapped_adam_equals_plain_step(golden_dir):
+    """OverlappedAdam (the optimizer step range by range on a second stream while backward runs, gradients zeroed behind
+    it) leaves bit-identical parameters, moments and bf16 shadow to FusedAdam.step after backward, over two steps; its
+    ranges tile the flat buffer and the gradient buffer is all zeros afterwards."""
+    from pvpuformer_amd.optim import FusedAdam, OverlappedAdam
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    states = []
+    for overlapped in (False, True):
+        fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "bf16")
+        model.train()
+        eng = model._ensure_engine()
+        eng.refresh_weights()
+        opt = FusedAdam(model, lr=1e-3)
+        ov = OverlappedAdam(opt, eng) if overlapped else None
+        gt, pts, img = batch["instances"].cuda(), batch["points"].cuda(), img4.cuda()
+        eng.zero_grad()
+        for it in range(2):
+            inst, _ = eng.forward(img, pts, None, 0, None, training=True, materialize_aux=False)
+            losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+            if ov is not None:
+                ov.begin()
+                eng.backward(d_inst, None, d_sim_low=d_sim)
+                ov.finish()
+                spans = sorted(ov.done)
+                assert spans[0][0] == 0 and spans[-1][1] == eng.total
+                assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            else:
+                eng.backward(d_inst, None, d_sim_low=d_sim)
+                opt.step()
+                eng.zero_grad()
+        torch.cuda.synchronize()
+        if ov is not None:
+            assert float(eng.gflat.abs().max()) == 0.0
+        states.append((eng.flat.clone(), opt.m.clone(), opt.v.clone(), eng.shadow.clone()))
+        eng.grad_ready_hook = None
+    for a, b in zip(*states):
+        assert torch.equal(a, b)
+
+
 def test_graph_inference_equals_eager(golden_dir):
     """graph_inference: the no-grad forward replayed from a captured hipGraph returns bit-identical outputs to the eager
     launches, for new inputs copied into the captured buffers and for a second prompt-row count (second graph)."""
