@@ -915,6 +915,134 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny problems: the DMA neck's prompt-token GEMMs (M = B*48 = 576 rows, N, K <= 2048; at inference M = 96).  With the
+// 128x128 tile they are 15-30 tiles of 12+ K-tiles each, run as split-K slabs + a reduce launch (~16 us per GEMM, 50 of
+// them per training step).  Here a workgroup owns one 64x64 output tile and its FOUR WAVES SPLIT K: every wave walks a
+// quarter of K for the whole tile through its own private LDS images (no block barrier in the loop, the next K-step's
+// operands in registers while the current one is multiplied), the four partial tiles are summed through LDS in wave
+// order (deterministic) and go through the full epilogue: one launch, no slabs.
+// TB = 1 (dgrad: B is [K][N]): the B pieces go into a K-major image and are read with ds_read_b64_tr_b16.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_T = 64;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+template <int TB>
+__global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const vpu_gemm_desc p, const int tiles_n, const int kw,
+                                                               const int vec) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // per wave: one K-contiguous image (+ one K-major image, TB = 1)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * SK_T, n0 = tile_n * SK_T;
+    const int kbeg = wave * kw, kend = (kbeg + kw < p.K) ? kbeg + kw : p.K;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // Every operand goes global -> registers -> the wave's PRIVATE LDS image -> MFMA fragments: the global loads are whole
+    // 128-byte row segments (8 rows x 8 chunks per wave-instruction); fragment-shaped loads straight from global memory
+    // (16 rows x 64 B) measured 9.7 us against 7.3 us for the 576 x 768 x 768 problem.  Wave-local: a wave's LDS
+    // operations complete in order, so no barrier is needed inside the loop.
+    char* imgK = lds + wave * (TB ? 2 : 1) * TILE_BYTES;     // [128 rows][64 k]: rows 0..63 = A, rows 64..127 = B (TB = 0)
+    char* imgB = imgK + TILE_BYTES;                          // TB = 1: [64 k][128 cols] K-major image of B, columns 0..63
+    // piece pc of a K-contiguous operand: rows 8 pc .. + 8, lane -> (row 8 pc + lane / 8, 16-byte chunk lane % 8)
+    auto ldKC = [&](__amdgpu_buffer_rsrc_t r, int ld, int x0, int X, int pc, int k0) -> u32x4v {
+        const int gx = x0 + pc * 8 + (lane >> 3), gk = k0 + (lane & 7) * 8;
+        const int off = (gx < X && gk < kend) ? (gx * ld + gk) * 2 : OOB_OFFSET;
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    };
+    // piece pc of the K-major B: k rows 8 pc .. + 8, lane -> (k = 8 pc + lane / 8, 8 columns (lane % 8) * 8)
+    auto ldKM = [&](int pc, int k0) -> u32x4v {
+        const int gk = k0 + pc * 8 + (lane >> 3), gn = n0 + (lane & 7) * 8;
+        const int off = (gk < kend && gn < p.N) ? (gk * p.ldb + gn) * 2 : OOB_OFFSET;
+        return __builtin_amdgcn_raw_buffer_load_b128(rB, off, 0, 0);
+    };
+    const int nsteps = kend > kbeg ? (kend - kbeg + 63) / 64 : 0;
+    u32x4v na[8], nb[8];
+    if (nsteps > 0) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            na[pc] = ldKC(rA, p.lda, m0, p.M, pc, kbeg);
+            nb[pc] = TB ? ldKM(pc, kbeg) : ldKC(rB, p.ldb, n0, p.N, pc, kbeg);
+        }
+    }
+    for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            const int r8 = pc * 8 + (lane >> 3);
+            *reinterpret_cast<u32x4v*>(imgK + kc_off(r8, lane & 7)) = na[pc];
+            if (TB) *reinterpret_cast<u32x4v*>(imgB + km_off(r8, (lane & 7) * 2)) = nb[pc];
+            else *reinterpret_cast<u32x4v*>(imgK + kc_off(64 + r8, lane & 7)) = nb[pc];
+        }
+        if (st + 1 < nsteps) {   // the next step's operands fly under this step's fragment reads and MFMAs
+            const int k1 = kbeg + (st + 1) * 64;
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) {
+                na[pc] = ldKC(rA, p.lda, m0, p.M, pc, k1);
+                nb[pc] = TB ? ldKM(pc, k1) : ldKC(rB, p.ldb, n0, p.N, pc, k1);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<0>(imgK, i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = TB ? read_frag<1>(imgB, j * 16, ks, lane) : read_frag<0>(imgK, 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's fragment reads are done before the images are rewritten
+    }
+    __syncthreads();   // every wave is done with its images: the partial tiles reuse the same LDS
+    // ---- the four waves' partial tiles -> LDS [wave][64 rows][64 cols] (column group XOR-swizzled by the row group)
+    float* wl = reinterpret_cast<float*>(lds) + wave * (SK_T * SK_T);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + fq * 4 + r;
+                wl[row * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[i][j][r];
+            }
+    __syncthreads();
+    // thread -> row tid / 4, 16 columns (tid % 4) * 16: two groups of 8, summed over the waves in wave order
+    const float* all = reinterpret_cast<const float*>(lds);
+    const int row = tid >> 2;
+    const int m = m0 + row;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c8 = (tid & 3) * 16 + h * 8;
+        const int n = n0 + c8;
+        if (m < p.M && n < p.N) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w_ = 0; w_ < 4; ++w_) {
+                float t[8];
+                load8(all + w_ * (SK_T * SK_T) + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t[j];
+            }
+            if (vec && n + 8 <= p.N) {
+                EpiPre e;
+                e.has_pre = false; e.has_bias = false; e.pre = make_uint4(0, 0, 0, 0);
+                epilogue_store8(p, p.flags, 0, 0, m, n, v, e);
+            } else {
+                for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, 0, 0, m, n + j, v[j]);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc p, const int splitk,
                                                             const float* __restrict__ ws, const int vec8) {
@@ -1080,6 +1208,7 @@ std::atomic<int> g_opt_ring{-1};
 // sc1 loads: the acquire drops the XCD's L2) -- the write-through slab stores and sc1 loads cost more than the reduce
 // launch they save, at every slab size of this model.  Kept (and tested) for shapes where a launch boundary is dearer.
 std::atomic<int> g_opt_inlaunch{-1};
+std::atomic<int> g_opt_skinny{-1};   // -1 environment default (VPU_GEMM_SKINNY, 1 if unset), 0 off, 1 on
 inline int inlaunch_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_INLAUNCH"); return e ? atoi(e) : 0; }();
     return v;
@@ -1168,6 +1297,24 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 kchunk = (int)(((d->K + want - 1) / want + BK - 1) / BK * BK);
                 splitk = (d->K + kchunk - 1) / kchunk;
             }
+        }
+        // skinny problems (see gemm_bf16_skinny_kernel): few rows, moderate N and K, plain or K-major B
+        static const int skinny_env = [] { const char* e = getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+        const int skinny_opt = g_opt_skinny.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny.load(std::memory_order_relaxed) : skinny_env;
+        if (skinny_opt && !big && !d->transA && d->batch == 1 && !d->colsum && d->M <= 1024 && d->N <= 4096 &&
+            d->K >= 128 && d->K <= 4096 && (int64_t)((d->M + 63) / 64) * ((d->N + 63) / 64) <= 1024) {
+            const int tn64 = (d->N + SK_T - 1) / SK_T, tm64 = (d->M + SK_T - 1) / SK_T;
+            const int kw = (int)(((d->K + 3) / 4 + 63) / 64 * 64);
+            static bool attr_sk = false;
+            if (!attr_sk) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
+                attr_sk = true;
+            }
+            dim3 sgrid((unsigned)(tm64 * tn64)), sblock(256);
+            if (d->transB) gemm_bf16_skinny_kernel<1><<<sgrid, sblock, 8 * TILE_BYTES, s>>>(*d, tn64, kw, vec ? 1 : 0);
+            else gemm_bf16_skinny_kernel<0><<<sgrid, sblock, 4 * TILE_BYTES, s>>>(*d, tn64, kw, vec ? 1 : 0);
+            return vpu_check_launch("vpu_gemm");
         }
         static const bool noepi = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
         static const bool nostore = [] { const char* e = getenv("VPU_GEMM_NOSTORE"); return e && e[0] == '1'; }();
@@ -1309,12 +1456,17 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_ring.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
+    if (name && !strcmp(name, "skinny") && value >= -1 && value <= 1) {
+        g_opt_skinny.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
     if (name && !strcmp(name, "splitk_inlaunch") && value >= -1 && value <= 4096) {
         g_opt_inlaunch.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
     vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere), "
-                  "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine)");
+                  "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine), "
+                  "skinny (-1 environment default, 0 off, 1 on)");
     return VPU_ERR_ARG;
 }
 

@@ -96,6 +96,7 @@ class Engine:
         # full-K tiles -- one round of the persistent grid, no split-K slabs, no reduce launches --, the neck's 576-row
         # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
+        self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "64"))      # flush_group: largest problem (output tiles) grouped
         self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
         self._csq = []         # queued column sums of norm-layer gradient partials: (part, out, rows, cols)
@@ -262,7 +263,7 @@ class Engine:
     def flush_group(self):
         q, self._gq = self._gq, []
         self._gq_out = set()
-        is_small = [((a[3] + 127) // 128) * ((a[4] + 127) // 128) <= 64 and a[5] <= 2048 for a, _ in q]
+        is_small = [((a[3] + 127) // 128) * ((a[4] + 127) // 128) <= self.group_tiles and a[5] <= 2048 for a, _ in q]
         if sum(is_small) >= 2:
             ops.gemm_grouped([e for e, sm in zip(q, is_small) if sm])
             q = [e for e, sm in zip(q, is_small) if not sm]

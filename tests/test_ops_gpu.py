@@ -829,6 +829,7 @@ def test_gemm_split_k_inlaunch_combine_stress(ops, shape):
         outs = []
         for mode in (1, 0):
             ops.gemm_set_option("splitk_inlaunch", mode)
+            ops.gemm_set_option("skinny", 0)      # (the 576-row shapes would otherwise take the one-launch skinny kernel)
             try:
                 C32 = torch.full((M, N), float(it), device="cuda")
                 cs = torch.full((M,), 2.0, device="cuda") if (tA and tB) else None
@@ -836,12 +837,60 @@ def test_gemm_split_k_inlaunch_combine_stress(ops, shape):
                          flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)
             finally:
                 ops.gemm_set_option("splitk_inlaunch", -1)
+                ops.gemm_set_option("skinny", -1)
             outs.append((C32, cs))
         torch.cuda.synchronize()
         for C32, cs in outs:
             assert torch.equal(C32.cpu(), ref + float(it)), (it, (C32.cpu() - ref - it).abs().max())
             if cs is not None:
                 assert torch.equal(cs.cpu(), A.sum(1) + 2.0), it
+
+
+@pytest.mark.parametrize("tB", [0, 1])
+@pytest.mark.parametrize("shape", [(576, 768, 768), (576, 384, 768), (576, 2048, 904), (576, 768, 2048), (96, 768, 384),
+                                   (50, 136, 200), (1000, 72, 4096)])
+def test_gemm_skinny_kernel(ops, tB, shape):
+    """The one-launch kernel for few-row problems (64x64 tile per workgroup, its four waves split K, partial tiles summed
+    through LDS in wave order): bit-exact on exact-integer data for plain / K-major B, ragged M, N and K (K % 8 == 0),
+    fp32 ACCUM output; and equal to the split-K path (same fp32 sums up to their order) through the full epilogue
+    (bias, ReLU / residual, bf16 output) on random data."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(17)
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+    ref = A @ Bm.t()
+    Ad = dev(A).to(torch.bfloat16)
+    Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+    ldb = N if tB else K
+    try:
+        for sk in (1, 0):
+            ops.gemm_set_option("skinny", sk)
+            C32 = torch.full((M, N), 3.0, device="cuda")
+            ops.gemm(Ad, Bd, C32, M, N, K, K, ldb, N, 0, transB=bool(tB), flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM)
+            assert torch.equal(C32.cpu(), ref + 3.0), (sk, float((C32.cpu() - ref - 3.0).abs().max()))
+        Ar, Br = dev(rnd(M, K, seed=70)).to(torch.bfloat16), dev(rnd(K, N, seed=71) if tB else rnd(N, K, seed=71)).to(torch.bfloat16)
+        bias, R = dev(rnd(N, seed=72)), dev(rnd(M, N, seed=73)).to(torch.bfloat16)
+        for flags in (ops.EPI_BIAS | ops.EPI_RELU, ops.EPI_BIAS | ops.EPI_RESID, ops.EPI_DRELU):
+            outs = []
+            for sk in (1, 0):
+                ops.gemm_set_option("skinny", sk)
+                Cb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+                ops.gemm(Ar, Br, Cb, M, N, K, K, ldb, N, 0, transB=bool(tB), flags=flags, bias=bias, resid=R, ldr=N,
+                         aux=R, ldaux=N)
+                outs.append(Cb.float())
+            torch.testing.assert_close(outs[0], outs[1], atol=0.07, rtol=1e-2)
+            want = Ar.float() @ (Br.float() if tB else Br.float().t())
+            if flags & ops.EPI_BIAS:
+                want = want + bias
+            if flags & ops.EPI_RELU:
+                want = torch.relu(want)
+            if flags & ops.EPI_RESID:
+                want = want + R.float()
+            if flags & ops.EPI_DRELU:
+                want = want * (R.float() > 0)
+            torch.testing.assert_close(outs[0], want, atol=0.15, rtol=2e-2)
+    finally:
+        ops.gemm_set_option("skinny", -1)
 
 
 @pytest.mark.parametrize("tA,tB", [(1, 1), (0, 0), (0, 1)])
