@@ -178,21 +178,12 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, 
 //     (~1.8 MB for fc1 at bs 12) stay resident in the XCD's L2 while each B (weight) tile is fetched once per chunk.
 //     With the N-fastest order every row-panel re-streamed the whole weight (4.7 MB > L2): L2 hit rate 65 %,
 //     fabric fetch 160 MB for 19 MB of unique inputs (rocprofv3 TCC_HIT/MISS, FETCH_SIZE, round 1).
-// (3) chunk along the LONGER tile dimension: a weight gradient with few row-panels and many column tiles (fc2: 6 x 24)
-//     chunked by rows gives every XCD three quarters of the wide operand (PMC round 1: ~360 MB fetched for 72 MB of
-//     distinct bytes); chunked by columns an XCD's 18 tiles are 3 column strips x all 6 row strips.
+// (chunking along the longer tile dimension instead -- column chunks for a weight gradient with few row-panels, e.g. fc2's
+//  6 x 24 tiles -- was tried in round 1: no measurable change at ViT-B (706 vs 706 images/s), so the one rule is kept.)
 __device__ __forceinline__ void tile_coords(int bid, int nwg, int tiles_n, int& tile_m, int& tile_n) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tiles_m = nwg / tiles_n;
-    if (tiles_n > tiles_m) {
-        const int cn = (tiles_n + 7) >> 3;
-        const int chunk = v / (cn * tiles_m), rem = v - chunk * (cn * tiles_m);
-        const int ncount = (tiles_n - chunk * cn) < cn ? (tiles_n - chunk * cn) : cn;
-        tile_m = rem / ncount;
-        tile_n = chunk * cn + (rem - tile_m * ncount);
-        return;
-    }
     const int cm = (tiles_m + 7) >> 3;
     const int chunk = v / (cm * tiles_n), rem = v - chunk * (cm * tiles_n);
     const int mcount = (tiles_m - chunk * cm) < cm ? (tiles_m - chunk * cm) : cm;
@@ -1301,8 +1292,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // skinny problems (see gemm_bf16_skinny_kernel): few rows, moderate N and K, plain or K-major B
         static const int skinny_env = [] { const char* e = getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
         const int skinny_opt = g_opt_skinny.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny.load(std::memory_order_relaxed) : skinny_env;
-        if (skinny_opt && !big && !d->transA && d->batch == 1 && !d->colsum && d->M <= 1024 && d->N <= 4096 &&
-            d->K >= 128 && d->K <= 4096 && (int64_t)((d->M + 63) / 64) * ((d->N + 63) / 64) <= 1024) {
+        static const int skinny_m = [] { const char* e = getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 1024; }();
+        static const int skinny_n = [] { const char* e = getenv("VPU_GEMM_SKINNY_N"); return e ? atoi(e) : 4096; }();
+        static const int skinny_k = [] { const char* e = getenv("VPU_GEMM_SKINNY_K"); return e ? atoi(e) : 4096; }();
+        if (skinny_opt && !big && !d->transA && d->batch == 1 && !d->colsum && d->M <= skinny_m && d->N <= skinny_n &&
+            d->K >= 128 && d->K <= skinny_k && (int64_t)((d->M + 63) / 64) * ((d->N + 63) / 64) <= 65535) {
             const int tn64 = (d->N + SK_T - 1) / SK_T, tm64 = (d->M + SK_T - 1) / SK_T;
             const int kw = (int)(((d->K + 3) / 4 + 63) / 64 * 64);
             static bool attr_sk = false;
