@@ -1292,11 +1292,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // skinny problems (see gemm_bf16_skinny_kernel): few rows, moderate N and K, plain or K-major B
         static const int skinny_env = [] { const char* e = getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
         const int skinny_opt = g_opt_skinny.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny.load(std::memory_order_relaxed) : skinny_env;
-        static const int skinny_m = [] { const char* e = getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 1024; }();
+        static const int skinny_m = [] { const char* e = getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 2560; }();
         static const int skinny_n = [] { const char* e = getenv("VPU_GEMM_SKINNY_N"); return e ? atoi(e) : 4096; }();
         static const int skinny_k = [] { const char* e = getenv("VPU_GEMM_SKINNY_K"); return e ? atoi(e) : 4096; }();
+        // (under-filled launches only: fewer than 192 tiles of 128x128, the same bound as the split-K rule below)
         if (skinny_opt && !big && !d->transA && d->batch == 1 && !d->colsum && d->M <= skinny_m && d->N <= skinny_n &&
-            d->K >= 128 && d->K <= skinny_k && (int64_t)((d->M + 63) / 64) * ((d->N + 63) / 64) <= 65535) {
+            d->K >= 64 && d->K <= skinny_k && (int64_t)tiles_m * tiles_n < 192) {
             const int tn64 = (d->N + SK_T - 1) / SK_T, tm64 = (d->M + SK_T - 1) / SK_T;
             const int kw = (int)(((d->K + 3) / 4 + 63) / 64 * 64);
             static bool attr_sk = false;
