@@ -1045,15 +1045,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc 
         // many slices, few elements (weight gradients over 150528 rows: 128 slices of a 256 x 128 output): 8 lanes share one
         // group of 8 columns, lane j sums the slices j, j+8, ... and the eight partial sums are added in lane order through
         // LDS (fixed tree: deterministic).  One thread per group walked 128 slabs back to back: 63 us for 16 MB.
-        __shared__ float red[8][32][8];
-        const int eg = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        // (32 slice lanes x 8 column groups per block: with 8 slice lanes x 32 groups a 256 x 128 output was 128 blocks of 16
+        // dependent 32-byte loads per lane -- 35 us for 16.8 MB)
+        __shared__ float red[32][8][8];
+        const int eg = threadIdx.x & 7, sl = threadIdx.x >> 3;
         const int n8 = p.N >> 3;
-        const int64_t i = (int64_t)blockIdx.x * 32 + eg;
+        const int64_t i = (int64_t)blockIdx.x * 8 + eg;
         const bool live = i < (mn >> 3);
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live) {
 #pragma unroll 4
-            for (int s = sl; s < splitk; s += 8) {
+            for (int s = sl; s < splitk; s += 32) {
                 float t[8];
                 load8(w + s * mn + i * 8, t);
 #pragma unroll
@@ -1064,8 +1066,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc 
         for (int j = 0; j < 8; ++j) red[sl][eg][j] = v[j];
         __syncthreads();
         if (sl == 0 && live) {
-#pragma unroll
-            for (int q = 1; q < 8; ++q)
+#pragma unroll 4
+            for (int q = 1; q < 32; ++q)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += red[q][eg][j];
             EpiPre e;
@@ -1428,8 +1430,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         if (splitk > 1 && !inlaunch) {
             const int64_t mn = (int64_t)d->M * d->N;
             int vec8 = vec && d->N % 8 == 0 ? 1 : 0;
-            if (vec8 && splitk >= 16 && mn / 8 <= 32 * 65535) vec8 = 2;   // slice-parallel form
-            dim3 rgrid((unsigned)(vec8 == 2 ? (mn / 8 + 31) / 32 : vpu_grid_for(vec8 ? mn / 8 : mn, 256, 4096)), 1,
+            if (vec8 && splitk >= 16 && mn / 8 <= 8 * 65535) vec8 = 2;   // slice-parallel form
+            dim3 rgrid((unsigned)(vec8 == 2 ? (mn / 8 + 7) / 8 : vpu_grid_for(vec8 ? mn / 8 : mn, 256, 4096)), 1,
                        (unsigned)d->batch);
             splitk_reduce_kernel<bf16_t><<<rgrid, block, 0, s>>>(*d, splitk, ws, vec8);
         }

@@ -565,9 +565,13 @@ extern "C" int vpu_colsum_batched(const vpu_colsum_job* jobs, int32_t n, void* s
             return VPU_ERR_ARG;
         }
         jb.job[i] = jobs[i];
-        cmax = jobs[i].ncols > cmax ? jobs[i].ncols : cmax;
+        // blocks this job can use: 32 columns each, or (few-row form, same test as in the kernel) 1024 columns each
+        const bool few = jobs[i].nrows <= 16 && (jobs[i].ncols & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(jobs[i].in) | reinterpret_cast<uintptr_t>(jobs[i].out)) & 15) == 0;
+        const int need = few ? (jobs[i].ncols + 1023) / 1024 : (jobs[i].ncols + 31) / 32;
+        cmax = need > cmax ? need : cmax;
     }
-    dim3 grid((cmax + 31) / 32, n);
+    dim3 grid(cmax, n);
     colsum_batched_kernel<<<grid, 256, 0, ST>>>(jb);
     return vpu_check_launch("vpu_colsum_batched");
 }
