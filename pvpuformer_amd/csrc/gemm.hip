@@ -1096,11 +1096,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vpu_gemm_desc 
         epilogue_store<T>(p, coff, roff, (int)(i / p.N), (int)(i % p.N), v);
     }
     if (p.colsum != nullptr && z == 0) {
+        // fused bias gradient: 32 slice lanes x 8 rows per block, partial sums added in lane order through LDS (one
+        // thread per row walking up to 128 slices back to back was a ~30-us tail of the whole reduce launch)
+        __shared__ float redc[32][8];
         const float* wb = ws + (int64_t)gridDim.z * splitk * mn;
-        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
+        const int mi = threadIdx.x & 7, sl = threadIdx.x >> 3;
+        for (int mb = blockIdx.x * 8; mb < p.M; mb += gridDim.x * 8) {   // block-uniform trip count
+            const int m = mb + mi;
             float t = 0.f;
-            for (int s = 0; s < splitk; ++s) t += wb[(int64_t)s * p.M + m];
-            p.colsum[m] += t;
+            if (m < p.M)
+                for (int s = sl; s < splitk; s += 32) t += wb[(int64_t)s * p.M + m];
+            __syncthreads();
+            redc[sl][mi] = t;
+            __syncthreads();
+            if (sl == 0 && m < p.M) {
+                for (int q = 1; q < 32; ++q) t += redc[q][mi];
+                p.colsum[m] += t;
+            }
         }
     }
 }
