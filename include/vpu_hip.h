@@ -277,6 +277,12 @@ int vpu_nfl_dice_scratch_doubles(int32_t B);
 int vpu_nfl_dice_fwd_bwd(const float* logits, const float* gt, double* sums, float* out, float* dlogits, float w_nfl,
                          float w_dice, int32_t B, int64_t HW, void* stream);
 
+/* The logged scalars of one click iteration (trainer.py:399-419) from the loss kernels' partials, one launch:
+ * res[4] = {total, nfl, dice, p2cl}; out [B][2] from vpu_nfl_dice_fwd_bwd, part [npart] from vpu_p2cl(_up)_fwd_bwd,
+ * p2cl = sum(part) * inv_count, total = (w_nfl nfl + w_dice dice + w_pcl p2cl) * iter_weight. */
+int vpu_loss_finalize(const float* out, const float* part, int32_t B, int32_t npart, double inv_count, float w_nfl,
+                      float w_dice, float w_pcl, float iter_weight, float* res, void* stream);
+
 /* ---- optimizer (torch.optim.Adam as configured at vpu_base448_cocolvis.py:149-154) ---- */
 /* p,g,m,v fp32 [n]; shadow (bf16, optional) receives the rounded new parameters; lr_mult (optional) fp32 [n_seg] with
  * seg_of (int32 [n/seg_gran]) is not used in v1 (uniform lr). */

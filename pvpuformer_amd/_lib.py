@@ -87,6 +87,7 @@ SIGNATURES = {
     "vpu_p2cl_up_fwd_bwd": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P],
     "vpu_nfl_dice_scratch_doubles": [_I],
     "vpu_nfl_dice_fwd_bwd": [_P, _P, _P, _P, _P, _F, _F, _I, _L, _P],
+    "vpu_loss_finalize": [_P, _P, _I, _I, C.c_double, _F, _F, _F, _F, _P, _P],
     "vpu_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "vpu_adam_step_groups": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _F, _F, _F, _I, _I, _F, _P],
     "vpu_adam_step_hyper": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P],

@@ -334,6 +334,27 @@ __global__ void nfl_dice_final_kernel(const double* __restrict__ sums, float* __
     out[b * 2 + 1] = 1.f - (2.f * sm[2] + deps) / (sm[3] + sm[4] + deps);
 }
 
+// The logged scalars of one click iteration from the kernels' per-sample / per-plane partials in ONE launch (the torch
+// expression -- two means, a sum, a weighted total -- was eleven 5-us launches per step):
+// res = {total, nfl, dice, p2cl},  nfl = mean_b out[b][0], dice = mean_b out[b][1], p2cl = sum(part) * inv_count,
+// total = (w_nfl nfl + w_dice dice + w_pcl p2cl) * iter_weight  (trainer.py:399-419).  Sums in double, fixed order.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ out, const float* __restrict__ part,
+                                                            int B, int npart, double inv_count, float w_nfl, float w_dice,
+                                                            float w_pcl, float iter_weight, float* __restrict__ res) {
+    __shared__ double red[16];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) { a += out[2 * i]; b += out[2 * i + 1]; }
+    for (int i = threadIdx.x; i < npart; i += 256) c += part[i];
+    a = block_sum_d(a, red);
+    b = block_sum_d(b, red);
+    c = block_sum_d(c, red);
+    if (threadIdx.x == 0) {
+        const float nfl = (float)(a / B), dice = (float)(b / B), pcl = (float)(c * inv_count);
+        res[0] = (w_nfl * nfl + w_dice * dice + w_pcl * pcl) * iter_weight;
+        res[1] = nfl; res[2] = dice; res[3] = pcl;
+    }
+}
+
 }  // namespace
 
 extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_t* slot_mask_idx,
@@ -383,6 +404,14 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
     p2cl_up_kernel<<<(unsigned)(B * S * nband), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
                                                                   dsim_low, grad_scale, S, h, w, H, W, nband, max_rows, band);
     return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
+}
+
+extern "C" int vpu_loss_finalize(const float* out, const float* part, int32_t B, int32_t npart, double inv_count,
+                                 float w_nfl, float w_dice, float w_pcl, float iter_weight, float* res, void* stream) {
+    vpu_clear_stale_error();
+    if (!out || !part || !res || B < 1 || npart < 1) { vpu_set_error("loss_finalize: null pointer or empty input"); return VPU_ERR_ARG; }
+    loss_finalize_kernel<<<1, 256, 0, ST>>>(out, part, B, npart, inv_count, w_nfl, w_dice, w_pcl, iter_weight, res);
+    return vpu_check_launch("vpu_loss_finalize");
 }
 
 extern "C" int vpu_nfl_dice_scratch_doubles(int32_t B) { return B * (NFL_NBLK + 1) * 8; }

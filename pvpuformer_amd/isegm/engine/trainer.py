@@ -32,10 +32,9 @@ def vpu_step_losses(inst, aux, gt, slot_idx=None, override=None, iter_weight=1.0
         d_aux = torch.empty_like(sim_low) if want_grads else None
         ops.p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, part, d_aux, gs, B, S, sim_low.shape[2], sim_low.shape[3],
                             H, W)
-    nfl, dice = out[:, 0].mean(), out[:, 1].mean()
-    pcl = part.sum() / (B * S * H * W)
-    total = (w_nfl * nfl + w_dice * dice + w_pcl * pcl) * iter_weight
-    return {"total": total, "nfl": nfl, "dice": dice, "p2cl": pcl}, d_inst, d_aux
+    res = torch.empty(4, device=dev)
+    ops.loss_finalize(out, part, B, part.numel(), 1.0 / (B * S * H * W), w_nfl, w_dice, w_pcl, iter_weight, res)
+    return {"total": res[0], "nfl": res[1], "dice": res[2], "p2cl": res[3]}, d_inst, d_aux
 
 
 class VPUTrainStep:

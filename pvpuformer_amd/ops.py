@@ -324,6 +324,11 @@ def nfl_dice_fwd_bwd(logits, gt, sums, out, dlogits, w_nfl, w_dice, B, HW):
               _stream())
 
 
+def loss_finalize(out, part, B, npart, inv_count, w_nfl, w_dice, w_pcl, iter_weight, res):
+    _lib.call("vpu_loss_finalize", ptr(out), ptr(part), B, npart, float(inv_count), w_nfl, w_dice, w_pcl, iter_weight,
+              ptr(res), _stream())
+
+
 def adam_step_groups(p, g, m, v, shadow, n, seg_end, seg_lr, seg_wd, nseg, b1, b2, eps, decoupled, step, grad_scale=1.0):
     _lib.call("vpu_adam_step_groups", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, ptr(seg_end), ptr(seg_lr),
               ptr(seg_wd), nseg, b1, b2, eps, int(decoupled), step, grad_scale, _stream())
