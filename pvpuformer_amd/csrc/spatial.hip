@@ -737,6 +737,49 @@ __global__ __launch_bounds__(256) void convseg_fwd_kernel(const T* __restrict__ 
     s = wave_sum(s);
     if (lane == 0) out[row] = s + bias[0];
 }
+// C in {64, 128, 256, 512}: C / 8 lanes per pixel with 16-byte loads (a wave covers 64 / (C / 8) pixels per trip), weights
+// times dropout mask held in registers per sample -- the one-element-per-lane form above read 128 B per wave-instruction
+// (57 us for the 77-MB head map at ViT-B bs 12).
+template <typename T>
+__global__ __launch_bounds__(256) void convseg_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ mask, float* __restrict__ out,
+                                                              int64_t rows, int64_t HW, int C) {
+    const int lpr = C >> 3;                       // lanes per pixel
+    const int ppw = 64 / lpr;                     // pixels per wave and trip
+    const int lane = threadIdx.x & 63, sub = lane / lpr, cl = lane - sub * lpr;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    float ww[8], wm[8];
+    load8(w + cl * 8, ww);
+    int64_t cur_b = -1;
+    const float b0 = bias[0];
+    for (int64_t r0 = wave_id * ppw; r0 < rows; r0 += nwaves * ppw) {
+        const int64_t row = r0 + sub;
+        float s = 0.f;
+        if (row < rows) {
+            const int64_t b = row / HW;
+            if (b != cur_b) {
+                cur_b = b;
+                if (mask) {
+                    float mk[8];
+                    load8(mask + b * C + cl * 8, mk);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wm[j] = ww[j] * mk[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wm[j] = ww[j];
+                }
+            }
+            float v[8];
+            load8(x + row * C + cl * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j] * wm[j];
+        }
+        for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (cl == 0 && row < rows) out[row] = s + b0;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void convseg_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ mask,
@@ -1039,6 +1082,13 @@ extern "C" int vpu_gate_bwd(const void* dout, const void* x, const float* cg, co
 extern "C" int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out,
                                int64_t rows, int64_t HW, int32_t C, int32_t dtype, void* stream) {
     vpu_clear_stale_error();
+    if ((C == 64 || C == 128 || C == 256 || C == 512) && reinterpret_cast<uintptr_t>(x) % 32 == 0 &&
+        (reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mask)) % 32 == 0) {
+        const int64_t trips = (rows + (64 / (C / 8)) - 1) / (64 / (C / 8));   // wave trips
+        const unsigned grid = (unsigned)(trips / 4 < 1 ? 1 : (trips / 4 > 4096 ? 4096 : trips / 4));
+        DISPATCH_T(dtype, convseg_fwd_vec_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, w, bias, mask, out, rows, HW, C);)
+        return vpu_check_launch("vpu_convseg_fwd");
+    }
     DISPATCH_T(dtype, convseg_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)x, w, bias, mask, out,
                                                                                        rows, HW, C);)
     return vpu_check_launch("vpu_convseg_fwd");

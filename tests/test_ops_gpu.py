@@ -639,6 +639,9 @@ def test_gates_and_convseg(ops, dtype):
     ff, wf = f.float().requires_grad_(True), w.clone().requires_grad_(True)
     refo = ((ff.view(B, HW, Cc) * mask.view(B, 1, Cc)) * wf).sum(-1).view(rows) + bias
     torch.testing.assert_close(o, refo, atol=1e-4, rtol=1e-4)
+    f40, w40, o40 = dev(rnd(rows, 40, seed=45)).to(td), dev(rnd(40, seed=46, scale=0.1)), torch.empty(rows, device="cuda")
+    ops.convseg_fwd(f40, w40, bias, None, o40, rows, HW, 40)       # C = 40: the one-element-per-lane form, no mask
+    torch.testing.assert_close(o40, (f40.float() * w40).sum(-1) + bias, atol=1e-4, rtol=1e-4)
     do = dev(rnd(rows, seed=43))
     refo.backward(do)
     nb = ops.convseg_bwd_nblk(rows)
