@@ -64,6 +64,16 @@ def main():
     partl = torch.empty(ops.layernorm_bwd_nblk(rows), 2, Cd, device=dev)
     cases["layernorm_fwd"] = (lambda: ops.layernorm_fwd(xl, wl, bl, yl, mean, rstd, rows, Cd, 1e-6), rows * Cd * 4)
     cases["layernorm_bwd"] = (lambda: ops.layernorm_bwd(dyl, xl, wl, mean, rstd, drl, dxl, partl, rows, Cd), rows * Cd * 8)
+    Bg, HWg, Cg = 12, 12544, 128
+    xg = torch.randn(Bg * HWg, Cg, device=dev).to(torch.bfloat16)
+    dyg, yg, dxg = torch.randn_like(xg), torch.empty_like(xg), torch.empty_like(xg)
+    wg_, bg_ = torch.rand(Cg, device=dev), torch.rand(Cg, device=dev)
+    mg, rg = torch.empty(Bg, device=dev), torch.empty(Bg, device=dev)
+    nch = ops.groupnorm_nchunk()
+    stg = torch.empty(Bg, nch, 2, device=dev, dtype=torch.float64)
+    pg = torch.empty(Bg * nch, 2, Cg, device=dev)
+    cases["groupnorm_fwd"] = (lambda: ops.groupnorm_fwd(xg, wg_, bg_, yg, mg, rg, stg, Bg, HWg, Cg, 1e-5, True), xg.numel() * 6)
+    cases["groupnorm_bwd"] = (lambda: ops.groupnorm_bwd(dyg, xg, wg_, bg_, mg, rg, dxg, pg, stg, Bg, HWg, Cg, True), xg.numel() * 10)
     for name, (fn, nbytes) in cases.items():
         if only and not any(t in name for t in only):
             continue
