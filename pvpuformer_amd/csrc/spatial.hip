@@ -1,6 +1,7 @@
 // Spatial kernels of the VPUFormer path on channels-last maps: patch im2col (window token order), token
 // permutation, pixel shuffle for 2x2/stride-2 (transposed) convolutions, GroupNorm(1,C)[+GELU], bilinear resize,
 // DMA gates, conv_seg, final align_corners=True upsample.  All HBM-bound: vector accesses, fp32 math.
+#include <stdlib.h>
 #include "vpu_common.h"
 #include "../../include/vpu_hip.h"
 
@@ -579,6 +580,70 @@ __global__ __launch_bounds__(256) void bilinear_cl_bwd_int_kernel(const T* __res
     }
 }
 
+// The same gather with the (2R)^2 window of one input pixel cut into FOUR row slices (C = 256: 32 chunk lanes x 2 slices
+// per wave, 2 waves per pixel, two pixels per block): at R = 8 one thread per (pixel, chunk) walked 256 taps back to back
+// with only 75k threads in flight (93 us for the 14 x 14 level of the head); the slices are summed in a fixed order
+// (lane pair by shuffle, wave pair through LDS).
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bilinear_cl_bwd_int4_kernel(const T* __restrict__ dout, int ld_out,
+                                                                   T* __restrict__ din, int ld_in, int B, int h, int w) {
+    __shared__ float red[2][32][8];
+    const int H = R * h, W = R * w;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ck = lane & 31, part = (lane >> 5) | ((wave & 1) << 1);
+    const int64_t pix = (int64_t)blockIdx.x * 2 + (wave >> 1);
+    const bool live = pix < (int64_t)B * h * w;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (live) {
+        const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
+        const int Xs = R * x - R / 2, Ys = R * y - R / 2;
+        float wx[2 * R];
+#pragma unroll
+        for (int u = 0; u < 2 * R; ++u) {
+            const int X = Xs + u;
+            int x0, x1; float lx;
+            src_index_half(X < 0 ? 0 : X, sw, w, x0, x1, lx);
+            const float wgt = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            wx[u] = (X >= 0 && X < W) ? wgt : 0.f;
+        }
+#pragma unroll
+        for (int vv = 0; vv < R / 2; ++vv) {
+            const int Y = Ys + part * (R / 2) + vv;
+            if (Y < 0 || Y >= H) continue;
+            int y0, y1; float ly;
+            src_index_half(Y, sh, h, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            const T* rowp = dout + (((int64_t)b * H + Y) * W) * ld_out + ck * 8;
+#pragma unroll
+            for (int u = 0; u < 2 * R; ++u) {
+                const int X = Xs + u;
+                if (X >= 0 && X < W) {
+                    float g[8];
+                    load8(rowp + (int64_t)X * ld_out, g);
+                    const float ww = wy * wx[u];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += ww * g[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], 32, 64);
+    if ((wave & 1) && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave >> 1][ck][j] = acc[j];
+    }
+    __syncthreads();
+    if (!(wave & 1) && lane < 32 && live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += red[wave >> 1][ck][j];
+        store8(din + pix * ld_in + ck * 8, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------ DMA gates
 template <typename T>
 __global__ __launch_bounds__(256) void gate_colmax_kernel(const T* __restrict__ Q, float* __restrict__ cg,
@@ -1034,6 +1099,14 @@ extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, 
     if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl_bwd: C, ld % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * h * w * (C / 8);
     const int R = (h > 0 && w > 0 && H % h == 0 && W % w == 0 && H / h == W / w) ? H / h : 0;
+    static const int split_min = [] { const char* e = getenv("VPU_BILINEAR_SPLIT_R"); return e ? atoi(e) : 8; }();
+    if ((R == 4 || R == 8) && R >= split_min && C == 256) {   // few input pixels, long gathers: four slices per window
+        const unsigned g2 = (unsigned)(((int64_t)B * h * w + 1) / 2);
+        DISPATCH_T(dtype,
+                   if (R == 4) bilinear_cl_bwd_int4_kernel<T, 4><<<g2, 256, 0, ST>>>((const T*)dout, ld_out, (T*)din, ld_in, B, h, w);
+                   else bilinear_cl_bwd_int4_kernel<T, 8><<<g2, 256, 0, ST>>>((const T*)dout, ld_out, (T*)din, ld_in, B, h, w);)
+        return vpu_check_launch("vpu_bilinear_cl_bwd");
+    }
     if (R == 2 || R == 4 || R == 8) {
         DISPATCH_T(dtype,
                    if (R == 2) bilinear_cl_bwd_int_kernel<T, 2><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(

@@ -549,6 +549,22 @@ def test_groupnorm(ops, dtype, C, gelu):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("h", [14, 28])
+def test_bilinear_backward_sliced_windows(ops, dtype, h, monkeypatch):
+    """C = 256, ratio 8 (and 4 with VPU_BILINEAR_SPLIT_R=4 set before the library is first used): the gather window of
+    an input pixel is cut into four row slices summed in a fixed order -- same result as autograd of F.interpolate."""
+    td = TD[dtype]
+    B, C, H = 2, 256, 112
+    dout = dev(rnd(B, H, H, C, seed=80)).to(td)
+    xf = torch.zeros(B, C, h, h, device="cuda", requires_grad=True)
+    F.interpolate(xf, size=(H, H), mode="bilinear", align_corners=False).backward(dout.float().permute(0, 3, 1, 2))
+    din = torch.empty(B, h, h, C, device="cuda", dtype=td)
+    ops.bilinear_cl_bwd(dout, C, din, C, B, h, h, H, H, C, dtype)
+    torch.testing.assert_close(din.float(), xf.grad.permute(0, 2, 3, 1), atol=0.25 if dtype == 0 else 2e-5,
+                               rtol=3e-2 if dtype == 0 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("h", [14, 28, 56, 112])
 def test_bilinear_channels_last(ops, dtype, h):
     td = TD[dtype]
