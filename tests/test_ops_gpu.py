@@ -375,6 +375,15 @@ def test_colsum_l2norm_add_cast(ops, dtype):
     dx = torch.empty_like(xs)
     ops.l2norm_bwd(dy, y, inv, dx, rows, C)
     torch.testing.assert_close(dx.float(), xf.grad, atol=2e-2 if dtype == 0 else 1e-5, rtol=5e-2 if dtype == 0 else 1e-4)
+    x40 = dev(rnd(77, 40, seed=20)).to(td)          # C = 40: the one-element-per-lane kernels
+    y40, inv40, dx40 = torch.empty_like(x40), torch.empty(77, device="cuda"), torch.empty_like(x40)
+    ops.l2norm_fwd(x40, y40, inv40, 77, 40)
+    x40f = x40.float().requires_grad_(True)
+    r40 = F.normalize(x40f, p=2, dim=1)
+    torch.testing.assert_close(y40.float(), r40, **tol)
+    r40.backward(torch.ones_like(r40))
+    ops.l2norm_bwd(torch.ones_like(x40), y40, inv40, dx40, 77, 40)
+    torch.testing.assert_close(dx40.float(), x40f.grad, atol=3e-2 if dtype == 0 else 1e-5, rtol=5e-2 if dtype == 0 else 1e-4)
     a, pe = dev(rnd(6, 40, 64, seed=17)).to(td), dev(rnd(40, 64, seed=18)).to(td)
     o = torch.empty_like(a)
     ops.add_bcast(a, pe, o, a.numel(), pe.numel())
