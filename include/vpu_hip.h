@@ -236,7 +236,7 @@ int vpu_gate_apply(const void* x, const float* cg, const float* sg, void* out, i
                    int32_t dtype, void* stream);
 /* backward: dx (+)= dout*(1+cg+sg) (accum!=0 adds into dx); dQ[b][argq][c] += dcg*cg*(1-cg);
  * dK[b][n][argc] += dsg*sg*(1-sg).  dQ / dK must already hold the upstream gradient (they are accumulated into).
- * part = workspace fp32 [B][nblk][C]. */
+ * part = workspace fp32 [B][64][C]. */
 int vpu_gate_bwd(const void* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
                  const int32_t* argc, void* dx, int32_t accum, void* dQ, void* dK, float* part, int32_t B, int32_t nq,
                  int32_t N, int32_t C, int32_t dtype, void* stream);

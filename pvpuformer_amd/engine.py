@@ -685,7 +685,7 @@ class Engine:
                         xr.g = torch.empty_like(xr.t)
                     for t_ in (xr.g, qi.g, ki.g):
                         self._writable(t_)
-                    part = self._new(B, 16, D, dtype=torch.float32)
+                    part = self._new(B, 64, D, dtype=torch.float32)
                     ops.gate_bwd(xg.g, xr.t, cg, aq, sg, ac, xr.g, accum, qi.g, ki.g, part, B, nq, NT, D)
                 self.tape.append(bwd_gate)
             maps.append(xg)

@@ -648,7 +648,7 @@ def test_gates_and_convseg(ops, dtype):
     dx = dev(rnd(B, N, C, seed=38)).to(td)
     dx0 = dx.float().clone()
     dQ, dK = torch.zeros_like(Q), torch.zeros_like(K)
-    part = torch.zeros(B, 16, C, device="cuda")
+    part = torch.zeros(B, 64, C, device="cuda")
     ops.gate_bwd(dout, x, cg, aq, sg, ac, dx, True, dQ, dK, part, B, nq, N, C)
     bt = dict(atol=6e-2, rtol=3e-2) if dtype == 0 else dict(atol=2e-5, rtol=1e-4)
     torch.testing.assert_close(dx.float(), dx0 + xf.grad, **bt)
