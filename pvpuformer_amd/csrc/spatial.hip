@@ -36,6 +36,26 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
         const int win = tw / (wg * wg), inner = tw % (wg * wg);
         const int ty = (win / nwx) * wg + inner / wg, tx = (win % nwx) * wg + inner % wg;
         float o[8];
+        if ((P & 7) == 0) {
+            // P % 8 == 0 (patch 16): the 8 columns of a chunk are 8 consecutive pixels of one patch row of one channel --
+            // one set of index divisions and two 16-byte loads per thread (the element-wise form below: six divisions and
+            // a 4-byte load per element, 53 us at ViT-B bs 12)
+            const int k = ck * 8;
+            const int half = k / K3P, kk = k - half * K3P;
+            const int chl = kk / (P * P), rem = kk - chl * (P * P);
+            const int ch = half * 3 + chl;
+            const int y = ty * P + rem / P, x = tx * P + rem % P;
+            const float* src = ch < 4 ? img4 + (((int64_t)b * 4 + ch) * H + y) * W + x
+                                      : disks + (((int64_t)b * 2 + (ch - 4)) * H + y) * W + x;
+            load8(src, o);
+            if (ch < 3) {
+                const float mu = c_mean[ch], isd = c_std[ch];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (o[j] - mu) / isd;
+            }
+            store8(cols + row * KK + ck * 8, o);
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = ck * 8 + j;
