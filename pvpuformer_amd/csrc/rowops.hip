@@ -306,13 +306,16 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__
 }
 
 constexpr int CS_SLABS = 64;   // rows of the caller's partial buffer ([64][C], include/vpu_hip.h)
-// block = 16 column-lanes (8 columns each = 128 columns) x 16 row groups; grid = (C/128, 64 row slabs)
-template <typename T>
+// block = CL column-lanes (8 columns each) x 256/CL row groups; grid = (C / (8 CL), 64 row slabs).  CL = 16 for wide maps;
+// narrow ones (C <= 256 over 150528 rows: the bias gradient of the FPN's transposed convolutions) take CL = 8 / 4 so that
+// the launch still has >= 256 workgroups (two column blocks x 64 slabs = 128 workgroups streamed 77 MB in 29 us).
+template <typename T, int CL>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ in, int ld, float* __restrict__ part,
                                                           int64_t rows, int C) {
-    __shared__ float red[16][129];
-    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = (blockIdx.x * 16 + cl) * 8;
+    constexpr int RG = 256 / CL;
+    __shared__ float red[RG][CL * 8 + 1];
+    const int cl = threadIdx.x % CL, grp = threadIdx.x / CL;
+    const int c = (blockIdx.x * CL + cl) * 8;
     const int64_t per = (rows + CS_SLABS - 1) / CS_SLABS;
     const int64_t r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float a[8];
@@ -320,14 +323,14 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (c < C) {
         int64_t r = r0 + grp;
-        for (; r + 16 < r1; r += 32) {  // two independent 16-byte loads in flight per lane
+        for (; r + RG < r1; r += 2 * RG) {  // two independent 16-byte loads in flight per lane
             float v0[8], v1[8];
             load8(in + r * ld + c, v0);
-            load8(in + (r + 16) * ld + c, v1);
+            load8(in + (r + RG) * ld + c, v1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += v0[j] + v1[j];
         }
-        for (; r < r1; r += 16) {
+        for (; r < r1; r += RG) {
             float v[8];
             load8(in + r * ld + c, v);
 #pragma unroll
@@ -337,12 +340,12 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[grp][cl * 8 + j] = a[j];
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int cc = blockIdx.x * 128 + threadIdx.x;
+    if (threadIdx.x < CL * 8) {
+        const int cc = blockIdx.x * CL * 8 + threadIdx.x;
         if (cc < C) {
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+            for (int g = 0; g < RG; ++g) t += red[g][threadIdx.x];
             part[(int64_t)blockIdx.y * C + cc] = t;
         }
     }
@@ -634,8 +637,16 @@ extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, i
         DISPATCH_T(dtype, colsum_small_kernel<T><<<g, 256, 0, ST>>>((const T*)in, ld, out, (int)rows, C, beta);)
         return vpu_check_launch("vpu_colsum");
     }
-    dim3 grid((C + 127) / 128, CS_SLABS);
-    DISPATCH_T(dtype, colsum_part_kernel<T><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
+    if (C <= 128) {
+        dim3 grid((C + 31) / 32, CS_SLABS);
+        DISPATCH_T(dtype, colsum_part_kernel<T, 4><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
+    } else if (C <= 256) {
+        dim3 grid((C + 63) / 64, CS_SLABS);
+        DISPATCH_T(dtype, colsum_part_kernel<T, 8><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
+    } else {
+        dim3 grid((C + 127) / 128, CS_SLABS);
+        DISPATCH_T(dtype, colsum_part_kernel<T, 16><<<grid, 256, 0, ST>>>((const T*)in, ld, part, rows, C);)
+    }
     colsum_f32_kernel<<<(C + 31) / 32, 256, 0, ST>>>(part, out, CS_SLABS, C, beta);
     return vpu_check_launch("vpu_colsum");
 }
