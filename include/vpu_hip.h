@@ -244,7 +244,9 @@ int vpu_gate_bwd(const void* dout, const void* x, const float* cg, const int32_t
  * rows = B*HW; mask fp32 [B][C] (keep/(1-p)) or NULL; out fp32 [rows]. */
 int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out, int64_t rows,
                     int64_t HW, int32_t C, int32_t dtype, void* stream);
-/* dx[r][c] = dout[r]*w[c]*mask (accum!=0: added into dx); dw partials -> part[nblk][C]; db partial -> part_b[nblk] */
+/* dx[r][c] = dout[r]*w[c]*mask (accum bit 0: added into dx; bit 1: the result is multiplied by [x > 0], i.e. x is a ReLU
+ * output whose gradient is complete with this call and dx leaves as the pre-activation gradient);
+ * dw partials -> part[nblk][C]; db partial -> part_b[nblk] */
 int vpu_convseg_bwd_nblk(int64_t rows);
 int vpu_convseg_bwd(const float* dout, const void* x, const float* w, const float* mask, void* dx, int32_t accum,
                     float* part, float* part_b, int64_t rows, int64_t HW, int32_t C, int32_t dtype, void* stream);

@@ -902,7 +902,8 @@ __global__ __launch_bounds__(256) void convseg_bwd_kernel(const float* __restric
                 const float xv = to_f32(x[row * C + c]);
                 dwa[i] += d * xv * mk;
                 float o = d * w[c] * mk;
-                if (accum) o += to_f32(dx[row * C + c]);
+                if (accum & 1) o += to_f32(dx[row * C + c]);
+                if ((accum & 2) && !(to_f32(x[row * C + c]) > 0.f)) o = 0.f;   // ReLU' of the map x itself (see vec kernel)
                 dx[row * C + c] = from_f32<T>(o);
             }
         }
@@ -952,11 +953,15 @@ __global__ __launch_bounds__(256) void convseg_bwd_vec_kernel(const float* __res
             load8(x + row * C + c8, xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { dwa[j] += d * xv[j] * mk[j]; o[j] = d * wv[j] * mk[j]; }
-            if (accum) {
+            if (accum & 1) {
                 float old[8];
                 load8(dx + row * C + c8, old);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] += old[j];
+            }
+            if (accum & 2) {   // x is the output of a ReLU and dx its complete gradient: hand back the pre-activation gradient
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = xv[j] > 0.f ? o[j] : 0.f;
             }
             store8(dx + row * C + c8, o);
         }

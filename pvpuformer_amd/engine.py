@@ -739,12 +739,16 @@ class Engine:
             ops.gemm(ys[i].t, (wf[0], wf[1] + i * Cc), z, B * s * s, Cc, Cc, Cc, ldf, Cc, self.dt)
             zs.append((z, s, s))
         ops.upsum_relu(fused.t, zs, B, Hs, Hs, Cc, self.dt)
+        relu_done = [False]     # conv_seg's backward (the last writer of fused.g) has already applied fused's ReLU'
         if training:
             def bwd_fusion():
                 if fused.g is None:
                     return
-                dt_ = self._new(B * HW4, Cc)
-                ops.act_bwd(fused.g, Cc, fused.t, Cc, dt_, Cc, B * HW4, Cc, 0, self.dt)
+                if relu_done[0]:
+                    dt_ = fused.g
+                else:
+                    dt_ = self._new(B * HW4, Cc)
+                    ops.act_bwd(fused.g, Cc, fused.t, Cc, dt_, Cc, B * HW4, Cc, 0, self.dt)
                 self._wgrad(dt_, Cc, ys[0].t, Cc, gf, Cc, Cc, B * HW4, ldc=ldf, bias="head.fusion_conv.conv.bias")
                 self._dgrad(dt_, Cc, wf, ldf, ys[0], B * HW4, Cc, Cc)
                 for i in (1, 2, 3):
@@ -811,8 +815,11 @@ class Engine:
                     if not accum:
                         fused.g = torch.empty_like(fused.t)
                     self._writable(fused.g)
-                    ops.convseg_bwd(dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask, fused.g, accum, part,
+                    # accum bit 1: fused.g is complete with this call -> it leaves multiplied by [fused > 0] (one pass less
+                    # over the 77-MB map than a separate ReLU' kernel)
+                    ops.convseg_bwd(dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask, fused.g, int(accum) | 2, part,
                                     part_b, B * HW4, HW4, Cc)
+                    relu_done[0] = True
                     ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
                     ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
             # must run BEFORE the closures of query / fused: insert at the position just after they were recorded

@@ -676,6 +676,12 @@ def test_gates_and_convseg(ops, dtype):
     torch.testing.assert_close(dfe.float(), ff.grad, atol=2e-3 if dtype == 0 else 1e-6, rtol=2e-2 if dtype == 0 else 1e-5)
     torch.testing.assert_close(part.sum(0), wf.grad, atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(part_b.sum(), do.sum(), atol=1e-3, rtol=1e-4)
+    # accum bit 1: the gradient leaves multiplied by [x > 0] (x = output of a ReLU); bit 0 adds into dx first
+    base = dev(rnd(rows, Cc, seed=47)).to(td)
+    dfm = base.clone()
+    ops.convseg_bwd(do, f, w, mask, dfm, 3, part, part_b, rows, HW, Cc)
+    want = (ff.grad + base.float()) * (f.float() > 0)
+    torch.testing.assert_close(dfm.float(), want, atol=2e-2 if dtype == 0 else 1e-6, rtol=2e-2 if dtype == 0 else 1e-5)
 
 
 def test_upsample_and_losses(ops):
