@@ -271,8 +271,10 @@ class Engine:
             ops.gemm(*args, **kw)
 
     # ------------------------------------------------------------------------------------------ ops with backward
-    def linear(self, x, wname, bname, M, N, K, act=None, resid=None, out=None, x_grad=True, group=False):
-        """y = act(x W^T + b) [+ resid].  ``out`` = (Var, col_offset, ld) writes into a column slice of a wider map."""
+    def linear(self, x, wname, bname, M, N, K, act=None, resid=None, out=None, x_grad=True, group=False, pre_masked=None):
+        """y = act(x W^T + b) [+ resid].  ``out`` = (Var, col_offset, ld) writes into a column slice of a wider map.
+        ``pre_masked``: a one-element list the producer of y.g sets to True when it has already multiplied the gradient
+        by the ReLU mask of y (e.g. in a dgrad epilogue, EPI_DRELU with aux = y) -- the separate mask pass is skipped."""
         assert not (act and resid is not None)
         if out is None:
             y = Var(self._new(M, N))
@@ -296,7 +298,7 @@ class Engine:
                 if resid is not None:
                     assert out is None
                     self.acc(resid, y.g, take=True)
-                if act == "relu":
+                if act == "relu" and not (pre_masked is not None and pre_masked[0]):
                     dz = self._new(M, N)
                     ops.act_bwd(dy, ldc, (yt, yoff), ldc, dz, N, M, N, 0, self.dt)
                     dy, ld = dz, N
@@ -726,10 +728,11 @@ class Engine:
         wf, ldf = self.W("head.fusion_conv.conv.weight"), 4 * Cc
         gf = self.G("head.fusion_conv.conv.weight")
         ys, zs = [], []
+        ymask = [[False] for _ in range(4)]     # set by bwd_fusion: its dgrads apply the ReLU' of ys[i] in their epilogue
         for i in range(4):
             f, s = feats[i]
             ys.append(self.linear(f, f"head.convs.{i}.conv.weight", f"head.convs.{i}.conv.bias", B * s * s, Cc, o[i],
-                                  act="relu"))
+                                  act="relu", pre_masked=ymask[i]))
         fused = Var(self._new(B * HW4, Cc))
         ops.gemm(ys[0].t, wf, fused.t, B * HW4, Cc, Cc, Cc, ldf, Cc, self.dt, flags=EPI_BIAS,
                  bias=self.Pm("head.fusion_conv.conv.bias"))
@@ -750,13 +753,18 @@ class Engine:
                     dt_ = self._new(B * HW4, Cc)
                     ops.act_bwd(fused.g, Cc, fused.t, Cc, dt_, Cc, B * HW4, Cc, 0, self.dt)
                 self._wgrad(dt_, Cc, ys[0].t, Cc, gf, Cc, Cc, B * HW4, ldc=ldf, bias="head.fusion_conv.conv.bias")
-                self._dgrad(dt_, Cc, wf, ldf, ys[0], B * HW4, Cc, Cc)
+                fuse_mask = self.dt == BF16      # (the fp32 parity path keeps the separate mask pass)
+                mk = dict(flags=EPI_DRELU, ldaux=Cc) if fuse_mask else {}
+                self._dgrad(dt_, Cc, wf, ldf, ys[0], B * HW4, Cc, Cc, **(dict(mk, aux=ys[0].t) if fuse_mask else {}))
+                ymask[0][0] = fuse_mask
                 for i in (1, 2, 3):
                     s = feats[i][1]
                     dz = self._new(B * s * s, Cc)
                     ops.bilinear_cl_bwd(dt_, Cc, dz, Cc, B, s, s, Hs, Hs, Cc, self.dt)
                     self._wgrad(dz, Cc, ys[i].t, Cc, (gf[0], gf[1] + i * Cc), Cc, Cc, B * s * s, ldc=ldf)
-                    self._dgrad(dz, Cc, (wf[0], wf[1] + i * Cc), ldf, ys[i], B * s * s, Cc, Cc)
+                    self._dgrad(dz, Cc, (wf[0], wf[1] + i * Cc), ldf, ys[i], B * s * s, Cc, Cc,
+                                **(dict(mk, aux=ys[i].t) if fuse_mask else {}))
+                    ymask[i][0] = fuse_mask
             self.tape.append(bwd_fusion)
         seg = self._new(B * HW4, dtype=torch.float32)
         ops.convseg_fwd(fused.t, self.Pm("head.conv_seg.weight"), self.Pm("head.conv_seg.bias"), drop_mask, seg,
