@@ -87,6 +87,9 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     float* sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
     float* sg = sm + (BAND + 2) * w;    // sg[(y - r0) * w + x]
     float* hr = sg + BAND * w;          // hr[(y - (r0 - 1)) * W + X]: rows of sv interpolated along x
+    // (gp in raster order: the cell pass's stride-4 gathers are 4-way bank conflicts -- 27 % of the kernel's LDS cycles, PMC --
+    // but a column-permuted layout that makes them conflict-free costs four 4-byte stores per pixel quad in the pixel pass
+    // and measured slower, 570 vs 547 us: the kernel is issue-bound, not LDS-bound)
     float* gp = hr + (BAND + 2) * W;    // gp[(Y - Y0) * W + X]
     const int ov = slot_idx ? slot_idx[plane] : -1;
     const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
