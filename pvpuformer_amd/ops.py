@@ -21,8 +21,21 @@ def code_of(t):
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+# The raw handle of torch's current stream: torch.cuda.current_stream() builds a Stream object through three layers of
+# Python device-index helpers (~5 us, once per kernel launch: ~2 ms of host time per training step);
+# torch._C._cuda_getCurrentRawStream is the C entry point the same value comes from.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_handle(device_index=None):
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device() if device_index is None else device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 def ptr(t, off=0):
@@ -41,7 +54,7 @@ _WORKSPACE = {}
 def split_k_workspace(device, nbytes=128 << 20):
     """fp32 scratch shared by every GEMM launched on ``device`` (launches on one stream are serialised, so one buffer
     is enough).  Passed to vpu_gemm, whose host side decides per launch whether to split K."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)   # one scratch buffer per stream
+    key = (device.index if device.index is not None else -1, _stream_handle(device.index))   # one scratch buffer per stream
     ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)   # (zeroed: its tail holds tile counters)
