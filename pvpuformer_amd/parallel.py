@@ -8,14 +8,16 @@ through ``Engine.grad_ready_hook``.  The reducer coalesces ranges into buckets o
 asynchronous SUM all-reduce per bucket as soon as it is complete, so the exchange overlaps the rest of backward; the
 29 never-used tensors are just zeros inside the flat buffer (no find_unused_parameters machinery).  The mean is folded
 into the optimizer (grad_scale = 1/world_size).  xGMI is point-to-point (7 links x ~153 GB/s): few large buckets keep
-every link busy; ViT-B's 489 MB of fp32 gradients go out in ~8 collectives.
+every link busy.  Bucket size: the engine reports one range per ViT block (28 MB of fp32 gradients at ViT-B) after the
+152-MB head + neck range; with 25-MB buckets every block's range goes out as soon as it is final, so the only exchange left
+after backward ends is block 0 (28 MB) + the patch embeddings -- with 64-MB buckets it was the last three blocks (85 MB).
 """
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_grad, group=None, bucket_bytes=64 << 20):
+    def __init__(self, flat_grad, group=None, bucket_bytes=25 << 20):
         self.g = flat_grad
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
