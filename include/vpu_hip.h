@@ -228,6 +228,14 @@ int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, int32_t ld_
  * align_corners False (wrappers.py:8-28); in place; n <= 3. */
 int vpu_upsum_relu(void* io, const void* const* z, const int32_t* h, const int32_t* w, int32_t n, int32_t B, int32_t H,
                    int32_t W, int32_t C, int32_t dtype, void* stream);
+/* Head backward of the fused map in one pass (bf16, C in {64,128,256,512}): the gradient through the L2 normalisation of
+ * the P2CL branch (dfn = gradient of fn = y, inv = 1/|fused| from vpu_l2norm_fwd) + conv_seg's input gradient (dout [rows]
+ * fp32, w [C], mask [B][C] or NULL) with the ReLU' of the fused map x applied to the sum; conv_seg's weight / bias gradient
+ * partials go to part[nblk][C] / part_b[nblk] with nblk = vpu_convseg_bwd_nblk(rows)
+ * (swin_transformer.py:744-767, decode_head.py:210-215).  Equals vpu_l2norm_bwd followed by vpu_convseg_bwd(accum = 3). */
+int vpu_head_grad_fused(const void* dfn, const void* y, const float* inv, const float* dout, const void* x, const float* w,
+                        const float* mask, void* dx, float* part, float* part_b, int64_t rows, int64_t HW, int32_t C,
+                        int32_t dtype, void* stream);
 /* DMA gates (is_vpu_model.py:106-121): cg[b][c] = sigmoid(max_q Q[b][q][c]), sg[b][n] = sigmoid(max_c K[b][n][c]),
  * out = x*(1+cg+sg). arg* record the arg-max for backward. */
 int vpu_gate_stats(const void* Q, const void* Kt, float* cg, int32_t* argq, float* sg, int32_t* argc, int32_t B,

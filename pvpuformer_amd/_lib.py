@@ -73,6 +73,7 @@ SIGNATURES = {
     "vpu_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P],
     "vpu_bilinear_cl_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpu_bilinear_cl_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_head_grad_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P],
     "vpu_upsum_relu": [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _I, _I, _I, _P],
     "vpu_gate_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpu_gate_apply": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

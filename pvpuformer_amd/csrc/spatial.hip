@@ -982,6 +982,75 @@ __global__ __launch_bounds__(256) void convseg_bwd_vec_kernel(const float* __res
     if (threadIdx.x == 0) part_b[blockIdx.x] = redb[0] + redb[1] + redb[2] + redb[3];
 }
 
+// Head backward, both gradient paths of the fused map in ONE pass: the P2CL path (gradient of fn = fused / |fused| through
+// the L2 normalisation, losses.py:155-176 via swin_transformer.py:759-767) and the mask path (conv_seg + Dropout2d,
+// decode_head.py:210-215), with the ReLU' of the fused map applied to their sum:
+//     dx[r][c] = [x > 0] * ( inv[r] * (dfn[r][c] - y[r][c] * sum_c' dfn[r][c'] y[r][c']) + dout[r] * w[c] * mask[b][c] )
+// plus conv_seg's weight / bias gradient partials.  The separate kernels (l2norm_bwd, then convseg_bwd accumulating into
+// its output) moved the 77-MB gradient map through HBM twice more.  bf16, C in {64, 128, 256, 512}.
+__global__ __launch_bounds__(256) void head_grad_fused_kernel(const bf16_t* __restrict__ dfn, const bf16_t* __restrict__ y,
+                                                              const float* __restrict__ inv, const float* __restrict__ dout,
+                                                              const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ mask, bf16_t* __restrict__ dx,
+                                                              float* __restrict__ part, float* __restrict__ part_b,
+                                                              int64_t rows, int64_t HW, int C, int nblk) {
+    __shared__ float red[4][512];
+    __shared__ float redb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lpr = C >> 3, rpp = 64 / lpr;
+    const int sub = lane / lpr, c8 = (lane % lpr) * 8;
+    float wv[8];
+    load8(w + c8, wv);
+    float dwa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dba = 0.f;
+    const int64_t per = (rows + nblk - 1) / nblk;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    for (int64_t rb = r0 + (int64_t)wave * rpp; rb < r1; rb += 4 * rpp) {
+        const int64_t row = rb + sub;
+        const bool live = row < r1;
+        float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, yv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8];
+        float d = 0.f, iv = 0.f;
+        if (live) {
+            load8(dfn + row * C + c8, g);
+            load8(y + row * C + c8, yv);
+            load8(x + row * C + c8, xv);
+            d = dout[row];
+            iv = inv[row];
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sdot += g[j] * yv[j];
+        for (int o = lpr >> 1; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);   // (every lane takes part: rows beyond r1 add 0)
+        if (live) {
+            const int64_t b = row / HW;
+            if (c8 == 0) dba += d;
+            float mk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (mask) load8(mask + b * C + c8, mk);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dwa[j] += d * xv[j] * mk[j];
+                const float t = iv * (g[j] - yv[j] * sdot) + d * wv[j] * mk[j];
+                o[j] = xv[j] > 0.f ? t : 0.f;
+            }
+            store8(dx + row * C + c8, o);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int o = lpr; o < 64; o <<= 1) dwa[j] += __shfl_xor(dwa[j], o, 64);
+    dba = wave_sum(dba);
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][c8 + j] = dwa[j];
+    }
+    if (lane == 0) redb[wave] = dba;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        part[(int64_t)blockIdx.x * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (threadIdx.x == 0) part_b[blockIdx.x] = redb[0] + redb[1] + redb[2] + redb[3];
+}
+
 // ------------------------------------------------------------------------------ align_corners=True upsample (planes)
 __device__ __forceinline__ void src_index_ac(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
     const float s = scale * (float)dst;
@@ -1247,6 +1316,23 @@ extern "C" int vpu_convseg_bwd(const float* dout, const void* x, const float* w,
     DISPATCH_T(dtype, convseg_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dout, (const T*)x, w, mask, (T*)dx, accum, part,
                                                                  part_b, rows, HW, C, nblk);)
     return vpu_check_launch("vpu_convseg_bwd");
+}
+extern "C" int vpu_head_grad_fused(const void* dfn, const void* y, const float* inv, const float* dout, const void* x,
+                                   const float* w, const float* mask, void* dx, float* part, float* part_b, int64_t rows,
+                                   int64_t HW, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (dtype != VPU_BF16 || !(C == 64 || C == 128 || C == 256 || C == 512) || !dfn || !y || !inv || !dout || !x || !w ||
+        !dx || !part || !part_b || rows < 1 ||
+        (reinterpret_cast<uintptr_t>(dfn) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) |
+         reinterpret_cast<uintptr_t>(dx)) % 16 != 0 ||
+        (reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mask)) % 32 != 0) {
+        vpu_set_error("head_grad_fused: bf16, C in {64,128,256,512}, 16-byte aligned maps, 32-byte aligned w / mask");
+        return VPU_ERR_ARG;
+    }
+    const int nblk = vpu_convseg_bwd_nblk(rows);
+    head_grad_fused_kernel<<<nblk, 256, 0, ST>>>((const bf16_t*)dfn, (const bf16_t*)y, inv, dout, (const bf16_t*)x, w, mask,
+                                                 (bf16_t*)dx, part, part_b, rows, HW, C, nblk);
+    return vpu_check_launch("vpu_head_grad_fused");
 }
 extern "C" int vpu_upsample_ac_fwd(const float* in, float* out, int64_t planes, int32_t h, int32_t w, int32_t H,
                                    int32_t W, void* stream) {

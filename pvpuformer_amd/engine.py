@@ -811,14 +811,26 @@ class Engine:
                              inner=1, sA=(nq * HW4, 0), sB=(HW4 * Cc, 0), sC=(nq * Cc, 0))
                     ops.gemm(dsim_t, qn.t, fn.g, HW4, Cc, nq, HW4, Cc, Cc, self.dt, transA=True, transB=True, alpha=0.5,
                              batch=B, inner=1, sA=(nq * HW4, 0), sB=(nq * Cc, 0), sC=(HW4 * Cc, 0))
-                    query.g, fused.g = torch.empty_like(query.t), torch.empty_like(fused.t)
+                    query.g = torch.empty_like(query.t)
                     ops.l2norm_bwd(qn.g, qn.t, inv_q, query.g, B * nq, Cc)
-                    ops.l2norm_bwd(fn.g, fn.t, inv_f, fused.g, B * HW4, Cc)
+                    # both gradient paths of the fused map in one pass (vpu_head_grad_fused) when the mask loss is there too
+                    one_pass = d_inst is not None and self.dt == BF16 and Cc in (64, 128, 256, 512)
+                    if not one_pass:
+                        fused.g = torch.empty_like(fused.t)
+                        ops.l2norm_bwd(fn.g, fn.t, inv_f, fused.g, B * HW4, Cc)
                 if d_inst is not None:
                     dseg = self._new(B * HW4, dtype=torch.float32)
                     ops.upsample_ac_bwd(d_inst, dseg, B, Hs, Hs, H, W_)
                     nb = ops.convseg_bwd_nblk(B * HW4)
                     part, part_b = self._new(nb, Cc, dtype=torch.float32), self._new(nb, dtype=torch.float32)
+                    if (d_aux is not None or d_sim_low is not None) and one_pass:
+                        fused.g = torch.empty_like(fused.t)
+                        ops.head_grad_fused(fn.g, fn.t, inv_f, dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask,
+                                            fused.g, part, part_b, B * HW4, HW4, Cc)
+                        relu_done[0] = True
+                        ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
+                        ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
+                        return
                     accum = fused.g is not None
                     if not accum:
                         fused.g = torch.empty_like(fused.t)

@@ -307,6 +307,11 @@ def convseg_bwd(dout, x, w, mask, dx, accum, part, part_b, rows, HW, Cdim):
               rows, HW, Cdim, code_of(x), _stream())
 
 
+def head_grad_fused(dfn, y, inv, dout, x, w, mask, dx, part, part_b, rows, HW, Cdim):
+    _lib.call("vpu_head_grad_fused", ptr(dfn), ptr(y), ptr(inv), ptr(dout), ptr(x), ptr(w), ptr(mask), ptr(dx), ptr(part),
+              ptr(part_b), rows, HW, Cdim, code_of(x), _stream())
+
+
 def upsample_ac_fwd(inp, out, planes, h, w, H, W):
     _lib.call("vpu_upsample_ac_fwd", ptr(inp), ptr(out), planes, h, w, H, W, _stream())
 

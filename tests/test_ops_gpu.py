@@ -676,6 +676,19 @@ def test_gates_and_convseg(ops, dtype):
     torch.testing.assert_close(dfe.float(), ff.grad, atol=2e-3 if dtype == 0 else 1e-6, rtol=2e-2 if dtype == 0 else 1e-5)
     torch.testing.assert_close(part.sum(0), wf.grad, atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(part_b.sum(), do.sum(), atol=1e-3, rtol=1e-4)
+    if dtype == 0:   # vpu_head_grad_fused == l2norm_bwd followed by convseg_bwd(accum = 3), one pass
+        yn, invn = torch.empty_like(f), torch.empty(rows, device="cuda")
+        ops.l2norm_fwd(f, yn, invn, rows, Cc)
+        dfn = dev(rnd(rows, Cc, seed=48)).to(td)
+        two = torch.empty_like(f)
+        ops.l2norm_bwd(dfn, yn, invn, two, rows, Cc)
+        p2, pb2 = torch.zeros(nb, Cc, device="cuda"), torch.zeros(nb, device="cuda")
+        ops.convseg_bwd(do, f, w, mask, two, 3, p2, pb2, rows, HW, Cc)
+        one, p1, pb1 = torch.empty_like(f), torch.zeros(nb, Cc, device="cuda"), torch.zeros(nb, device="cuda")
+        ops.head_grad_fused(dfn, yn, invn, do, f, w, mask, one, p1, pb1, rows, HW, Cc)
+        torch.testing.assert_close(one.float(), two.float(), atol=2e-2, rtol=2e-2)   # (the two-pass form rounds to bf16 in between)
+        torch.testing.assert_close(p1, p2, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(pb1, pb2, atol=1e-5, rtol=1e-5)
     # accum bit 1: the gradient leaves multiplied by [x > 0] (x = output of a ReLU); bit 0 adds into dx first
     base = dev(rnd(rows, Cc, seed=47)).to(td)
     dfm = base.clone()
