@@ -77,10 +77,10 @@ def cpu_baseline(batch_size):
 
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of the dominant GEMM variant from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
-    WRITE_SIZE, separate passes: tools/run_pmc_bench.sh + tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json).  Counters
+    WRITE_SIZE, separate passes: tools/run_pmc_bench.sh + tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json).  Counters
     cannot be read from inside this process, so the number is the one measured for the default workload; any other
     workload reports null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path) or args.model != "vitb" or args.batch != 12 or args.dtype != "bf16":
         return None
     tab = json.load(open(path))
@@ -89,26 +89,6 @@ def pmc_traffic(kernel, args):
         return None
     n, tot = v["launches"], v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"])
     return round(tot / n)
-
-
-def gemm_kernel_name(tA, tB, M, N, K, flags, batch, colsum):
-    """The kernel instantiation vpu_gemm's host side picks for a bf16 problem (mirror of the dispatch in
-    pvpuformer_amd/csrc/gemm.hip: skinny kernel for under-filled problems, split-K slab form, compile-time epilogues,
-    generic form) -- the names are the ones rocprofv3 prints, so the bench line and profiles/*kernel_stats*.csv can be
-    compared row by row.  (Default knobs only: no VPU_GEMM_* environment overrides.)"""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if not tA and batch == 1 and not colsum and M <= 2560 and N <= 4096 and 64 <= K <= 4096 and tiles < 192:
-        return f"gemm_bf16_skinny_kernel<{int(tB)}>"
-    cs = "true" if colsum else "false"
-    split = 1
-    if tiles * batch < 192 and K >= 512:
-        split = min((384 + tiles * batch - 1) // (tiles * batch), K // 256, 128)
-    if split > 1 and N % 8 == 0:
-        return f"gemm_bf16_kernel<{int(tA)}, {int(tB)}, true, {cs}, 65536, 0>"
-    key = (int(tA), int(tB))
-    spec = {(0, 0): (1, 65, 1029, 9, 0), (0, 1): (32, 0, 2048, 256)}.get(key, ())
-    fl = flags if (not colsum and split == 1 and N % 8 == 0 and flags in spec) else -1
-    return f"gemm_bf16_kernel<{int(tA)}, {int(tB)}, true, {cs}, {fl}, 0>"
 
 
 class GemmProbe:
@@ -123,9 +103,7 @@ class GemmProbe:
             e0.record()
             self.orig(A, B, C, M, N, K, lda, ldb, ldc, dtype, transA=transA, transB=transB, **kw)
             e1.record()
-            name = (gemm_kernel_name(transA, transB, M, N, K, kw.get("flags", 0), kw.get("batch", 1),
-                                     kw.get("colsum") is not None) if dtype == 0
-                    else f"gemm_f32_kernel<{int(transA)}, {int(transB)}>")
+            name = self.ops.gemm_last_kernel()      # the instantiation the C dispatcher picked, as rocprofv3 prints it
             self.rec.append((name, 2.0 * M * N * K * kw.get("batch", 1), e0, e1))
             self.shapes.append((int(transA), int(transB), M, N, K, kw.get("batch", 1), kw.get("flags", 0)))
         def wrapped_grouped(problems):   # one launch for several problems (the queued weight gradients)
@@ -135,8 +113,7 @@ class GemmProbe:
             e1.record()
             (a0, k0) = problems[0]
             fl = sum(2.0 * a[3] * a[4] * a[5] for a, _ in problems)
-            ta, tb = int(k0.get('transA', False)), int(k0.get('transB', False))
-            self.rec.append((f"gemm_bf16_grouped_kernel<{ta}, {tb}, {'true' if ta and tb else 'false'}>", fl, e0, e1))
+            self.rec.append((self.ops.gemm_last_kernel(), fl, e0, e1))
             self.shapes.append(("grouped", len(problems), sum(a[3] for a, _ in problems), a0[4], a0[5], 1, 0))
         self.ops.gemm = wrapped
         self.ops.gemm_grouped = wrapped_grouped
@@ -170,6 +147,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # the extension is (re)built BEFORE anything touches the GPU or RCCL: a stale .so means 8 hipcc children, which must
+    # neither inherit a profiler preload nor keep the other ranks waiting inside a collective.  Rank 0 builds, the others
+    # poll the file's freshness.
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    else:
+        srcdir = os.path.join(ROOT, "pvpuformer_amd", "csrc")
+        lib = os.path.join(ROOT, "pvpuformer_amd", "libvpu_hip.so")
+        t_wait = time.time()
+        while ge._stale(lib, srcdir):
+            if time.time() - t_wait > 900:
+                raise SystemExit("bench.py: rank 0 did not finish building libvpu_hip.so within 15 minutes")
+            time.sleep(1.0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
     # rehearsal on a one-GPU box (never used by the driver): VPU_DIST_SHARE_GPU=1 puts every rank on cuda:0 and
@@ -187,11 +178,6 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
     from pvpuformer_amd import ops
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
     from pvpuformer_amd.isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model

@@ -83,10 +83,16 @@ int vpu_gemm(const vpu_gemm_desc* d, void* stream);
 /* Kernel-selection knobs of vpu_gemm (tuning / tests; the defaults are the measured-fastest choices).
  * "ring": main loop of the 128x128 bf16 kernel = three LDS stages in a ring with a counted vmcnt instead of two stages:
  * -1 environment default (VPU_GEMM_RING, 0 if unset), 0 off, 1 one-wave problems (96..256 tiles, K <= 1536), 2 always.
+ * "k2" (round 2): the 256-row-tile kernels (128 x 64 outputs per wave, one workgroup per CU): -1 environment default
+ * (VPU_GEMM_K2, 2 if unset), 0 off, 1 the 256 x 128 form wherever legal, 2 the measured-fastest mix of 256 x 256 / 256 x 128 /
+ * 128 x 128, 3 the 256 x 256 form wherever legal.
  * "splitk_inlaunch": 0 (default; VPU_GEMM_INLAUNCH) a separate reduce launch sums the split-K slices; 1 they are summed,
  * in slice order, by the slice that arrives last at the tile's counter, inside the GEMM launch; n > 1: that, but only
  * when the slabs of the launch total at most n MiB.  Same results bit for bit; the default is the measured-faster one. */
 int vpu_gemm_set_option(const char* name, int32_t value);
+/* Name (as rocprofv3 prints it) of the kernel instantiation the calling host thread's last vpu_gemm / vpu_gemm_grouped call
+ * launched -- lets a measurement harness label launches without mirroring the dispatch rules.  "" before the first call. */
+const char* vpu_gemm_last_kernel(void);
 /* n (1..VPU_GEMM_GROUP_MAX) independent bf16 GEMMs in one persistent launch, every problem un-split over its whole K:
  * meant for sets whose tiles together fill the chip (the four weight gradients of a ViT block: models_vit.py:38-40,16-18
  * backward) or whose K is short (the DMA neck's 576-row problems), where separate launches each pay split-K slabs + a

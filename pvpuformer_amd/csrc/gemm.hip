@@ -11,6 +11,7 @@
 // Replaces cuBLAS/cuDNN calls behind nn.Linear / Conv2d / ConvTranspose2d / matmul of the reference
 // (isegm/model/modeling/models_vit.py:38-52,16-27,91; transformer.py:484-517; is_vpu_model.py:55-86;
 // swin_transformer.py:680-756).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -104,6 +105,7 @@ struct TileLoader {
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 constexpr int OOB_OFFSET = (int)0x80000000;  // >= num_records of the descriptors below: the load returns zeros
 
 // LDS-DMA staging of one 128x64 (K-contiguous) or 64x128 (K-major) bf16 tile: 16 pieces of 1 KiB, each one
@@ -222,6 +224,23 @@ __device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, const int f
 // `pre` (optional): the 8 bf16 of the residual (VPU_EPI_RESID) or of aux (DGELU/DRELU/MULAUX) for this position, fetched
 // before the main loop so that their HBM latency is hidden behind the MFMA work.
 // (everything by value / whole-array reference: a pointer to one element of a local array forces it into scratch)
+// v <- gelu(v), d <- gelu'(v) for 8 values (see the derivation at its use in epilogue_store8)
+__device__ __forceinline__ void gelu_dgelu8(float (&v)[8], float (&d)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // explicit fmaf: the file is built with -ffp-contract=off
+        const float x = v[j];
+        const float u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);       // exp(-x^2/2)
+        const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.23164188892868984f, 1.0f));
+        float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+        poly = __builtin_fmaf(t, poly, 1.421413741f);
+        poly = __builtin_fmaf(t, poly, -0.284496736f);
+        poly = __builtin_fmaf(t, poly, 0.254829592f);
+        const float erfa = __builtin_fmaf(-(poly * t), u, 1.0f);       // erf(|x|/sqrt2)
+        const float phi = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);
+        d[j] = __builtin_fmaf(x * 0.3989422804014327f, u, phi);
+        v[j] = x * phi;
+    }
+}
 struct EpiPre {
     bool has_pre, has_bias;
     uint4 pre;        // 8 bf16 of resid or aux for this position
@@ -251,20 +270,7 @@ __device__ __forceinline__ void epilogue_store8(const vpu_gemm_desc& p, const in
         // erf(|x|/sqrt2) = 1 - poly(t)*u (Abramowitz-Stegun 7.1.26 on z = |x|/sqrt2, t = 1/(1+0.3275911 z),
         // |error| <= 1.5e-7, far below bf16 resolution) and pdf(x) = u/sqrt(2 pi).  (The fp32 parity path keeps erff.)
         float d[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {   // explicit fmaf: the file is built with -ffp-contract=off
-            const float x = v[j];
-            const float u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);       // exp(-x^2/2)
-            const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.23164188892868984f, 1.0f));
-            float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-            poly = __builtin_fmaf(t, poly, 1.421413741f);
-            poly = __builtin_fmaf(t, poly, -0.284496736f);
-            poly = __builtin_fmaf(t, poly, 0.254829592f);
-            const float erfa = __builtin_fmaf(-(poly * t), u, 1.0f);       // erf(|x|/sqrt2)
-            const float phi = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);
-            d[j] = __builtin_fmaf(x * 0.3989422804014327f, u, phi);
-            v[j] = x * phi;
-        }
+        gelu_dgelu8(v, d);
         if (flags & VPU_EPI_SAVE_DGELU) store8(reinterpret_cast<bf16_t*>(p.preact) + ci, d);
     }
     if (flags & VPU_EPI_RELU) {
@@ -907,6 +913,492 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2 (round 2): 256 x (64 WN) x 64 tile per 512-thread workgroup, 128 x 64 outputs per wave (8 x 4 accumulator tiles of
+// v_mfma_f32_16x16x32_bf16), one workgroup per CU, persistent tile loop.
+//   * twice the output per staged byte of the 128 x 128 tile and 0.375 instead of 0.5 LDS fragment bytes per MFMA -- the
+//     two quantities round 1 measured the 128 x 128 kernel to be bound by (L2 -> LDS requests, LDS reads per MFMA).
+//   * WN = 2 (256 x 128): the eight waves are 2 (K halves of every 64-deep stage) x 2 (M) x 2 (N); the two K-half groups
+//     each accumulate the whole 128 x 64 wave tile over their half of K and exchange half of it through LDS at the end, so
+//     every wave finishes a 64 x 64 quarter in the epilogue.  M = 9408 gives 222 / 666 / 888 tiles for N = 768 / 2304 /
+//     3072 -- 87 % of the 256 CUs in every round -- where a 256 x 256 tile has 111 / 333 / 444.
+//   * WN = 4 (256 x 256): 2 (M) x 4 (N) waves, no K split; for N >= 2048 shapes whose tile count fills the chip.
+//   * LDS-DMA ring of S stages (3 x 48 KiB / 2 x 64 KiB), a COUNTED s_waitcnt vmcnt + one raw s_barrier per K-tile; the
+//     per-lane DMA source offsets are computed once per tile, the K position rides in the scalar offset operand.
+//   * grouped form: the tiles of all problems are cut into 8 contiguous ranges of one global order (short tile dimension
+//     fastest inside a problem), one range per XCD, so that an XCD's concurrently running tiles share operand panels
+//     through its L2 instead of every XCD streaming every panel (round 1: 700 MB read for 231 MB of operands).
+// ------------------------------------------------------------------------------------------------
+constexpr int K2_BM = 256;
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const void* rfl_ptr(const void* q) {
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = (uint32_t)rfl((int)(uint32_t)u), hi = (uint32_t)rfl((int)(uint32_t)(u >> 32));
+    return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
+template <int WN> struct K2Cfg {
+    static constexpr int KG = WN == 2 ? 2 : 1;
+    static constexpr int NSUB = 2 + WN / 2;   // 16-KiB sub-tiles of a stage: A rows 0-127 | A rows 128-255 | B cols 0-127 [| 128-255]
+    static constexpr int STAGE = NSUB * TILE_BYTES;
+    static constexpr int S = WN == 2 ? 3 : 2;
+    static constexpr int PW = NSUB * 2;       // DMA pieces (1 KiB) per wave per stage
+    static constexpr int LDS = S * STAGE;
+    static constexpr int BN_ = 64 * WN;
+};
+
+template <int TA, int TB, int WN>
+__device__ __forceinline__ void k2_issue(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
+                                         const int (&voff)[K2Cfg<WN>::PW], const int soffA, const int soffB,
+                                         const bool live, char* __restrict__ wr, const int wave) {
+#pragma unroll
+    for (int i = 0; i < K2Cfg<WN>::PW; ++i) {
+        const int sub = i >> 1, pis = wave + 8 * (i & 1);
+        const int vo = live ? voff[i] : OOB_OFFSET;
+        if (sub < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(wr + sub * TILE_BYTES + pis * 1024), 16, vo, soffA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vptr)(wr + sub * TILE_BYTES + pis * 1024), 16, vo, soffB, 0, 0);
+    }
+}
+
+// One K-tile: DMA of a later K-tile into stage `wr`, fragments + MFMAs of the current one from stage `rd` (the stages are
+// __restrict__ parameters of an inlined function for the reason given at ring_step).
+template <int TA, int TB, int WN, bool CS, int WAITN>
+__device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
+                                        const int (&voff)[K2Cfg<WN>::PW], const int soffA, const int soffB, const bool live,
+                                        char* __restrict__ wr, const char* __restrict__ rd, const int wave, const int lane,
+                                        const int wm, const int wn, const int g, const bool do_cs, const bf16x8_t ones,
+                                        f32x4_t (&acc)[8][4], f32x4_t (&acc_cs)[4]) {
+    k2_issue<TA, TB, WN>(rA, rB, voff, soffA, soffB, live, wr, wave);
+    const char* la = rd + wm * TILE_BYTES;
+    const char* lb = rd + (2 + (wn >> 1)) * TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < (K2Cfg<WN>::KG == 2 ? 1 : 2); ++kk) {
+        const int ks = K2Cfg<WN>::KG == 2 ? g : kk;
+        bf16x8_t af[8], bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(lb, (wn & 1) * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = read_frag<TA>(la, i * 16, ks, lane);
+        if (WAITN >= 0) {
+            // ping-pong: the two K-half groups run one barrier apart, so that on every SIMD one wave is in this load
+            // section (DMA issue + fragment reads + waits) while its partner is in the MFMA section below.  The load
+            // section ends with this wave's pieces of the NEXT K-tile landed and its fragment reads complete (the stage
+            // it read may be overwritten by the other group's DMA right after the barrier).
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN >= 0 ? WAITN : 0) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (CS && do_cs) {   // the two N-halves of the wave grid share the A fragments: each sums four of the eight row blocks
+            if (wn == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4 + i], ones, acc_cs[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (WAITN >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// epilogue of one 64 x 64 block held as 4 x 4 accumulator tiles by one wave: transposed through the wave's private LDS
+// scratch (`wl`: RP rows x 64 fp32) in 64 / RP passes so that every lane owns 8 consecutive columns of a row (16-byte
+// accesses).  Generic form: run-time flags, plain pointer accesses.
+template <bool GEN, int RP>
+__device__ __forceinline__ void k2_epi64(const vpu_gemm_desc& p, const int FLG, const int vec, f32x4_t (&a)[4][4],
+                                         const int mrow0, const int ncol0, float* wl, const int lane) {
+    const bool fast = !GEN || vec == 1;
+    const bool use_pre = RP == 32 && fast && (FLG & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
+                         !((FLG & VPU_EPI_RESID) && (FLG & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
+    uint4 pre[2][4];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_) pre[a_][b_] = make_uint4(0, 0, 0, 0);
+    if (use_pre) prefetch_epi(p, FLG, 0, 0, mrow0, ncol0, lane, pre);
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ncol = ncol0 + (lane & 7) * 8;
+    const bool use_bias8 = fast && (FLG & VPU_EPI_BIAS) && ncol + 8 <= p.N;
+    if (use_bias8) load8(p.bias + ncol, bias8);
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int NI = RP / 16;
+#pragma unroll
+    for (int pass = 0; pass < 64 / RP; ++pass) {
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ii * 16 + fq * 4 + r;
+                    wl[row * 64 + ((j * 16 + fr) ^ (fq << 4))] = a[pass * NI + ii][j][r];
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < RP / 8; ++t) {
+            const int u = lane + 64 * t;
+            const int row = u >> 3, c8 = (u & 7) * 8;
+            const int m = mrow0 + pass * RP + row;
+            const int n = ncol0 + c8;
+            if (m < p.M && n < p.N) {
+                float v[8];
+                load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
+                if (fast && n + 8 <= p.N) {
+                    EpiPre e;
+                    e.has_pre = use_pre; e.has_bias = use_bias8; e.pre = RP == 32 ? pre[pass & 1][t & 3] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e.bias[j] = bias8[j];
+                    epilogue_store8(p, FLG, 0, 0, m, n, v, e);
+                } else {
+                    for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, 0, 0, m, n + j, v[j]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// Exact-count form for the compile-time flag sets (bf16 output): EVERY global access is an unconditional raw-buffer
+// instruction -- lanes outside the matrix carry an out-of-range offset (loads return zeros, stores are dropped) -- so the
+// number of vector-memory operations a wave issues between the next tile's first LDS-DMA and that tile's main loop is a
+// compile-time constant; the counted s_waitcnt vmcnt of that tile's first K-steps is built on it.
+template <int FL> struct K2Pre {
+    u32x4v x[4][2];   // residual or aux: [pass of 16 rows][group of 8 rows]
+    float bias[8];
+};
+template <int FL>
+__device__ __forceinline__ void k2_prefetch(const vpu_gemm_desc& p, const int mrow0, const int ncol0, const int lane,
+                                            K2Pre<FL>& q) {
+    constexpr bool IS_RES = (FL & VPU_EPI_RESID) != 0;
+    if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DRELU)) != 0) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IS_RES ? p.resid : p.aux), 0, 0x7FFFFFFF, 0x00020000);
+        const int ld = IS_RES ? p.ldr : p.ldaux;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int u = lane + 64 * t;
+                const int m = mrow0 + pass * 16 + (u >> 3), n = ncol0 + (u & 7) * 8;
+                const int row = (IS_RES && p.resid_period > 0) ? m % p.resid_period : m;
+                const int off = (m < p.M && n < p.N) ? (row * ld + n) * 2 : OOB_OFFSET;
+                q.x[pass][t] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+            }
+    }
+    if constexpr ((FL & VPU_EPI_BIAS) != 0) {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 0x7FFFFFFF, 0x00020000);
+        const int n = ncol0 + (lane & 7) * 8;
+        const int off = n < p.N ? n * 4 : OOB_OFFSET;
+        const u32x4v b0 = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
+        const u32x4v b1 = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 16, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q.bias[j] = __builtin_bit_cast(float, b0[j]);
+            q.bias[4 + j] = __builtin_bit_cast(float, b1[j]);
+        }
+    }
+}
+__device__ __forceinline__ u32x4v pack_bf16x8(const float (&v)[8]) {
+    bf16x8_t a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    return __builtin_bit_cast(u32x4v, a);
+}
+template <int FL>
+__device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)[4][4], const int mrow0, const int ncol0,
+                                            float* wl, const int lane, const K2Pre<FL>& q) {
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, 0x7FFFFFFF, 0x00020000);
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wl[(fq * 4 + r) * 64 + ((j * 16 + fr) ^ (fq << 4))] = a[pass][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = lane + 64 * t;
+            const int row = u >> 3, c8 = (u & 7) * 8;
+            const int m = mrow0 + pass * 16 + row, n = ncol0 + c8;
+            float v[8];
+            load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
+            if constexpr ((FL & VPU_EPI_BIAS) != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += q.bias[j];
+            }
+            const int off = (m < p.M && n < p.N) ? (m * p.ldc + n) * 2 : OOB_OFFSET;
+            if constexpr ((FL & VPU_EPI_GELU) != 0) {
+                float d[8];
+                gelu_dgelu8(v, d);
+                if constexpr ((FL & VPU_EPI_SAVE_DGELU) != 0) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rP, off, 0, 0);
+            }
+            if constexpr ((FL & VPU_EPI_RELU) != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DRELU)) != 0) {
+                const bf16x8_t e = __builtin_bit_cast(bf16x8_t, q.x[pass][t]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = (float)e[j];
+                    if (FL & VPU_EPI_MULAUX) v[j] *= x;
+                    else if (FL & VPU_EPI_DRELU) v[j] *= (x > 0.f ? 1.f : 0.f);
+                    else v[j] += x;
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rC, off, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+struct K2Tile {   // wave-uniform description of one output tile
+    int m0, n0, tile_n, grp, M, N, K, lda, ldb;
+    const void* A;
+    const void* B;
+};
+template <int WN, bool GRP>
+__device__ __forceinline__ void k2_tile_setup(const int work, const int total_work, const vpu_gemm_desc& p_arg,
+                                              const vpu_gemm_group* __restrict__ ga, const int tiles_n_arg, K2Tile& t) {
+    int grp = 0, tile_m, tile_n;
+    if constexpr (GRP) {
+        // one contiguous range of the global tile order per XCD label (work & 7); inside a problem the shorter tile
+        // dimension runs fastest, so a range is a compact block of the problem's tile grid
+        const int xcd = work & 7, q = total_work >> 3, r = total_work & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (work >> 3);
+        while (grp + 1 < ga->n && v >= ga->start[grp + 1]) ++grp;
+        grp = rfl(grp);
+        const int local = v - ga->start[grp];
+        const int tm = (ga->d[grp].M + K2_BM - 1) / K2_BM, tn = (ga->d[grp].N + K2Cfg<WN>::BN_ - 1) / K2Cfg<WN>::BN_;
+        if (tn <= tm) { tile_m = local / tn; tile_n = local - tile_m * tn; }
+        else { tile_n = local / tm; tile_m = local - tile_n * tm; }
+    } else {
+        tile_coords(work, total_work, tiles_n_arg, tile_m, tile_n);
+    }
+    const vpu_gemm_desc& p = GRP ? ga->d[grp] : p_arg;
+    t.grp = grp; t.tile_n = rfl(tile_n);
+    t.m0 = rfl(tile_m * K2_BM); t.n0 = rfl(tile_n * K2Cfg<WN>::BN_);
+    // (grouped form: the descriptor is picked by a run-time index; pin what the main loop uses to scalar registers)
+    t.M = rfl(p.M); t.N = rfl(p.N); t.K = rfl(p.K); t.lda = rfl(p.lda); t.ldb = rfl(p.ldb);
+    t.A = rfl_ptr(p.A); t.B = rfl_ptr(p.B);
+}
+// per-lane byte offset of every DMA piece this wave issues per stage, at k = 0 (K % 64 == 0: no k bound inside a tile)
+template <int TA, int TB, int WN>
+__device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const int lane, int (&voff)[K2Cfg<WN>::PW]) {
+#pragma unroll
+    for (int i = 0; i < K2Cfg<WN>::PW; ++i) {
+        const int sub = i >> 1, pis = wave + 8 * (i & 1);
+        const bool isA = sub < 2;
+        const int tr = isA ? TA : TB;
+        const int x0 = isA ? t.m0 + sub * 128 : t.n0 + (sub - 2) * 128;
+        const int X = isA ? t.M : t.N;
+        const int ld = isA ? t.lda : t.ldb;
+        if (tr == 0) {
+            const int row = pis * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int gx = x0 + row;
+            voff[i] = gx < X ? (gx * ld + chunk * 8) * 2 : OOB_OFFSET;
+        } else {
+            const int k = pis * 4 + (lane >> 4);
+            const int chunk = (lane & 15) ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
+            const int gx = x0 + chunk * 8;
+            voff[i] = gx < X ? (k * ld + gx) * 2 : OOB_OFFSET;
+        }
+    }
+}
+
+template <int TA, int TB, int WN, bool CS, int FL, bool GRP>
+__device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
+                                        const int tiles_m_arg, const int tiles_n_arg, const int vec) {
+    using Cf = K2Cfg<WN>;
+    static_assert(!CS || (WN == 2 && TA == 1), "fused column sums: weight-gradient form, 256 x 128 tile");
+    constexpr bool PP = WN == 2;       // ping-pong schedule of the two K-half groups + next tile's first stages requested early
+    constexpr bool GEN = FL < 0;
+    // vector-memory stores one wave issues in the exact-count epilogue of its 64 x 64 quarter
+    constexpr int NST = GEN ? 0 : 8 * ((FL & VPU_EPI_SAVE_DGELU) ? 2 : 1);
+    constexpr int W1 = GEN ? Cf::PW : Cf::PW + NST;   // first waits of a tile whose stages 0 / 1 were requested before those stores
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = Cf::KG == 2 ? wave >> 2 : 0;
+    const int wm = Cf::KG == 2 ? (wave >> 1) & 1 : wave >> 2;
+    const int wn = Cf::KG == 2 ? wave & 1 : wave & 3;
+    const int total_work = GRP ? ga->start[ga->n] : tiles_m_arg * tiles_n_arg;
+    int work = blockIdx.x;
+    K2Tile cur;
+    int voff[Cf::PW];
+    bool primed = false;
+    if (work < total_work) {
+        k2_tile_setup<WN, GRP>(work, total_work, p_arg, ga, tiles_n_arg, cur);
+        k2_voff<TA, TB, WN>(cur, wave, lane, voff);
+    }
+    while (work < total_work) {
+        const vpu_gemm_desc& p = GRP ? ga->d[cur.grp] : p_arg;
+        const int FLG = GEN ? p.flags : FL;
+        const int m0 = cur.m0, n0 = cur.n0;
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(cur.A), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(cur.B), 0, 0x7FFFFFFF, 0x00020000);
+        const int stepA = TA ? cur.lda * (BK * 2) : BK * 2, stepB = TB ? cur.ldb * (BK * 2) : BK * 2;
+        const int nk = cur.K / BK;
+
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bool do_cs = CS && p.colsum != nullptr && cur.tile_n == 0;   // block-uniform
+        f32x4_t acc_cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
+
+        char* s0 = lds;
+        char* s1 = lds + Cf::STAGE;
+        char* s2 = lds + (Cf::S - 1) * Cf::STAGE;
+        if (!primed) {
+            k2_issue<TA, TB, WN>(rA, rB, voff, 0, 0, true, s0, wave);
+            if (Cf::S == 3) k2_issue<TA, TB, WN>(rA, rB, voff, stepA, stepB, 1 < nk, s1, wave);
+        }
+        if constexpr (PP) {
+            // K-tile 0 has landed for every wave (a primed tile: its stages 0 / 1 were requested before the previous tile's
+            // NST epilogue stores, which may still be in flight); then group 1 drops one barrier behind group 0
+            if (primed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::PW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (g == 1) __builtin_amdgcn_s_barrier();
+            if (primed) k2_step<TA, TB, WN, CS, W1>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+            else k2_step<TA, TB, WN, CS, Cf::PW>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+            { char* t = s0; s0 = s1; s1 = s2; s2 = t; }
+            for (int kt = 1; kt < nk; ++kt) {
+                const int kn = kt + 2;
+                k2_step<TA, TB, WN, CS, Cf::PW>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+                char* t = s0; s0 = s1; s1 = s2; s2 = t;
+            }
+            if (g == 0) __builtin_amdgcn_s_barrier();   // the two groups meet again
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // K-tile kt has landed for every wave; every wave is done reading K-tile kt-1
+                const int kn = kt + 1;
+                k2_step<TA, TB, WN, CS, -1>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+                char* t = s0; s0 = s2; s2 = t;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the out-of-range tail pieces still write zeros into LDS)
+        const int nxt = work + gridDim.x;
+        const bool has_next = nxt < total_work;
+        K2Tile nt = cur;
+        int nvoff[Cf::PW];
+#pragma unroll
+        for (int i = 0; i < Cf::PW; ++i) nvoff[i] = voff[i];
+
+        if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
+            __syncthreads();
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
+        } else if constexpr (Cf::KG == 2) {
+            const int mq = m0 + wm * 128 + g * 64, nq = n0 + wn * 64;   // this wave's 64 x 64 quarter
+            K2Pre<GEN ? 0 : FL> q;
+            if constexpr (!GEN) k2_prefetch<FL>(p, mq, nq, lane, q);   // lands while the halves are exchanged
+            __syncthreads();
+            // the two K-half groups exchange half of their 128 x 64 partial tile: group 0 finishes rows 0-63, group 1 rows
+            // 64-127 of it.  Fragment layouts are identical in both waves, so the registers travel as they are (16-byte LDS
+            // accesses, lane-linear).  Wave w sends through [w * 16 KiB, + 16 KiB).
+            const int fr = lane & 15, fq = lane >> 4;
+            f32x4_t* mine = reinterpret_cast<f32x4_t*>(lds + wave * 16384) + lane;
+            const f32x4_t* theirs = reinterpret_cast<const f32x4_t*>(lds + (wave ^ 4) * 16384) + lane;
+            float* red = reinterpret_cast<float*>(lds + 8 * 16384);   // [2][256] fused column sums
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * 64] = g == 0 ? acc[4 + i][j] : acc[i][j];
+            if (CS && do_cs && fr == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[g * 256 + wm * 128 + (wn * 4 + i) * 16 + fq * 4 + r] = acc_cs[i][r];
+            }
+            __syncthreads();
+            if (CS && do_cs && tid < K2_BM && m0 + tid < cur.M) p.colsum[m0 + tid] += red[tid] + red[256 + tid];
+            f32x4_t fin[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fin[i][j] = (g == 0 ? acc[i][j] : acc[4 + i][j]) + theirs[(i * 4 + j) * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();   // every wave has taken its partner's half: stages 0 and 1 can receive the next tile
+            if (has_next) {
+                k2_tile_setup<WN, GRP>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+                k2_voff<TA, TB, WN>(nt, wave, lane, nvoff);
+                const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
+                const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
+                const int nsA = TA ? nt.lda * (BK * 2) : BK * 2, nsB = TB ? nt.ldb * (BK * 2) : BK * 2;
+                k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds, wave);
+                k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
+            }
+            float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
+            if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane);
+            else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q);
+        } else {
+            __syncthreads();
+            float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4_t fin[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fin[i][j] = acc[h * 4 + i][j];
+                k2_epi64<GEN, 32>(p, FLG, vec, fin, m0 + wm * 128 + h * 64, n0 + wn * 64, wl, lane);
+            }
+        }
+        // every wave is done with its epilogue LDS before the next tile's DMA / fragment reads touch it (raw barrier: the
+        // global stores stay in flight)
+        __builtin_amdgcn_s_barrier();
+        primed = PP && has_next && vec != 9;
+        if (has_next && !primed) {
+            k2_tile_setup<WN, GRP>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+            k2_voff<TA, TB, WN>(nt, wave, lane, nvoff);
+        }
+        cur = nt;
+#pragma unroll
+        for (int i = 0; i < Cf::PW; ++i) voff[i] = nvoff[i];
+        work = nxt;
+    }
+}
+
+template <int TA, int TB, int WN, int FL>
+__global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
+                                                           const int vec) {
+    k2_body<TA, TB, WN, false, FL, false>(p, nullptr, tiles_m, tiles_n, vec);
+}
+template <int TA, int TB, bool CS>
+__global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
+    // the descriptors are read where they already are, in the kernel-argument segment (scalar loads with a run-time
+    // index); taking the address of the by-value parameter makes hipcc copy all 3.5 KB of it to scratch first
+    const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
+    k2_body<TA, TB, 2, CS, -1, true>(ga->d[0], ga, 0, 0, vec);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny problems: the DMA neck's prompt-token GEMMs (M = B*48 = 576 rows, N, K <= 2048; at inference M = 96).  With the
 // 128x128 tile they are 15-30 tiles of 12+ K-tiles each, run as split-K slabs + a reduce launch (~16 us per GEMM, 50 of
 // them per training step).  Here a workgroup owns one 64x64 output tile and its FOUR WAVES SPLIT K: every wave walks a
@@ -916,7 +1408,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
 // TB = 1 (dgrad: B is [K][N]): the B pieces go into a K-major image and are read with ds_read_b64_tr_b16.
 // ------------------------------------------------------------------------------------------------
 constexpr int SK_T = 64;
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 template <int TB>
 __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const vpu_gemm_desc p, const int tiles_n, const int kw,
@@ -1205,6 +1696,10 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 
 // ring-pipeline selection: 0 off (default), 1 one-wave problems, 2 everywhere; VPU_GEMM_RING at start-up,
 // vpu_gemm_set_option("ring", v) at run time (tests)
+// name of the kernel instantiation the last vpu_gemm / vpu_gemm_grouped call of this host thread launched, as rocprofv3
+// prints it (vpu_gemm_last_kernel): lets a profiler harness label launches without mirroring the dispatch rules
+thread_local char g_last_kernel[160] = "";
+#define NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
 std::atomic<int> g_opt_ring{-1};
 // split-K slices combined by a separate reduce launch (0, default) or by the last-arriving workgroup of the same launch
 // (1: always, n > 1: only when all slabs of the launch total <= n MiB): VPU_GEMM_INLAUNCH at start-up,
@@ -1213,7 +1708,25 @@ std::atomic<int> g_opt_ring{-1};
 // sc1 loads: the acquire drops the XCD's L2) -- the write-through slab stores and sc1 loads cost more than the reduce
 // launch they save, at every slab size of this model.  Kept (and tested) for shapes where a launch boundary is dearer.
 std::atomic<int> g_opt_inlaunch{-1};
-std::atomic<int> g_opt_skinny{-1};   // -1 environment default (VPU_GEMM_SKINNY, 1 if unset), 0 off, 1 on
+std::atomic<int> g_opt_skinny{-1};
+// K2 kernels (256-row tiles, 128 x 64 per wave): -1 environment default (VPU_GEMM_K2, 2 if unset), 0 off, 1 the 256 x 128
+// form only, 2 also the 256 x 256 form where its tile count fills the chip, 3 the 256 x 256 form wherever it is legal
+std::atomic<int> g_opt_k2{-1};
+inline int k2_env0() {
+    static const int v = [] { const char* e = getenv("VPU_GEMM_K2"); return e ? atoi(e) : 2; }();
+    return v;
+}
+std::atomic<int> g_opt_k2pp{-1};
+inline int k2pp_opt() {
+    static const int e0 = [] { const char* e = getenv("VPU_GEMM_K2PP"); return e ? atoi(e) : 1; }();
+    const int v = g_opt_k2pp.load(std::memory_order_relaxed);
+    return v >= 0 ? v : e0;
+}
+inline int k2_opt() { const int v = g_opt_k2.load(std::memory_order_relaxed); return v >= 0 ? v : k2_env0(); }
+inline int cu_count() {
+    static const int v = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    return v;
+}   // -1 environment default (VPU_GEMM_SKINNY, 1 if unset), 0 off, 1 on
 inline int inlaunch_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_INLAUNCH"); return e ? atoi(e) : 0; }();
     return v;
@@ -1303,6 +1816,49 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 splitk = (d->K + kchunk - 1) / kchunk;
             }
         }
+        // K2: large problems whose 256 x 128 tiles fill the chip and whose epilogue is one of the ViT-block flag sets
+        {
+            static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            const int k2 = k2_opt();
+            const int tm2 = (d->M + K2_BM - 1) / K2_BM, tn2 = (d->N + 127) / 128;
+            if (k2 > 0 && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % BK == 0 && d->K >= 256 &&
+                (int64_t)tm2 * tn2 >= 160 && !d->transA && d->alpha == 1.0f &&
+                (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL && (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
+                constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
+                              F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
+                const bool wide = d->N % 256 == 0 && (k2 == 3 || (k2 == 2 && (int64_t)tm2 * (d->N / 256) >= 384));
+                // measured (tools/gemm_bench.py, GEMM_BENCH_K2=0,1,3, M = 9408): the 256 x 128 form wins for K >= 2304
+                // (fc2 45.1 vs 47.6 us, fc1 dgrad 42.1 vs 46.7, qkv dgrad 33.9 vs 36.7) and for many-tile short-K problems
+                // (qkv 42.3 vs 49.0); one round of 222 tiles over K = 768 stays with the 128 x 128 kernel (proj 21.9 vs 19.8)
+                const bool narrow_ok = k2 == 1 || k2 == 3 || d->K >= 1024 || (int64_t)tm2 * tn2 >= 400;
+                const int vec2 = noepi2 ? 9 : 1;
+                const int ncu = cu_count();
+                bool done = true;
+#define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_)                                                                             \
+    do {                                                                                                             \
+        static bool attr_ = false;                                                                                   \
+        auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_>;                                                         \
+        if (!attr_) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<WN_>::LDS); \
+            attr_ = true;                                                                                            \
+        }                                                                                                            \
+        const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
+        const int tot_ = tm2 * tn_;                                                                                  \
+        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d>", TA_, TB_, WN_, FL_);                                        \
+        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS, s>>>(*d, tm2, tn_, vec2);      \
+    } while (0)
+#define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2(TA_, TB_, 2, FL_); else done = false; } while (0)
+                if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
+                else if (key == 0 && f == F_BR) VPU_K2_BOTH(0, 0, F_BR);
+                else if (key == 0 && f == F_G) VPU_K2_BOTH(0, 0, F_G);
+                else if (key == 1 && f == 0) VPU_K2_BOTH(0, 1, 0);
+                else if (key == 1 && f == F_M) VPU_K2_BOTH(0, 1, F_M);
+                else done = false;
+#undef VPU_K2_BOTH
+#undef VPU_LAUNCH_K2
+                if (done) return vpu_check_launch("vpu_gemm");
+            }
+        }
         // skinny problems (see gemm_bf16_skinny_kernel): few rows, moderate N and K, plain or K-major B
         static const int skinny_env = [] { const char* e = getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
         const int skinny_opt = g_opt_skinny.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny.load(std::memory_order_relaxed) : skinny_env;
@@ -1321,6 +1877,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 attr_sk = true;
             }
             dim3 sgrid((unsigned)(tm64 * tn64)), sblock(256);
+            NOTE_KERNEL("gemm_bf16_skinny_kernel<%d>", d->transB ? 1 : 0);
             if (d->transB) gemm_bf16_skinny_kernel<1><<<sgrid, sblock, 8 * TILE_BYTES, s>>>(*d, tn64, kw, vec ? 1 : 0);
             else gemm_bf16_skinny_kernel<0><<<sgrid, sblock, 4 * TILE_BYTES, s>>>(*d, tn64, kw, vec ? 1 : 0);
             return vpu_check_launch("vpu_gemm");
@@ -1343,11 +1900,15 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
+        NOTE_KERNEL("gemm_bf16_kernel<%d, %d, %s, false, -1, 0>", TA_, TB_, use_dma ? "true" : "false");              \
         if (use_dma) gemm_bf16_kernel<TA_, TB_, true, false, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg); \
         else gemm_bf16_kernel<TA_, TB_, false, false, -1><<<pgrid, block, 2 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
     } while (0)
-#define VPU_LAUNCH_FL(TA_, TB_, FL_) \
-    gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg)
+#define VPU_LAUNCH_FL(TA_, TB_, FL_)                                                                  \
+    do {                                                                                              \
+        NOTE_KERNEL("gemm_bf16_kernel<%d, %d, true, false, %d, 0>", TA_, TB_, FL_);                    \
+        gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg); \
+    } while (0)
         // compile-time epilogues for the flag sets of the ViT blocks (engine.py: linear / mlp / _dgrad)
         static const bool no_spec = [] { const char* e = getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
         const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && (vec_arg & 255) == 1;
@@ -1361,6 +1922,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
             attr_ = true;                                                                                            \
         }                                                                                                            \
+        NOTE_KERNEL("gemm_bf16_kernel<%d, %d, true, %s, %d, 3>", TA_, TB_, CS_ ? "true" : "false", FL_);              \
         kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
     } while (0)
         if (ring && use_dma && vec_arg <= 1) {
@@ -1399,6 +1961,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 cnt_arg = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d->workspace) + d->workspace_bytes - CNT_BYTES);
                 inlaunch = true;
             }
+            if (d->colsum && key == 3) NOTE_KERNEL("gemm_bf16_kernel<1, 1, true, true, 65536, 0>");
             if (d->colsum && key == 3) gemm_bf16_kernel<1, 1, true, true, FL_SLAB><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
             else if (d->colsum) launched = false;
             else if (key == 3) VPU_LAUNCH_FL(1, 1, FL_SLAB);
@@ -1419,6 +1982,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 attr_done = true;
             }
             dim3 block2(512);
+            NOTE_KERNEL("gemm_bf16_big_kernel<%d, %d>", key >> 1, key & 1);
             switch (key) {
                 case 0: gemm_bf16_big_kernel<0, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
                 case 1: gemm_bf16_big_kernel<0, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
@@ -1427,6 +1991,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         } else {
             if (d->colsum) {  // weight-gradient GEMM with the fused bias gradient (always transA = transB = 1 in the engine)
+                NOTE_KERNEL("gemm_bf16_kernel<1, %d, true, true, -1, 0>", key == 3 ? 1 : 0);
                 if (key == 3) gemm_bf16_kernel<1, 1, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
                 else gemm_bf16_kernel<1, 0, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
             } else
@@ -1449,6 +2014,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
     } else {
         dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)d->batch), block(256);
+        NOTE_KERNEL("gemm_f32_kernel<%d, %d>", key >> 1, key & 1);
         switch (key) {
             case 0: gemm_f32_kernel<0, 0><<<grid, block, 0, s>>>(*d, tiles_n); break;
             case 1: gemm_f32_kernel<0, 1><<<grid, block, 0, s>>>(*d, tiles_n); break;
@@ -1458,6 +2024,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     }
     return vpu_check_launch("vpu_gemm");
 }
+
+extern "C" const char* vpu_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     vpu_clear_stale_error();
@@ -1469,13 +2037,22 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_skinny.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
+    if (name && !strcmp(name, "k2") && value >= -1 && value <= 3) {
+        g_opt_k2.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
+    if (name && !strcmp(name, "k2pp") && value >= -1 && value <= 1) {
+        g_opt_k2pp.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
     if (name && !strcmp(name, "splitk_inlaunch") && value >= -1 && value <= 4096) {
         g_opt_inlaunch.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
     vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere), "
                   "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine), "
-                  "skinny (-1 environment default, 0 off, 1 on)");
+                  "skinny (-1 environment default, 0 off, 1 on), "
+                  "k2 (-1 environment default, 0 off, 1 256x128 tiles, 2 + 256x256 where it fills the chip, 3 256x256 wherever legal)");
     return VPU_ERR_ARG;
 }
 
@@ -1527,9 +2104,36 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     }
     for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) ga.start[i] = total;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // K2 form: weight-gradient groups over a long reduction whose 256 x 128 tiles fill most of the chip
+    if (key == 3 && k2_opt() > 0 && vec) {
+        bool ok = true;
+        int total2 = 0;
+        vpu_gemm_group g2 = ga;
+        for (int i = 0; i < n; ++i) {
+            const vpu_gemm_desc* d = descs + i;
+            ok = ok && d->K % BK == 0 && d->K >= 2048 && d->N % 8 == 0 && d->M % 8 == 0;
+            g2.start[i] = total2;
+            total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128);
+        }
+        for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g2.start[i] = total2;
+        if (ok && total2 >= 192) {
+            static bool attr_ = false;
+            auto kern_ = gemm_bf16_k2_grouped_kernel<1, 1, true>;
+            if (!attr_) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS);
+                attr_ = true;
+            }
+            const int ncu = cu_count();
+            static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<1, 1, true>");
+            kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, noepi2 ? 9 : 1);
+            return vpu_check_launch("vpu_gemm_grouped");
+        }
+    }
     static const int persist_cap = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 512; }();
     dim3 grid((unsigned)(total < persist_cap ? total : persist_cap)), block(256);
     const int vec_arg = vec ? 1 : 0;
+    NOTE_KERNEL("gemm_bf16_grouped_kernel<%d, %d, %s>", key >> 1, key & 1, key == 3 ? "true" : "false");
     switch (key) {
         case 0: gemm_bf16_grouped_kernel<0, 0, false><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;
         case 1: gemm_bf16_grouped_kernel<0, 1, false><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;

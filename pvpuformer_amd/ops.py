@@ -107,6 +107,11 @@ def gemm_grouped(problems):
     _lib.call("vpu_gemm_grouped", arr, n, _stream())
 
 
+def gemm_last_kernel():
+    """rocprofv3 name of the kernel instantiation the last gemm / gemm_grouped call of this thread launched."""
+    return _lib.load().vpu_gemm_last_kernel().decode()
+
+
 def gemm_set_option(name, value):
     _lib.call("vpu_gemm_set_option", name.encode(), int(value))
 

@@ -1073,3 +1073,83 @@ def test_fused_upsample_p2cl_matches_unfused(ops, B, S, h, H):
     part3, dlow3 = torch.empty(B, S, device="cuda"), torch.empty_like(low)
     ops.p2cl_up_fwd_bwd(low, gt, idx, ov, part3, dlow3, gs, B, S, h, h, H, H)
     assert torch.equal(dlow3, dlow2) and torch.equal(part3, part2)
+
+
+@pytest.mark.parametrize("tB", [0, 1])
+@pytest.mark.parametrize("k2", [1, 3])
+@pytest.mark.parametrize("shape", [(2300, 1288, 256), (3000, 1024, 640)])
+def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
+    """The round-2 kernels (256-row tiles, 128 x 64 outputs per wave, K halves exchanged through LDS in the 256 x 128
+    form; vpu_gemm_set_option("k2", 1 / 3) = 256 x 128 / 256 x 256 tiles): exact-integer operands must give the fp32
+    matmul bit for bit (ragged M and N, several tiles per persistent workgroup, K of 4 and 10 K-tiles so that the ring's
+    out-of-range tail stages occur); then the flag sets of the ViT blocks against the 128 x 128 kernel's output."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(11)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[0, 1] = 3; A[1, 0] = -2; Bm[0, 1] = 1; Bm[1, 0] = -3
+    ref = A @ Bm.t()
+    Ad = dev(A).to(torch.bfloat16)
+    Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+    ldb = N if tB else K
+    bias = dev(torch.randint(-4, 5, (N,), generator=g).float())
+    R = dev(torch.randint(-4, 5, (M, N), generator=g).float()).to(torch.bfloat16)
+    aux = dev(torch.randint(-2, 3, (M, N), generator=g).float()).to(torch.bfloat16)
+
+    def run(opt, flags, **kw):
+        Cd = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        pre = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_set_option("k2", opt)
+        try:
+            ops.gemm(Ad, Bd, Cd, M, N, K, K, ldb, N, 0, transB=bool(tB), flags=flags, preact=pre, **kw)
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_set_option("k2", -1)
+        return Cd.float().cpu(), pre.float().cpu()
+
+    if tB == 0:
+        out, _ = run(k2, ops.EPI_BIAS, bias=bias)
+        assert torch.equal(out, (ref + bias.cpu()).to(torch.bfloat16).float())
+        out, _ = run(k2, ops.EPI_BIAS | ops.EPI_RESID, bias=bias, resid=R, ldr=N)
+        assert torch.equal(out, (ref + bias.cpu() + R.float().cpu()).to(torch.bfloat16).float())
+        fl = ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU
+        # GELU: small-magnitude operands so that the activation is exercised away from saturation
+        Ad_s, Bd_s = Ad, Bd
+        Ad = (Ad.float() * 0.125).to(torch.bfloat16)
+        o_new, p_new = run(k2, fl, bias=bias * 0.25)
+        o_old, p_old = run(0, fl, bias=bias * 0.25)
+        Ad = Ad_s
+        assert torch.equal(o_new, o_old) and torch.equal(p_new, p_old)
+    else:
+        out, _ = run(k2, 0)
+        assert torch.equal(out, ref.to(torch.bfloat16).float())
+        out, _ = run(k2, ops.EPI_MULAUX, aux=aux, ldaux=N)
+        assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
+
+
+def test_gemm_k2_grouped_wgrad(ops):
+    """Weight-gradient groups over a long reduction in the K2 form (vpu_gemm_grouped: one global tile order cut into a
+    contiguous range per XCD): bit-exact accumulation into pre-filled fp32 outputs + the fused bias-gradient column sums,
+    for problems whose short tile dimension is M or N, ragged edges included."""
+    g = torch.Generator().manual_seed(23)
+    shapes = [(3072, 768, 2048), (768, 3072, 2048), (2304, 776, 2048), (520, 760, 2048)]   # (M, N, K): 72 + 72 + 63 + 18 tiles
+    problems, checks = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A = torch.randint(-2, 3, (K, M), generator=g).float()
+        Bm = torch.randint(-2, 3, (K, N), generator=g).float()
+        Ad, Bd = dev(A).to(torch.bfloat16), dev(Bm).to(torch.bfloat16)
+        Cd = torch.full((M, N), float(i + 1), device="cuda")
+        cs = torch.full((M,), 5.0, device="cuda") if i != 1 else None
+        problems.append(((Ad, Bd, Cd, M, N, K, M, N, N, 0),
+                         dict(transA=True, transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)))
+        checks.append((Cd, cs, A.t() @ Bm + float(i + 1), A.sum(0) + 5.0))
+    ops.gemm_set_option("k2", 1)
+    try:
+        ops.gemm_grouped(problems)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_set_option("k2", -1)
+    for Cd, cs, ref, csref in checks:
+        assert torch.equal(Cd.cpu(), ref), (Cd.cpu() - ref).abs().max()
+        if cs is not None:
+            assert torch.equal(cs.cpu(), csref)

@@ -40,8 +40,45 @@ NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
 ]
 
 
+def set_k2(opt):
+    """'k2' or 'k2:pp' (pp = ping-pong schedule of the 256 x 128 form, 0 / 1)"""
+    a = opt.split(":")
+    ops.gemm_set_option("k2", int(a[0]))
+    ops.gemm_set_option("k2pp", int(a[1]) if len(a) > 1 else -1)
+
+
+def group_bench(reps):
+    """The four weight gradients of one ViT block as ONE grouped launch, per k2 option."""
+    dev = "cuda"
+    shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768)]
+    probs = []
+    fl = 0.0
+    for m, n in shapes:
+        A = (torch.rand(M, m, device=dev) - 0.5).to(torch.bfloat16)
+        Bm = (torch.rand(M, n, device=dev) - 0.5).to(torch.bfloat16)
+        C = torch.zeros(m, n, device=dev)
+        cs = torch.zeros(m, device=dev)
+        probs.append(((A, Bm, C, m, n, M, m, n, n, 0), dict(transA=True, transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)))
+        fl += 2.0 * m * n * M
+    for opt in [t for t in os.environ.get("GEMM_BENCH_K2", "0,1").split(",")]:
+        set_k2(opt)
+        for _ in range(3):
+            ops.gemm_grouped(probs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm_grouped(probs)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        print(f"wgrad group      k2={opt}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
+    set_k2("-1")
+
+
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    if os.environ.get("GEMM_BENCH_GROUP", "0") == "1":
+        group_bench(reps)
     dev = "cuda"
     tot_t, tot_f = 0.0, 0.0
     with_torch = os.environ.get("GEMM_BENCH_TORCH", "0") == "1"
@@ -59,6 +96,25 @@ def main():
         pre = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
         kw = dict(transA=bool(tA), transB=bool(tB), flags=flags, bias=bias, resid=R, ldr=n, aux=aux, ldaux=n, preact=pre)
         lda, ldb = (m if tA else k), (n if tB else k)
+        k2s = [t for t in os.environ.get("GEMM_BENCH_K2", "").split(",") if t]
+        if k2s:   # interleaved A/B of the kernel families in one process (guide rule 24): median of 5 rounds per option
+            res = {}
+            for rnd_ in range(5):
+                for opt in k2s:
+                    set_k2(opt)
+                    ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res.setdefault(opt, []).append(e0.elapsed_time(e1) * 1e-3 / reps)
+            set_k2("-1")
+            fl = 2.0 * m * n * k
+            txt = "  ".join(f"k2={o}: {sorted(v)[2] * 1e6:7.1f} us {fl / sorted(v)[2] / 1e12:6.0f} TF" for o, v in res.items())
+            print(f"{name:16s} M={m:6d} N={n:5d} K={k:5d}  {txt}")
+            continue
         for _ in range(3):
             ops.gemm(A, Bm, C, m, n, k, lda, ldb, n, 0, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -97,7 +153,8 @@ def main():
             tt = e0.elapsed_time(e1) * 1e-3 / reps
             extra = f"   | torch.matmul {tt * 1e6:8.1f} us {fl / tt / 1e12:7.1f} TFLOP/s"
         print(f"{name:16s} tA={tA} tB={tB} M={m:6d} N={n:5d} K={k:5d}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s{extra}")
-    print(f"{'block total':16s} {tot_t * 1e6:8.1f} us  {tot_f / tot_t / 1e12:7.1f} TFLOP/s (one ViT block's 12 GEMMs)")
+    if tot_t > 0:
+        print(f"{'block total':16s} {tot_t * 1e6:8.1f} us  {tot_f / tot_t / 1e12:7.1f} TFLOP/s (one ViT block's 12 GEMMs)")
 
 
 if __name__ == "__main__":
