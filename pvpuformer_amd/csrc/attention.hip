@@ -20,6 +20,9 @@
 //   backward: the same trick with the roles swapped: dK/dV kernel keeps 16 keys per wave and sums over queries,
 //   dQ kernel keeps 16 queries per wave and sums over keys (probabilities are recomputed from the saved
 //   log-sum-exp; no atomics, bitwise reproducible).
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
 #include "vpu_common.h"
 #include "../../include/vpu_hip.h"
 
@@ -425,11 +428,400 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole-chunk kernels (round 2).  The kernels above walk the keys 32 at a time: two barriers, an LDS restage and -- in the
+// forward -- one online-softmax step (running max, rescale of the output tile, two cross-lane reductions) per 8 MFMAs,
+// ~170 instructions per 16-query x 32-key block.  Here a chunk of up to 208 keys (13 tiles of 16; 112 for head dims above 64)
+// is staged ONCE per workgroup as one image per tensor and a wave takes all its score tiles for the chunk before it touches
+// the softmax:
+//   forward : 26 score MFMAs -> ONE max / exp2 / sum over the lane's 52 values -> 28 P.V MFMAs; a 196-token window is a
+//             single chunk, i.e. a plain (not online) softmax with no rescale at all; longer rows (784 global tokens) carry
+//             the running max / sum across 4 chunks;
+//   backward: no reduction is needed (log-sum-exp and delta are known), so both kernels stream 32-row steps over the
+//             resident chunk with no barrier between them.
+// One image serves both operand forms: it is laid out for the transposing read (tr_off), and its 16-byte chunks stay
+// contiguous under that swizzle, so the row-operand fragments are read from the same image with ds_read_b128
+// (conflict-free for 128-byte rows: the eight rows of a lane group at one chunk index land on eight different 16-byte slots).
+// ------------------------------------------------------------------------------------------------
+template <int HD> struct WC {
+    static constexpr int NKT = HD <= 64 ? 13 : 7;       // 16-row tiles per staged chunk
+    static constexpr int ROWS = NKT * 16;                // 208 / 112
+    static constexpr int NPS = (NKT + 1) / 2;            // 32-row steps of the products that sum over the chunk's rows
+    static constexpr int IMG_ROWS = NPS * 32;            // 224 / 128 (rows >= the valid ones are zeros)
+    static constexpr int IMG_BYTES = IMG_ROWS * HD * 2;  // 28672 / 32768
+    static constexpr int NLD = IMG_ROWS * (HD / 8) / 256;   // 16-byte chunks per thread per image (256 threads)
+};
+
+// rows [r0, r0 + IMG_ROWS) of a [*, ld] matrix -> registers (zeros beyond row n / column hd / image row `rows`)
+template <int HD>
+__device__ __forceinline__ void wc_fetch(const bf16_t* __restrict__ base, int ld, int r0, int n, int hd, int rows, int tid,
+                                         uint4 (&v)[WC<HD>::NLD]) {
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int i = 0; i < WC<HD>::NLD; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / CPR, ch = c % CPR;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (row < rows && r0 + row < n && ch * 8 < hd) x = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
+        v[i] = x;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void wc_put(char* img, int rows, int tid, const uint4 (&v)[WC<HD>::NLD]) {
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int i = 0; i < WC<HD>::NLD; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / CPR, ch = c % CPR;
+        if (row < rows) *reinterpret_cast<uint4*>(img + tr_off<HD>(row, ch * 2)) = v[i];
+    }
+}
+// MFMA row-operand fragment (16 rows from row16, k-step ks) out of a tr-layout image
+template <int HD> __device__ __forceinline__ bf16x8_t frag_img(const char* img, int row16, int ks, int lane) {
+    const int row = row16 + (lane & 15);
+    const int unit = (ks * 4 + (lane >> 4)) * 2;
+    const uint4 v = *reinterpret_cast<const uint4*>(img + tr_off<HD>(row, unit));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_wc_kernel(const AttnArgs a, const int qpw) {
+    using W = WC<HD>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* imgK = lds;
+    char* imgV = lds + W::IMG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const bf16_t* q = a.q + rbq * a.ldq + h * hd;
+    const bf16_t* k = a.k + rbk * a.ldk + h * hd;
+    const bf16_t* v = a.v + rbk * a.ldk + h * hd;
+    const int nchunks = (nk + W::ROWS - 1) / W::ROWS;
+    const float sc2 = a.scale * 1.44269504089f;
+    for (int qi = 0; qi < qpw; ++qi) {
+        const int q0 = ((blockIdx.x * qpw + qi) * 4 + wave) * 16;
+        const bool active = q0 < nq;   // wave-uniform; an idle wave still takes part in the staging barriers
+        bf16x8_t qf[HD / 32];
+        load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
+        float m = -INFINITY, l = 0.f;
+        f32x4_t acc[HD / 16];
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int kc0 = ch * W::ROWS;
+            const int kvalid = nk - kc0 < W::ROWS ? nk - kc0 : W::ROWS;   // keys of this chunk
+            if (nchunks > 1 || qi == 0) {   // block-uniform
+                uint4 rk[W::NLD], rv[W::NLD];
+                wc_fetch<HD>(k, a.ldk, kc0, nk, hd, W::ROWS, tid, rk);
+                wc_fetch<HD>(v, a.ldk, kc0, nk, hd, W::ROWS, tid, rv);
+                __syncthreads();
+                wc_put<HD>(imgK, W::IMG_ROWS, tid, rk);
+                wc_put<HD>(imgV, W::IMG_ROWS, tid, rv);
+                __syncthreads();
+            }
+            if (!active) continue;
+            // every tile of the chunk is computed (rows beyond the chunk's keys are zeros in the image): straight-line code
+            // with all 26 score MFMAs independent; only the masking differs -- a chunk that is full up to its last tile (a
+            // 196-token window: 12 full tiles + 4 keys) masks that one tile, a shorter one masks by comparison everywhere
+            f32x4_t s[W::NKT + 1];
+#pragma unroll
+            for (int kt = 0; kt < W::NKT; ++kt) {
+                s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgK, kt * 16, ks, lane), qf[ks], s[kt], 0, 0, 0);
+            }
+            s[W::NKT] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (kvalid > W::ROWS - 16) {   // uniform
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s[W::NKT - 1][r] = ((W::NKT - 1) * 16 + 4 * g + r < kvalid) ? s[W::NKT - 1][r] : -INFINITY;
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < W::NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + 4 * g + r < kvalid) ? s[kt][r] : -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < W::NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // log2 domain: p = exp2(s * sc2 - m): one FMA and one v_exp_f32 per element
+            const float mnew = fmaxf(m, mx * sc2);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < W::NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc2, -mnew));
+                    s[kt][r] = p;
+                    ps += p;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * alpha + ps;
+            m = mnew;
+            if (ch > 0) {   // only rows longer than one chunk ever rescale
+                float ar[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[dt][r] *= ar[r];
+            }
+#pragma unroll
+            for (int pss = 0; pss < W::NPS; ++pss) {
+                const bf16x8_t pf = pack_pair(s[2 * pss], s[2 * pss + 1]);
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(imgV + pss * 32 * HD * 2, dt, lane), acc[dt], 0, 0, 0);
+            }
+        }
+        if (active) {
+            const float il = 1.0f / l;
+            if (g == 0 && q0 + c < nq) a.lse[(int64_t)bh * nq + q0 + c] = (m + __builtin_amdgcn_logf(l)) * 0.69314718056f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = __shfl(il, 4 * g + r, 64);
+                const int qq = q0 + 4 * g + r;
+                if (qq < nq) {
+                    bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt)
+                        if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[dt][r] * s1);
+                }
+            }
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_wc_kernel(const AttnArgs a, const int qpw) {
+    using W = WC<HD>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* imgK = lds;
+    char* imgV = lds + W::IMG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const bf16_t* q = a.q + rbq * a.ldq + h * hd;
+    const bf16_t* k = a.k + rbk * a.ldk + h * hd;
+    const bf16_t* v = a.v + rbk * a.ldk + h * hd;
+    const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
+    const int nchunks = (nk + W::ROWS - 1) / W::ROWS;
+    const float sc2 = a.scale * 1.44269504089f;
+    for (int qi = 0; qi < qpw; ++qi) {
+        const int q0 = ((blockIdx.x * qpw + qi) * 4 + wave) * 16;
+        const bool active = q0 < nq;
+        const bool q_ok = q0 + c < nq;
+        const float lse2 = q_ok ? a.lse[(int64_t)bh * nq + q0 + c] * 1.44269504089f : 0.f;
+        bf16x8_t qf[HD / 32], dof[HD / 32];
+        load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
+        load_rows_as_b<HD>(d_o, a.ldo, q0, nq, lane, dof, hd);
+        // delta[q] = sum_d dO[q][d] * O[q][d] from the dO fragments the wave holds anyway; published for the dK/dV kernel
+        float dl_q = 0.f;
+        {
+            bf16x8_t of[HD / 32];
+            load_rows_as_b<HD>(a.o + rbq * a.ldo + h * hd, a.ldo, q0, nq, lane, of, hd);
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl_q += (float)dof[ks][j] * (float)of[ks][j];
+            dl_q += __shfl_xor(dl_q, 16, 64);
+            dl_q += __shfl_xor(dl_q, 32, 64);
+            if (q_ok && g == 0) a.delta[(int64_t)bh * nq + q0 + c] = dl_q;
+        }
+        f32x4_t adq[HD / 16];
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int kc0 = ch * W::ROWS;
+            if (nchunks > 1 || qi == 0) {
+                uint4 rk[W::NLD], rv[W::NLD];
+                wc_fetch<HD>(k, a.ldk, kc0, nk, hd, W::ROWS, tid, rk);
+                wc_fetch<HD>(v, a.ldk, kc0, nk, hd, W::ROWS, tid, rv);
+                __syncthreads();
+                wc_put<HD>(imgK, W::IMG_ROWS, tid, rk);
+                wc_put<HD>(imgV, W::IMG_ROWS, tid, rv);
+                __syncthreads();
+            }
+            if (!active) continue;
+            // straight-line over the whole image, no masks: a key beyond the chunk has an all-zero K row, so whatever its dS
+            // is, it adds nothing to dQ (dQ += dS[q][k] K[k])
+#pragma unroll
+            for (int pss = 0; pss < W::NPS; ++pss) {
+                f32x4_t ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int k16 = pss * 32 + t * 16;
+                    f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                    for (int ks = 0; ks < HD / 32; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgK, k16, ks, lane), qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgV, k16, ks, lane), dof[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)   // element [key = kc0 + k16 + 4g + r][query = q0 + c]
+                        ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc2, -lse2)) * (dp[r] - dl_q);
+                }
+                const bf16x8_t dsf = pack_pair(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+                    adq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(imgK + pss * 32 * HD * 2, dt, lane), adq[dt], 0, 0, 0);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + 4 * g + r;
+                if (qq < nq) {
+                    bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd;
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt)
+                        if (dt * 16 < hd) qr[dt * 16 + c] = (bf16_t)(adq[dt][r] * a.scale);
+                }
+            }
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_wc_kernel(const AttnArgs a, const int kpw) {
+    using W = WC<HD>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* imgQ = lds;
+    char* imgO = lds + W::IMG_BYTES;
+    float* lseS = reinterpret_cast<float*>(lds + 2 * W::IMG_BYTES);   // log-sum-exp (log2 domain) and delta of the chunk's queries
+    float* dlS = lseS + W::IMG_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const bf16_t* q = a.q + rbq * a.ldq + h * hd;
+    const bf16_t* k = a.k + rbk * a.ldk + h * hd;
+    const bf16_t* v = a.v + rbk * a.ldk + h * hd;
+    const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
+    const float* lse = a.lse + (int64_t)bh * nq;
+    const float* dl = a.delta + (int64_t)bh * nq;
+    const int nchunks = (nq + W::ROWS - 1) / W::ROWS;
+    const float sc2 = a.scale * 1.44269504089f;
+    for (int ki = 0; ki < kpw; ++ki) {
+        const int key0 = ((blockIdx.x * kpw + ki) * 4 + wave) * 16;
+        const bool active = key0 < nk;
+        bf16x8_t kf[HD / 32], vf[HD / 32];
+        load_rows_as_b<HD>(k, a.ldk, key0, nk, lane, kf, hd);
+        load_rows_as_b<HD>(v, a.ldk, key0, nk, lane, vf, hd);
+        f32x4_t adk[HD / 16], adv[HD / 16];
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int qc0 = ch * W::ROWS;
+            const int qvalid = nq - qc0 < W::ROWS ? nq - qc0 : W::ROWS;
+            if (nchunks > 1 || ki == 0) {
+                uint4 rq[W::NLD], ro[W::NLD];
+                wc_fetch<HD>(q, a.ldq, qc0, nq, hd, W::ROWS, tid, rq);
+                wc_fetch<HD>(d_o, a.ldo, qc0, nq, hd, W::ROWS, tid, ro);
+                const float l2 = tid < qvalid ? lse[qc0 + tid] * 1.44269504089f : 0.f;
+                const float d2 = tid < qvalid ? dl[qc0 + tid] : 0.f;
+                __syncthreads();
+                wc_put<HD>(imgQ, W::IMG_ROWS, tid, rq);
+                wc_put<HD>(imgO, W::IMG_ROWS, tid, ro);
+                if (tid < W::IMG_ROWS) { lseS[tid] = l2; dlS[tid] = d2; }
+                __syncthreads();
+            }
+            if (!active) continue;
+            // straight-line, no masks: a query beyond the chunk has all-zero Q and dO rows, so its P / dS add nothing to dV
+            // (+= P[q][k] dO[q]) and dK (+= dS[q][k] Q[q])
+#pragma unroll
+            for (int pss = 0; pss < W::NPS; ++pss) {
+                f32x4_t P[2], dS[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q16 = pss * 32 + t * 16;
+                    const f32x4_t lv = *reinterpret_cast<const f32x4_t*>(lseS + q16 + 4 * g);
+                    const f32x4_t dv4 = *reinterpret_cast<const f32x4_t*>(dlS + q16 + 4 * g);
+                    f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                    for (int ks = 0; ks < HD / 32; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgQ, q16, ks, lane), kf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgO, q16, ks, lane), vf[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // element [query = qc0 + q16 + 4g + r][key = key0 + c]
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc2, -lv[r]));
+                        P[t][r] = p;
+                        dS[t][r] = p * (dp[r] - dv4[r]);
+                    }
+                }
+                const bf16x8_t pf = pack_pair(P[0], P[1]), dsf = pack_pair(dS[0], dS[1]);
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt) {
+                    adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(imgO + pss * 32 * HD * 2, dt, lane), adv[dt], 0, 0, 0);
+                    adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(imgQ + pss * 32 * HD * 2, dt, lane), adk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = key0 + 4 * g + r;
+                if (kk < nk) {
+                    bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd;
+                    bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd;
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt)
+                        if (dt * 16 < hd) {
+                            kr[dt * 16 + c] = (bf16_t)(adk[dt][r] * a.scale);
+                            vr[dt * 16 + c] = (bf16_t)adv[dt][r];
+                        }
+                }
+            }
+        }
+    }
+}
+
+// tiles per wave of the whole-chunk kernels: a problem whose reduction side fits one chunk runs in ONE workgroup (every wave
+// takes up to four 16-row tiles against the one staged image pair); longer reductions get one tile per wave
+template <int HD> inline int wc_tiles_per_wave(int n_own, int n_red) {
+    if (n_red > WC<HD>::ROWS) return 1;
+    const int t = (n_own + 63) / 64;
+    return t < 4 ? t : 4;
+}
+// Measured (tools/op_bench.py attn, ViT-B bs 12, both builds with MFMA results in VGPRs): window forward 37.6 us against
+// 30.4 us for the 32-key-step kernels, window backward 79.8 / 79.1, global forward 79.4 / 77.2, global backward 173.1 /
+// 176.9 -- the whole-chunk form issues ~2.5x fewer instructions per score element but runs two workgroups per CU (57 KiB
+// of LDS, ~215 VGPRs) where the step kernels run eight, and a (window, head) problem is too short (2.25 workgroups per CU)
+// for the leaner stream to make up for the exposed staging latency.  Kept selectable (VPU_ATTN_WC=1 /
+// vpu_attn_set_option("whole_chunk", 1)) and tested; the step kernels stay the default.
+std::atomic<int> g_opt_wc{-1};
+inline bool wc_enabled() {
+    static const int e0 = [] { const char* e = getenv("VPU_ATTN_WC"); return e ? atoi(e) : 0; }();
+    const int v = g_opt_wc.load(std::memory_order_relaxed);
+    return (v >= 0 ? v : e0) != 0;
+}
+template <typename K> inline void wc_attr(K kern, int bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 inline bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int hd_image(int hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : 128); }
 
 }  // namespace
+
+extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
+    vpu_clear_stale_error();
+    if (name && !strcmp(name, "whole_chunk") && value >= -1 && value <= 1) {
+        g_opt_wc.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
+    vpu_set_error("vpu_attn_set_option: known options: whole_chunk (-1 environment default VPU_ATTN_WC, 0 off, 1 on)");
+    return VPU_ERR_ARG;
+}
 
 extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
                              int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
@@ -443,6 +835,21 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale;
+    hipStream_t s0 = reinterpret_cast<hipStream_t>(stream);
+    if (wc_enabled() && hd_image(hd) >= 64) {
+        if (hd_image(hd) == 64) {
+            static const bool once = (wc_attr(attn_fwd_wc_kernel<64>, 2 * WC<64>::IMG_BYTES), true);
+            (void)once;
+            const int qpw = wc_tiles_per_wave<64>(nq, nk);
+            attn_fwd_wc_kernel<64><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, 2 * WC<64>::IMG_BYTES, s0>>>(a, qpw);
+        } else {
+            static const bool once = (wc_attr(attn_fwd_wc_kernel<128>, 2 * WC<128>::IMG_BYTES), true);
+            (void)once;
+            const int qpw = wc_tiles_per_wave<128>(nq, nk);
+            attn_fwd_wc_kernel<128><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, 2 * WC<128>::IMG_BYTES, s0>>>(a, qpw);
+        }
+        return vpu_check_launch("vpu_xattn_fwd");
+    }
     static const int qt2 = [] { const char* e = getenv("VPU_ATTN_QT"); return e ? atoi(e) : 2; }();
     // two query tiles per wave (128 queries per workgroup) for the 196-token windows: 33.9 vs 35.4 us (bs 12, round 1);
     // for the global blocks one tile per wave stays ahead (84.1 vs 86.0 us).  Time grows linearly with the number of
@@ -485,6 +892,24 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (wc_enabled() && hd_image(hd) >= 64) {
+        if (hd_image(hd) == 64) {
+            constexpr int LQ = 2 * WC<64>::IMG_BYTES, LK = LQ + 2 * WC<64>::IMG_ROWS * 4;
+            static const bool once = (wc_attr(attn_bwd_dq_wc_kernel<64>, LQ), wc_attr(attn_bwd_dkdv_wc_kernel<64>, LK), true);
+            (void)once;
+            const int qpw = wc_tiles_per_wave<64>(nq, nk), kpw = wc_tiles_per_wave<64>(nk, nq);
+            attn_bwd_dq_wc_kernel<64><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, LQ, s>>>(a, qpw);     // also writes delta
+            attn_bwd_dkdv_wc_kernel<64><<<dim3((nk + 64 * kpw - 1) / (64 * kpw), nb * H), 256, LK, s>>>(a, kpw);
+        } else {
+            constexpr int LQ = 2 * WC<128>::IMG_BYTES, LK = LQ + 2 * WC<128>::IMG_ROWS * 4;
+            static const bool once = (wc_attr(attn_bwd_dq_wc_kernel<128>, LQ), wc_attr(attn_bwd_dkdv_wc_kernel<128>, LK), true);
+            (void)once;
+            const int qpw = wc_tiles_per_wave<128>(nq, nk), kpw = wc_tiles_per_wave<128>(nk, nq);
+            attn_bwd_dq_wc_kernel<128><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, LQ, s>>>(a, qpw);
+            attn_bwd_dkdv_wc_kernel<128><<<dim3((nk + 64 * kpw - 1) / (64 * kpw), nb * H), 256, LK, s>>>(a, kpw);
+        }
+        return vpu_check_launch("vpu_xattn_bwd");
+    }
     dim3 gk((nk + 63) / 64, nb * H), gq((nq + 63) / 64, nb * H);
     switch (hd_image(hd)) {
         case 32:

@@ -7,7 +7,10 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-
 mkdir -p build
 pids=()
 for f in gemm attention rowops spatial prompt loss optim; do
-  $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+  # attention.hip: MFMA results straight into VGPRs (the softmax consumes every score tile with VALU instructions; with the
+  # accumulator-register form hipcc copies each tile through v_accvgpr_read and the kernels drop to one wave per SIMD)
+  EXTRA=""; [ $f = attention ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+  $HIPCC $FLAGS $EXTRA -c $f.hip -o build/$f.o &
   pids+=($!)
 done
 $HIPCC $FLAGS -c common.cpp -o build/common.o &

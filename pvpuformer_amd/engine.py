@@ -24,6 +24,26 @@ from ._lib import (BF16, F32, EPI_BIAS, EPI_PREACT, EPI_GELU, EPI_RELU, EPI_DGEL
                    EPI_ACCUM, EPI_OUT_F32, EPI_SAVE_DGELU, EPI_MULAUX)
 
 
+class Tape:
+    """The backward closures of ONE forward call plus that call's output-gradient slots.  ``Engine.forward`` returns a new
+    one per call (``Engine.last_tape``), so several forwards may be pending at once -- the reference trainer sums the
+    losses of up to three click iterations before a single ``loss.backward()`` (trainer.py:342-455), which reaches the
+    autograd bridge once per forward."""
+    __slots__ = ("fns", "out_grads", "done", "sim_low")
+
+    def __init__(self):
+        self.fns = []
+        self.out_grads = [None, None, None]
+        self.done = False
+        self.sim_low = None
+
+    def append(self, fn):
+        self.fns.append(fn)
+
+    def __len__(self):
+        return len(self.fns)
+
+
 class Var:
     """An activation and (lazily) its gradient."""
     __slots__ = ("t", "g")
@@ -81,7 +101,10 @@ class Engine:
         self.C = c["head_channels"]
         self.out_dims = tuple(c["out_dims"])
         self.names = None
-        self.tape = []
+        self.tape = Tape()
+        self.last_tape = None
+        self.params = []
+        self.norm_radius = float(c.get("norm_radius", 5))
         self.training = False
         self.shadow_valid = False
         self._const_ready = False
@@ -117,12 +140,14 @@ class Engine:
         self.total = off
         self.flat = torch.zeros(off, device=self.dev, dtype=torch.float32)
         self.gflat = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        self.params = []
         for n, p in named_params.items():
             o, shape, numel = self.names[n]
             view = self.flat[o:o + numel].view(shape)
             view.copy_(p.data)
             p.data = view
             p.grad = self.gflat[o:o + numel].view(shape)
+            self.params.append((p, o, shape, numel))
         self.shadow = torch.zeros(off, device=self.dev, dtype=torch.bfloat16) if self.dt == BF16 else None
         D, P = self.D, self.P
         self.k3p = _rup(3 * P * P, 8)   # each half of the fused patch-embed K is padded to 16 bytes (P = 14: 588 -> 592)
@@ -167,6 +192,30 @@ class Engine:
 
     def zero_grad(self):
         self.gflat.zero_()
+
+    def attach_grads(self):
+        """``param.grad`` must be the views of the flat gradient buffer the kernels accumulate into.  A caller that ran
+        ``optimizer.zero_grad()`` (``set_to_none=True`` is torch's default, as used by the reference at trainer.py:197,202)
+        has dropped them: the buffer is then zeroed -- that call's meaning -- and the views are attached again; a gradient
+        tensor of the caller's own is copied in first.  Two sentinel parameters are checked per call, all of them only
+        when a sentinel is off."""
+        if not self.params:
+            return
+        def ok(e):
+            p, o, shape, numel = e
+            return p.grad is not None and p.grad.data_ptr() == self.gflat.data_ptr() + 4 * o
+        if ok(self.params[0]) and ok(self.params[-1]):
+            return
+        for e in self.params:
+            p, o, shape, numel = e
+            if ok(e):
+                continue
+            seg = self.gflat[o:o + numel]
+            if p.grad is None:
+                seg.zero_()
+            else:
+                seg.copy_(p.grad.reshape(-1))
+            p.grad = seg.view(shape)
 
     # ------------------------------------------------------------------------------------------ helpers
     def _new(self, *shape, dtype=None):
@@ -547,7 +596,8 @@ class Engine:
         if not self.shadow_valid:
             self.refresh_weights()
         self.training = training
-        self.tape = []
+        self.tape = Tape()
+        tape = self.tape
         c = self.cfg
         B, H, W_ = image4.shape[0], image4.shape[2], image4.shape[3]
         assert H == self.img and W_ == self.img, "re-gridding for other sizes is not supported by this build"
@@ -560,7 +610,7 @@ class Engine:
             boxes = boxes.to(device=self.dev, dtype=torch.int32).contiguous()
         # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
         disks = self._new(B, 2, H, W_, dtype=torch.float32)
-        ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, 5.0)
+        ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, self.norm_radius)
         KP = 2 * self.k3p
         cols = self._new(M, KP)
         ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg)
@@ -790,10 +840,10 @@ class Engine:
         if materialize_aux:
             aux = self._new(B, nq, H, W_, dtype=torch.float32)
             ops.upsample_ac_fwd(sim, aux, B * nq, Hs, Hs, H, W_)
-        self._out_grads = [None, None, None]
+        tape.sim_low = self.sim_low
         if training:
             def bwd_head():
-                d_inst, d_aux, d_sim_low = self._out_grads
+                d_inst, d_aux, d_sim_low = tape.out_grads
                 if d_aux is not None or d_sim_low is not None:
                     if d_sim_low is not None:
                         dsim = d_sim_low.view(B, nq, HW4)
@@ -844,6 +894,7 @@ class Engine:
                     ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
             # must run BEFORE the closures of query / fused: insert at the position just after they were recorded
             self.tape.append(bwd_head)
+        self.last_tape = tape if training else None
         return inst, aux
 
     def _mark_ready(self, first_name, next_name):
@@ -945,15 +996,26 @@ class Engine:
         if t is not None and t.data_ptr() in self._frozen:
             self.join_side()
 
-    def backward(self, d_inst, d_aux, d_sim_low=None):
-        """Runs the recorded tape.  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None (or d_sim_low fp32
-        [B,S,h,w], the gradient of the low-resolution similarities from the fused loss).  Parameter gradients are
-        ACCUMULATED into the flat gradient buffer (call zero_grad() between optimizer steps)."""
-        self._out_grads = [None if d_inst is None else d_inst.contiguous(), None if d_aux is None else d_aux.contiguous(),
-                           None if d_sim_low is None else d_sim_low.contiguous()]
-        for fn in reversed(self.tape):
+    def backward(self, d_inst, d_aux, d_sim_low=None, tape=None):
+        """Runs a recorded tape (``tape``: the one ``forward`` left in ``last_tape`` at that call; default: the most recent
+        forward's).  d_inst fp32 [B,1,H,W] or None; d_aux fp32 [B,S,H,W] or None (or d_sim_low fp32 [B,S,h,w], the
+        gradient of the low-resolution similarities from the fused loss).  Parameter gradients are ACCUMULATED into the
+        flat gradient buffer (call zero_grad() between optimizer steps).  A tape runs once: a second backward of the same
+        forward, or a backward with no training-mode forward before it, raises."""
+        tape = self.last_tape if tape is None else tape
+        if tape is None or tape.done or len(tape) == 0:
+            raise RuntimeError("Engine.backward: no pending training-mode forward to back-propagate (its tape was "
+                               "already run, or forward ran with training=False)")
+        self.attach_grads()
+        tape.out_grads[:] = [None if d_inst is None else d_inst.contiguous(), None if d_aux is None else d_aux.contiguous(),
+                             None if d_sim_low is None else d_sim_low.contiguous()]
+        for fn in reversed(tape.fns):
             fn()
-        self.tape = []
+        tape.fns = []
+        tape.done = True
+        if tape is self.last_tape:
+            self.last_tape = None
+        self.tape = Tape()
         self.flush_colsums()
         self.join_side()
         if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0

@@ -73,6 +73,11 @@ class VPUTrainStep:
         state = PromptState(B, S, H, W, dev, max_rounds=self.max_clicks)
         num_iters = num_iters or rng.randint(1, self.max_clicks)
         logged, boxes = {}, None
+        from pvpuformer_amd.optim import FusedAdam
+        if not isinstance(self.opt, FusedAdam):
+            # an external optimizer stepped the fp32 master parameters: the bf16 shadow and the derived operands are stale
+            # (the fused optimizer writes the shadow itself and refreshes the rest)
+            eng.shadow_valid = False
         eng.zero_grad()
         if self.red is not None:
             self.red.begin()

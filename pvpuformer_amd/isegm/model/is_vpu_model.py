@@ -59,11 +59,13 @@ class _VPUFunction(torch.autograd.Function):
     def forward(ctx, anchor, model, image, points, boxes, prompt_type, drop_mask):
         ctx.engine = model._engine
         inst, aux = model._engine.forward(image, points, boxes, prompt_type, drop_mask, training=True)
+        ctx.tape = model._engine.last_tape      # THIS call's tape: several forwards may be pending before one backward
         return inst, aux
 
     @staticmethod
     def backward(ctx, d_inst, d_aux):
-        ctx.engine.backward(d_inst, d_aux)
+        ctx.engine.backward(d_inst, d_aux, tape=ctx.tape)
+        ctx.tape = None
         return (None,) * 7
 
 
@@ -116,7 +118,7 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         return dict(embed_dim=self.embed_dim, depth=b.depth, num_heads=b.num_heads, img=self.image_size[0],
                     patch=self.vit_patch_size[0], mlp_ratio=int(b.mlp_ratio), out_dims=tuple(self.neck.out_dims),
                     head_channels=self.head.channels, num_max_points=self.num_max_points,
-                    head_d_model=self.head.d_model)
+                    head_d_model=self.head.d_model, norm_radius=self.norm_radius)
 
     def set_compute_dtype(self, dtype):
         """'bf16' (MFMA, default) or 'f32' (exact-fp32 parity mode)."""

@@ -112,6 +112,10 @@ def gemm_last_kernel():
     return _lib.load().vpu_gemm_last_kernel().decode()
 
 
+def attn_set_option(name, value):
+    _lib.call("vpu_attn_set_option", name.encode(), int(value))
+
+
 def gemm_set_option(name, value):
     _lib.call("vpu_gemm_set_option", name.encode(), int(value))
 

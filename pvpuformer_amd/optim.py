@@ -8,6 +8,16 @@ import torch
 from . import ops
 
 
+# Tensors of the VPU model that never receive a gradient (unused at upsample='x1' / never called in forward):
+# the reference leaves their .grad at None, so torch.optim.Adam skips them -- no weight decay, no moment update.
+NEVER_USED_PREFIXES = ("backbone.cls_token", "backbone.fc_norm.", "backbone.head.", "head.logit_scale", "head.up_conv1.",
+                       "head.up_conv2.", "point_embeddings.", "not_a_point_embed.", "head_aux.")
+
+
+def is_never_used(name):
+    return any(name == p or name.startswith(p) for p in NEVER_USED_PREFIXES)
+
+
 class FusedAdam:
     def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled_weight_decay=False,
                  per_param=None, capturable=False):
@@ -22,6 +32,8 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.decoupled = decoupled_weight_decay
         self.per_param = dict(per_param) if per_param else None
+        if self.per_param is None and weight_decay != 0.0:
+            self.per_param = {}      # the segment table is what exempts never-used / frozen tensors from weight decay
         self.step_count = 0
         self.m = self.v = None
         self._seg = None
@@ -41,10 +53,13 @@ class FusedAdam:
         """(seg_end int64, lr_scale fp32, wd fp32) on the device, one segment per tensor of the flat buffer."""
         if self._seg is None:
             names = list(eng.names.items())
+            frozen = {n for n, p in self.model.named_parameters() if not p.requires_grad}
             ends, scales, wds = [], [], []
             for i, (n, (off, _, numel)) in enumerate(names):
                 end = names[i + 1][1][0] if i + 1 < len(names) else eng.total   # padding belongs to the tensor before it
                 sc, wd = self.per_param.get(n, (1.0, self.weight_decay))
+                if is_never_used(n) or n in frozen:   # torch.optim.Adam skips tensors whose .grad is None / frozen ones
+                    sc, wd = 0.0, 0.0
                 ends.append(end); scales.append(float(sc)); wds.append(float(wd))
             dev = eng.flat.device
             self._seg = (torch.tensor(ends, dtype=torch.int64, device=dev), torch.tensor(scales, device=dev),

@@ -989,10 +989,19 @@ def test_gemm_fused_bias_gradient(ops, K):
     assert torch.equal(db.cpu(), dY.sum(0) + 3.0)
 
 
-@pytest.mark.parametrize("hd,n,nb", [(64, 196, 3), (64, 784, 1), (32, 196, 2), (64, 50, 2)])
-def test_flash_attention_fwd_bwd(ops, hd, n, nb):
+@pytest.fixture(params=[0, 1], ids=["step32", "whole_chunk"])
+def attn_form(request, ops):
+    """both kernel families behind the attention entry points (vpu_attn_set_option)"""
+    ops.attn_set_option("whole_chunk", request.param)
+    yield request.param
+    ops.attn_set_option("whole_chunk", -1)
+
+
+@pytest.mark.parametrize("hd,n,nb", [(64, 196, 3), (64, 784, 1), (32, 196, 2), (64, 50, 2), (64, 256, 2), (80, 256, 1)])
+def test_flash_attention_fwd_bwd(ops, attn_form, hd, n, nb):
     """Fused attention vs torch fp32 on the bf16-rounded inputs: forward within bf16 output rounding, gradients
-    within 2e-2 of their scale.  n = 196 (window), 784 (global), 50 (ragged: masks keys and queries)."""
+    within 2e-2 of their scale.  n = 196 (window), 784 (global: four chunks of the whole-chunk form), 50 (ragged: masks
+    keys and queries), 256 (ViT-H windows: two chunks, head dim 80 in the 128-column image)."""
     H = 3
     D = H * hd
     qkv = dev(rnd(nb * n, 3 * D, seed=60, scale=1.5)).to(torch.bfloat16)
@@ -1019,7 +1028,7 @@ def test_flash_attention_fwd_bwd(ops, hd, n, nb):
 
 
 @pytest.mark.parametrize("hd,nq,nk,nb", [(96, 48, 48, 2), (48, 48, 784, 2), (48, 784, 48, 2), (48, 50, 70, 1), (16, 20, 33, 3)])
-def test_cross_attention_fwd_bwd(ops, hd, nq, nk, nb):
+def test_cross_attention_fwd_bwd(ops, attn_form, hd, nq, nk, nb):
     """The DMA neck's attention (transformer.py:499-521): separate query and key/value matrices, head dims 48 / 96 (run in
     the 64 / 128-column instantiation with zero-staged padding), ragged nq / nk.  Same tolerances as the self-attention."""
     H = 8
