@@ -321,6 +321,9 @@ def simulator_fixtures():
         fx[f"r{rnd_i}_changed_slots"] = changed
         fx[f"r{rnd_i}_changed_sums"] = (ed_out.sum(dim=(2, 3)) * torch.from_numpy(changed)).numpy()
         fx[f"r{rnd_i}_jitter"] = np.asarray(jitter)
+        # the click-only simulator (trainer.py:615-654) on the same inputs, its own seed
+        np.random.seed(300 + rnd_i)
+        fx[f"r{rnd_i}_next_points"] = rt.get_next_points(torch.from_numpy(pred), gt, pts).numpy()
     fx["gt_seed"] = np.asarray(11)
     # click packing of the predictor (base.py:195-213)
     bp = BasePredictor.__new__(BasePredictor)

@@ -3,21 +3,60 @@
 Hand-written HIP kernels for gfx950 behind a C ABI (``include/vpu_hip.h``, ``libvpu_hip.so``), driven from Python
 through ctypes, mirroring the reference's ``isegm.model.is_vpu_model`` / ``isegm.inference`` API.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 
-def install():
-    """Registers the API mirror as the top-level ``isegm`` package (if the reference's own ``isegm`` is not already
-    imported), so reference drivers and checkpoint ``config['class']`` paths resolve to this implementation."""
-    import importlib
+def _other_isegm_dir(mirror_dir, reference_root=None):
+    """The ``isegm`` package directory that the interpreter would import if this package did not exist: the first
+    ``<entry>/isegm`` along ``reference_root`` / ``sys.path`` that is not the mirror itself."""
+    import os
     import sys
-    if "isegm" in sys.modules and not sys.modules["isegm"].__name__.startswith("pvpuformer_amd"):
-        return sys.modules["isegm"]
+    entries = ([reference_root] if reference_root else []) + list(sys.path)
+    for e in entries:
+        d = os.path.join(e or os.getcwd(), "isegm")
+        if os.path.isdir(d) and os.path.realpath(d) != os.path.realpath(mirror_dir):
+            return d
+    return None
+
+
+def install(reference_root=None):
+    """Makes ``import isegm...`` resolve to this implementation FOR THE HOT PATH AND TO THE REST OF THE REFERENCE FOR
+    EVERYTHING ELSE (an overlay, not a replacement):
+
+    * every module of the API mirror (``pvpuformer_amd/isegm/**``) is registered under its ``isegm.*`` name, so
+      ``isegm.model.is_vpu_model``, ``isegm.engine.trainer``, ``isegm.inference.predictors`` ... -- and the dotted class
+      paths stored in checkpoints -- are this package's;
+    * the mirror packages' ``__path__`` is extended with the matching directories of the next ``isegm`` package on
+      ``sys.path`` (or under ``reference_root``), so modules the mirror does not ship -- ``isegm.utils.exp``,
+      ``isegm.utils.vis``, ``isegm.utils.log``, ``isegm.model.losses``, ``isegm.data`` ... -- are imported from there,
+      as sub-modules of the same ``isegm`` package (their relative imports keep working).
+
+    Call it before the first ``import isegm``: if the reference's own package is already imported it is left alone and
+    returned.  Idempotent."""
+    import importlib
+    import os
+    import pkgutil
+    import sys
+    cur = sys.modules.get("isegm")
+    if cur is not None and not cur.__name__.startswith("pvpuformer_amd"):
+        return cur
     pkg = importlib.import_module("pvpuformer_amd.isegm")
-    sys.modules["isegm"] = pkg
+    mirror_dir = os.path.dirname(os.path.abspath(pkg.__file__))
     prefix = "pvpuformer_amd.isegm."
-    for name in ("model", "model.is_model", "model.is_vpu_model", "model.modeling", "model.modeling.models_vit",
-                 "model.modeling.pos_embed", "utils", "utils.serialization", "engine", "engine.trainer", "inference",
-                 "inference.clicker", "inference.utils", "inference.predictors", "inference.predictors.base"):
+    names = [m.name[len(prefix):] for m in pkgutil.walk_packages([mirror_dir], prefix)]   # before __path__ grows
+    sys.modules["isegm"] = pkg
+    for name in names:
         sys.modules["isegm." + name] = importlib.import_module(prefix + name)
+    other = _other_isegm_dir(mirror_dir, reference_root)
+    if other is not None:
+        def extend(mod, rel):
+            d = os.path.join(other, *rel.split(".")) if rel else other
+            if os.path.isdir(d) and d not in list(mod.__path__):
+                mod.__path__.append(d)
+        extend(pkg, "")
+        for name in names:
+            mod = sys.modules["isegm." + name]
+            if hasattr(mod, "__path__"):
+                extend(mod, name)
+    pkg.__vpu_overlay__ = other
     return pkg

@@ -110,3 +110,185 @@ class VPUTrainStep:
             self.opt.step(grad_scale=scale)
         logged["num_iters"] = num_iters
         return logged, points
+
+
+def get_next_points(pred, gt, points, pred_thresh=0.49, np_rng=None):
+    """The click-only simulator of the reference (isegm/engine/trainer.py:615-654): per sample one new click at a random
+    pixel of the inner half (distance > max/2) of the larger of the false-negative / false-positive regions, written into
+    the first free positive (negative) slot with order = largest order so far + 1.  pred [B,1,H,W] probabilities, gt
+    [B,1,H,W], points [B,2n,3]; returns the updated points (a copy) on points' device.  The distance maps come from the
+    exact transform (``vpu_edt`` on a CUDA ``pred``, scipy otherwise; the reference's cv2 chamfer transform is not
+    available here: prompt_sim's parity note)."""
+    import numpy as np
+
+    from .prompt_sim import next_click
+    pred_np = pred.detach().float().cpu().numpy()[:, 0]
+    gt_np = gt.detach().cpu().numpy()[:, 0] > 0.5
+    new_pts, _, _, _ = next_click(pred_np, gt_np, points.detach().float().cpu().numpy(), pred_thresh,
+                                  np_rng or np.random, device=pred.device if pred.is_cuda else None)
+    return torch.from_numpy(new_pts).to(points.device)
+
+
+class ISTrainer:
+    """Constructor- and method-compatible mirror of the reference's trainer for the VPU configuration
+    (isegm/engine/trainer.py:25-308; built exactly as models/iSegNet/vpu_base448_cocolvis.py:163-179 does), over
+    ``VPUTrainStep``: ``ISTrainer(model, cfg, model_cfg, loss_cfg, trainset, valset, optimizer='adam', ...).run(n)``.
+
+    What it does per batch is ``VPUTrainStep.batch_forward`` (1-3 click iterations, iteration-weighted NFL + Dice + P2CL,
+    backward, gradient exchange, fused optimizer step); per epoch the learning-rate schedule and the checkpoint rule
+    (``checkpoint_interval`` int or [(from_epoch, every)]).  Experiment logging, TensorBoard, image dumps, tqdm and the
+    AMP grad scaler of the reference are outside the hot path and are not mirrored (bf16 needs no scaler); metrics
+    objects are accepted and, when they offer ``update`` / ``reset_epoch_stats``, fed.  Only the configuration the
+    reference can actually run is accepted: ``ed_loss`` with ``as_multi_prompts_ed_loss`` (its other two branches call
+    ``_forward`` with too few arguments, trainer.py:395,397)."""
+
+    def __init__(self, model, cfg, model_cfg, loss_cfg, trainset, valset, optimizer='adam', optimizer_params=None,
+                 layerwise_decay=False, image_dump_interval=200, checkpoint_interval=10, tb_dump_period=25,
+                 max_interactive_points=0, lr_scheduler=None, metrics=None, additional_val_metrics=None,
+                 net_inputs=('images', 'points'), max_num_next_clicks=0, click_models=None, prev_mask_drop_prob=0.0,
+                 use_iterloss=False, iterloss_weights=None, use_random_clicks=True, iter_train='epochiter',
+                 penalty_loss=False, ed_loss=False, pclout=False, as_multi_prompts_ed_loss=False, as_allmask=True):
+        from torch.utils.data import DataLoader
+
+        from .optimizer import get_optimizer, get_optimizer_with_layerwise_decay
+        if not (ed_loss and as_multi_prompts_ed_loss) or pclout or click_models is not None or penalty_loss:
+            raise NotImplementedError("ISTrainer mirror: the VPU configuration only (ed_loss=True, "
+                                      "as_multi_prompts_ed_loss=True, no click_models / pclout / penalty_loss)")
+        self.cfg, self.model_cfg, self.loss_cfg = cfg, model_cfg, loss_cfg
+        self.max_interactive_points, self.net_inputs = max_interactive_points, net_inputs
+        self.max_num_next_clicks = max_num_next_clicks
+        self.use_iterloss, self.iterloss_weights = use_iterloss, iterloss_weights
+        self.as_allmask, self.ed_loss, self.as_multi_prompts_ed_loss = as_allmask, ed_loss, as_multi_prompts_ed_loss
+        self.checkpoint_interval, self.image_dump_interval, self.tb_dump_period = checkpoint_interval, image_dump_interval, tb_dump_period
+        self.train_metrics = list(metrics or [])
+        self.val_metrics = list(metrics or []) + list(additional_val_metrics or [])
+        self.task_prefix, self.current_epoch = '', 0
+        get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        self._get = get
+        distributed = bool(get("distributed", False))
+        if distributed:
+            cfg.batch_size //= cfg.ngpus
+            cfg.val_batch_size //= cfg.ngpus
+        self.trainset, self.valset = trainset, valset
+
+        def loader(ds, bs, shuffle):
+            if ds is None:
+                return None
+            sampler = None
+            if distributed:
+                sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=shuffle)
+            return DataLoader(ds, bs, sampler=sampler, shuffle=(shuffle and sampler is None), drop_last=True,
+                              pin_memory=True, num_workers=get("workers", 0))
+        self.train_data = loader(trainset, cfg.batch_size, True)
+        self.val_data = loader(valset, get("val_batch_size", cfg.batch_size), False)
+        self.device = get("device", "cuda")
+        self.net = model.to(self.device)
+        self.optim = (get_optimizer_with_layerwise_decay if layerwise_decay else get_optimizer)(
+            self.net, optimizer, dict(optimizer_params or {}))
+        self.lr = (optimizer_params or {}).get('lr')
+        self.distributed, self.reducer, self._ready = distributed, None, False
+        weights = (1, 2, 3) if not use_iterloss or not iterloss_weights else tuple(iterloss_weights)
+        lw = (float(loss_cfg.get('instance_loss_weight', 1.0)), float(loss_cfg.get('instance_aux_loss_weight', 1.0)),
+              float(loss_cfg.get('instance_aux3_loss_weight', 2.0)))
+        self.step_fn = VPUTrainStep(self.net, self.optim, None, max_num_next_clicks=max(1, max_num_next_clicks),
+                                    iterloss_weights=weights if use_iterloss else (1,) * max(1, max_num_next_clicks),
+                                    as_allmask=as_allmask, loss_weights=lw)
+        if lr_scheduler is not None:
+            self.lr_scheduler = self._make_scheduler(lr_scheduler, self.optim)
+            for _ in range(int(get("start_epoch", 0))):
+                self.lr_scheduler.step()
+
+    @staticmethod
+    def _make_scheduler(factory, opt):
+        """The model scripts pass ``partial(torch.optim.lr_scheduler.MultiStepLR, milestones=..., gamma=...)``
+        (vpu_base448_cocolvis.py:153-154); torch's class only accepts a torch.optim.Optimizer, the fused optimizer gets
+        this package's scheduler of the same rule."""
+        if getattr(factory, "func", factory) is torch.optim.lr_scheduler.MultiStepLR:
+            from pvpuformer_amd.optim import MultiStepLR
+            return MultiStepLR(opt, *getattr(factory, "args", ()), **(getattr(factory, "keywords", None) or {}))
+        return factory(optimizer=opt)
+
+    def _setup_device_side(self):
+        """First batch: bind the engine (needs the GPU), and under ``cfg.distributed`` do what DDP's constructor does --
+        broadcast rank 0's parameters and buffers -- and attach the bucketed gradient reducer."""
+        if self._ready:
+            return
+        from pvpuformer_amd.parallel import GradReducer, broadcast_parameters
+        eng = self.net._ensure_engine()
+        if self.distributed:
+            broadcast_parameters(eng.flat)           # DDP's constructor broadcast (trainer.py:118-120)
+            for b in self.net.buffers():             # e.g. the random pe_layer.positional_encoding_gaussian_matrix
+                broadcast_parameters(b)
+            eng.shadow_valid = False
+            self.reducer = GradReducer(eng.gflat)
+            self.step_fn.red = self.reducer
+        self._ready = True
+
+    @property
+    def is_master(self):
+        return int(self._get("local_rank", 0)) == 0
+
+    def run(self, num_epochs, start_epoch=None, validation=True):
+        start_epoch = int(self._get("start_epoch", 0)) if start_epoch is None else start_epoch
+        for epoch in range(start_epoch, num_epochs):
+            self.current_epoch = epoch
+            self.training(epoch)
+            if validation and self.val_data is not None:
+                self.validation(epoch)
+
+    def batch_forward(self, batch_data, validation=False):
+        """One batch through the step (training) or a no-grad loss evaluation (validation).  Returns
+        (loss, losses_logging, batch, outputs) like the reference (outputs: the logged scalars only -- the 38.5-MB/image
+        auxiliary tensor is never materialised in training)."""
+        self._setup_device_side()
+        batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch_data.items()}
+        if validation:
+            with torch.no_grad():
+                image = batch['images']
+                B, _, H, W = image.shape
+                x = torch.cat([image, torch.zeros(B, 1, H, W, device=image.device)], 1).contiguous()
+                eng = self.net._ensure_engine()
+                inst, _ = eng.forward(x, batch['points'].float(), None, 0, None, training=False, materialize_aux=False)
+                losses, _, _ = vpu_step_losses(inst, None, batch['instances'].float(), None, None, want_grads=False,
+                                               sim_low=eng.sim_low, w_nfl=self.step_fn.lw[0], w_dice=self.step_fn.lw[1],
+                                               w_pcl=self.step_fn.lw[2])
+            return losses["total"], dict(losses), batch, {"instances": inst}
+        logged, _ = self.step_fn.batch_forward(batch)
+        n = logged.pop("num_iters")
+        loss = sum(v for k, v in logged.items() if k.startswith("total_"))
+        logged["num_iters"] = n
+        return loss, logged, batch, {}
+
+    def training(self, epoch):
+        from pvpuformer_amd.parallel import reduce_loss_dict
+        if hasattr(getattr(self.train_data, "sampler", None), "set_epoch"):
+            self.train_data.sampler.set_epoch(epoch)
+        for m in self.train_metrics:
+            if hasattr(m, "reset_epoch_stats"):
+                m.reset_epoch_stats()
+        self.net.train()
+        self.last_train_loss = None
+        for i, batch_data in enumerate(self.train_data):
+            loss, logged, _, _ = self.batch_forward(batch_data)
+            scal = {k: v for k, v in logged.items() if torch.is_tensor(v)}
+            scal['overall'] = loss
+            self.last_train_loss = reduce_loss_dict(scal)['overall']
+        if self.is_master:
+            ci = self.checkpoint_interval
+            if isinstance(ci, (list, tuple)):
+                ci = [x for x in ci if x[0] <= epoch][-1][1]
+            if ci and epoch % ci == 0 and self._get("CHECKPOINTS_PATH") is not None:
+                from ..utils.misc import save_checkpoint
+                save_checkpoint(self.net, self._get("CHECKPOINTS_PATH"), prefix=self.task_prefix, epoch=epoch)
+        if hasattr(self, 'lr_scheduler'):
+            self.lr_scheduler.step()
+
+    def validation(self, epoch):
+        self.net.eval()
+        tot, n = 0.0, 0
+        for batch_data in self.val_data:
+            loss, _, _, _ = self.batch_forward(batch_data, validation=True)
+            tot += float(loss)
+            n += 1
+        self.last_val_loss = tot / max(n, 1)
+        return self.last_val_loss

@@ -1,0 +1,188 @@
+"""The drop-in boundary end to end on CPU: after ``pvpuformer_amd.install()`` the reference's
+own driver imports resolve -- hot-path modules to this package, everything else to the ``isegm`` package that is next on
+``sys.path`` -- a reference-style model script builds the model and the trainer, and the only thing that needs the GPU is
+``forward``.
+
+The "rest of isegm" is a stand-in tree written by the test (the reference itself cannot travel and its snapshot lacks
+``isegm.data``): tiny modules with the names and relative imports the drivers use.  Each case runs in a fresh interpreter
+so that ``sys.modules`` starts clean."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REST = {
+    "isegm/__init__.py": "",
+    "isegm/utils/__init__.py": "raise RuntimeError('the mirror package must win over this __init__')\n",
+    "isegm/utils/log.py": "import logging\nlogger = logging.getLogger('root')\ndef add_logging(p, prefix):\n    return None\n",
+    "isegm/utils/distributed.py": "def synchronize():\n    return None\ndef get_world_size():\n    return 1\n",
+    "isegm/utils/exp.py": textwrap.dedent("""
+        from .log import logger, add_logging                 # relative import inside the OTHER tree
+        from .distributed import synchronize, get_world_size
+        from isegm.utils.serialization import load_model      # resolves to the mirror
+        def init_experiment(args, model_name):
+            return dict(model_name=model_name, batch_size=2)
+        def load_config_file(path, model_name=None, return_edict=False):
+            return {'EXPS_PATH': path}
+        """),
+    "isegm/utils/vis.py": "def draw_probmap(x):\n    return x\ndef draw_with_blend_and_clicks(*a, **k):\n    return None\n"
+                          "def draw_with_blend_and_prompts(*a, **k):\n    return None\ndef draw_with_error(*a, **k):\n    return None\n",
+    "isegm/utils/exp_imports/__init__.py": "",
+    "isegm/utils/exp_imports/default.py": textwrap.dedent("""
+        import torch
+        from functools import partial
+        from isegm.data.datasets import *
+        from isegm.model.losses import *
+        from isegm.engine.trainer import ISTrainer
+        from isegm.model.metrics import AdaptiveIoU
+        from isegm.utils.log import logger
+        from isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model
+        """),
+    "isegm/model/__init__.py": "raise RuntimeError('the mirror package must win over this __init__')\n",
+    "isegm/model/losses.py": textwrap.dedent("""
+        from isegm.utils import misc                           # mirror's misc through the shared package
+        class NormalizedFocalLossSigmoid:
+            def __init__(self, **k): self.k = k
+        class DiceLoss(NormalizedFocalLossSigmoid): pass
+        class SigmoidBinaryCrossEntropyLoss(NormalizedFocalLossSigmoid): pass
+        __all__ = ['NormalizedFocalLossSigmoid', 'DiceLoss', 'SigmoidBinaryCrossEntropyLoss']
+        """),
+    "isegm/model/metrics.py": "class AdaptiveIoU:\n    name = 'aiou'\n    def reset_epoch_stats(self):\n        pass\n",
+    "isegm/data/__init__.py": "",
+    "isegm/data/datasets.py": textwrap.dedent("""
+        import torch
+        class ToyDataset(torch.utils.data.Dataset):
+            def __init__(self, n=4, img=448): self.n, self.img = n, img
+            def __len__(self): return self.n
+            def get_samples_number(self): return self.n
+            def __getitem__(self, i):
+                g = torch.Generator().manual_seed(i)
+                gt = torch.zeros(1, self.img, self.img); gt[:, 100:300, 150:350] = 1
+                pts = -torch.ones(48, 3); pts[0] = torch.tensor([200., 250., 0.])
+                return {'images': torch.rand(3, self.img, self.img, generator=g), 'instances': gt, 'points': pts}
+        __all__ = ['ToyDataset']
+        """),
+    "model_script.py": textwrap.dedent("""
+        from isegm.utils.exp_imports.default import *
+        MODEL_NAME = 'toy_vpu'
+        def init_model(cfg):
+            bp = dict(img_size=(448, 448), patch_size=(16, 16), in_chans=3, embed_dim=128, depth=8, num_heads=4,
+                      mlp_ratio=4, qkv_bias=True)
+            model = VitMultiGaussianVector_ed_Model(
+                use_disks=True, norm_radius=5, with_prev_mask=True, with_aux_output=True, backbone_params=bp,
+                neck_params=dict(in_dim=128, out_dims=[16, 32, 64, 128], img_size=(448, 448)),
+                head_params=dict(in_channels=[16, 32, 64, 128], in_index=[0, 1, 2, 3], dropout_ratio=0.1, num_classes=1,
+                                 loss_decode=None, align_corners=False, upsample='x1', ed_loss=True, channels=32),
+                random_split=False, residual=True)
+            return model
+        def make_trainer(model, cfg):
+            from types import SimpleNamespace
+            loss_cfg = dict(instance_loss=NormalizedFocalLossSigmoid(alpha=0.5, gamma=2), instance_loss_weight=1.0,
+                            instance_aux_loss=DiceLoss(), instance_aux_loss_weight=1.0,
+                            instance_aux3_loss=SigmoidBinaryCrossEntropyLoss(from_sigmoid=True), instance_aux3_loss_weight=2.0)
+            return ISTrainer(model, cfg, SimpleNamespace(num_max_points=24), loss_cfg, ToyDataset(), ToyDataset(),
+                             optimizer='adam', optimizer_params={'lr': 5e-5, 'betas': (0.9, 0.999), 'eps': 1e-8},
+                             layerwise_decay=cfg.layerwise_decay,
+                             lr_scheduler=partial(torch.optim.lr_scheduler.MultiStepLR, milestones=[190, 210], gamma=0.1),
+                             checkpoint_interval=[(0, 5), (190, 1)], image_dump_interval=300, metrics=[AdaptiveIoU()],
+                             max_interactive_points=24, max_num_next_clicks=3, use_iterloss=True,
+                             iterloss_weights=[1, 2, 3], use_random_clicks=True, ed_loss=True,
+                             as_multi_prompts_ed_loss=True, as_allmask=False)
+        """),
+}
+
+DRIVER = textwrap.dedent("""
+    import sys, importlib.util
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {rest!r})
+    import pvpuformer_amd
+    pkg = pvpuformer_amd.install()
+    assert pkg.__vpu_overlay__ and pkg.__vpu_overlay__.startswith({rest!r}), pkg.__vpu_overlay__
+    # ---- the import block of the reference's train.py (lines 1-7) and scripts/evaluate_vpumodel.py (lines 13-18)
+    import torch
+    from isegm.utils.exp import init_experiment
+    from isegm.inference import utils
+    from isegm.utils.exp import load_config_file
+    from isegm.utils.vis import draw_probmap, draw_with_blend_and_clicks, draw_with_blend_and_prompts, draw_with_error
+    from isegm.inference.predictors import get_predictor
+    from isegm.inference.vpu_evaluation import evaluate_dataset
+    from isegm.model.modeling.pos_embed import interpolate_pos_embed_inference
+    # who provides what
+    import isegm.utils.exp, isegm.model.is_vpu_model, isegm.engine.trainer, isegm.inference.transforms, isegm.utils.lr_decay
+    import isegm.engine.optimizer, isegm.utils.misc
+    assert isegm.utils.exp.__file__.startswith({rest!r})
+    for m in (isegm.model.is_vpu_model, isegm.engine.trainer, isegm.inference.transforms, isegm.utils.lr_decay,
+              isegm.engine.optimizer, isegm.inference.vpu_evaluation, isegm.utils.misc, isegm.inference.predictors):
+        assert {root!r} in m.__file__ and m.__name__.startswith('pvpuformer_amd.'), m
+    from isegm.inference.transforms import ZoomIn, AddHorizontalFlip, SigmoidForPred, LimitLongestSide
+    from isegm.inference.clicker import Clicker
+    import isegm.model.losses
+    assert isegm.model.losses.misc is isegm.utils.misc              # the other tree's import landed on the mirror's module
+    # ---- a reference-style model script, loaded the way train.py:97-102 loads it
+    spec = importlib.util.spec_from_file_location('model_script', {rest!r} + '/model_script.py')
+    ms = importlib.util.module_from_spec(spec); spec.loader.exec_module(ms)
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(batch_size=2, val_batch_size=2, distributed=False, workers=0, device='cpu', start_epoch=0,
+                          layerwise_decay={lwd}, local_rank=0, CHECKPOINTS_PATH=None,
+                          get=lambda k, d=None: getattr(cfg, k, d))
+    model = ms.init_model(cfg)
+    assert type(model).__module__ == 'pvpuformer_amd.isegm.model.is_vpu_model'
+    assert model._config['class'] == 'isegm.model.is_vpu_model.VitMultiGaussianVector_ed_Model'
+    from isegm.utils.serialization import load_model
+    again = load_model(model._config)                               # the dotted path in a checkpoint resolves under the overlay
+    assert type(again) is type(model)
+    trainer = ms.make_trainer(model, cfg)
+    assert type(trainer).__name__ == 'ISTrainer' and len(trainer.train_data) == 2
+    lr0 = trainer.optim.lr
+    for _ in range(191):
+        trainer.lr_scheduler.step()
+    assert abs(trainer.optim.lr - lr0 * 0.1) < 1e-12
+    predictor = get_predictor(model, 'NoBRS', 'cpu', with_flip=True, zoom_in_params=dict(skip_clicks=-1, target_size=(448, 448)))
+    # ---- the GPU is needed at forward, and only there
+    try:
+        model(torch.zeros(1, 4, 448, 448), -torch.ones(1, 2, 3))
+    except RuntimeError as e:
+        assert 'MI355X' in str(e), e
+    else:
+        raise AssertionError('forward on CPU must raise: there is no CPU path')
+    print('DROPIN-OK')
+    """)
+
+
+def _run(tmp_path, lwd):
+    rest = tmp_path / "ref"
+    for rel, src in REST.items():
+        f = rest / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(src)
+    code = DRIVER.format(root=ROOT, rest=str(rest), lwd=lwd)
+    env = dict(os.environ, PYTHONPATH="")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=600)
+    assert r.returncode == 0 and "DROPIN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_overlay_serves_reference_drivers_and_model_script(tmp_path):
+    _run(tmp_path, False)
+
+
+def test_overlay_with_layerwise_decay_optimizer(tmp_path):
+    _run(tmp_path, True)
+
+
+def test_install_without_another_isegm_is_the_mirror_alone(tmp_path):
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import pvpuformer_amd
+        pkg = pvpuformer_amd.install()
+        assert pkg.__vpu_overlay__ is None
+        import isegm.model.is_vpu_model
+        try:
+            import isegm.utils.exp
+        except ModuleNotFoundError:
+            print('ALONE-OK')
+        """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=""), timeout=600)
+    assert r.returncode == 0 and "ALONE-OK" in r.stdout, r.stdout + r.stderr

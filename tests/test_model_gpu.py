@@ -550,3 +550,73 @@ def test_torch_adam_with_zero_grad_set_to_none(golden_dir):
     # near-zero-gradient entries, so the bound is on the bulk
     diffs = torch.cat([(p.detach().cpu() - ref_params[n].detach()).abs().flatten() for n, p in model.named_parameters()])
     assert float(diffs.median()) < 1e-5 and float((diffs > 1.5e-3).float().mean()) < 2e-3, (float(diffs.median()), worst)
+
+
+def test_istrainer_mirror_runs_epochs_and_evaluate_dataset(golden_dir, tmp_path):
+    """The trainer / evaluator mirrors end to end on the GPU (tiny model): ``ISTrainer(...)`` built with the reference's
+    keyword set (vpu_base448_cocolvis.py:163-179) runs two epochs over a 4-sample dataset (parameters move, the schedule
+    steps, the checkpoint of epoch 0 is written in the reference's {'state_dict','config'} format and rebuilds the same
+    network), then ``evaluate_dataset`` drives the NoBRS predictor over a two-object dataset."""
+    from functools import partial
+    from types import SimpleNamespace
+    from pvpuformer_amd.isegm.engine.trainer import ISTrainer
+    from pvpuformer_amd.isegm.inference.predictors import get_predictor
+    from pvpuformer_amd.isegm.inference.vpu_evaluation import evaluate_dataset
+    from pvpuformer_amd.isegm.utils.serialization import load_model
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "bf16")
+    big = vo.synth_batch(4, cfg["img"], seed=21)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 4
+
+        def get_samples_number(self):
+            return 4
+
+        def __getitem__(self, i):
+            return {k: big[k][i] for k in ("images", "instances", "points")}
+    tcfg = SimpleNamespace(batch_size=2, val_batch_size=2, distributed=False, workers=0, device="cuda", start_epoch=0,
+                           local_rank=0, CHECKPOINTS_PATH=str(tmp_path))
+    tcfg.get = lambda k, d=None: getattr(tcfg, k, d)
+    loss_cfg = dict(instance_loss_weight=1.0, instance_aux_loss_weight=1.0, instance_aux3_loss_weight=2.0)
+    import random
+    random.seed(3); np.random.seed(4)
+    tr = ISTrainer(model, tcfg, SimpleNamespace(num_max_points=24), loss_cfg, DS(), DS(), optimizer="adam",
+                   optimizer_params={"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8}, layerwise_decay=False,
+                   lr_scheduler=partial(torch.optim.lr_scheduler.MultiStepLR, milestones=[1], gamma=0.1),
+                   checkpoint_interval=[(0, 5)], image_dump_interval=300, metrics=[], max_interactive_points=24,
+                   max_num_next_clicks=3, use_iterloss=True, iterloss_weights=[1, 2, 3], use_random_clicks=True,
+                   ed_loss=True, as_multi_prompts_ed_loss=True, as_allmask=False)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    tr.run(num_epochs=2, validation=True)
+    assert abs(tr.optim.lr - 1e-4) < 1e-12 and tr.optim.step_count == 4
+    assert torch.isfinite(tr.last_train_loss).item() and np.isfinite(tr.last_val_loss)
+    moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert len(moved) > 300 and "backbone.head.weight" not in moved
+    ck = torch.load(os.path.join(str(tmp_path), "000.pth"), weights_only=False)
+    assert set(ck) == {"state_dict", "config"} and list(ck["state_dict"]) == list(model.state_dict())
+    again = load_model(ck["config"])
+    again.load_state_dict(ck["state_dict"], strict=True)
+    # evaluation protocol
+    model.eval()
+    model.weights_frozen = False
+    gt = (big["instances"][:2, 0].numpy() > 0.5).astype(np.int32)
+    imgs = (big["images"][:2].permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)
+
+    class Sample:
+        def __init__(self, i):
+            self.image, self.objects_ids, self._i = imgs[i], [0], i
+
+        def gt_mask(self, oid):
+            return gt[self._i]
+
+    class EvalDS:
+        def __len__(self):
+            return 2
+
+        def get_sample(self, i):
+            return Sample(i)
+    pred = get_predictor(model, "NoBRS", "cuda", with_flip=True, zoom_in_params=dict(skip_clicks=-1, target_size=(448, 448)))
+    all_ious, secs = evaluate_dataset(EvalDS(), pred, max_iou_thr=0.99, pred_thr=0.49, max_clicks=3)
+    assert len(all_ious) == 2 and all(a.dtype == np.float32 and 1 <= len(a) <= 3 and np.all((a >= 0) & (a <= 1)) for a in all_ious)
+    assert secs > 0

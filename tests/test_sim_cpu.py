@@ -100,3 +100,21 @@ def test_max_connected_regions_equals_reference_scan():
         if t % 2:
             m = ndimage.binary_opening(m)
         assert np.array_equal(max_connected_regions(m).astype(np.int64), reference_scan(m)), t
+
+
+def test_get_next_points_bit_exact(golden_dir):
+    """The click-only simulator (trainer.py:615-654) against the reference's own output on the same seeded inputs: which
+    slot the click takes, its order and its coordinates (drawn with np.random from the inner half of the larger error
+    region), incl. the full-positive-slots fallback (round 1) and the perfect-prediction case that adds nothing (round 2)."""
+    from pvpuformer_amd.isegm.engine.trainer import get_next_points
+    fx = np.load(os.path.join(golden_dir, "sim.npz"))
+    B, H = 4, 448
+    gt = vo.synth_batch(B, H, seed=int(fx["gt_seed"]))["instances"]
+    for r in range(3):
+        vals = fx[f"r{r}_pred_vals"]
+        pred = np.unpackbits(fx[f"r{r}_pred"])[:B * H * H].reshape(B, 1, H, H).astype(np.float32) * 0.9
+        pts = torch.from_numpy(fx[f"r{r}_points_in"])
+        np.random.seed(300 + r)
+        out = get_next_points(torch.from_numpy(pred), gt, pts)
+        assert np.array_equal(out.numpy(), fx[f"r{r}_next_points"]), f"round {r}"
+        assert np.array_equal(pts.numpy(), fx[f"r{r}_points_in"]), "the input points must not be modified"
