@@ -184,6 +184,17 @@ int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64_t ld_aux, 
  * out64 (optional, may be NULL) receives the float64 rows exactly as the reference returns them. */
 int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
                    int32_t B, int32_t n, int32_t num_max, int32_t img, int32_t ld, int32_t dtype, void* stream);
+/* Scribble prompts (prompt type 2).  vpu_pue_scribble_rows: after vpu_pue_encode (click mode), the LAST valid positive row
+ * of every sample is replaced by that sample's scribble vectors vec[b] = (x profile [img] | y profile [img]) + label
+ * one-hot 0 (is_vpu_model.py:294-352); a sample without a valid positive click keeps its rows.  The profiles come from the
+ * host (GaussianVector_scribble, ops.py:244-296, draws from Python's `random` while deleting points: sequential by
+ * construction).  out / out64 / ld as in vpu_pue_encode.
+ * vpu_draw_polyline: ISModel.draw_scribble (is_model.py:123-146): the open poly-line through curve[b][0..P) (int32 x, y)
+ * with thickness 3 is OR-ed into the positive channel of disks [B][2][H][W]; a pixel is set iff its squared distance to a
+ * segment is <= 1 (cv2.polylines itself is not available to pin against). */
+int vpu_pue_scribble_rows(const float* points, const double* vec, void* out, double* out64, int32_t B, int32_t n,
+                          int32_t num_max, int32_t img, int32_t ld, int32_t dtype, void* stream);
+int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, int32_t P, int32_t H, int32_t W, void* stream);
 /* Exact Euclidean distance transform of B masks: dist[b][y][x] = distance of a non-zero pixel to the nearest zero pixel
  * (0 at zero pixels; +inf when there is none), float32(sqrt(float64)) of the exact integer squared distance -- the map
  * whose arg-max the click simulators take (clicker.py:29-56, trainer.py:628-629, 673-674, 736-737).  zero_border != 0:

@@ -436,18 +436,79 @@ def scribble_fixture(ref_vpu):
                         seed=np.asarray(123), pue=ref)
 
 
+def scribble_model_fixture(ref_vpu):
+    """a3 poly-line + a9 through the whole model (prompt type 2), tiny configuration: the reference's forward with its
+    ``draw_scribble`` routed through the oracle's rasteriser (cv2 is absent; same arrangement as the box outline) and the
+    debug ``ops.draw_scribble`` (cv2.imwrite to a hard-coded path) replaced by a no-op.  The vectors draw from the global
+    ``random`` state: seeded right before the call, recorded in the fixture."""
+    import random
+    import isegm.model.ops as ref_ops
+    ref_ops.draw_scribble = lambda *a, **k: None
+    cfg = vo.make_cfg(embed_dim=128, depth=8, num_heads=4, out_dims=(16, 32, 64, 128), head_channels=32)
+    model, sd = build_reference(cfg, ref_vpu)
+
+    def draw_scribble(image_, scribble_, bounding_rectangle_, gt_mask=None):
+        arr = vo.polyline_raster(image_.cpu().numpy().copy(), np.asarray(scribble_[0]))
+        image_[:] = torch.from_numpy(arr)
+        return image_
+    model.draw_scribble = draw_scribble
+    B, P, H = 2, 200, cfg["img"]
+    batch = vo.synth_batch(B, H, seed=3)
+    img4 = torch.cat([batch["images"], torch.zeros(B, 1, H, H)], 1)
+    img4[0, 3] = torch.sigmoid(4 * (batch["instances"][0, 0] - 0.5))
+    pts, boxes, gt = batch["points"], batch["boxes"], batch["instances"]
+    rs = np.random.RandomState(17)
+    t = np.linspace(0, 1, P)
+    scr = np.zeros((B, 1, P, 2), np.float64)
+    rects = np.zeros((B, 1, 4), np.int64)
+    for b in range(B):
+        ys, xs = np.nonzero(gt[b, 0].numpy() > 0.5)
+        x0, x1, y0, y1 = xs.min(), xs.max(), ys.min(), ys.max()
+        scr[b, 0, :, 0] = x0 + (x1 - x0) * t + rs.uniform(-1.5, 1.5, P)
+        scr[b, 0, :, 1] = (y0 + y1) / 2 + 0.35 * (y1 - y0) * np.sin(5 * t + b) + rs.uniform(-1.5, 1.5, P)
+        rects[b, 0] = ((x0 + x1) // 2, (y0 + y1) // 2, x1 - x0, y1 - y0)
+    seed = 321
+    random.seed(seed)
+    with torch.no_grad():
+        out = model(img4.clone(), pts.clone(), [pts, boxes, [scr, rects]], 2, True, False)
+    random.seed(seed)
+    with torch.no_grad():
+        pue_ref = model._guassinvector_scribble(pts, [scr, rects]).numpy()
+    taps = {}
+    with torch.no_grad():
+        o_or = vo.vpu_forward(sd, cfg, img4, pts, boxes, 2, taps=taps, scribbles=(scr, rects), rng=random.Random(seed))
+    for k in ("instances", "instances_aux"):
+        err = (o_or[k] - out[k]).abs().max().item()
+        print(f"[tiny_scribble] oracle vs reference {k}: max abs err {err:.3e}")
+        assert err <= 2e-5 * max(1.0, out[k].abs().max().item())
+    got = vo.pue_scribble(pts.numpy(), scr.astype(np.int32), rects, random.Random(seed), 24, H)
+    assert np.abs(got - pue_ref).max() == 0.0
+    fx = {"cfg_" + k: np.asarray(v) for k, v in cfg.items()}
+    fx.update(B=np.asarray(B), images_seed=np.asarray(3), seed=np.asarray(seed), points=pts.numpy(), boxes=boxes.numpy(),
+              scribbles=scr, rects=rects, pue=pue_ref, coord_sum=taps["coord"].sum(dim=(2, 3)).numpy(),
+              coord_bits=np.packbits(taps["coord"][:, 1].numpy() > 0.5),
+              q_out=taps["q_out"].numpy(), seg_lowres=taps["seg_lowres"].numpy(),
+              sim_lowres_sub=taps["sim_lowres"][:, ::6, ::2, ::2].contiguous().numpy(),
+              instances_sub=sub(out["instances"].detach()), instances_aux_sub=sub(out["instances_aux"].detach()[:, ::6]))
+    np.savez_compressed(os.path.join(OUT, "tiny_scribble.npz"), **fx)
+    print("[tiny_scribble] written; pixels the poly-line adds per sample:",
+          (taps["coord"][:, 1].sum(dim=(1, 2)) - torch.from_numpy(vo.disk_maps(pts.numpy(), H, H))[:, 0].sum(dim=(1, 2))).tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom", "lrd", "scribble"]
+    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom", "lrd", "scribble", "tiny_scribble"]
     if "zoom" in which:
         zoom_fixtures()
     if "lrd" in which:
         lrd_fixture(ref_vpu)
     if "scribble" in which:
         scribble_fixture(ref_vpu)
+    if "tiny_scribble" in which:
+        scribble_model_fixture(ref_vpu)
     if "sim" in which:
         simulator_fixtures()
     if "pue" in which:

@@ -396,10 +396,42 @@ def box_outline(canvas, box, n_points, thickness=3):
     return canvas
 
 
-def coord_features(prev_mask, points, boxes=None, prompt_type=0, radius=5):
-    """ISModel.get_coord_features_with_prompt (is_model.py:78-95): cat(prev_mask, disks)."""
+def polyline_raster(canvas, curve, thickness=3):
+    """ISModel.draw_scribble (is_model.py:123-146): an open poly-line of thickness 3 through the int32-truncated scribble
+    points, OR-ed into channel 0 (always the positive channel).  PARITY UNPINNED like the box outline: the reference calls
+    cv2.polylines, absent here.  Rule of this rasteriser (exact integer arithmetic, shared with the HIP kernel): a pixel is
+    set iff its squared Euclidean distance to one of the segments is <= ((thickness - 1) / 2)^2 = 1: for a pixel whose
+    projection falls inside the segment cross^2 <= len^2, otherwise the nearer end point within distance 1."""
+    pts = np.asarray(curve)
+    pts = np.column_stack((pts[:, 0].astype(np.int32), pts[:, 1].astype(np.int32))).astype(np.int64)
+    r2 = ((thickness - 1) // 2) ** 2
+    H, W = canvas.shape[-2:]
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.int64)
+    hit = np.zeros((H, W), bool)
+    for (x0, y0), (x1, y1) in zip(pts[:-1], pts[1:]):
+        dx, dy = x1 - x0, y1 - y0
+        px, py = xs - x0, ys - y0
+        L2 = dx * dx + dy * dy
+        dot = px * dx + py * dy
+        cross = px * dy - py * dx
+        inside = (L2 > 0) & (dot >= 0) & (dot <= L2) & (cross * cross <= r2 * L2)   # (a repeated point is its end disks only)
+        e0 = px * px + py * py <= r2
+        e1 = (xs - x1) ** 2 + (ys - y1) ** 2 <= r2
+        hit |= inside | e0 | e1
+    if len(pts) == 1:
+        hit |= (xs - pts[0, 0]) ** 2 + (ys - pts[0, 1]) ** 2 <= r2
+    canvas[0] = np.where(hit, np.float32(1.0), canvas[0])
+    return canvas
+
+
+def coord_features(prev_mask, points, boxes=None, prompt_type=0, radius=5, scribbles=None):
+    """ISModel.get_coord_features_with_prompt (is_model.py:78-95): cat(prev_mask, disks).  ``scribbles`` (prompt type 2):
+    array [B,1,P,2] of (x, y)."""
     B, _, H, W = prev_mask.shape
     d = disk_maps(points.detach().cpu().numpy(), H, W, radius)
+    if prompt_type == 2:
+        for b in range(B):
+            d[b] = polyline_raster(d[b], np.asarray(scribbles)[b][0])
     if prompt_type == 1:
         n = points.shape[1] // 2
         bx = boxes.detach().cpu().numpy() if torch.is_tensor(boxes) else np.asarray(boxes)
@@ -614,11 +646,13 @@ def head_forward(sd, cfg, feats, q_out, drop_mask=None, taps=None):
 
 
 def vpu_forward(sd, cfg, image4, points, boxes=None, prompt_type=0, drop_mask=None, taps=None,
-                pue_override=None):
-    """VitMultiGaussianVector_ed_Model.forward (is_vpu_model.py:422-438) with edloss=True."""
+                pue_override=None, scribbles=None, rng=None):
+    """VitMultiGaussianVector_ed_Model.forward (is_vpu_model.py:422-438) with edloss=True.  Prompt type 2:
+    ``scribbles`` = (array [B,1,P,2] of (x, y), rects [B,1,4] of (x_center, y_center, width, height)) and ``rng`` a
+    ``random.Random`` standing for the reference's global ``random`` state at the call."""
     rgb = normalize_image(image4[:, :3])
     prev = image4[:, 3:]
-    coord = coord_features(prev, points, boxes, prompt_type)
+    coord = coord_features(prev, points, boxes, prompt_type, scribbles=None if scribbles is None else scribbles[0])
     x = vit_backbone(sd, cfg, rgb, coord, taps)
     if taps is not None:
         taps["backbone"] = x
@@ -627,6 +661,9 @@ def vpu_forward(sd, cfg, image4, points, boxes=None, prompt_type=0, drop_mask=No
         pue = pue_override
     elif prompt_type == 0:
         pue = pue_click(points.detach().cpu().numpy(), cfg["num_max_points"], cfg["img"])
+    elif prompt_type == 2:
+        pue = pue_scribble(points.detach().cpu().numpy(), np.asarray(scribbles[0]).astype(np.int32), np.asarray(scribbles[1]),
+                           rng, cfg["num_max_points"], cfg["img"])
     else:
         pue = pue_box(points.detach().cpu().numpy(),
                       boxes.detach().cpu().numpy() if torch.is_tensor(boxes) else boxes,

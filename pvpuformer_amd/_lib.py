@@ -64,6 +64,8 @@ SIGNATURES = {
     "vpu_pue_encode": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_cc_roots": [_P, _P, _I, _I, _I, _P],
     "vpu_edt": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vpu_pue_scribble_rows": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_draw_polyline": [_P, _P, _I, _I, _I, _I, _P],
     "vpu_disk_maps": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpu_patch_im2col": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_window_permute": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -145,6 +145,67 @@ __global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict_
 
 
 // ------------------------------------------------------------------------------------------------
+// Scribble prompts (prompt type 2).
+// (1) _guassinvector_scribble (is_vpu_model.py:294-352): after the click rows, the LAST valid positive row of a sample is
+//     replaced by that sample's scribble vectors (x profile | y profile | label one-hot 0).  The profiles themselves come
+//     from the host: GaussianVector_scribble (ops.py:244-296) is a sequential walk that deletes rows of the point list and
+//     draws from Python's global `random` -- its results only match the reference when drawn from that very generator.
+// (2) ISModel.draw_scribble (is_model.py:123-146): open poly-line of thickness 3 OR-ed into the positive disk channel.
+//     cv2.polylines is not available to pin against; rule (exact integers, shared with the oracle's rasteriser): a pixel is
+//     set iff its squared distance to a segment is <= 1.
+template <typename T>
+__global__ __launch_bounds__(256) void pue_scribble_rows_kernel(const float* __restrict__ points, const double* __restrict__ vec,
+                                                                T* __restrict__ out, double* __restrict__ out64, int n,
+                                                                int num_max, int img, int ld) {
+    const int b = blockIdx.x;
+    __shared__ int row_s;
+    if (threadIdx.x == 0) {
+        int row = -1;
+        for (int i = 0; i < n; ++i)
+            if (points[((int64_t)b * 2 * n + i) * 3 + 2] != -1.0f) row = i;
+        row_s = row;
+    }
+    __syncthreads();
+    const int row = row_s;
+    if (row < 0) return;                 // no valid positive click: nothing is replaced (is_vpu_model.py:337-339)
+    const int E = 2 * img + 3;
+    T* o = out + ((int64_t)b * 2 * num_max + row) * ld;
+    double* o64 = out64 ? out64 + ((int64_t)b * 2 * num_max + row) * E : nullptr;
+    const double* v = vec + (int64_t)b * 2 * img;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        double x = 0.0;
+        if (j < 2 * img) x = v[j];
+        else if (j == 2 * img) x = 1.0;
+        o[j] = from_f32<T>((float)x);
+        if (o64 && j < E) o64[j] = x;
+    }
+}
+
+// one block per (segment, sample): the threads walk the segment's bounding box grown by one pixel
+__global__ __launch_bounds__(256) void draw_polyline_kernel(const int* __restrict__ curve, float* __restrict__ disks, int P,
+                                                            int H, int W) {
+    const int seg = blockIdx.x, b = blockIdx.y;
+    const int* c = curve + ((int64_t)b * P + seg) * 2;
+    const long long x0 = c[0], y0 = c[1];
+    const bool last = seg + 1 >= P;
+    const long long x1 = last ? x0 : c[2], y1 = last ? y0 : c[3];
+    const long long dx = x1 - x0, dy = y1 - y0, L2 = dx * dx + dy * dy;
+    const int bx0 = (int)max(min(x0, x1) - 1, 0LL), bx1 = (int)min(max(x0, x1) + 1, (long long)W - 1);
+    const int by0 = (int)max(min(y0, y1) - 1, 0LL), by1 = (int)min(max(y0, y1) + 1, (long long)H - 1);
+    if (bx1 < bx0 || by1 < by0) return;
+    const int bw = bx1 - bx0 + 1, npx = bw * (by1 - by0 + 1);
+    float* ch0 = disks + (int64_t)b * 2 * H * W;          // channel 0: always the positive channel (is_model.py:124,145)
+    for (int i = threadIdx.x; i < npx; i += 256) {
+        const int x = bx0 + i % bw, y = by0 + i / bw;
+        const long long px = x - x0, py = y - y0;
+        const long long dot = px * dx + py * dy, cross = px * dy - py * dx;
+        const bool inside = L2 > 0 && dot >= 0 && dot <= L2 && cross * cross <= L2;
+        const long long qx = x - x1, qy = y - y1;
+        if (inside || px * px + py * py <= 1 || qx * qx + qy * qy <= 1) ch0[(int64_t)y * W + x] = 1.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exact Euclidean distance transform: distance of every non-zero pixel to the nearest zero pixel (0 at zero pixels) --
 // what the click simulators take the arg-max of (isegm/inference/clicker.py:29-56 cv2.distanceTransform(DIST_L2, 0),
 // isegm/engine/trainer.py:628-629, 673-674, 736-737; scipy.ndimage.distance_transform_edt in this build's mirror).
@@ -293,6 +354,26 @@ extern "C" int vpu_pue_encode(const float* points, const int32_t* boxes, const f
         pue_encode_kernel<float><<<grid, 256, 0, ST>>>(points, boxes, lut, (float*)out, out64, n, num_max, img, ld);
     else { vpu_set_error("pue_encode: dtype"); return VPU_ERR_ARG; }
     return vpu_check_launch("vpu_pue_encode");
+}
+
+extern "C" int vpu_pue_scribble_rows(const float* points, const double* vec, void* out, double* out64, int32_t B, int32_t n,
+                                     int32_t num_max, int32_t img, int32_t ld, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (!points || !vec || !out || n > num_max || ld < 2 * img + 3 || B <= 0) {
+        vpu_set_error("pue_scribble_rows: non-null operands, n <= num_max, ld >= 2*img+3");
+        return VPU_ERR_ARG;
+    }
+    if (dtype == VPU_BF16) pue_scribble_rows_kernel<bf16_t><<<B, 256, 0, ST>>>(points, vec, (bf16_t*)out, out64, n, num_max, img, ld);
+    else if (dtype == VPU_F32) pue_scribble_rows_kernel<float><<<B, 256, 0, ST>>>(points, vec, (float*)out, out64, n, num_max, img, ld);
+    else { vpu_set_error("pue_scribble_rows: dtype"); return VPU_ERR_ARG; }
+    return vpu_check_launch("vpu_pue_scribble_rows");
+}
+
+extern "C" int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, int32_t P, int32_t H, int32_t W, void* stream) {
+    vpu_clear_stale_error();
+    if (!curve || !disks || B <= 0 || P <= 0 || P > 65535 || H <= 0 || W <= 0) { vpu_set_error("draw_polyline: sizes"); return VPU_ERR_ARG; }
+    draw_polyline_kernel<<<dim3((unsigned)P, (unsigned)B), 256, 0, ST>>>(curve, disks, P, H, W);
+    return vpu_check_launch("vpu_draw_polyline");
 }
 
 extern "C" int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H,

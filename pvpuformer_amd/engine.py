@@ -587,8 +587,9 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ model
     def forward(self, image4, points, boxes=None, prompt_type=0, drop_mask=None, training=False, taps=None,
-                materialize_aux=True):
-        """image4 fp32 [B,4,H,W]; points fp32 [B,2n,3]; boxes int32 [B,5] (prompt_type 1).
+                materialize_aux=True, scribble=None):
+        """image4 fp32 [B,4,H,W]; points fp32 [B,2n,3]; boxes int32 [B,5] (prompt_type 1); scribble (prompt_type 2) =
+        (curve int32 [B,P,2] poly-line vertices, profiles float64 [B, 2*img] from isegm/model/scribble.py).
         Returns instances fp32 [B,1,H,W] (logits) and instances_aux fp32 [B,S,H,W].  ``materialize_aux=False`` skips the
         38.5 MB/img upsample of the P2CL similarities: aux is None, the low-resolution planes stay in ``self.sim_low``
         [B,S,h,w] for the fused loss (ops.p2cl_up_fwd_bwd) and backward() takes their gradient as ``d_sim_low``."""
@@ -608,9 +609,18 @@ class Engine:
         use_box = prompt_type == 1
         if use_box:
             boxes = boxes.to(device=self.dev, dtype=torch.int32).contiguous()
+        use_scr = prompt_type == 2
+        if use_scr:
+            curve = scribble[0].to(device=self.dev, dtype=torch.int32).contiguous()
+            prof = scribble[1].to(device=self.dev, dtype=torch.float64).contiguous()
+            assert curve.shape[0] == B and tuple(prof.shape) == (B, 2 * self.img)
         # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
         disks = self._new(B, 2, H, W_, dtype=torch.float32)
         ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, self.norm_radius)
+        if use_scr:     # ISModel.draw_scribble (is_model.py:123-146): poly-line into the positive channel
+            ops.draw_polyline(curve, disks, B, curve.shape[1], H, W_)
+        if taps is not None:
+            taps["disks"] = disks
         KP = 2 * self.k3p
         cols = self._new(M, KP)
         ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg)
@@ -677,6 +687,8 @@ class Engine:
         nq = 2 * self.nmax
         pue = Var(self._new(B * nq, self.Epad))
         ops.pue_encode(points, boxes if use_box else None, self.lut, pue.t, None, B, n, self.nmax, self.img, self.Epad)
+        if use_scr:     # _guassinvector_scribble (is_vpu_model.py:294-352): the last valid positive row becomes the scribble
+            ops.pue_scribble_rows(points, prof, pue.t, None, B, n, self.nmax, self.img, self.Epad)
         # ---- a10/a11: DMA neck
         q0 = self.mlp(pue, "neck.ffn_layer.lin1", "neck.ffn_layer.lin2", B * nq, self.Epad, 2048, D, "relu",
                       w1=self.w_lin1p, k_grad=self.E, x_grad=False)

@@ -120,6 +120,62 @@ def cal_box(gt_mask, fn_mask, fp_mask, points, as_allmask=True, jitter_box=True,
     return out
 
 
+def _bezier(ctrl, ts):
+    """Bezier curve of degree len(ctrl) - 1 through the Bernstein basis (what bezier.Curve.evaluate_multi returns; that
+    package is not in this image)."""
+    from math import comb
+    k = len(ctrl) - 1
+    basis = np.stack([comb(k, i) * ts ** i * (1 - ts) ** (k - i) for i in range(k + 1)], 1)   # [T, k+1]
+    return basis @ ctrl
+
+
+def cal_scribble(gt_mask, min_p=3, max_p=10, num_samples=1000, rng=random, np_rng=np.random):
+    """Scribble simulator (trainer.py:1133-1243): per sample a smooth stroke through 3-10 random pixels of the largest
+    region of ``gt_mask`` [B,H,W] -- one per stratum of the region's row range -- either as the Bezier curve of those
+    control points or as the interpolating spline over the rows (coin flip per sample), clipped to the region's bounding
+    box and truncated to integers.  Returns [scribbles float [B,1,num_samples,2] of (x, y), rectangles int [B,1,4] of
+    (x_center, y_center, width, height)], the layout the model's scribble branch takes.  PARITY UNPINNED: the reference
+    draws its curves with the ``bezier`` package (absent here) and is never asked for scribbles by the shipped trainer
+    (trainer.py:367); the generator order of the draws (num_p, then per stratum row and pixel, then the coin) follows it."""
+    from scipy.interpolate import make_interp_spline
+    B = len(gt_mask)
+    scr = np.zeros((B, 1, num_samples, 2), np.float64)
+    rects = np.zeros((B, 1, 4), np.int64)
+    for b in range(B):
+        if not np.any(gt_mask[b]):
+            continue
+        rc = np.argwhere(max_connected_regions(gt_mask[b]) == 1)       # (row, col) pixels of the kept region
+        num_p = rng.randint(min_p, max_p)
+        r0, r1, c0, c1 = rc[:, 0].min(), rc[:, 0].max(), rc[:, 1].min(), rc[:, 1].max()
+        gap = int(r1 - r0) // num_p
+        ctrl, lo = [], int(r0)
+        for _ in range(num_p):
+            row = rng.randint(lo, lo + gap - 1) if gap > 0 else rng.randint(lo, lo + gap)
+            cand = rc[rc[:, 0] == row]
+            if len(cand):
+                ctrl.append(cand[rng.randint(0, len(cand) - 1)])
+            lo += gap
+        if not ctrl:
+            continue
+        ctrl = np.asarray(ctrl, np.float64)
+        inline = np_rng.rand() > 0.5
+        curve = None
+        if not inline:
+            try:
+                spline = make_interp_spline(ctrl[:, 0], ctrl[:, 1])
+                rows = np.linspace(ctrl[:, 0].min(), ctrl[:, 0].max(), num_samples)
+                curve = np.stack([rows, spline(rows)], 1)
+            except Exception:
+                curve = None
+        if curve is None:
+            curve = _bezier(ctrl, np.linspace(0.0, 1.0, num_samples))
+        rows_i = np.clip(curve[:, 0], r0, r1).astype(int)
+        cols_i = np.clip(curve[:, 1], c0, c1).astype(int)
+        scr[b, 0] = np.stack([cols_i, rows_i], 1)
+        rects[b, 0] = (int(0.5 * (c0 + c1)), int(0.5 * (r0 + r1)), int(c1 - c0), int(r1 - r0))
+    return [scr, rects]
+
+
 def next_click(pred, gt, points, pred_thresh=0.49, np_rng=np.random, device=None):
     """The shared body of get_next_points / get_next_promts (trainer.py:615-654, 733-764): for each sample the new
     click (or None), its slot, and whether it is positive.  pred: float [B,H,W]; gt: bool [B,H,W]; points float

@@ -94,7 +94,14 @@ class VPUTrainStep:
                                    slot_idx=state.slot_idx.clone(), override=state.override.clone()))
             last = it == num_iters - 1
             eng.grad_ready_hook = self.red.ready if (self.red is not None and last) else None
-            inst, _ = eng.forward(net_input, points, boxes, ptype, mask, training=True, materialize_aux=False)
+            scribble = None
+            if ptype == 2:   # stroke over the ground-truth region, vectors drawn from `rng` (the reference: global random)
+                from ..model.scribble import scribble_curves, scribble_profiles
+                from .prompt_sim import cal_scribble
+                scr, rects = cal_scribble(gt[:, 0].detach().cpu().numpy() > 0.5, rng=rng, np_rng=np_rng)
+                scribble = (torch.from_numpy(scribble_curves(scr)), torch.from_numpy(scribble_profiles(scr, rects, H, rng)))
+            inst, _ = eng.forward(net_input, points, boxes, ptype, mask, training=True, materialize_aux=False,
+                                  scribble=scribble)
             losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, state.slot_idx, state.override,
                                                     iter_weight=float(self.iter_w[it]), w_nfl=self.lw[0],
                                                     w_dice=self.lw[1], w_pcl=self.lw[2], sim_low=eng.sim_low)

@@ -56,9 +56,9 @@ class _VPUFunction(torch.autograd.Function):
     Parameter gradients are accumulated directly into ``param.grad`` (views of the flat gradient buffer)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, image, points, boxes, prompt_type, drop_mask):
+    def forward(ctx, anchor, model, image, points, boxes, prompt_type, drop_mask, scribble):
         ctx.engine = model._engine
-        inst, aux = model._engine.forward(image, points, boxes, prompt_type, drop_mask, training=True)
+        inst, aux = model._engine.forward(image, points, boxes, prompt_type, drop_mask, training=True, scribble=scribble)
         ctx.tape = model._engine.last_tape      # THIS call's tape: several forwards may be pending before one backward
         return inst, aux
 
@@ -66,7 +66,7 @@ class _VPUFunction(torch.autograd.Function):
     def backward(ctx, d_inst, d_aux):
         ctx.engine.backward(d_inst, d_aux, tape=ctx.tape)
         ctx.tape = None
-        return (None,) * 7
+        return (None,) * 8
 
 
 class VitMultiGaussianVector_ed_Model(ISModel):
@@ -165,16 +165,24 @@ class VitMultiGaussianVector_ed_Model(ISModel):
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, image, points=None, prompts=None, as_prompt_type=0, edloss=True, pclout=False):
         """image [B,4,H,W] (rgb in [0,1] + previous mask), points [B,2n,3] (row, col, order; -1 pad),
-        prompts = (points, boxes[B,5] int32, scribbles) for as_prompt_type 1 (is_vpu_model.py:383-438)."""
+        prompts = (points, boxes[B,5] int32, scribbles) for as_prompt_type 1 and 2; scribbles = [points array [B,1,P,2] of
+        (x, y), bounding rectangles [B,1,4] of (x_center, y_center, width, height)] as ``cal_scribble`` returns them
+        (numpy, not tensors: trainer.py:1192-1243) (is_vpu_model.py:383-438)."""
         eng = self._ensure_engine()
         if not edloss:
             raise NotImplementedError("edloss=False (plain head.forward) is not used by the VPU trainer / predictor")
-        boxes = None
+        boxes, scribble = None, None
         if as_prompt_type == 1:
             points, boxes, _ = prompts
+        elif as_prompt_type == 2:
+            from .scribble import scribble_curves, scribble_profiles
+            points, _, (scr_pts, scr_rects) = prompts
+            if torch.is_tensor(scr_pts):
+                scr_pts, scr_rects = scr_pts.detach().cpu().numpy(), scr_rects.detach().cpu().numpy()
+            scribble = (torch.from_numpy(scribble_curves(scr_pts)),
+                        torch.from_numpy(scribble_profiles(scr_pts, scr_rects, self.image_size[0])))   # draws from `random`
         elif as_prompt_type != 0:
-            raise NotImplementedError("scribble prompts (as_prompt_type=2) are never sampled by the shipped trainer or "
-                                      "evaluator (trainer.py:367, vpu_evaluation.py:51); not built")
+            raise ValueError(f"as_prompt_type must be 0 (clicks), 1 (box) or 2 (scribble), got {as_prompt_type}")
         image = image.contiguous().float()
         if not self.weights_frozen or not eng.shadow_valid:
             eng.refresh_weights()
@@ -183,11 +191,11 @@ class VitMultiGaussianVector_ed_Model(ISModel):
             keep = 1.0 - self.head.dropout_ratio
             drop_mask = torch.bernoulli(torch.full((image.shape[0], self.head.channels), keep, device=image.device)) / keep
         if torch.is_grad_enabled():
-            inst, aux = _VPUFunction.apply(self._anchor, self, image, points, boxes, as_prompt_type, drop_mask)
-        elif self.graph_inference and self.weights_frozen and drop_mask is None and image.is_cuda:
+            inst, aux = _VPUFunction.apply(self._anchor, self, image, points, boxes, as_prompt_type, drop_mask, scribble)
+        elif self.graph_inference and self.weights_frozen and drop_mask is None and image.is_cuda and scribble is None:
             inst, aux = self._graph_forward(eng, image, points, boxes, as_prompt_type)
         else:
-            inst, aux = eng.forward(image, points, boxes, as_prompt_type, drop_mask, training=False)
+            inst, aux = eng.forward(image, points, boxes, as_prompt_type, drop_mask, training=False, scribble=scribble)
         return {'instances': inst, 'instances_aux': aux if self.with_aux_output else None}
 
     def _graph_forward(self, eng, image, points, boxes, ptype):

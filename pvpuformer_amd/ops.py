@@ -241,6 +241,15 @@ def pue_encode(points, boxes, lut, out, out64, B, n, num_max, img, ld):
               code_of(out), _stream())
 
 
+def pue_scribble_rows(points, vec64, out, out64, B, n, num_max, img, ld):
+    _lib.call("vpu_pue_scribble_rows", ptr(points), ptr(vec64), ptr(out), ptr(out64), B, n, num_max, img, ld, code_of(out),
+              _stream())
+
+
+def draw_polyline(curve_i32, disks, B, P, H, W):
+    _lib.call("vpu_draw_polyline", ptr(curve_i32), ptr(disks), B, P, H, W, _stream())
+
+
 def disk_maps(points, boxes, out, B, n, H, W, radius):
     _lib.call("vpu_disk_maps", ptr(points), ptr(boxes), ptr(out), B, n, H, W, float(radius), _stream())
 

@@ -592,7 +592,9 @@ def test_istrainer_mirror_runs_epochs_and_evaluate_dataset(golden_dir, tmp_path)
     assert abs(tr.optim.lr - 1e-4) < 1e-12 and tr.optim.step_count == 4
     assert torch.isfinite(tr.last_train_loss).item() and np.isfinite(tr.last_val_loss)
     moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
-    assert len(moved) > 300 and "backbone.head.weight" not in moved
+    from pvpuformer_amd.optim import is_never_used
+    used = [n for n in before if not is_never_used(n)]
+    assert len(moved) >= len(used) - 8 and not any(is_never_used(n) for n in moved)   # (a few biases have ~zero gradients)
     ck = torch.load(os.path.join(str(tmp_path), "000.pth"), weights_only=False)
     assert set(ck) == {"state_dict", "config"} and list(ck["state_dict"]) == list(model.state_dict())
     again = load_model(ck["config"])
@@ -620,3 +622,90 @@ def test_istrainer_mirror_runs_epochs_and_evaluate_dataset(golden_dir, tmp_path)
     all_ious, secs = evaluate_dataset(EvalDS(), pred, max_iou_thr=0.99, pred_thr=0.49, max_clicks=3)
     assert len(all_ious) == 2 and all(a.dtype == np.float32 and 1 <= len(a) <= 3 and np.all((a >= 0) & (a <= 1)) for a in all_ious)
     assert secs > 0
+
+
+def test_scribble_prompt_rows_and_polyline_bit_exact(golden_dir):
+    """a9 + a3 (prompt type 2) at the kernel level: the PuE rows after the scribble-row overwrite equal the REFERENCE's
+    float64 rows bit for bit (scribble.npz: crafted clicks incl. a sample without a valid positive row; tiny_scribble.npz:
+    profiles with non-zero entries), and the poly-line kernel sets exactly the pixels of the oracle's rasteriser (ragged
+    bounding boxes at the image border, repeated points, a single-point line)."""
+    import random
+    from pvpuformer_amd import ops
+    from pvpuformer_amd.engine import click_lut
+    from pvpuformer_amd.isegm.model.scribble import scribble_curves, scribble_profiles
+    lut = torch.from_numpy(click_lut()).cuda()
+    for name in ("scribble.npz", "tiny_scribble.npz"):
+        fx = np.load(os.path.join(golden_dir, name))
+        pts = torch.from_numpy(fx["points"]).cuda()
+        B, n, img = pts.shape[0], pts.shape[1] // 2, 448
+        prof = torch.from_numpy(scribble_profiles(fx["scribbles"], fx["rects"], img, random.Random(int(fx["seed"])))).cuda()
+        E = 2 * img + 3
+        out = torch.zeros(B, 48, 904, device="cuda")
+        out64 = torch.zeros(B, 48, E, device="cuda", dtype=torch.float64)
+        ops.pue_encode(pts, None, lut, out, out64, B, n, 24, img, 904)
+        ops.pue_scribble_rows(pts, prof, out, out64, B, n, 24, img, 904)
+        assert np.array_equal(out64.cpu().numpy(), fx["pue"]), name
+        assert np.array_equal(out[..., :E].cpu().numpy().astype(np.float64), fx["pue"].astype(np.float32).astype(np.float64))
+        assert float(out[..., E:].abs().max()) == 0.0
+    rs = np.random.RandomState(3)
+    curves = np.zeros((3, 1, 40, 2), np.float64)
+    curves[0, 0] = np.stack([np.linspace(-5, 120, 40), np.linspace(90, 20, 40)], 1) + rs.uniform(-2, 2, (40, 2))
+    curves[1, 0] = np.stack([np.full(40, 95.7), np.linspace(3, 110, 40)], 1)
+    curves[1, 0, 10:14] = curves[1, 0, 10]                          # repeated points: zero-length segments
+    curves[2, 0] = (50.2, 60.9)                                     # every vertex the same pixel
+    H, W = 100, 96
+    disks = torch.zeros(3, 2, H, W, device="cuda")
+    disks[0, 0, 5, 5] = 1.0
+    ops.draw_polyline(torch.from_numpy(scribble_curves(curves)).cuda(), disks, 3, 40, H, W)
+    ref = np.zeros((3, 2, H, W), np.float32)
+    ref[0, 0, 5, 5] = 1.0
+    for b in range(3):
+        ref[b] = vo.polyline_raster(ref[b], curves[b, 0])
+    assert np.array_equal(disks.cpu().numpy(), ref) and ref[2].sum() == 5 and ref[:, 1].sum() == 0
+
+
+def test_tiny_scribble_mode_matches_reference(golden_dir):
+    """Prompt type 2 through the whole model against the reference's own forward (tiny_scribble.npz; its draw_scribble
+    routed through the oracle's rasteriser, as for boxes): coordinate features bit-exact, mask logits within 1e-3
+    relative in the fp32 engine mode; the global ``random`` state is what the reference's vector walk draws from."""
+    import random
+    fx = np.load(os.path.join(golden_dir, "tiny_scribble.npz"))
+    cfg = cfg_from_fixture(fx)
+    sd = vo.synth_state_dict(vo.param_shapes(cfg), seed=0)
+    model = make_model(cfg).cuda()
+    model.load_state_dict(sd, strict=True)
+    model.set_compute_dtype("f32")
+    model.eval()
+    B = int(fx["B"])
+    batch = vo.synth_batch(B, cfg["img"], seed=int(fx["images_seed"]))
+    img4 = torch.cat([batch["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1)
+    img4[0, 3] = torch.sigmoid(4 * (batch["instances"][0, 0] - 0.5))
+    pts = torch.from_numpy(fx["points"]).cuda()
+    prompts = (pts, torch.from_numpy(fx["boxes"]).cuda(), [fx["scribbles"], fx["rects"]])
+    random.seed(int(fx["seed"]))
+    with torch.no_grad():
+        out = model(img4.cuda(), pts, prompts, 2)
+    assert _relerr(out["instances"][..., ::7, ::7].cpu().numpy(), fx["instances_sub"]) < 1e-3
+    assert _relerr(out["instances_aux"][:, ::6, ::7, ::7].cpu().numpy(), fx["instances_aux_sub"]) < 1e-3
+    # taps: coordinate features and the neck's query output
+    from pvpuformer_amd.isegm.model.scribble import scribble_curves, scribble_profiles
+    eng = model._ensure_engine()
+    taps = {}
+    scr = (torch.from_numpy(scribble_curves(fx["scribbles"])),
+           torch.from_numpy(scribble_profiles(fx["scribbles"], fx["rects"], cfg["img"], random.Random(int(fx["seed"])))))
+    with torch.no_grad():
+        eng.forward(img4.cuda(), pts, None, 2, None, training=False, taps=taps, scribble=scr)
+    assert np.array_equal(np.packbits(taps["disks"][:, 0].cpu().numpy() > 0.5), fx["coord_bits"])
+    assert _relerr(taps["q_out"].float().view(B, 48, -1).cpu().numpy(), fx["q_out"]) < 1e-3
+    assert _relerr(taps["seg_lowres"].cpu().numpy(), fx["seg_lowres"]) < 1e-3
+    # train mode: the scribble path back-propagates (bf16), gradients finite and non-trivial
+    model.set_compute_dtype("bf16")
+    model.train()
+    model.zero_grad()
+    random.seed(int(fx["seed"]))
+    o = model(img4.cuda(), pts, prompts, 2)
+    gt = batch["instances"].cuda()
+    total, _ = vo.step_loss(o, gt, vo.ed_mask_label(gt))
+    total.backward()
+    g = dict(model.named_parameters())["neck.ffn_layer.lin1.weight"].grad
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0

@@ -118,3 +118,22 @@ def test_get_next_points_bit_exact(golden_dir):
         out = get_next_points(torch.from_numpy(pred), gt, pts)
         assert np.array_equal(out.numpy(), fx[f"r{r}_next_points"]), f"round {r}"
         assert np.array_equal(pts.numpy(), fx[f"r{r}_points_in"]), "the input points must not be modified"
+
+
+def test_cal_scribble_stays_inside_the_region_box():
+    """The scribble simulator: strokes are integer (x, y) samples inside the bounding box of the largest region, the
+    rectangle is that box as (x_center, y_center, width, height); an empty mask gives zeros (which the profile walk
+    treats as "no scribble", ops.py:246-247)."""
+    import random as _r
+    m = np.zeros((3, 120, 160), bool)
+    m[0, 20:90, 30:140] = True
+    m[1, 50:60, 10:20] = True; m[1, 5:8, 100:103] = True           # the small blob is dropped (< 10 %)
+    out, rects = ps.cal_scribble(m, rng=_r.Random(3), np_rng=np.random.RandomState(4), num_samples=200)
+    assert out.shape == (3, 1, 200, 2) and rects.shape == (3, 1, 4)
+    assert tuple(rects[0, 0]) == (84, 54, 109, 69) and tuple(rects[1, 0]) == (14, 54, 9, 9) and not rects[2].any()
+    for b, (x0, x1, y0, y1) in enumerate([(30, 139, 20, 89), (10, 19, 50, 59)]):
+        s = out[b, 0]
+        assert np.all(s == np.floor(s)) and s[:, 0].min() >= x0 and s[:, 0].max() <= x1 and s[:, 1].min() >= y0 and s[:, 1].max() <= y1
+    assert not out[2].any()
+    a, _ = ps.cal_scribble(m, rng=_r.Random(3), np_rng=np.random.RandomState(4), num_samples=200)
+    assert np.array_equal(a, out)

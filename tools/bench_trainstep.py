@@ -4,7 +4,8 @@
 click / box prompt type per iteration, the next click and the error-mask label simulated between the iterations
 (host bookkeeping, distance transforms on the GPU), each iteration back-propagated, one fused Adam step.
 Prints optimizer steps/s and images/s (images = batch size per step, as the reference counts them) next to the
-single-iteration rate of bench.py.   usage: python tools/bench_trainstep.py [steps] [batch]"""
+single-iteration rate of bench.py.   usage: python tools/bench_trainstep.py [steps] [batch]
+BENCH_PROMPTS=0,1,2 samples click / box / scribble prompts per iteration (BASELINE.json config 4's mix)."""
 import os
 import random
 import sys
@@ -33,6 +34,10 @@ def main():
     step = VPUTrainStep(model, optimizer=FusedAdam(model, lr=5e-5))
     batch = synth_batch(B, 448, seed=3, device="cuda")
     rng, np_rng = random.Random(0), np.random.RandomState(0)
+    mixed = os.environ.get("BENCH_PROMPTS", "")          # e.g. "0,1,2": config 4's click / box / scribble mix
+    if mixed:
+        step.ptypes = tuple(int(t) for t in mixed.split(","))
+        print("prompt types sampled per iteration:", step.ptypes)
     for fixed in (1, None):
         iters = 0
         for i in range(steps + 2):
