@@ -202,6 +202,20 @@ int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, int32_t P, 
  * scratch: int32 [B][H][W]. */
 int vpu_edt(const uint8_t* mask, int32_t* scratch, float* dist, int32_t B, int32_t H, int32_t W, int32_t zero_border,
             void* stream);
+/* NoBRS-loop reductions over maps that stay on the device (zoom_in.py:30-165, clicker.py:29-56).
+ * vpu_mask_bbox: out[b] = {pixels with prob > thr, rmin, rmax, cmin, cmax} of image b of prob [B][H][W], the box joined
+ * with the nclicks positive clicks pos_clicks (int32 (row, col) pairs; zoom_in.py:153-158 sets them in the mask first);
+ * an empty mask without clicks gives {0, H, -1, W, -1}.
+ * vpu_masked_argmax: per plane of dist [planes][H][W] the maximum of dist * keep (keep uint8 [H][W], shared) and the FIRST
+ * raster index attaining it (numpy's tie rule), packed as (float bits of the maximum) << 32 | (0xFFFFFFFF - index). */
+int vpu_mask_bbox(const float* prob, float thr, const int32_t* pos_clicks, int32_t nclicks, int32_t* out, int32_t B,
+                  int32_t H, int32_t W, void* stream);
+/* out uint8 [2][H][W] = (gt & !pred & valid, !gt & pred & valid): the false-negative / false-positive masks the Clicker
+ * takes the distance transforms of (clicker.py:30-31); pred, gt, valid uint8 [H][W]. */
+int vpu_error_masks(const uint8_t* pred, const uint8_t* gt, const uint8_t* valid, uint8_t* out, int32_t H, int32_t W,
+                    void* stream);
+int vpu_masked_argmax(const float* dist, const uint8_t* keep, uint64_t* out, int32_t planes, int32_t H, int32_t W,
+                      void* stream);
 /* 8-connected components of B masks [B][H][W]: roots[i] = smallest linear index (within the whole [B][H][W] array) of the
  * component of non-zero pixel i, -1 on zero pixels.  Sorted by root, the components are in the raster order of their first
  * pixel -- the label order of the reference's skimage.measure.label(connectivity=2) in max_connected_regions

@@ -66,6 +66,9 @@ SIGNATURES = {
     "vpu_edt": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_pue_scribble_rows": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_draw_polyline": [_P, _P, _I, _I, _I, _I, _P],
+    "vpu_mask_bbox": [_P, _F, _P, _I, _P, _I, _I, _I, _P],
+    "vpu_masked_argmax": [_P, _P, _P, _I, _I, _I, _P],
+    "vpu_error_masks": [_P, _P, _P, _P, _I, _I, _P],
     "vpu_disk_maps": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpu_patch_im2col": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_window_permute": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -206,6 +206,77 @@ __global__ __launch_bounds__(256) void draw_polyline_kernel(const int* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// NoBRS loop bookkeeping on the device (isegm/inference/transforms/zoom_in.py:30-165, isegm/inference/clicker.py:29-56):
+// the previous prediction never leaves the GPU; these two reductions replace the host passes over it.
+// (1) bounding box of {prob > thr} joined with the positive clicks (the reference sets those pixels in a copy of the mask
+//     before taking the box: same box): out[b] = {count of mask pixels, rmin, rmax, cmin, cmax}.
+// (2) arg-max with numpy's tie rule (first index in raster order) of dist * keep over each of P planes, as ONE 64-bit key
+//     per plane: (float bits of the maximum) << 32 | (0xFFFFFFFF - linear index) -- distances are >= 0, so their bit
+//     patterns order like the values, and the larger low half is the smaller index.
+__global__ __launch_bounds__(256) void mask_bbox_kernel(const float* __restrict__ prob, float thr, int* __restrict__ out,
+                                                        int H, int W) {
+    const int b = blockIdx.y;
+    const float* p = prob + (int64_t)b * H * W;
+    int cnt = 0, r0 = H, r1 = -1, c0 = W, c1 = -1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+        if (p[i] > thr) {
+            const int r = i / W, c = i - r * W;
+            ++cnt; r0 = min(r0, r); r1 = max(r1, r); c0 = min(c0, c); c1 = max(c1, c);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+        r0 = min(r0, __shfl_xor(r0, o, 64)); r1 = max(r1, __shfl_xor(r1, o, 64));
+        c0 = min(c0, __shfl_xor(c0, o, 64)); c1 = max(c1, __shfl_xor(c1, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && cnt > 0) {
+        int* o5 = out + b * 5;
+        atomicAdd(o5, cnt); atomicMin(o5 + 1, r0); atomicMax(o5 + 2, r1); atomicMin(o5 + 3, c0); atomicMax(o5 + 4, c1);
+    }
+}
+__global__ void mask_bbox_init_kernel(int* __restrict__ out, const int* __restrict__ clicks, int nclicks, int B, int H, int W) {
+    const int b = threadIdx.x;
+    if (b >= B) return;
+    int r0 = H, r1 = -1, c0 = W, c1 = -1;
+    for (int i = 0; i < nclicks; ++i) {        // positive clicks of this image: (row, col) pairs
+        const int r = clicks[2 * i], c = clicks[2 * i + 1];
+        r0 = min(r0, r); r1 = max(r1, r); c0 = min(c0, c); c1 = max(c1, c);
+    }
+    int* o5 = out + b * 5;
+    o5[0] = 0; o5[1] = r0; o5[2] = r1; o5[3] = c0; o5[4] = c1;
+}
+
+// false-negative / false-positive masks of one prediction against the ground truth, restricted to the labelled pixels
+// (clicker.py:30-31): out[0] = gt & !pred & valid, out[1] = !gt & pred & valid
+__global__ __launch_bounds__(256) void error_masks_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt,
+                                                          const uint8_t* __restrict__ valid, uint8_t* __restrict__ out, int HW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const bool p = pred[i] != 0, g = gt[i] != 0, v = valid[i] != 0;
+    out[i] = (g && !p && v) ? 1 : 0;
+    out[HW + i] = (!g && p && v) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restrict__ dist, const uint8_t* __restrict__ keep,
+                                                            unsigned long long* __restrict__ out, int HW) {
+    const int pl = blockIdx.y;
+    const float* d = dist + (int64_t)pl * HW;
+    unsigned long long best = 0ull;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float v = keep[i] ? d[i] : 0.0f;                       // (dist * not_clicked_map: a clicked pixel counts as 0)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(best, o, 64);
+        best = t > best ? t : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out + pl, best);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exact Euclidean distance transform: distance of every non-zero pixel to the nearest zero pixel (0 at zero pixels) --
 // what the click simulators take the arg-max of (isegm/inference/clicker.py:29-56 cv2.distanceTransform(DIST_L2, 0),
 // isegm/engine/trainer.py:628-629, 673-674, 736-737; scipy.ndimage.distance_transform_edt in this build's mirror).
@@ -374,6 +445,38 @@ extern "C" int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, 
     if (!curve || !disks || B <= 0 || P <= 0 || P > 65535 || H <= 0 || W <= 0) { vpu_set_error("draw_polyline: sizes"); return VPU_ERR_ARG; }
     draw_polyline_kernel<<<dim3((unsigned)P, (unsigned)B), 256, 0, ST>>>(curve, disks, P, H, W);
     return vpu_check_launch("vpu_draw_polyline");
+}
+
+extern "C" int vpu_mask_bbox(const float* prob, float thr, const int32_t* pos_clicks, int32_t nclicks, int32_t* out, int32_t B,
+                             int32_t H, int32_t W, void* stream) {
+    vpu_clear_stale_error();
+    if (!prob || !out || B < 1 || B > 64 || H < 1 || W < 1 || nclicks < 0 || (nclicks > 0 && !pos_clicks)) {
+        vpu_set_error("mask_bbox: sizes (1 <= B <= 64)");
+        return VPU_ERR_ARG;
+    }
+    mask_bbox_init_kernel<<<1, 64, 0, ST>>>(out, pos_clicks, nclicks, B, H, W);
+    const int nb = (H * W + 2047) / 2048;
+    mask_bbox_kernel<<<dim3((unsigned)(nb < 128 ? nb : 128), (unsigned)B), 256, 0, ST>>>(prob, thr, out, H, W);
+    return vpu_check_launch("vpu_mask_bbox");
+}
+
+extern "C" int vpu_error_masks(const uint8_t* pred, const uint8_t* gt, const uint8_t* valid, uint8_t* out, int32_t H, int32_t W,
+                               void* stream) {
+    vpu_clear_stale_error();
+    if (!pred || !gt || !valid || !out || H < 1 || W < 1) { vpu_set_error("error_masks: sizes"); return VPU_ERR_ARG; }
+    error_masks_kernel<<<(H * W + 255) / 256, 256, 0, ST>>>(pred, gt, valid, out, H * W);
+    return vpu_check_launch("vpu_error_masks");
+}
+
+extern "C" int vpu_masked_argmax(const float* dist, const uint8_t* keep, uint64_t* out, int32_t planes, int32_t H, int32_t W,
+                                 void* stream) {
+    vpu_clear_stale_error();
+    if (!dist || !keep || !out || planes < 1 || H < 1 || W < 1) { vpu_set_error("masked_argmax: sizes"); return VPU_ERR_ARG; }
+    if (hipMemsetAsync(out, 0, sizeof(uint64_t) * planes, ST) != hipSuccess) { vpu_set_error("masked_argmax: memset"); return VPU_ERR_LAUNCH; }
+    const int nb = (H * W + 2047) / 2048;
+    masked_argmax_kernel<<<dim3((unsigned)(nb < 128 ? nb : 128), (unsigned)planes), 256, 0, ST>>>(
+        dist, keep, reinterpret_cast<unsigned long long*>(out), H * W);
+    return vpu_check_launch("vpu_masked_argmax");
 }
 
 extern "C" int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H,

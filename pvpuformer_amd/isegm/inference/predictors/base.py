@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from ...engine.prompt_sim import get_next_promts
-from ..transforms import AddHorizontalFlip, LimitLongestSide, SigmoidForPred, get_roi_image_nd, resize_align_corners
+from ..transforms import AddHorizontalFlip, LimitLongestSide, SigmoidForPred, crop_resize, resize_align_corners
 
 
 class BasePredictor:
@@ -16,6 +16,7 @@ class BasePredictor:
         self.net_clicks_limit, self.with_flip, self.with_sigmoid = net_clicks_limit, with_flip, with_sigmoid
         self.original_image = None
         self.prev_prediction = None
+        self.always_simulate_prompts = bool(kwargs.get('always_simulate_prompts', False))
         self.zoom_in = zoom_in
         self.transforms = [zoom_in] if zoom_in is not None else []
         if max_size is not None:
@@ -92,14 +93,18 @@ class BasePredictor:
         the ZoomIn region of interest."""
         image_nd, clicks_lists, prev = self._net_input(clicker, prev_mask)
         points_nd = self.get_points_nd(clicks_lists).float()
-        gt = torch.from_numpy(np.asarray(gt_mask, dtype=np.float32))[None, None].to(self.device)
-        if self.with_flip:
-            gt = torch.cat([gt, torch.flip(gt, dims=[3])], dim=0)
-            prev = torch.cat([prev, torch.flip(prev, dims=[3])], dim=0)
-        if self.zoom_in is not None and self.zoom_in._object_roi is not None:
-            gt = get_roi_image_nd(gt, self.zoom_in._object_roi, self.zoom_in.target_size)
-            prev = get_roi_image_nd(prev, self.zoom_in._object_roi, self.zoom_in.target_size)
-        _, boxes = get_next_promts(prev, gt, points_nd, None, as_allmask=False, jitter_box=False)
+        boxes = None
+        if as_prompt_type != 0 or self.always_simulate_prompts:
+            # the reference derives the box prompt on EVERY click (base.py:176), also for click prompts, where the network
+            # never reads it: here it is simulated only when it is consumed (~3 ms of a 7.5-ms click otherwise)
+            gt = torch.from_numpy(np.asarray(gt_mask, dtype=np.float32))[None, None].to(self.device)
+            if self.with_flip:
+                gt = torch.cat([gt, torch.flip(gt, dims=[3])], dim=0)
+                prev = torch.cat([prev, torch.flip(prev, dims=[3])], dim=0)
+            if self.zoom_in is not None and self.zoom_in._object_roi is not None:
+                gt = crop_resize(gt, self.zoom_in._object_roi, self.zoom_in.target_size)
+                prev = crop_resize(prev, self.zoom_in._object_roi, self.zoom_in.target_size)
+            _, boxes = get_next_promts(prev, gt, points_nd, None, as_allmask=False, jitter_box=False)
         prompts = (points_nd, boxes, None)
         logits = self.net(image_nd, points_nd, prompts, as_prompt_type)['instances']
         pred = self._finish(logits, image_nd)

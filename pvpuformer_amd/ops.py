@@ -250,6 +250,32 @@ def draw_polyline(curve_i32, disks, B, P, H, W):
     _lib.call("vpu_draw_polyline", ptr(curve_i32), ptr(disks), B, P, H, W, _stream())
 
 
+def mask_bbox(prob, thr, pos_clicks=None):
+    """{count, rmin, rmax, cmin, cmax} (int32 [B,5], on the device) of prob[b] > thr joined with the positive clicks
+    ``pos_clicks`` (int32 [n,2] (row, col) device tensor or None); prob: fp32 [B,H,W] contiguous."""
+    B, H, W = prob.shape
+    out = torch.empty(B, 5, device=prob.device, dtype=torch.int32)
+    n = 0 if pos_clicks is None else int(pos_clicks.shape[0])
+    _lib.call("vpu_mask_bbox", ptr(prob), float(thr), ptr(pos_clicks) if n else None, n, ptr(out), B, H, W, _stream())
+    return out
+
+
+def error_masks(pred_u8, gt_u8, valid_u8):
+    """uint8 [2,H,W] on the device: (false negatives, false positives) of pred against gt inside valid"""
+    H, W = gt_u8.shape
+    out = torch.empty(2, H, W, device=gt_u8.device, dtype=torch.uint8)
+    _lib.call("vpu_error_masks", ptr(pred_u8), ptr(gt_u8), ptr(valid_u8), ptr(out), H, W, _stream())
+    return out
+
+
+def masked_argmax(dist, keep_u8):
+    """per plane of dist [P,H,W]: packed (max of dist * keep, first raster index) keys, uint64 as int64 [P] on the device"""
+    P, H, W = dist.shape
+    out = torch.empty(P, device=dist.device, dtype=torch.int64)
+    _lib.call("vpu_masked_argmax", ptr(dist), ptr(keep_u8), ptr(out), P, H, W, _stream())
+    return out
+
+
 def disk_maps(points, boxes, out, B, n, H, W, radius):
     _lib.call("vpu_disk_maps", ptr(points), ptr(boxes), ptr(out), B, n, H, W, float(radius), _stream())
 
