@@ -200,7 +200,7 @@ def main():
     # RCCL collectives from the backward tape and always run eagerly
     use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "0") == "1"
     opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, capturable=use_graph)
-    red = GradReducer(eng.gflat)
+    red = GradReducer(eng.gflat, wire=os.environ.get("VPU_DIST_WIRE", "fp32"))   # VPU_DIST_WIRE=bf16: half the bytes per link
     eng.grad_ready_hook = red.ready if red.enabled else None
     # VPU_ADAM_OVERLAP=1: the optimizer step runs range by range on a second stream while backward continues
     # (OverlappedAdam; also zeroes the gradients it has consumed).  Off by default: bit-identical results, but measured

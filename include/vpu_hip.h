@@ -86,6 +86,9 @@ int vpu_gemm(const vpu_gemm_desc* d, void* stream);
  * "k2" (round 2): the 256-row-tile kernels (128 x 64 outputs per wave, one workgroup per CU): -1 environment default
  * (VPU_GEMM_K2, 2 if unset), 0 off, 1 the 256 x 128 form wherever legal, 2 the measured-fastest mix of 256 x 256 / 256 x 128 /
  * 128 x 128, 3 the 256 x 256 form wherever legal.
+ * "reserve_cus": n (0..128, default 0): the persistent launches size their grids for (CUs - n), leaving room for the
+ * channel kernels of a collective that runs beside them (pvpuformer_amd/parallel.py sets it while gradient buckets are
+ * in flight).
  * "splitk_inlaunch": 0 (default; VPU_GEMM_INLAUNCH) a separate reduce launch sums the split-K slices; 1 they are summed,
  * in slice order, by the slice that arrives last at the tile's counter, inside the GEMM launch; n > 1: that, but only
  * when the slabs of the launch total at most n MiB.  Same results bit for bit; the default is the measured-faster one. */

@@ -1723,9 +1723,14 @@ inline int k2pp_opt() {
     return v >= 0 ? v : e0;
 }
 inline int k2_opt() { const int v = g_opt_k2.load(std::memory_order_relaxed); return v >= 0 ? v : k2_env0(); }
+// CUs the persistent launches leave unclaimed (vpu_gemm_set_option("reserve_cus")): room for the channel kernels of a
+// collective that runs beside backward (pvpuformer_amd/parallel.py)
+std::atomic<int> g_opt_reserve{0};
 inline int cu_count() {
     static const int v = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    return v;
+    const int r = g_opt_reserve.load(std::memory_order_relaxed);
+    const int left = (v - r) & ~7;       // a multiple of 8: the work index's low bits stay the XCD label
+    return left >= 64 ? left : v;
 }   // -1 environment default (VPU_GEMM_SKINNY, 1 if unset), 0 off, 1 on
 inline int inlaunch_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_INLAUNCH"); return e ? atoi(e) : 0; }();
@@ -1891,7 +1896,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // persistent launch of the 128x128 kernel: at most VPU_GEMM_PERSIST (default 2 per CU = 512) workgroups walk the
         // (tile, split-K slice, batch) list
         const int64_t total_work = (int64_t)tiles_m * tiles_n * splitk * d->batch;
-        static const int persist_cap = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 512; }();
+        static const int persist_env = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+        const int persist_cap = persist_env > 0 ? persist_env : 2 * cu_count();
         dim3 pgrid((unsigned)(total_work < persist_cap ? total_work : persist_cap), 1, 1);
         // staging: LDS-DMA + two stages (fragment reads -> DMA of the next tile -> MFMAs) is the default; it beats register
         // staging on every ViT-B shape once the DMA is no longer drained by the compiler's vmcnt(0) (tools/gemm_bench.py:
@@ -2041,6 +2047,10 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_k2.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
+    if (name && !strcmp(name, "reserve_cus") && value >= 0 && value <= 128) {
+        g_opt_reserve.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
     if (name && !strcmp(name, "k2pp") && value >= -1 && value <= 1) {
         g_opt_k2pp.store(value, std::memory_order_relaxed);
         return VPU_OK;
@@ -2052,7 +2062,8 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     vpu_set_error("vpu_gemm_set_option: known options: ring (-1 environment default, 0 off, 1 one-wave problems, 2 everywhere), "
                   "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine), "
                   "skinny (-1 environment default, 0 off, 1 on), "
-                  "k2 (-1 environment default, 0 off, 1 256x128 tiles, 2 + 256x256 where it fills the chip, 3 256x256 wherever legal)");
+                  "k2 (-1 environment default, 0 off, 1 256x128 tiles, 2 + 256x256 where it fills the chip, 3 256x256 wherever legal), "
+                  "reserve_cus (0..128 CUs the persistent launches leave unclaimed)");
     return VPU_ERR_ARG;
 }
 
@@ -2130,7 +2141,8 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             return vpu_check_launch("vpu_gemm_grouped");
         }
     }
-    static const int persist_cap = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 512; }();
+    static const int persist_env = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+    const int persist_cap = persist_env > 0 ? persist_env : 2 * cu_count();
     dim3 grid((unsigned)(total < persist_cap ? total : persist_cap)), block(256);
     const int vec_arg = vec ? 1 : 0;
     NOTE_KERNEL("gemm_bf16_grouped_kernel<%d, %d, %s>", key >> 1, key & 1, key == 3 ? "true" : "false");

@@ -17,12 +17,32 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_grad, group=None, bucket_bytes=25 << 20):
+    """``wire``: "fp32" (the reference's DDP exchanges fp32 gradients) or "bf16": a bucket is rounded to bf16 into a
+    staging buffer, summed in bf16 by the collective and widened back into the fp32 gradient -- half the bytes per xGMI
+    link (a single ring is bound by one ~153 GB/s link; 489 MB of fp32 gradients cost 5.6 ms there, more than
+    the compute of a 50 %-roofline step), at bf16 summation error over <= 8 addends.  ``force``: run the collectives even
+    at world size 1 (tests: exercises RCCL launch / stream-wait plumbing on one GPU).
+    ``reserve_cus``: while a step's buckets are in flight the persistent GEMM launches leave that many CUs unclaimed
+    (vpu_gemm_set_option("reserve_cus")): RCCL's channel kernels are ordinary workgroups that need a CU to land on, and a
+    persistent GEMM grid of one workgroup per CU (144 KiB of LDS, 2 x 256 registers per SIMD) leaves none -- without the
+    reserve either the collective waits for a launch boundary, or, once its workgroups hold some CUs, every later
+    256-workgroup persistent launch runs its last workgroups in a second round.  UNMEASURED on hardware (one GPU per box
+    here); 0 disables."""
+
+    def __init__(self, flat_grad, group=None, bucket_bytes=25 << 20, wire="fp32", force=False, reserve_cus=None):
+        assert wire in ("fp32", "bf16")
         self.g = flat_grad
         self.group = group
+        self.wire = wire
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        ready = dist.is_available() and dist.is_initialized()
+        self.enabled = ready and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.enabled else 1
+        if reserve_cus is None:
+            import os
+            reserve_cus = int(os.environ.get("VPU_DIST_RESERVE_CUS", "16"))
+        self.reserve_cus = reserve_cus if (self.enabled and flat_grad.is_cuda) else 0
+        self._staged = []         # (lo, hi, bf16 staging tensor) of the bf16 buckets in flight
         self._pending_hi = None   # current open bucket is [lo, hi) growing downwards
         self._pending_lo = None
         self._works = []
@@ -32,7 +52,11 @@ class GradReducer:
     def begin(self):
         self._pending_hi = self._pending_lo = None
         self._works = []
+        self._staged = []
         self.launched = []
+        if self.reserve_cus:
+            from . import ops
+            ops.gemm_set_option("reserve_cus", self.reserve_cus)
 
     def ready(self, lo, hi):
         """gflat[lo:hi] is final.  Ranges arrive tail-first and contiguous; anything else is flushed separately."""
@@ -51,7 +75,12 @@ class GradReducer:
             return
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
-        work = dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.wire == "bf16":
+            stage = self.g[lo:hi].to(torch.bfloat16)
+            work = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._staged.append((lo, hi, stage))
+        else:
+            work = dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(work)
         self.launched.append((lo, hi))
         if self.on_bucket is not None:
@@ -65,6 +94,12 @@ class GradReducer:
             for w in self._works:
                 w.wait()
             self._works = []
+            for lo, hi, stage in self._staged:
+                self.g[lo:hi].copy_(stage)
+            self._staged = []
+            if self.reserve_cus:
+                from . import ops
+                ops.gemm_set_option("reserve_cus", 0)
         return 1.0 / self.world
 
 

@@ -1,0 +1,104 @@
+"""Child process of tests/test_dist_gpu.py: one rank of a data-parallel job on ONE GPU box.
+
+  nccl1  world size 1 on RCCL (backend "nccl"): the bucketed reducer forced on -- asynchronous all-reduces launched from the
+         backward tape's markers, stream waits in finish(), the reserve-CUs knob -- must leave the gradients bit-identical
+         to a step without a reducer (a SUM over one rank is the identity); the bf16 wire format within bf16 rounding.
+  gloo2  world size 2, both ranks on cuda:0, gradients exchanged through gloo (RCCL refuses two ranks on one device):
+         parameter + buffer broadcast makes the replicas identical, and 2 ranks x 1 sample give the gradient of 1 rank x
+         2 samples (the losses are per-sample means averaged over the batch).
+usage: python tests/dist_worker.py <mode> <rank> <world> <port> <outdir>"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import vpu_oracle as vo                                                    # noqa: E402  (synthetic weights / batches only)
+from test_api_cpu import TINY, make_model                                  # noqa: E402
+from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses            # noqa: E402
+from pvpuformer_amd.parallel import GradReducer, broadcast_parameters      # noqa: E402
+
+
+def build(dtype):
+    cfg = vo.make_cfg(**TINY)
+    model = make_model(cfg).cuda()
+    model.load_state_dict(vo.synth_state_dict(vo.param_shapes(cfg), seed=0), strict=True)
+    model.set_compute_dtype(dtype)
+    model.train()
+    model.head.dropout_ratio = 0.0
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    return cfg, model, eng
+
+
+def step(eng, img4, pts, gt, red=None):
+    eng.zero_grad()
+    if red is not None:
+        red.begin()
+        eng.grad_ready_hook = red.ready
+    inst, _ = eng.forward(img4, pts, None, 0, None, training=True, materialize_aux=False)
+    _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+    eng.backward(d_inst, None, d_sim_low=d_sim)
+    scale = red.finish() if red is not None else 1.0
+    eng.grad_ready_hook = None
+    torch.cuda.synchronize()
+    return eng.gflat.clone() * scale
+
+
+def main():
+    mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if mode == "nccl1":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        cfg, model, eng = build("bf16")
+        b = vo.synth_batch(2, cfg["img"], seed=5)
+        img4 = torch.cat([b["images"], torch.zeros(2, 1, cfg["img"], cfg["img"])], 1).cuda()
+        pts, gt = b["points"].cuda(), b["instances"].cuda()
+        plain = step(eng, img4, pts, gt)
+        red = GradReducer(eng.gflat, bucket_bytes=1 << 20, force=True, reserve_cus=16)
+        assert red.enabled and red.world == 1
+        with_red = step(eng, img4, pts, gt, red)
+        launched = list(red.launched)
+        red16 = GradReducer(eng.gflat, bucket_bytes=1 << 20, force=True, wire="bf16", reserve_cus=0)
+        with_bf16 = step(eng, img4, pts, gt, red16)
+        again = step(eng, img4, pts, gt)               # the reserve knob is back to 0: same kernels as the first step
+        np.savez(os.path.join(out, "nccl1.npz"), plain=plain.cpu().numpy(), with_red=with_red.cpu().numpy(),
+                 with_bf16=with_bf16.cpu().numpy(), again=again.cpu().numpy(), launched=np.asarray(launched),
+                 total=np.asarray(eng.total))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cfg, model, eng = build("f32")
+        buf = model.pe_layer.positional_encoding_gaussian_matrix
+        buf.copy_(torch.full_like(buf, float(rank + 1)))
+        if rank == 1:
+            eng.flat.mul_(1.5)
+        broadcast_parameters(eng.flat)
+        for t in model.buffers():
+            broadcast_parameters(t)
+        eng.shadow_valid = False
+        eng.refresh_weights()
+        b = vo.synth_batch(2, cfg["img"], seed=5)
+        img4 = torch.cat([b["images"], torch.zeros(2, 1, cfg["img"], cfg["img"])], 1).cuda()
+        pts, gt = b["points"].cuda(), b["instances"].cuda()
+        red = GradReducer(eng.gflat, bucket_bytes=256 << 10)
+        mine = step(eng, img4[rank:rank + 1].contiguous(), pts[rank:rank + 1].contiguous(), gt[rank:rank + 1].contiguous(), red)
+        res = dict(flat=eng.flat.cpu().numpy(), buf=buf.cpu().numpy(), mine=mine.cpu().numpy(),
+                   launched=np.asarray(red.launched))
+        if rank == 0:
+            res["full"] = step(eng, img4, pts, gt).cpu().numpy()
+        np.savez(os.path.join(out, f"gloo2_rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("WORKER-OK", mode, rank)
+
+
+if __name__ == "__main__":
+    main()

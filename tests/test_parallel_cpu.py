@@ -44,6 +44,12 @@ def _worker(rank, world, port, q):
     red.ready(500, 1000); red.ready(0, 500)
     red.finish()
     ok = ok and torch.all(g == 3.0).item()
+    # bf16 wire format: each rank's bucket is rounded to bf16, summed in bf16, widened back (exact on these small integers)
+    g.copy_(torch.arange(n, dtype=torch.float32).remainder(64) * (rank + 1))
+    red16 = GradReducer(g, bucket_bytes=4 * 300, wire="bf16")
+    red16.begin()
+    red16.ready(500, 1000); red16.ready(0, 500)
+    ok = ok and red16.finish() == 0.5 and torch.equal(g, torch.arange(n, dtype=torch.float32).remainder(64) * 3)
     q.put((rank, bool(ok), red.launched))
     dist.destroy_process_group()
 
@@ -59,6 +65,31 @@ def test_grad_reducer_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def _solo(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from pvpuformer_amd.parallel import GradReducer
+    g = torch.arange(100, dtype=torch.float32)
+    plain = GradReducer(g)
+    forced = GradReducer(g, bucket_bytes=4 * 30, force=True)
+    forced.begin()
+    for lo, hi in [(70, 100), (40, 70), (0, 40)]:
+        forced.ready(lo, hi)
+    scale = forced.finish()
+    q.put((not plain.enabled) and forced.enabled and scale == 1.0 and len(forced.launched) == 3
+          and torch.equal(g, torch.arange(100, dtype=torch.float32)))
+    dist.destroy_process_group()
+
+
+def test_forced_reducer_at_world_size_1_runs_real_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
 
 
 def test_reducer_is_a_noop_without_process_group():
