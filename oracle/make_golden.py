@@ -500,7 +500,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_vpu, ref_losses = ref_import.import_reference()
-    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitb", "sim", "zoom", "lrd", "scribble", "tiny_scribble"]
+    which = sys.argv[1:] or ["pue", "tiny", "tinyh", "vitl8", "vitb", "sim", "zoom", "lrd", "scribble", "tiny_scribble"]
     if "zoom" in which:
         zoom_fixtures()
     if "lrd" in which:
@@ -519,6 +519,8 @@ def main():
     if "tinyh" in which:   # ViT-H geometry in small: patch 14 (32 x 32 tokens, 16 x 16 windows), head dim 80
         cfg = vo.make_cfg(embed_dim=640, depth=8, num_heads=8, patch=14, out_dims=(16, 32, 64, 128), head_channels=32)
         run_model_fixture("tinyh", cfg, 2, ref_vpu, ref_losses)
+    if "vitl8" in which:   # ViT-L width (D = 1024, 16 heads of 64) at reduced depth: config 4's GEMM / attention shapes
+        run_model_fixture("vitl8", vo.make_cfg(embed_dim=1024, depth=8, num_heads=16), 2, ref_vpu, ref_losses)
     if "vitb" in which:
         run_model_fixture("vitb", vo.make_cfg(), 2, ref_vpu, ref_losses)
 

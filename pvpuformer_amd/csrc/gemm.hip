@@ -1096,16 +1096,14 @@ __device__ __forceinline__ void k2_prefetch(const vpu_gemm_desc& p, const int mr
             }
     }
     if constexpr ((FL & VPU_EPI_BIAS) != 0) {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 0x7FFFFFFF, 0x00020000);
+        // plain loads (a wave-uniform skip of out-of-range columns is fine: only the STORES of this epilogue are counted, the
+        // loads are consumed before the first of them).  NOT raw_buffer_load_b128 here: on a float* resource ROCm 7.2's
+        // hipcc lowered it to a ONE-dword load (all 8 bias values became the first; seen in the ISA and caught by the
+        // exact-integer test at a K2-eligible shape)
         const int n = ncol0 + (lane & 7) * 8;
-        const int off = n < p.N ? n * 4 : OOB_OFFSET;
-        const u32x4v b0 = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
-        const u32x4v b1 = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 16, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            q.bias[j] = __builtin_bit_cast(float, b0[j]);
-            q.bias[4 + j] = __builtin_bit_cast(float, b1[j]);
-        }
+        for (int j = 0; j < 8; ++j) q.bias[j] = 0.f;
+        if (n + 8 <= p.N) load8(p.bias + n, q.bias);
     }
 }
 __device__ __forceinline__ u32x4v pack_bf16x8(const float (&v)[8]) {

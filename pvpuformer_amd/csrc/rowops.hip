@@ -352,8 +352,9 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- softmax
-constexpr int SM_MAX = 16;  // ncols <= 1024
-template <typename T>
+// a wave holds a whole row in registers: SM_MAX * 64 columns.  16 covers the training shapes (784 / 1024 keys); 64 the global
+// attention of an evaluation at a larger input (672^2: 1764 keys for patch 16, 2304 for patch 14) in the unfused parity path
+template <typename T, int SM_MAX>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, int lds_, T* __restrict__ P,
                                                           int ldp, int64_t rows, int ncols) {
     const int lane = threadIdx.x & 63;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
     }
 }
 
-template <typename T>
+template <typename T, int SM_MAX>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, int ldp,
                                                           const float* __restrict__ dP, int lddp, T* __restrict__ dS,
                                                           int64_t rows, int ncols, float scale) {
@@ -653,16 +654,17 @@ extern "C" int vpu_colsum(const void* in, int32_t ld, float* out, float* part, i
 extern "C" int vpu_softmax_fwd(const float* S, int32_t lds_, void* P, int32_t ldp, int64_t rows, int32_t ncols,
                                int32_t dtype, void* stream) {
     vpu_clear_stale_error();
-    if (ncols > SM_MAX * 64 || ldp > SM_MAX * 64 || ldp < ncols) { vpu_set_error("softmax: ncols <= 1024"); return VPU_ERR_ARG; }
-    DISPATCH_T(dtype, softmax_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(S, lds_, (T*)P, ldp, rows, ncols);)
+    if (ncols > 4096 || ldp > 4096 || ldp < ncols) { vpu_set_error("softmax: ncols <= 4096"); return VPU_ERR_ARG; }
+    if (ldp <= 1024) { DISPATCH_T(dtype, (softmax_fwd_kernel<T, 16><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(S, lds_, (T*)P, ldp, rows, ncols));) }
+    else { DISPATCH_T(dtype, (softmax_fwd_kernel<T, 64><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>(S, lds_, (T*)P, ldp, rows, ncols));) }
     return vpu_check_launch("vpu_softmax_fwd");
 }
 extern "C" int vpu_softmax_bwd(const void* P, int32_t ldp, const float* dP, int32_t lddp, void* dS, int64_t rows,
                                int32_t ncols, float scale, int32_t dtype, void* stream) {
     vpu_clear_stale_error();
-    if (ncols > SM_MAX * 64 || ldp > SM_MAX * 64 || ldp < ncols) { vpu_set_error("softmax_bwd: ncols <= 1024"); return VPU_ERR_ARG; }
-    DISPATCH_T(dtype, softmax_bwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)P, ldp, dP, lddp,
-                                                                                       (T*)dS, rows, ncols, scale);)
+    if (ncols > 4096 || ldp > 4096 || ldp < ncols) { vpu_set_error("softmax_bwd: ncols <= 4096"); return VPU_ERR_ARG; }
+    if (ldp <= 1024) { DISPATCH_T(dtype, (softmax_bwd_kernel<T, 16><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)P, ldp, dP, lddp, (T*)dS, rows, ncols, scale));) }
+    else { DISPATCH_T(dtype, (softmax_bwd_kernel<T, 64><<<(unsigned)((rows + 3) / 4), 256, 0, ST>>>((const T*)P, ldp, dP, lddp, (T*)dS, rows, ncols, scale));) }
     return vpu_check_launch("vpu_softmax_bwd");
 }
 extern "C" int vpu_l2norm_fwd(const void* x, void* y, float* inv, int64_t rows, int32_t C, int32_t dtype, void* stream) {

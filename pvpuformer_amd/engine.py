@@ -155,6 +155,7 @@ class Engine:
         self.b_patch = torch.zeros(D, device=self.dev, dtype=torch.float32)
         self.w_lin1p = torch.zeros(2048, self.Epad, device=self.dev, dtype=self.td)
         self.pos_win = torch.zeros(self.NT, D, device=self.dev, dtype=self.td)
+        self._pos_cache, self._kpe_cache = {}, {}
         self.shadow_valid = False
         if not self._const_ready:
             self.kpe = pos2d_table(D, self.g, self.g).to(self.dev).to(self.td)
@@ -188,7 +189,34 @@ class Engine:
         po = self.names["backbone.pos_embed"][0]
         ops.cast2d((self.flat, po + D), D, tmp, D, self.NT, D)
         ops.window_permute(tmp, self.pos_win, 1, self.g, self.wg, D, to_raster=False)
+        self._pos_cache = {self.g: self.pos_win}      # other grids are re-derived from the new weights on demand
         self.shadow_valid = True
+
+    def _pos_for(self, g):
+        """Window-ordered position embedding for a g x g token grid.  The trained grid is used as it is; any other one
+        (evaluation at another input size: scripts/evaluate_vpumodel.py:125 -> pos_embed.py:99-128, e.g. DAVIS at 672^2 =
+        42 x 42 tokens, 9 windows) is the bicubic re-gridding of the trained embedding, exactly the tensor the reference
+        installs with interpolate_pos_embed_inference -- computed once per grid and weight state (torch's bicubic
+        interpolate: load-time plumbing, not the hot path)."""
+        pw = self._pos_cache.get(g)
+        if pw is None:
+            import torch.nn.functional as F
+            D, g0 = self.D, self.g
+            po = self.names["backbone.pos_embed"][0]
+            grid = self.flat[po + D: po + D + g0 * g0 * D].view(1, g0, g0, D).permute(0, 3, 1, 2)
+            new = F.interpolate(grid, size=(g, g), mode="bicubic", align_corners=False).permute(0, 2, 3, 1)
+            tmp = new.reshape(g * g, D).to(self.td).contiguous()
+            pw = torch.empty(g * g, D, device=self.dev, dtype=self.td)
+            ops.window_permute(tmp, pw, 1, g, self.wg, D, to_raster=False)
+            self._pos_cache[g] = pw
+        return pw
+
+    def _kpe_for(self, g):
+        k = self._kpe_cache.get(g)
+        if k is None:
+            k = self.kpe if g == self.g else pos2d_table(self.D, g, g).to(self.dev).to(self.td)
+            self._kpe_cache[g] = k
+        return k
 
     def zero_grad(self):
         self.gflat.zero_()
@@ -601,8 +629,17 @@ class Engine:
         tape = self.tape
         c = self.cfg
         B, H, W_ = image4.shape[0], image4.shape[2], image4.shape[3]
-        assert H == self.img and W_ == self.img, "re-gridding for other sizes is not supported by this build"
-        D, P, g, NT, heads = self.D, self.P, self.g, self.NT, self.heads
+        D, P, heads = self.D, self.P, self.heads
+        # the token grid follows the INPUT (the prompt vectors keep the constructor's image size, as in the reference:
+        # is_vpu_model.py:189-230 builds them from self.image_size)
+        if H != W_ or H % (P * self.wg) != 0:
+            raise ValueError(f"input {H}x{W_}: square inputs whose side is a multiple of the {P * self.wg}-pixel window")
+        g = H // P
+        NT, nw_side = g * g, g // self.wg
+        if training and g != self.g:
+            raise NotImplementedError("training at an input size other than the constructor's (the adjoint of the position "
+                                      "re-gridding is not built); evaluation works at any window multiple")
+        pos_win, kpe_tab = self._pos_for(g), self._kpe_for(g)
         M = B * NT
         n = points.shape[1] // 2
         points = points.to(self.dev).contiguous().float()
@@ -626,7 +663,7 @@ class Engine:
         ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg)
         x = Var(self._new(M, D))
         ops.gemm(cols, self.w_patch, x.t, M, D, KP, KP, KP, D, self.dt,
-                 flags=EPI_BIAS | EPI_RESID, bias=self.b_patch, resid=self.pos_win, ldr=D, resid_period=NT)
+                 flags=EPI_BIAS | EPI_RESID, bias=self.b_patch, resid=pos_win, ldr=D, resid_period=NT)
         if training:
             x0 = x
 
@@ -653,7 +690,7 @@ class Engine:
                 self._mark_ready(f"backbone.blocks.{i - 1}.norm1.weight",
                                  f"backbone.blocks.{i}.norm1.weight" if i < self.depth else "backbone.fc_norm.weight")
             is_global = (i % self.group) == 0
-            nwin = 1 if is_global else self.nw * self.nw
+            nwin = 1 if is_global else nw_side * nw_side
             nt = NT // nwin
             p = f"backbone.blocks.{i - 1}."
             h1 = self.layernorm(x, p + "norm1", M, D, 1e-6)
@@ -704,7 +741,7 @@ class Engine:
                 q = self.mha(p + ".self_attn", qq, qq, q, B, nq, nq, D, resid=q)
             q = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5)
             qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
-            kk = self.add_pe(k, self.kpe, nK, NT * D)
+            kk = self.add_pe(k, kpe_tab, nK, NT * D)
             q = self.mha(p + ".cross_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
             q = self.layernorm(q, p + ".norm2", B * nq, D, 1e-5)
             q = self.mlp(q, p + ".mlp.lin1", p + ".mlp.lin2", B * nq, D, 1024, D, "relu", resid=q)
@@ -715,7 +752,7 @@ class Engine:
             if l != 2:
                 hs.append((q, k))
         qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
-        kk = self.add_pe(k, self.kpe, nK, NT * D)
+        kk = self.add_pe(k, kpe_tab, nK, NT * D)
         q = self.mha("neck.att.final_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
         q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
         hs.append((q, k))

@@ -26,15 +26,26 @@ def interpolate_pos_embed(model, checkpoint_model):
 
 
 def interpolate_pos_embed_inference(model, infer_img_size, device):
-    """Eval-time re-gridding (pos_embed.py:99-128): replaces model.pos_embed and patch_embed.grid_size."""
-    pe = model.pos_embed
+    """Eval-time re-gridding (pos_embed.py:99-128, called by scripts/evaluate_vpumodel.py:125 before an evaluation at
+    another input size).  The reference REPLACES ``model.pos_embed`` by its bicubic re-gridding; here the trained embedding
+    stays where it is -- inside the engine's flat parameter buffer -- and the engine derives the embedding of whatever
+    token grid an input has from it on demand (``Engine._pos_for``: the same bicubic interpolation, cached per grid), so
+    this call only records the evaluation grid on ``patch_embed`` as the reference does."""
+    ps = model.patch_embed.patch_size
+    new = (infer_img_size[0] // ps[0], infer_img_size[1] // ps[1])
+    model.patch_embed.grid_size = new
+    model.patch_embed.num_patches = new[0] * new[1]
+    model.infer_grid_size = new
+
+
+def regridded_pos_embed(model, infer_img_size):
+    """The tensor the reference would install as ``pos_embed`` for ``infer_img_size`` (class token kept, grid tokens
+    bicubically re-gridded) -- for checkpoints meant to be read back by the reference at that size."""
+    pe = model.pos_embed.detach()
     dim = pe.shape[-1]
     ps = model.patch_embed.patch_size
-    old = model.patch_embed.grid_size
     new = (infer_img_size[0] // ps[0], infer_img_size[1] // ps[1])
-    extra = pe.shape[-2] - old[0] * old[1]
-    if tuple(old) != tuple(new):
-        tokens = _regrid(pe[:, extra:].detach(), tuple(old), new, dim)
-        model.pos_embed = torch.nn.Parameter(torch.cat((pe[:, :extra].detach(), tokens), dim=1).to(device))
-        model.patch_embed.grid_size = new
-        model.patch_embed.num_patches = new[0] * new[1]
+    old = int(round((pe.shape[-2] - 1) ** 0.5))
+    if (old, old) == tuple(new):
+        return pe.clone()
+    return torch.cat((pe[:, :1], _regrid(pe[:, 1:], (old, old), new, dim)), dim=1)

@@ -748,3 +748,198 @@ def test_nobrs_vitb_20_clicks_config3(golden_dir):
     assert same >= 3, (ch[:4], co[:4])
     assert np.all(np.abs(ih[:same] - io_[:same]) <= 0.1), (ih[:same], io_[:same])
     assert abs(float(ih.max()) - float(io_.max())) <= 0.1
+
+
+def test_eval_at_672_regrids_the_position_embedding(golden_dir):
+    """f4 / SURVEY 5: evaluation at another input size (DAVIS at 672^2: 42 x 42 tokens, 9 windows of 14 x 14).  After
+    ``interpolate_pos_embed_inference`` the HIP model takes a 672 x 672 input and matches the CPU oracle fed the
+    reference's re-gridded ``pos_embed`` (bicubic, pos_embed.py:99-128) -- the prompt vectors keep the constructor's 448
+    (is_vpu_model.py:189-230), so clicks beyond column 448 fall under the encoder's range rule.  fp32 engine: mask logits
+    within 1e-3 relative; then the model goes back to 448 inputs unchanged (caches are per grid)."""
+    from pvpuformer_amd.isegm.model.modeling.pos_embed import interpolate_pos_embed_inference, regridded_pos_embed
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    with torch.no_grad():
+        base = _run(model, img4, batch, 0)["instances"].clone()
+    S = 672
+    interpolate_pos_embed_inference(model.backbone, (S, S), "cuda")
+    assert tuple(model.backbone.patch_embed.grid_size) == (42, 42)
+    big = vo.synth_batch(2, S, seed=9)
+    x = torch.cat([big["images"], torch.zeros(2, 1, S, S)], 1)
+    x[0, 3] = torch.sigmoid(4 * (big["instances"][0, 0] - 0.5))
+    pts = big["points"].clone()
+    pts[1, 1] = torch.tensor([600.0, 630.0, 5.0])                   # a click outside the 448-wide prompt vectors
+    with torch.no_grad():
+        out = model(x.cuda(), pts.cuda())
+    assert tuple(out["instances"].shape) == (2, 1, S, S) and tuple(out["instances_aux"].shape) == (2, 48, S, S)
+    sd2 = dict(sd)
+    sd2["backbone.pos_embed"] = regridded_pos_embed(model.backbone, (S, S)).cpu()
+    assert tuple(sd2["backbone.pos_embed"].shape) == (1, 1 + 42 * 42, cfg["embed_dim"])
+    cfg2 = dict(cfg, img=S)
+    pue = vo.pue_click(pts.numpy(), cfg["num_max_points"], cfg["img"])      # prompt vectors at the constructor's size
+    with torch.no_grad():
+        ref = vo.vpu_forward(sd2, cfg2, x, pts, None, 0, pue_override=pue)
+    assert _relerr(out["instances"].cpu().numpy(), ref["instances"].numpy()) < 1e-3
+    assert _relerr(out["instances_aux"][:, ::6].cpu().numpy(), ref["instances_aux"][:, ::6].numpy()) < 1e-3
+    with torch.no_grad():
+        again = _run(model, img4, batch, 0)["instances"]
+    assert torch.equal(again, base)
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 4, 448, 672, device="cuda"), -torch.ones(1, 2, 3, device="cuda"))
+
+
+def _check_fp32_grads_against_fixture(model, fx, mode, rtol_norm=2e-3):
+    """every gradient norm and the stored full gradients / slices of the fixture"""
+    names = [str(n) for n in fx[f"{mode}_grad_names"]]
+    norms = fx[f"{mode}_grad_norms"]
+    params = dict(model.named_parameters())
+    bad = []
+    for n, ref in zip(names, norms):
+        g = params[n].grad
+        if ref < 0:
+            assert g is None or float(g.abs().max()) == 0.0, n
+        elif abs(float(g.norm()) - ref) > rtol_norm * ref + 2e-8:
+            bad.append((n, float(g.norm()), float(ref)))
+    assert not bad, bad[:10]
+    for k in fx.files:
+        if k.startswith(f"{mode}_grad::"):
+            n = k.split("::")[1]
+            np.testing.assert_allclose(params[n].grad.cpu().numpy(), fx[k], rtol=5e-3, atol=2e-6 + 1e-3 * np.abs(fx[k]).max(), err_msg=n)
+        elif k.startswith(f"{mode}_grad_slice::"):
+            n = k.split("::")[1]
+            step = (17, 13) if "qkv" in n else (64, 29)
+            g = params[n].grad[::step[0], ::step[1]].cpu().numpy()
+            np.testing.assert_allclose(g, fx[k], rtol=5e-3, atol=1e-3 * np.abs(g).max() + 1e-9, err_msg=n)
+
+
+@pytest.mark.parametrize("fixture", ["vitb.npz", "vitl8.npz"])
+def test_full_width_fp32_backward_matches_reference(golden_dir, fixture):
+    """ViT-B/448 (all 12 blocks) and the ViT-L width (D = 1024, 16 heads, 8 blocks: config 4's GEMM / attention shapes) in
+    the exact-fp32 engine mode against the reference's own backward: the loss scalars, EVERY gradient norm within 2e-3
+    and the stored gradients / slices element-wise -- round 1 checked ViT-B gradients in bf16 by norm only."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "f32")
+    model.zero_grad()
+    out = _run(model, img4, batch, 0)
+    assert _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["click_instances_sub"]) < 1e-3
+    gt = batch["instances"].cuda()
+    total, parts = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+    np.testing.assert_allclose([total.item(), parts["nfl"].item(), parts["dice"].item(), parts["p2cl"].item()],
+                               fx["click_loss"], rtol=2e-4)
+    total.backward()
+    _check_fp32_grads_against_fixture(model, fx, "click")
+
+
+def test_vitl_width_bf16_close_to_reference(golden_dir):
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitl8.npz", "bf16")
+    model.zero_grad()
+    out = _run(model, img4, batch, 1)
+    assert _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["box_instances_sub"]) < 5e-2
+    gt = batch["instances"].cuda()
+    total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+    assert abs(total.item() - fx["box_loss"][0]) < 2e-2 * abs(fx["box_loss"][0])
+    total.backward()
+    params = dict(model.named_parameters())
+    norms = dict(zip([str(n) for n in fx["box_grad_names"]], fx["box_grad_norms"]))
+    rel = {n: abs(float(params[n].grad.norm()) - v) / v for n, v in norms.items() if v > 1e-3}
+    assert max(rel.values()) < 0.1, sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+
+
+def test_bench_shape_bf16_step_matches_oracle(golden_dir):
+    """The TIMED path at the benchmark's own shapes: ViT-B, B = 12 (M = 9408 token rows: the 256-row-tile GEMM kernels, the
+    grouped weight-gradient launch over 216 tiles, the sliced neck gradients -- instantiations the B = 2 fixtures never
+    select), bf16, one training step exactly as bench.py runs it (fused upsample + P2CL, no materialised aux), against the
+    CPU oracle on the same batch.  Bounds (bf16 has 8 significant bits, ~60 layers deep): mask logits within 3e-2 of their
+    range, the three loss scalars within 2e-2, every compared gradient within 10 % in norm and cosine > 0.98 element-wise."""
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    from pvpuformer_amd import ops
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    B = 12
+    big = vo.synth_batch(B, cfg["img"], seed=100)
+    x = torch.cat([big["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1)
+    x[:, 3] = torch.sigmoid(3 * (big["instances"][:, 0] - 0.4))
+    gt = big["instances"]
+    model.train()
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    eng.zero_grad()
+    kernels = []
+    orig_gemm, orig_grouped = ops.gemm, ops.gemm_grouped
+    def spy(*a, **k):
+        orig_gemm(*a, **k); kernels.append(ops.gemm_last_kernel())
+    def spy_g(p):
+        orig_grouped(p); kernels.append(ops.gemm_last_kernel())
+    eng_ops = __import__("pvpuformer_amd.engine", fromlist=["ops"]).ops
+    eng_ops.gemm, eng_ops.gemm_grouped = spy, spy_g
+    try:
+        inst, _ = eng.forward(x.cuda(), big["points"].cuda(), None, 0, None, training=True, materialize_aux=False)
+        losses, d_inst, d_sim = vpu_step_losses(inst, None, gt.cuda(), None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
+        torch.cuda.synchronize()
+    finally:
+        eng_ops.gemm, eng_ops.gemm_grouped = orig_gemm, orig_grouped
+    used = set(kernels)
+    assert any(k.startswith("gemm_bf16_k2_kernel<0, 0, 4") for k in used) and any(k.startswith("gemm_bf16_k2_kernel<0, 1, 2") for k in used)
+    assert "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
+    # oracle on the same batch (fp32, CPU)
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    out = vo.vpu_forward(sdg, cfg, x, big["points"])
+    total, parts = vo.step_loss(out, gt, vo.ed_mask_label(gt))
+    total.backward()
+    ref_inst = out["instances"].detach()
+    err = float((inst.cpu() - ref_inst).abs().max()) / float(ref_inst.abs().max())
+    assert err < 3e-2, err
+    for k in ("total", "nfl", "dice", "p2cl"):
+        a, b = float(losses[k]), float(total if k == "total" else parts[k])
+        assert abs(a - b) < 2e-2 * abs(b), (k, a, b)
+    worst = []
+    for n in ["backbone.blocks.0.attn.qkv.weight", "backbone.blocks.5.mlp.fc1.weight", "backbone.blocks.11.mlp.fc2.weight",
+              "backbone.blocks.6.attn.proj.weight", "backbone.blocks.11.norm2.weight", "backbone.patch_embed.proj.weight",
+              "patch_embed_coords.proj.weight", "backbone.pos_embed", "neck.ffn_layer.lin1.weight",
+              "neck.att.layers.1.cross_attn_token_to_image.k_proj.weight", "neck.att.layers.2.mlp.lin1.weight",
+              "neck.down_4.0.weight", "neck.down_16.0.weight", "head.fusion_conv.conv.weight", "head.conv_seg.weight",
+              "head.ffn_layer.lin1.weight", "backbone.blocks.3.attn.qkv.bias", "neck.down_8.3.weight"]:
+        off, shape, numel = eng.names[n]
+        g = eng.gflat[off:off + numel].cpu().double()
+        r = sdg[n].grad.flatten().double()
+        if r.norm() < 1e-3:
+            continue
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm()))
+        rel = abs(float(g.norm()) - float(r.norm())) / float(r.norm())
+        worst.append((n, cos, rel))
+    assert len(worst) >= 14 and all(c > 0.98 and r < 0.1 for _, c, r in worst), sorted(worst, key=lambda t: t[1])[:4]
+
+
+def test_bf16_error_budget_per_stage(golden_dir):
+    """WHERE the bf16 path's ~1e-2 logit error comes from: the same ViT-B forward in the exact-fp32 engine mode and in the
+    bf16 mode, stage by stage (taps).  Every tensor between kernels is stored in bf16 (one rounding of relative size
+    <= 2^-9 per store) and each GEMM accumulates in fp32, so the error of a stage is a random walk over the roundings
+    before it: of the order 2^-9 * sqrt(number of bf16 stores in series), amplified by the layer gains.  Asserted: the error
+    grows monotonically along the path within those budgets (backbone after 12 blocks ~ 50 stores in series -> a few
+    1e-3 ... 1e-2; neck / FPN / head add ~40 more), the fp32 mode itself sits at ~1e-6 of the reference, and the final
+    logits' error equals what the head's input error propagates to -- nothing else (no kernel-specific defect) hides in
+    the total."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "f32")
+    taps = {}
+    for mode in ("f32", "bf16"):
+        model.set_compute_dtype(mode)
+        eng = model._ensure_engine()
+        eng.refresh_weights()
+        t = {}
+        with torch.no_grad():
+            inst, aux = eng.forward(img4.cuda(), batch["points"].cuda(), None, 0, None, training=False, taps=t)
+        t["instances"] = inst
+        taps[mode] = {k: v.float().clone() for k, v in t.items() if k in ("tokens0_win", "backbone", "q_out", "fpn0", "fpn1", "fpn2", "fpn3", "fused", "seg_lowres", "sim_lowres", "instances")}
+    rel = {k: float((taps["bf16"][k] - taps["f32"][k]).norm() / taps["f32"][k].norm()) for k in taps["f32"]}
+    eps = 2.0 ** -9
+    stores = dict(tokens0_win=1, backbone=12 * 4 + 1, q_out=12 * 4 + 30, fpn0=12 * 4 + 38, fpn1=12 * 4 + 36, fpn2=12 * 4 + 34,
+                  fpn3=12 * 4 + 36, fused=12 * 4 + 42, seg_lowres=12 * 4 + 43, sim_lowres=12 * 4 + 46, instances=12 * 4 + 44)
+    report = {k: (rel[k], eps * stores[k] ** 0.5) for k in rel}
+    # (1) the patch embedding is one rounding; (2) nothing is more than 4x the random-walk estimate of its depth; (3) the
+    # error never shrinks along backbone -> FPN -> fused -> logits by more than the gain of those (contractive) stages
+    assert rel["tokens0_win"] < 2 * eps, report
+    assert all(v < 4 * est for v, est in report.values()), report
+    assert rel["backbone"] > rel["tokens0_win"] and rel["fused"] > 0.5 * rel["backbone"], report
+    # the fp32 engine mode against the reference (fixtures): the parity bound, three orders of magnitude below
+    assert _relerr(taps["f32"]["instances"][..., ::7, ::7].cpu().numpy(), fx["click_instances_sub"]) < 1e-4
+    e_final = _relerr(taps["bf16"]["instances"][..., ::7, ::7].cpu().numpy(), fx["click_instances_sub"])
+    assert e_final < 3e-2, e_final
+    print("bf16 error budget (relative L2 vs fp32 mode, random-walk estimate):", {k: (round(a, 5), round(b, 5)) for k, (a, b) in report.items()})

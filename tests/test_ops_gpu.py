@@ -1086,7 +1086,7 @@ def test_fused_upsample_p2cl_matches_unfused(ops, B, S, h, H):
 
 @pytest.mark.parametrize("tB", [0, 1])
 @pytest.mark.parametrize("k2", [1, 3])
-@pytest.mark.parametrize("shape", [(2300, 1288, 256), (3000, 1024, 640)])
+@pytest.mark.parametrize("shape", [(2300, 1288, 256), (3000, 1024, 640), (1568, 3072, 1024), (9408, 768, 768)])
 def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
     """The round-2 kernels (256-row tiles, 128 x 64 outputs per wave, K halves exchanged through LDS in the 256 x 128
     form; vpu_gemm_set_option("k2", 1 / 3) = 256 x 128 / 256 x 256 tiles): exact-integer operands must give the fp32
