@@ -147,10 +147,9 @@ int vpu_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
 int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                  float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H, int32_t n, int32_t hd, int32_t ld,
                  int32_t ldo, int32_t ldg, float scale, void* stream);
-/* Kernel-selection knob of the attention entry points: "whole_chunk" = 1 runs head dims >= 48 on the round-2 kernels that
- * stage up to 208 keys once per workgroup and take one (not online) softmax per chunk; 0 (default, measured faster at the
- * VPUFormer shapes) keeps the 32-key-step kernels; -1 = environment default (VPU_ATTN_WC).  Same results within bf16
- * rounding of the probabilities. */
+/* Kernel-selection knob of the attention entry points: "lean" = 1 (default) runs the round-2 kernels (buffer-load staging
+ * with hardware zero fill, thresholded running maximum, two tiles per wave), 0 the round-1 32-key-step kernels,
+ * -1 = environment default (VPU_ATTN_LEAN).  Same results within bf16 rounding; both are covered by the tests. */
 int vpu_attn_set_option(const char* name, int32_t value);
 /* General form (the DMA neck's Attention, transformer.py:484-521): queries are rows [b*nq, (b+1)*nq) of a matrix with
  * row stride ldq, keys / values rows [b*nk, (b+1)*nk) of matrices with row stride ldk; hd % 16 == 0, hd <= 128;

@@ -429,183 +429,218 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Whole-chunk kernels (round 2).  The kernels above walk the keys 32 at a time: two barriers, an LDS restage and -- in the
-// forward -- one online-softmax step (running max, rescale of the output tile, two cross-lane reductions) per 8 MFMAs,
-// ~170 instructions per 16-query x 32-key block.  Here a chunk of up to 208 keys (13 tiles of 16; 112 for head dims above 64)
-// is staged ONCE per workgroup as one image per tensor and a wave takes all its score tiles for the chunk before it touches
-// the softmax:
-//   forward : 26 score MFMAs -> ONE max / exp2 / sum over the lane's 52 values -> 28 P.V MFMAs; a 196-token window is a
-//             single chunk, i.e. a plain (not online) softmax with no rescale at all; longer rows (784 global tokens) carry
-//             the running max / sum across 4 chunks;
-//   backward: no reduction is needed (log-sum-exp and delta are known), so both kernels stream 32-row steps over the
-//             resident chunk with no barrier between them.
-// One image serves both operand forms: it is laid out for the transposing read (tr_off), and its 16-byte chunks stay
-// contiguous under that swizzle, so the row-operand fragments are read from the same image with ds_read_b128
-// (conflict-free for 128-byte rows: the eight rows of a lane group at one chunk index land on eight different 16-byte slots).
+// Lean kernels (round 2, the default).  The step kernels above spend ~240 VALU instructions per 32-key step of a wave for 16
+// MFMAs (measured: SQ_INSTS_VALU 1677 per wave of the window forward, VALU pipe 45 % busy, MFMA pipe 13 %): address
+// arithmetic and bounds checks of the staging loads re-done every step, the key mask applied on every step, an online-
+// softmax rescale of the whole output tile plus eight ds_bpermute broadcasts per step, per-element branches in backward.
+// Same data flow (32 rows per step through LDS, S^T trick, P never in LDS), but:
+//   * staging through raw buffer loads whose resource ends with the last valid row: rows past the end read as zeros with
+//     no compare, the per-thread global / LDS offsets are computed once, the LDS blocks are double-buffered (one barrier
+//     per step instead of two);
+//   * zero rows make every mask of the backward kernels unnecessary (a padded key row contributes dS * 0, a padded query
+//     row has dO = 0); the forward masks keys only in the last step;
+//   * forward: the running maximum is only raised when a step's scores exceed it by more than 2^8 (all probabilities of a
+//     row stay relative to one reference, the row sum uses the same reference, so the result is exact up to rounding);
+//     the common step has no rescale, no cross-lane traffic, and the row sums come out of one extra MFMA against a ones
+//     fragment -- already in the layout of the output tile, so the final 1 / l needs no broadcast either;
+//   * exp2 with the scale folded into one FMA per score; two 16-row tiles per wave share every LDS fragment read.
 // ------------------------------------------------------------------------------------------------
-template <int HD> struct WC {
-    static constexpr int NKT = HD <= 64 ? 13 : 7;       // 16-row tiles per staged chunk
-    static constexpr int ROWS = NKT * 16;                // 208 / 112
-    static constexpr int NPS = (NKT + 1) / 2;            // 32-row steps of the products that sum over the chunk's rows
-    static constexpr int IMG_ROWS = NPS * 32;            // 224 / 128 (rows >= the valid ones are zeros)
-    static constexpr int IMG_BYTES = IMG_ROWS * HD * 2;  // 28672 / 32768
-    static constexpr int NLD = IMG_ROWS * (HD / 8) / 256;   // 16-byte chunks per thread per image (256 threads)
+constexpr float LOG2E = 1.44269504089f, LN2 = 0.69314718056f;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+// buffer resource over rows [0, n) x cols [0, cols) of a [*, ld] matrix of elem-byte elements: everything past the last
+// valid element of row n - 1 is out of range (reads as zero)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* base, int n, int ld, int cols, int elem) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, ((n - 1) * ld + cols) * elem, 0x00020000);
+}
+
+// per-thread loop invariants of staging one [CH x HD] block with 256 threads (16-byte pieces)
+template <int HD> struct Stg {
+    static constexpr int CPR = HD / 8, NCH = CH * CPR, NI = (NCH + 255) / 256;
+    int lrc[NI], ltr[NI];
+    bool live[NI];
+    __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
+            live[i] = c < NCH;
+            lrc[i] = rc_off<HD>(row, ch);
+            ltr[i] = tr_off<HD>(row, ch * 2);
+        }
+    }
+    // byte offsets of this thread's pieces within rows [0, CH) of a matrix with row stride ld; columns >= hd: never valid
+    __device__ __forceinline__ void offsets(int tid, int ld, int hd, int (&voff)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
+            voff[i] = (live[i] && ch * 8 < hd) ? (row * ld + ch * 8) * 2 : 0x40000000;
+        }
+    }
+    __device__ __forceinline__ static void fetch(const __amdgpu_buffer_rsrc_t rs, const int (&voff)[NI], int base, u32x4v (&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i] + base, 0, 0);
+    }
+    __device__ __forceinline__ void put_rc(char* lds, const u32x4v (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (live[i]) *reinterpret_cast<u32x4v*>(lds + lrc[i]) = v[i];
+    }
+    __device__ __forceinline__ void put_tr(char* lds, const u32x4v (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (live[i]) *reinterpret_cast<u32x4v*>(lds + ltr[i]) = v[i];
+    }
 };
 
-// rows [r0, r0 + IMG_ROWS) of a [*, ld] matrix -> registers (zeros beyond row n / column hd / image row `rows`)
-template <int HD>
-__device__ __forceinline__ void wc_fetch(const bf16_t* __restrict__ base, int ld, int r0, int n, int hd, int rows, int tid,
-                                         uint4 (&v)[WC<HD>::NLD]) {
-    constexpr int CPR = HD / 8;
-#pragma unroll
-    for (int i = 0; i < WC<HD>::NLD; ++i) {
-        const int c = tid + i * 256;
-        const int row = c / CPR, ch = c % CPR;
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (row < rows && r0 + row < n && ch * 8 < hd) x = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + ch * 8);
-        v[i] = x;
-    }
+// max of eight MFMA results: v_max3_f32 directly (fmaxf would first canonicalise every operand with a v_max_f32 x, x)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
-template <int HD>
-__device__ __forceinline__ void wc_put(char* img, int rows, int tid, const uint4 (&v)[WC<HD>::NLD]) {
-    constexpr int CPR = HD / 8;
-#pragma unroll
-    for (int i = 0; i < WC<HD>::NLD; ++i) {
-        const int c = tid + i * 256;
-        const int row = c / CPR, ch = c % CPR;
-        if (row < rows) *reinterpret_cast<uint4*>(img + tr_off<HD>(row, ch * 2)) = v[i];
-    }
-}
-// MFMA row-operand fragment (16 rows from row16, k-step ks) out of a tr-layout image
-template <int HD> __device__ __forceinline__ bf16x8_t frag_img(const char* img, int row16, int ks, int lane) {
-    const int row = row16 + (lane & 15);
-    const int unit = (ks * 4 + (lane >> 4)) * 2;
-    const uint4 v = *reinterpret_cast<const uint4*>(img + tr_off<HD>(row, unit));
-    return __builtin_bit_cast(bf16x8_t, v);
+__device__ __forceinline__ float max8(const f32x4_t& a, const f32x4_t& b) {
+    return max3(max3(a[0], a[1], a[2]), max3(a[3], b[0], b[1]), max3(b[2], b[3], b[3]));
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_wc_kernel(const AttnArgs a, const int qpw) {
-    using W = WC<HD>;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* imgK = lds;
-    char* imgV = lds + W::IMG_BYTES;
+constexpr float RESCALE_TH = 8.0f;   // log2 units: probabilities relative to the reference maximum stay below 2^8
+
+template <int HD, int QT>
+__global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
+    using S = Stg<HD>;
+    __shared__ __attribute__((aligned(16))) char ldsK[2][CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsV[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
-    const int nchunks = (nk + W::ROWS - 1) / W::ROWS;
-    const float sc2 = a.scale * 1.44269504089f;
-    for (int qi = 0; qi < qpw; ++qi) {
-        const int q0 = ((blockIdx.x * qpw + qi) * 4 + wave) * 16;
-        const bool active = q0 < nq;   // wave-uniform; an idle wave still takes part in the staging barriers
-        bf16x8_t qf[HD / 32];
-        load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
-        float m = -INFINITY, l = 0.f;
-        f32x4_t acc[HD / 16];
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const float sc2 = a.scale * LOG2E;
+    bf16x8_t qf[QT][HD / 32];
+    float mref[QT];
+    f32x4_t acc[QT][HD / 16], accl[QT];
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int kc0 = ch * W::ROWS;
-            const int kvalid = nk - kc0 < W::ROWS ? nk - kc0 : W::ROWS;   // keys of this chunk
-            if (nchunks > 1 || qi == 0) {   // block-uniform
-                uint4 rk[W::NLD], rv[W::NLD];
-                wc_fetch<HD>(k, a.ldk, kc0, nk, hd, W::ROWS, tid, rk);
-                wc_fetch<HD>(v, a.ldk, kc0, nk, hd, W::ROWS, tid, rv);
-                __syncthreads();
-                wc_put<HD>(imgK, W::IMG_ROWS, tid, rk);
-                wc_put<HD>(imgV, W::IMG_ROWS, tid, rv);
-                __syncthreads();
+    for (int u = 0; u < QT; ++u) {
+        load_rows_as_b<HD>(q, a.ldq, q0 + 16 * u, nq, lane, qf[u], hd);
+        mref[u] = -INFINITY;
+        accl[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    S st;
+    st.init(tid);
+    int voff[S::NI];
+    st.offsets(tid, a.ldk, hd, voff);
+    const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(k, nk, a.ldk, hd, 2), rsV = rows_rsrc(v, nk, a.ldk, hd, 2);
+    const int nch = (nk + CH - 1) / CH, cstep = CH * a.ldk * 2;
+    u32x4v pk[S::NI], pv[S::NI];
+    S::fetch(rsK, voff, 0, pk);
+    S::fetch(rsV, voff, 0, pv);
+    st.put_rc(ldsK[0], pk);
+    st.put_tr(ldsV[0], pv);
+    if (nch > 1) { S::fetch(rsK, voff, cstep, pk); S::fetch(rsV, voff, cstep, pv); }
+    for (int i = 0; i < nch; ++i) {
+        __syncthreads();    // block i is visible; every wave is done with block i - 1 (the buffer block i + 1 goes into)
+        if (i + 1 < nch) { st.put_rc(ldsK[(i + 1) & 1], pk); st.put_tr(ldsV[(i + 1) & 1], pv); }
+        if (i + 2 < nch) { S::fetch(rsK, voff, (i + 2) * cstep, pk); S::fetch(rsV, voff, (i + 2) * cstep, pv); }
+        const char* sK = ldsK[i & 1];
+        const char* sV = ldsV[i & 1];
+        const int kc = i * CH;
+        f32x4_t s[QT][2];
+#pragma unroll
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) s[u][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const bf16x8_t kfr = frag_rc<HD>(sK, 16 * t, ks, lane);
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    s[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][ks], s[u][t], 0, 0, 0);
             }
-            if (!active) continue;
-            // every tile of the chunk is computed (rows beyond the chunk's keys are zeros in the image): straight-line code
-            // with all 26 score MFMAs independent; only the masking differs -- a chunk that is full up to its last tile (a
-            // 196-token window: 12 full tiles + 4 keys) masks that one tile, a shorter one masks by comparison everywhere
-            f32x4_t s[W::NKT + 1];
+        if (kc + CH > nk) {   // the last step: keys past the end (block-uniform)
 #pragma unroll
-            for (int kt = 0; kt < W::NKT; ++kt) {
-                s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks)
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgK, kt * 16, ks, lane), qf[ks], s[kt], 0, 0, 0);
-            }
-            s[W::NKT] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (kvalid > W::ROWS - 16) {   // uniform
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s[W::NKT - 1][r] = ((W::NKT - 1) * 16 + 4 * g + r < kvalid) ? s[W::NKT - 1][r] : -INFINITY;
-            } else {
+                    if (kc + 16 * t + 4 * g + r >= nk) {
 #pragma unroll
-                for (int kt = 0; kt < W::NKT; ++kt)
+                        for (int u = 0; u < QT; ++u) s[u][t][r] = -INFINITY;
+                    }
+        }
+        float lm[QT];
+        bool need = false;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + 4 * g + r < kvalid) ? s[kt][r] : -INFINITY;
-            }
-            float mx = -INFINITY;
+        for (int u = 0; u < QT; ++u) {
+            lm[u] = max8(s[u][0], s[u][1]) * sc2;
+            need = need || (lm[u] > mref[u] + RESCALE_TH);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {   // rare after the first step: raise the reference, rescale
 #pragma unroll
-            for (int kt = 0; kt < W::NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // log2 domain: p = exp2(s * sc2 - m): one FMA and one v_exp_f32 per element
-            const float mnew = fmaxf(m, mx * sc2);
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < W::NKT; ++kt)
+            for (int u = 0; u < QT; ++u) {
+                float xm = lm[u];
+                xm = fmaxf(xm, __shfl_xor(xm, 16, 64));
+                xm = fmaxf(xm, __shfl_xor(xm, 32, 64));
+                const float mnew = (xm > mref[u] + RESCALE_TH) ? xm : mref[u];
+                const float alpha = __builtin_amdgcn_exp2f(mref[u] - mnew);
+                mref[u] = mnew;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc2, -mnew));
-                    s[kt][r] = p;
-                    ps += p;
+                    const float ar = __shfl(alpha, 4 * g + r, 64);
+                    accl[u][r] *= ar;
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt][r] *= ar;
                 }
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
-            l = l * alpha + ps;
-            m = mnew;
-            if (ch > 0) {   // only rows longer than one chunk ever rescale
-                float ar[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[dt][r] *= ar[r];
-            }
-#pragma unroll
-            for (int pss = 0; pss < W::NPS; ++pss) {
-                const bf16x8_t pf = pack_pair(s[2 * pss], s[2 * pss + 1]);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt)
-                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(imgV + pss * 32 * HD * 2, dt, lane), acc[dt], 0, 0, 0);
             }
         }
-        if (active) {
-            const float il = 1.0f / l;
-            if (g == 0 && q0 + c < nq) a.lse[(int64_t)bh * nq + q0 + c] = (m + __builtin_amdgcn_logf(l)) * 0.69314718056f;
+        bf16x8_t pf[QT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s1 = __shfl(il, 4 * g + r, 64);
-                const int qq = q0 + 4 * g + r;
-                if (qq < nq) {
-                    bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
+        for (int u = 0; u < QT; ++u) {
+            const float nm = -mref[u];
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt)
-                        if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[dt][r] * s1);
-                }
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sc2, nm));
+            pf[u] = pack_pair(s[u][0], s[u][1]);
+            accl[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], ones, accl[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            const bf16x8_t vfr = frag_tr_perm<HD>(sV, dt, lane);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], vfr, acc[u][dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const int qu = q0 + 16 * u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mrow = __shfl(mref[u], 4 * g + r, 64);
+            const float l = accl[u][r], il = 1.0f / l;
+            const int qq = qu + 4 * g + r;
+            if (qq < nq) {
+                if (c == 0) a.lse[(int64_t)bh * nq + qq] = (mrow + __builtin_amdgcn_logf(l)) * LN2;
+                bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+                    if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[u][dt][r] * il);
             }
         }
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_wc_kernel(const AttnArgs a, const int qpw) {
-    using W = WC<HD>;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* imgK = lds;
-    char* imgV = lds + W::IMG_BYTES;
+// dQ (and delta): QT query tiles per wave, keys streamed
+template <int HD, int QT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a) {
+    using S = Stg<HD>;
+    __shared__ __attribute__((aligned(16))) char ldsKr[2][CH * HD * 2], ldsKt[2][CH * HD * 2], ldsVr[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
@@ -613,91 +648,117 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wc_kernel(const AttnArgs a
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
     const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
-    const int nchunks = (nk + W::ROWS - 1) / W::ROWS;
-    const float sc2 = a.scale * 1.44269504089f;
-    for (int qi = 0; qi < qpw; ++qi) {
-        const int q0 = ((blockIdx.x * qpw + qi) * 4 + wave) * 16;
-        const bool active = q0 < nq;
-        const bool q_ok = q0 + c < nq;
-        const float lse2 = q_ok ? a.lse[(int64_t)bh * nq + q0 + c] * 1.44269504089f : 0.f;
-        bf16x8_t qf[HD / 32], dof[HD / 32];
-        load_rows_as_b<HD>(q, a.ldq, q0, nq, lane, qf, hd);
-        load_rows_as_b<HD>(d_o, a.ldo, q0, nq, lane, dof, hd);
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const float sc2 = a.scale * LOG2E;
+    bf16x8_t qf[QT][HD / 32], dof[QT][HD / 32];
+    float nl2[QT], nds[QT];    // -lse * log2 e, -delta * scale of query q0 + 16 u + c
+    f32x4_t adq[QT][HD / 16];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const int qu = q0 + 16 * u;
+        const bool q_ok = qu + c < nq;
+        nl2[u] = q_ok ? -a.lse[(int64_t)bh * nq + qu + c] * LOG2E : 0.f;
+        load_rows_as_b<HD>(q, a.ldq, qu, nq, lane, qf[u], hd);
+        load_rows_as_b<HD>(d_o, a.ldo, qu, nq, lane, dof[u], hd);
         // delta[q] = sum_d dO[q][d] * O[q][d] from the dO fragments the wave holds anyway; published for the dK/dV kernel
-        float dl_q = 0.f;
-        {
-            bf16x8_t of[HD / 32];
-            load_rows_as_b<HD>(a.o + rbq * a.ldo + h * hd, a.ldo, q0, nq, lane, of, hd);
+        bf16x8_t of[HD / 32];
+        load_rows_as_b<HD>(a.o + rbq * a.ldo + h * hd, a.ldo, qu, nq, lane, of, hd);
+        float dl = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks)
+        for (int ks = 0; ks < HD / 32; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dl_q += (float)dof[ks][j] * (float)of[ks][j];
-            dl_q += __shfl_xor(dl_q, 16, 64);
-            dl_q += __shfl_xor(dl_q, 32, 64);
-            if (q_ok && g == 0) a.delta[(int64_t)bh * nq + q0 + c] = dl_q;
+            for (int j = 0; j < 8; ++j) dl += (float)dof[u][ks][j] * (float)of[ks][j];
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        if (q_ok && g == 0) a.delta[(int64_t)bh * nq + qu + c] = dl;
+        nds[u] = -dl * a.scale;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) adq[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    S st;
+    st.init(tid);
+    int voff[S::NI];
+    st.offsets(tid, a.ldk, hd, voff);
+    const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(k, nk, a.ldk, hd, 2), rsV = rows_rsrc(v, nk, a.ldk, hd, 2);
+    const int nch = (nk + CH - 1) / CH, cstep = CH * a.ldk * 2;
+    u32x4v pk[S::NI], pv[S::NI];
+    S::fetch(rsK, voff, 0, pk);
+    S::fetch(rsV, voff, 0, pv);
+    st.put_rc(ldsKr[0], pk); st.put_tr(ldsKt[0], pk); st.put_rc(ldsVr[0], pv);
+    if (nch > 1) { S::fetch(rsK, voff, cstep, pk); S::fetch(rsV, voff, cstep, pv); }
+    for (int i = 0; i < nch; ++i) {
+        __syncthreads();
+        if (i + 1 < nch) {
+            const int nb = (i + 1) & 1;
+            st.put_rc(ldsKr[nb], pk); st.put_tr(ldsKt[nb], pk); st.put_rc(ldsVr[nb], pv);
         }
-        f32x4_t adq[HD / 16];
+        if (i + 2 < nch) { S::fetch(rsK, voff, (i + 2) * cstep, pk); S::fetch(rsV, voff, (i + 2) * cstep, pv); }
+        const char* sKr = ldsKr[i & 1];
+        const char* sKt = ldsKt[i & 1];
+        const char* sVr = ldsVr[i & 1];
+        const int kc = i * CH;
+        f32x4_t dS[QT][2];
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) adq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int kc0 = ch * W::ROWS;
-            if (nchunks > 1 || qi == 0) {
-                uint4 rk[W::NLD], rv[W::NLD];
-                wc_fetch<HD>(k, a.ldk, kc0, nk, hd, W::ROWS, tid, rk);
-                wc_fetch<HD>(v, a.ldk, kc0, nk, hd, W::ROWS, tid, rv);
-                __syncthreads();
-                wc_put<HD>(imgK, W::IMG_ROWS, tid, rk);
-                wc_put<HD>(imgV, W::IMG_ROWS, tid, rv);
-                __syncthreads();
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s[QT], dp[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const bf16x8_t kfr = frag_rc<HD>(sKr, 16 * t, ks, lane), vfr = frag_rc<HD>(sVr, 16 * t, ks, lane);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][ks], s[u], 0, 0, 0);
+                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[u][ks], dp[u], 0, 0, 0);
+                }
             }
-            if (!active) continue;
-            // straight-line over the whole image, no masks: a key beyond the chunk has an all-zero K row, so whatever its dS
-            // is, it adds nothing to dQ (dQ += dS[q][k] K[k])
 #pragma unroll
-            for (int pss = 0; pss < W::NPS; ++pss) {
-                f32x4_t ds[2];
+            for (int u = 0; u < QT; ++u)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int k16 = pss * 32 + t * 16;
-                    f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+                for (int r = 0; r < 4; ++r)   // element [key = kc + 16 t + 4 g + r][query = q0 + 16 u + c]
+                    dS[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sc2, nl2[u])) * __builtin_fmaf(dp[u][r], a.scale, nds[u]);
+        }
+        if (kc + CH > nk) {   // last step: a padded key has K = 0, so its dS only has to be finite
 #pragma unroll
-                    for (int ks = 0; ks < HD / 32; ++ks) {
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgK, k16, ks, lane), qf[ks], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgV, k16, ks, lane), dof[ks], dp, 0, 0, 0);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kc + 16 * t + 4 * g + r >= nk) {
+#pragma unroll
+                        for (int u = 0; u < QT; ++u) dS[u][t][r] = 0.f;
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)   // element [key = kc0 + k16 + 4g + r][query = q0 + c]
-                        ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc2, -lse2)) * (dp[r] - dl_q);
-                }
-                const bf16x8_t dsf = pack_pair(ds[0], ds[1]);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt)
-                    adq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(imgK + pss * 32 * HD * 2, dt, lane), adq[dt], 0, 0, 0);
-            }
         }
-        if (active) {
+        bf16x8_t dsf[QT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qq = q0 + 4 * g + r;
-                if (qq < nq) {
-                    bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd;
+        for (int u = 0; u < QT; ++u) dsf[u] = pack_pair(dS[u][0], dS[u][1]);
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt)
-                        if (dt * 16 < hd) qr[dt * 16 + c] = (bf16_t)(adq[dt][r] * a.scale);
-                }
-            }
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            const bf16x8_t ktf = frag_tr_perm<HD>(sKt, dt, lane);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) adq[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[u], ktf, adq[u][dt], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = q0 + 16 * u + 4 * g + r;
+            if (qq < nq) {
+                bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd;
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+                    if (dt * 16 < hd) qr[dt * 16 + c] = (bf16_t)adq[u][dt][r];
+            }
+        }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_wc_kernel(const AttnArgs a, const int kpw) {
-    using W = WC<HD>;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* imgQ = lds;
-    char* imgO = lds + W::IMG_BYTES;
-    float* lseS = reinterpret_cast<float*>(lds + 2 * W::IMG_BYTES);   // log-sum-exp (log2 domain) and delta of the chunk's queries
-    float* dlS = lseS + W::IMG_ROWS;
+// dK, dV: KT key tiles per wave, queries streamed (needs nq % 4 == 0: the log-sum-exp / delta values of four consecutive
+// queries are one 16-byte buffer load, zeros past the end)
+template <int HD, int KT>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnArgs a) {
+    using S = Stg<HD>;
+    __shared__ __attribute__((aligned(16))) char ldsQr[2][CH * HD * 2], ldsQt[2][CH * HD * 2];
+    __shared__ __attribute__((aligned(16))) char ldsOr[2][CH * HD * 2], ldsOt[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
@@ -705,106 +766,110 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_wc_kernel(const AttnArgs
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
     const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
-    const float* lse = a.lse + (int64_t)bh * nq;
-    const float* dl = a.delta + (int64_t)bh * nq;
-    const int nchunks = (nq + W::ROWS - 1) / W::ROWS;
-    const float sc2 = a.scale * 1.44269504089f;
-    for (int ki = 0; ki < kpw; ++ki) {
-        const int key0 = ((blockIdx.x * kpw + ki) * 4 + wave) * 16;
-        const bool active = key0 < nk;
-        bf16x8_t kf[HD / 32], vf[HD / 32];
-        load_rows_as_b<HD>(k, a.ldk, key0, nk, lane, kf, hd);
-        load_rows_as_b<HD>(v, a.ldk, key0, nk, lane, vf, hd);
-        f32x4_t adk[HD / 16], adv[HD / 16];
+    const int key0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
+    const float sc2 = a.scale * LOG2E;
+    bf16x8_t kf[KT][HD / 32], vf[KT][HD / 32];
+    f32x4_t adk[KT][HD / 16], adv[KT][HD / 16];
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int qc0 = ch * W::ROWS;
-            const int qvalid = nq - qc0 < W::ROWS ? nq - qc0 : W::ROWS;
-            if (nchunks > 1 || ki == 0) {
-                uint4 rq[W::NLD], ro[W::NLD];
-                wc_fetch<HD>(q, a.ldq, qc0, nq, hd, W::ROWS, tid, rq);
-                wc_fetch<HD>(d_o, a.ldo, qc0, nq, hd, W::ROWS, tid, ro);
-                const float l2 = tid < qvalid ? lse[qc0 + tid] * 1.44269504089f : 0.f;
-                const float d2 = tid < qvalid ? dl[qc0 + tid] : 0.f;
-                __syncthreads();
-                wc_put<HD>(imgQ, W::IMG_ROWS, tid, rq);
-                wc_put<HD>(imgO, W::IMG_ROWS, tid, ro);
-                if (tid < W::IMG_ROWS) { lseS[tid] = l2; dlS[tid] = d2; }
-                __syncthreads();
-            }
-            if (!active) continue;
-            // straight-line, no masks: a query beyond the chunk has all-zero Q and dO rows, so its P / dS add nothing to dV
-            // (+= P[q][k] dO[q]) and dK (+= dS[q][k] Q[q])
+    for (int u = 0; u < KT; ++u) {
+        load_rows_as_b<HD>(k, a.ldk, key0 + 16 * u, nk, lane, kf[u], hd);
+        load_rows_as_b<HD>(v, a.ldk, key0 + 16 * u, nk, lane, vf[u], hd);
 #pragma unroll
-            for (int pss = 0; pss < W::NPS; ++pss) {
-                f32x4_t P[2], dS[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int q16 = pss * 32 + t * 16;
-                    const f32x4_t lv = *reinterpret_cast<const f32x4_t*>(lseS + q16 + 4 * g);
-                    const f32x4_t dv4 = *reinterpret_cast<const f32x4_t*>(dlS + q16 + 4 * g);
-                    f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
-#pragma unroll
-                    for (int ks = 0; ks < HD / 32; ++ks) {
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgQ, q16, ks, lane), kf[ks], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_img<HD>(imgO, q16, ks, lane), vf[ks], dp, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {   // element [query = qc0 + q16 + 4g + r][key = key0 + c]
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc2, -lv[r]));
-                        P[t][r] = p;
-                        dS[t][r] = p * (dp[r] - dv4[r]);
-                    }
-                }
-                const bf16x8_t pf = pack_pair(P[0], P[1]), dsf = pack_pair(dS[0], dS[1]);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt) {
-                    adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr_perm<HD>(imgO + pss * 32 * HD * 2, dt, lane), adv[dt], 0, 0, 0);
-                    adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr_perm<HD>(imgQ + pss * 32 * HD * 2, dt, lane), adk[dt], 0, 0, 0);
-                }
-            }
+        for (int dt = 0; dt < HD / 16; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
+    }
+    S st;
+    st.init(tid);
+    int voq[S::NI], voo[S::NI];
+    st.offsets(tid, a.ldq, hd, voq);
+    st.offsets(tid, a.ldo, hd, voo);
+    const __amdgpu_buffer_rsrc_t rsQ = rows_rsrc(q, nq, a.ldq, hd, 2), rsO = rows_rsrc(d_o, nq, a.ldo, hd, 2);
+    const __amdgpu_buffer_rsrc_t rsL = rows_rsrc(reinterpret_cast<const char*>(a.lse + (int64_t)bh * nq), 1, 0, nq, 4);
+    const __amdgpu_buffer_rsrc_t rsD = rows_rsrc(reinterpret_cast<const char*>(a.delta + (int64_t)bh * nq), 1, 0, nq, 4);
+    const int nch = (nq + CH - 1) / CH, qstep = CH * a.ldq * 2, ostep = CH * a.ldo * 2;
+    u32x4v pq[S::NI], po[S::NI];
+    S::fetch(rsQ, voq, 0, pq);
+    S::fetch(rsO, voo, 0, po);
+    st.put_rc(ldsQr[0], pq); st.put_tr(ldsQt[0], pq); st.put_rc(ldsOr[0], po); st.put_tr(ldsOt[0], po);
+    if (nch > 1) { S::fetch(rsQ, voq, qstep, pq); S::fetch(rsO, voo, ostep, po); }
+    for (int i = 0; i < nch; ++i) {
+        __syncthreads();
+        if (i + 1 < nch) {
+            const int nb = (i + 1) & 1;
+            st.put_rc(ldsQr[nb], pq); st.put_tr(ldsQt[nb], pq); st.put_rc(ldsOr[nb], po); st.put_tr(ldsOt[nb], po);
         }
-        if (active) {
+        if (i + 2 < nch) { S::fetch(rsQ, voq, (i + 2) * qstep, pq); S::fetch(rsO, voo, (i + 2) * ostep, po); }
+        const int b = i & 1, qc = i * CH;
+        f32x4_t nl2[2], nds[2];   // -lse * log2 e, -delta * scale of queries qc + 16 t + 4 g + r (zeros past the end)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = key0 + 4 * g + r;
-                if (kk < nk) {
-                    bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd;
-                    bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd;
+        for (int t = 0; t < 2; ++t) {
+            const int off = (qc + 16 * t + 4 * g) * 4;
+            const f32x4_t lv = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsL, off, 0, 0));
+            const f32x4_t dv = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
+            nl2[t] = lv * (-LOG2E);
+            nds[t] = dv * (-a.scale);
+        }
+        f32x4_t P[KT][2], dS[KT][2];
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt)
-                        if (dt * 16 < hd) {
-                            kr[dt * 16 + c] = (bf16_t)(adk[dt][r] * a.scale);
-                            vr[dt * 16 + c] = (bf16_t)adv[dt][r];
-                        }
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s[KT], dp[KT];
+#pragma unroll
+            for (int u = 0; u < KT; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const bf16x8_t qfr = frag_rc<HD>(ldsQr[b], 16 * t, ks, lane), ofr = frag_rc<HD>(ldsOr[b], 16 * t, ks, lane);
+#pragma unroll
+                for (int u = 0; u < KT; ++u) {
+                    s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], s[u], 0, 0, 0);
+                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[u][ks], dp[u], 0, 0, 0);
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < KT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // element [query = qc + 16 t + 4 g + r][key = key0 + 16 u + c]
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sc2, nl2[t][r]));
+                    P[u][t][r] = p;
+                    dS[u][t][r] = p * __builtin_fmaf(dp[u][r], a.scale, nds[t][r]);
+                }
+        }
+        bf16x8_t pf[KT], dsf[KT];
+#pragma unroll
+        for (int u = 0; u < KT; ++u) { pf[u] = pack_pair(P[u][0], P[u][1]); dsf[u] = pack_pair(dS[u][0], dS[u][1]); }
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            const bf16x8_t otf = frag_tr_perm<HD>(ldsOt[b], dt, lane), qtf = frag_tr_perm<HD>(ldsQt[b], dt, lane);
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], otf, adv[u][dt], 0, 0, 0);
+                adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[u], qtf, adk[u][dt], 0, 0, 0);
             }
         }
     }
+#pragma unroll
+    for (int u = 0; u < KT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = key0 + 16 * u + 4 * g + r;
+            if (kk < nk) {
+                bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd;
+                bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd;
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt)
+                    if (dt * 16 < hd) {
+                        kr[dt * 16 + c] = (bf16_t)adk[u][dt][r];
+                        vr[dt * 16 + c] = (bf16_t)adv[u][dt][r];
+                    }
+            }
+        }
 }
 
-// tiles per wave of the whole-chunk kernels: a problem whose reduction side fits one chunk runs in ONE workgroup (every wave
-// takes up to four 16-row tiles against the one staged image pair); longer reductions get one tile per wave
-template <int HD> inline int wc_tiles_per_wave(int n_own, int n_red) {
-    if (n_red > WC<HD>::ROWS) return 1;
-    const int t = (n_own + 63) / 64;
-    return t < 4 ? t : 4;
-}
-// Measured (tools/op_bench.py attn, ViT-B bs 12, both builds with MFMA results in VGPRs): window forward 37.6 us against
-// 30.4 us for the 32-key-step kernels, window backward 79.8 / 79.1, global forward 79.4 / 77.2, global backward 173.1 /
-// 176.9 -- the whole-chunk form issues ~2.5x fewer instructions per score element but runs two workgroups per CU (57 KiB
-// of LDS, ~215 VGPRs) where the step kernels run eight, and a (window, head) problem is too short (2.25 workgroups per CU)
-// for the leaner stream to make up for the exposed staging latency.  Kept selectable (VPU_ATTN_WC=1 /
-// vpu_attn_set_option("whole_chunk", 1)) and tested; the step kernels stay the default.
-std::atomic<int> g_opt_wc{-1};
-inline bool wc_enabled() {
-    static const int e0 = [] { const char* e = getenv("VPU_ATTN_WC"); return e ? atoi(e) : 0; }();
-    const int v = g_opt_wc.load(std::memory_order_relaxed);
+// "lean" = 1 (default): the kernels above; 0: the round-1 step kernels (kept for A/B runs and as a second implementation in
+// the tests).  VPU_ATTN_LEAN sets the process default.
+std::atomic<int> g_opt_lean{-1};
+inline bool lean_enabled() {
+    static const int e0 = [] { const char* e = getenv("VPU_ATTN_LEAN"); return e ? atoi(e) : 1; }();
+    const int v = g_opt_lean.load(std::memory_order_relaxed);
     return (v >= 0 ? v : e0) != 0;
-}
-template <typename K> inline void wc_attr(K kern, int bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 inline bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -815,11 +880,11 @@ int hd_image(int hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : 128); }
 
 extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
     vpu_clear_stale_error();
-    if (name && !strcmp(name, "whole_chunk") && value >= -1 && value <= 1) {
-        g_opt_wc.store(value, std::memory_order_relaxed);
+    if (name && !strcmp(name, "lean") && value >= -1 && value <= 1) {
+        g_opt_lean.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
-    vpu_set_error("vpu_attn_set_option: known options: whole_chunk (-1 environment default VPU_ATTN_WC, 0 off, 1 on)");
+    vpu_set_error("vpu_attn_set_option: known options: lean (-1 environment default VPU_ATTN_LEAN, 0 round-1 step kernels, 1 lean kernels)");
     return VPU_ERR_ARG;
 }
 
@@ -828,46 +893,36 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
                              void* stream) {
     vpu_clear_stale_error();
     if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || nb <= 0 ||
-        H <= 0 || nq <= 0 || nk <= 0) {
-        vpu_set_error("xattn_fwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0");
+        H <= 0 || nq <= 0 || nk <= 0 || (int64_t)nk * ldk >= (1 << 29)) {
+        vpu_set_error("xattn_fwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0, one batch entry of k/v below 1 GiB");
         return VPU_ERR_ARG;
     }
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale;
-    hipStream_t s0 = reinterpret_cast<hipStream_t>(stream);
-    if (wc_enabled() && hd_image(hd) >= 64) {
-        if (hd_image(hd) == 64) {
-            static const bool once = (wc_attr(attn_fwd_wc_kernel<64>, 2 * WC<64>::IMG_BYTES), true);
-            (void)once;
-            const int qpw = wc_tiles_per_wave<64>(nq, nk);
-            attn_fwd_wc_kernel<64><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, 2 * WC<64>::IMG_BYTES, s0>>>(a, qpw);
-        } else {
-            static const bool once = (wc_attr(attn_fwd_wc_kernel<128>, 2 * WC<128>::IMG_BYTES), true);
-            (void)once;
-            const int qpw = wc_tiles_per_wave<128>(nq, nk);
-            attn_fwd_wc_kernel<128><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, 2 * WC<128>::IMG_BYTES, s0>>>(a, qpw);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (lean_enabled()) {
+        // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
+        const bool two = nq > 64 && hd_image(hd) <= 64;
+        dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
+        switch (hd_image(hd) * 4 + (two ? 2 : 1)) {
+            case 32 * 4 + 2: attn_fwd_lean_kernel<32, 2><<<grid, 256, 0, s>>>(a); break;
+            case 32 * 4 + 1: attn_fwd_lean_kernel<32, 1><<<grid, 256, 0, s>>>(a); break;
+            case 64 * 4 + 2: attn_fwd_lean_kernel<64, 2><<<grid, 256, 0, s>>>(a); break;
+            case 64 * 4 + 1: attn_fwd_lean_kernel<64, 1><<<grid, 256, 0, s>>>(a); break;
+            default: attn_fwd_lean_kernel<128, 1><<<grid, 256, 0, s>>>(a); break;
         }
         return vpu_check_launch("vpu_xattn_fwd");
     }
     static const int qt2 = [] { const char* e = getenv("VPU_ATTN_QT"); return e ? atoi(e) : 2; }();
-    // two query tiles per wave (128 queries per workgroup) for the 196-token windows: 33.9 vs 35.4 us (bs 12, round 1);
-    // for the global blocks one tile per wave stays ahead (84.1 vs 86.0 us).  Time grows linearly with the number of
-    // (window, head) problems from ~300 workgroups on (tools/attn_scale.py): the kernel is issue-bound on the softmax's
-    // dependent VALU / cross-lane chain (~160 instructions per 32-key step for 8 MFMAs), not on latency or LDS traffic.
     const bool two = qt2 == 2 && nq > 64 && nk <= 256 && hd_image(hd) <= 64;
     dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (two) {
         if (hd_image(hd) == 32) attn_fwd_kernel<32, 1, 2><<<grid, 256, 0, s>>>(a);
         else attn_fwd_kernel<64, 1, 2><<<grid, 256, 0, s>>>(a);
         return vpu_check_launch("vpu_xattn_fwd");
     }
     switch (hd_image(hd)) {
-        // staged block = NS x 32 keys.  NS = 1 everywhere: measured (tools/op_bench.py attn, round 1) window forward 35.8 us
-        // at NS = 1, 36.2 at NS = 2, 41.8 at NS = 7 (a whole 196-token window resident, one barrier pair); backward 111.7 /
-        // 119.2 / 144.3 us -- the loop is bound by its softmax dependency chain, and the 8-KiB blocks' occupancy (8 per CU)
-        // hides more of it than fewer round trips save
         case 32: attn_fwd_kernel<32, 1, 1><<<grid, 256, 0, s>>>(a); break;
         case 64: attn_fwd_kernel<64, 1, 1><<<grid, 256, 0, s>>>(a); break;
         default: attn_fwd_kernel<128, 1, 1><<<grid, 256, 0, s>>>(a); break;
@@ -881,8 +936,9 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
                              int32_t ldgk, float scale, void* stream) {
     vpu_clear_stale_error();
     if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || !ok16(o) ||
-        !ok16(d_o) || nb <= 0 || H <= 0 || nq <= 0 || nk <= 0) {
-        vpu_set_error("xattn_bwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0");
+        !ok16(d_o) || nb <= 0 || H <= 0 || nq <= 0 || nk <= 0 || (int64_t)nk * ldk >= (1 << 29) ||
+        (int64_t)nq * ldq >= (1 << 29) || (int64_t)nq * ldo >= (1 << 29)) {
+        vpu_set_error("xattn_bwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0, one batch entry per matrix below 1 GiB");
         return VPU_ERR_ARG;
     }
     AttnArgs a{};
@@ -892,21 +948,22 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (wc_enabled() && hd_image(hd) >= 64) {
-        if (hd_image(hd) == 64) {
-            constexpr int LQ = 2 * WC<64>::IMG_BYTES, LK = LQ + 2 * WC<64>::IMG_ROWS * 4;
-            static const bool once = (wc_attr(attn_bwd_dq_wc_kernel<64>, LQ), wc_attr(attn_bwd_dkdv_wc_kernel<64>, LK), true);
-            (void)once;
-            const int qpw = wc_tiles_per_wave<64>(nq, nk), kpw = wc_tiles_per_wave<64>(nk, nq);
-            attn_bwd_dq_wc_kernel<64><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, LQ, s>>>(a, qpw);     // also writes delta
-            attn_bwd_dkdv_wc_kernel<64><<<dim3((nk + 64 * kpw - 1) / (64 * kpw), nb * H), 256, LK, s>>>(a, kpw);
-        } else {
-            constexpr int LQ = 2 * WC<128>::IMG_BYTES, LK = LQ + 2 * WC<128>::IMG_ROWS * 4;
-            static const bool once = (wc_attr(attn_bwd_dq_wc_kernel<128>, LQ), wc_attr(attn_bwd_dkdv_wc_kernel<128>, LK), true);
-            (void)once;
-            const int qpw = wc_tiles_per_wave<128>(nq, nk), kpw = wc_tiles_per_wave<128>(nk, nq);
-            attn_bwd_dq_wc_kernel<128><<<dim3((nq + 64 * qpw - 1) / (64 * qpw), nb * H), 256, LQ, s>>>(a, qpw);
-            attn_bwd_dkdv_wc_kernel<128><<<dim3((nk + 64 * kpw - 1) / (64 * kpw), nb * H), 256, LK, s>>>(a, kpw);
+    if (lean_enabled() && nq % 4 == 0) {
+        const bool q2 = nq > 64 && hd_image(hd) <= 64, k2 = nk > 64 && hd_image(hd) <= 64;
+        dim3 gq(q2 ? (nq + 127) / 128 : (nq + 63) / 64, nb * H), gk(k2 ? (nk + 127) / 128 : (nk + 63) / 64, nb * H);
+        switch (hd_image(hd) * 4 + (q2 ? 2 : 1)) {     // also writes delta
+            case 32 * 4 + 2: attn_bwd_dq_lean_kernel<32, 2><<<gq, 256, 0, s>>>(a); break;
+            case 32 * 4 + 1: attn_bwd_dq_lean_kernel<32, 1><<<gq, 256, 0, s>>>(a); break;
+            case 64 * 4 + 2: attn_bwd_dq_lean_kernel<64, 2><<<gq, 256, 0, s>>>(a); break;
+            case 64 * 4 + 1: attn_bwd_dq_lean_kernel<64, 1><<<gq, 256, 0, s>>>(a); break;
+            default: attn_bwd_dq_lean_kernel<128, 1><<<gq, 256, 0, s>>>(a); break;
+        }
+        switch (hd_image(hd) * 4 + (k2 ? 2 : 1)) {
+            case 32 * 4 + 2: attn_bwd_dkdv_lean_kernel<32, 2><<<gk, 256, 0, s>>>(a); break;
+            case 32 * 4 + 1: attn_bwd_dkdv_lean_kernel<32, 1><<<gk, 256, 0, s>>>(a); break;
+            case 64 * 4 + 2: attn_bwd_dkdv_lean_kernel<64, 2><<<gk, 256, 0, s>>>(a); break;
+            case 64 * 4 + 1: attn_bwd_dkdv_lean_kernel<64, 1><<<gk, 256, 0, s>>>(a); break;
+            default: attn_bwd_dkdv_lean_kernel<128, 1><<<gk, 256, 0, s>>>(a); break;
         }
         return vpu_check_launch("vpu_xattn_bwd");
     }
