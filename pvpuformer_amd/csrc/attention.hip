@@ -444,6 +444,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 //     the common step has no rescale, no cross-lane traffic, and the row sums come out of one extra MFMA against a ones
 //     fragment -- already in the layout of the output tile, so the final 1 / l needs no broadcast either;
 //   * exp2 with the scale folded into one FMA per score; two 16-row tiles per wave share every LDS fragment read.
+// Measured and NOT kept (tools/op_bench.py attn, ViT-B bs 12, window fwd / dQ / dKdV 22.7 / 28.8 / 40.3 us as shipped):
+//   * a "resident" form for the 196-token windows -- every row requested in the prologue, one tr-layout image per matrix
+//     (57 KiB per workgroup), no barrier or global load in the loop: 51.8 / 58.8 / 56.8 us (the earlier whole-chunk
+//     kernels, same idea with a heavier loop, had measured 37.6 us forward); padding the streaming kernels' LDS to the
+//     same 2 workgroups per CU only costs 22.7 -> 26.6 us, so it is not the occupancy;
+//   * one workgroup of seven waves x two tiles per window problem (keys staged once): 23.6 vs 23.1 us;
+//   * forcing the dQ kernel to 128 VGPRs (4 waves per SIMD, 20 bytes of scratch): 34.0 vs 28.6 us.
 // ------------------------------------------------------------------------------------------------
 constexpr float LOG2E = 1.44269504089f, LN2 = 0.69314718056f;
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -543,14 +550,21 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
     st.put_rc(ldsK[0], pk);
     st.put_tr(ldsV[0], pv);
     if (nch > 1) { S::fetch(rsK, voff, cstep, pk); S::fetch(rsV, voff, cstep, pv); }
-    for (int i = 0; i < nch; ++i) {
+    f32x4_t s[QT][2];
+    float lm[QT];
+    // one step = stage (barrier, restage, next fetch) -> scores -> [raise] -> probs_pv.  The steps run in TWO loops: the
+    // common one never touches the output tiles outside the MFMAs (a conditional rescale inside one loop makes the register
+    // allocator copy every tile on every step); a wave whose scores outgrow the reference leaves it for the second loop,
+    // which rescales on every step.  The waves of a workgroup may be in different loops: each still passes one barrier
+    // per step.
+    auto stage = [&](int i) {
         __syncthreads();    // block i is visible; every wave is done with block i - 1 (the buffer block i + 1 goes into)
         if (i + 1 < nch) { st.put_rc(ldsK[(i + 1) & 1], pk); st.put_tr(ldsV[(i + 1) & 1], pv); }
         if (i + 2 < nch) { S::fetch(rsK, voff, (i + 2) * cstep, pk); S::fetch(rsV, voff, (i + 2) * cstep, pv); }
+    };
+    auto scores = [&](int i) {
         const char* sK = ldsK[i & 1];
-        const char* sV = ldsV[i & 1];
         const int kc = i * CH;
-        f32x4_t s[QT][2];
 #pragma unroll
         for (int u = 0; u < QT; ++u)
 #pragma unroll
@@ -574,31 +588,35 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
                         for (int u = 0; u < QT; ++u) s[u][t][r] = -INFINITY;
                     }
         }
-        float lm[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) lm[u] = max8(s[u][0], s[u][1]) * sc2;
+    };
+    auto outgrown = [&]() {
         bool need = false;
 #pragma unroll
+        for (int u = 0; u < QT; ++u) need = need || (lm[u] > mref[u] + RESCALE_TH);
+        return __builtin_amdgcn_ballot_w64(need) != 0;
+    };
+    auto raise = [&]() {   // reference <- this step's maximum where it is more than 2^8 above; everything rescaled
+#pragma unroll
         for (int u = 0; u < QT; ++u) {
-            lm[u] = max8(s[u][0], s[u][1]) * sc2;
-            need = need || (lm[u] > mref[u] + RESCALE_TH);
-        }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {   // rare after the first step: raise the reference, rescale
+            float xm = lm[u];
+            xm = fmaxf(xm, __shfl_xor(xm, 16, 64));
+            xm = fmaxf(xm, __shfl_xor(xm, 32, 64));
+            const float mnew = (xm > mref[u] + RESCALE_TH) ? xm : mref[u];
+            const float alpha = __builtin_amdgcn_exp2f(mref[u] - mnew);
+            mref[u] = mnew;
 #pragma unroll
-            for (int u = 0; u < QT; ++u) {
-                float xm = lm[u];
-                xm = fmaxf(xm, __shfl_xor(xm, 16, 64));
-                xm = fmaxf(xm, __shfl_xor(xm, 32, 64));
-                const float mnew = (xm > mref[u] + RESCALE_TH) ? xm : mref[u];
-                const float alpha = __builtin_amdgcn_exp2f(mref[u] - mnew);
-                mref[u] = mnew;
+            for (int r = 0; r < 4; ++r) {
+                const float ar = __shfl(alpha, 4 * g + r, 64);
+                accl[u][r] *= ar;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ar = __shfl(alpha, 4 * g + r, 64);
-                    accl[u][r] *= ar;
-#pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt][r] *= ar;
-                }
+                for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt][r] *= ar;
             }
         }
+    };
+    auto probs_pv = [&](int i) {
+        const char* sV = ldsV[i & 1];
         bf16x8_t pf[QT];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
@@ -616,6 +634,20 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
 #pragma unroll
             for (int u = 0; u < QT; ++u) acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], vfr, acc[u][dt], 0, 0, 0);
         }
+    };
+    stage(0); scores(0); raise();      // the first step sets the reference (alpha = 0 on all-zero tiles)
+    int i = 0;
+    bool go;
+    do {    // single exit, the output tiles only change in the MFMAs: they accumulate in place
+        probs_pv(i);
+        ++i;
+        go = i < nch;
+        if (go) { stage(i); scores(i); go = !outgrown(); }
+    } while (go);
+    while (i < nch) {   // left the common loop with the scores of step i in hand
+        raise(); probs_pv(i);
+        ++i;
+        if (i < nch) { stage(i); scores(i); }
     }
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
