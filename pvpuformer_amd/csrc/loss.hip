@@ -72,6 +72,7 @@ __device__ __forceinline__ int ac_i0(int dst, float scale, int in_size) {
 // band's own anchor rows only.
 constexpr int P2_BAND_MAX = 8;   // anchor rows per block: min(8, 1024 / w - 1) so that (band + 1) * w threads fit one block
 constexpr int P2_SPAN = 5;   // most full-resolution pixels per low-resolution cell and axis
+constexpr int P2_W_MAX = 512;   // widest low-resolution map (host-side check)
 
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
                                                        const int* __restrict__ slot_idx,
@@ -81,6 +82,10 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
                                                        int max_rows, int BAND) {
     extern __shared__ float sm[];   // [(BAND+2)*w] values (rows r0-1..r1) | [BAND*w] gradients | [(BAND+2)*W] hr | [max_rows*W] d loss / d prob
     __shared__ double red[16];
+    // first full-resolution column / row whose bilinear anchor is >= a given low-resolution column / anchor row of the block
+    // (the anchor index is monotone, so cell x0 owns columns [tXa[x0], tXa[x0 + 1])).  Built once per block: the search loops
+    // used to run in every thread of both passes (PMC: 1969 VALU instructions per wave, the kernel is VALU-bound).
+    __shared__ int tXa[P2_W_MAX + 2], tYa[P2_BAND_MAX + 3];
     const int plane = blockIdx.x / nband, band = blockIdx.x % nband;
     const int b = plane / S, s = plane % S;
     const int r0 = band * BAND, r1 = (r0 + BAND < h) ? r0 + BAND : h;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     const bool invert = ov < 0 && s >= S / 2;
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const float fh = sh > 0.f ? 1.f / sh : 0.f, fw = sw > 0.f ? 1.f / sw : 0.f;
+    const float fh = sh > 0.f ? 1.f / sh : 0.f;
     // pixel rows of the block: the first row anchored at max(r0-1, 0) .. the last row anchored at r1-1
     const int ya = r0 > 0 ? r0 - 1 : 0;
     int Y0 = (int)(fh * (float)ya) - 1; Y0 = Y0 < 0 ? 0 : Y0;
@@ -104,6 +109,21 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     int Y1 = (int)(fh * (float)r1) - 1; Y1 = Y1 < Y0 ? Y0 : (Y1 > H ? H : Y1);
     while (Y1 < H && ac_i0(Y1, sh, h) < r1) ++Y1;          // one past the last row anchored below r1
     if (Y1 - Y0 > max_rows) Y1 = Y0 + max_rows;            // (cannot happen: host-side bound)
+    for (int i = threadIdx.x; i <= w; i += blockDim.x) tXa[i] = W;
+    if (threadIdx.x < BAND + 3) {      // anchor rows r0 - 1 .. r1 + 1
+        const int arow = r0 - 1 + (int)threadIdx.x;
+        int Yf = 0;
+        if (arow > 0) {
+            Yf = (int)(fh * (float)arow) - 1; Yf = Yf < 0 ? 0 : (Yf > H ? H : Yf);
+            while (Yf < H && ac_i0(Yf, sh, h) < arow) ++Yf;
+        }
+        tYa[threadIdx.x] = Yf;
+    }
+    __syncthreads();
+    for (int X = threadIdx.x; X < W; X += blockDim.x) {
+        const int cur = ac_i0(X, sw, w), prev = X > 0 ? ac_i0(X - 1, sw, w) : -1;
+        for (int x = prev + 1; x <= cur; ++x) tXa[x] = X;
+    }
     const int W4 = W >> 2;
     // pixel-pass mapping: thread -> (anchor row yq = r0-1+g, 4-pixel column group X4); it walks the <= P2_SPAN pixel
     // rows anchored at yq.  Every label vector it needs is requested before anything else (independent 16-byte loads
@@ -112,11 +132,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     const int yq = r0 - 1 + pg;
     const bool plive = pg <= (r1 - r0) && yq >= 0 && yq < h;
     int Ya = 0, Yb = 0;
-    if (plive) {
-        Ya = (int)(fh * (float)yq) - 1; Ya = Ya < 0 ? 0 : Ya;
-        while (Ya < H && ac_i0(Ya, sh, h) < yq) ++Ya;
-        Yb = Ya; while (Yb < H && ac_i0(Yb, sh, h) == yq) ++Yb;
-    }
+    if (plive) { Ya = tYa[pg]; Yb = tYa[pg + 1]; }
     float4 lv[P2_SPAN];
 #pragma unroll
     for (int k = 0; k < P2_SPAN; ++k) {
@@ -190,12 +206,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
     if (live) {
         // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone)
-        int Ya = (int)(fh * (float)y0) - 1; Ya = Ya < 0 ? 0 : Ya;
-        while (Ya < H && ac_i0(Ya, sh, h) < y0) ++Ya;
-        int Yb = Ya; while (Yb < H && ac_i0(Yb, sh, h) == y0) ++Yb;
-        int Xa = (int)(fw * (float)x0) - 1; Xa = Xa < 0 ? 0 : Xa;
-        while (Xa < W && ac_i0(Xa, sw, w) < x0) ++Xa;
-        int Xb = Xa; while (Xb < W && ac_i0(Xb, sw, w) == x0) ++Xb;
+        const int Ya = tYa[ly_], Yb = tYa[ly_ + 1], Xa = tXa[x0], Xb = tXa[x0 + 1];
 #pragma unroll
         for (int iy = 0; iy < P2_SPAN; ++iy) {
             const int Y = Ya + iy;
@@ -394,14 +405,14 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
     // pixel rows one block can own: (band + 1) anchor rows x (H-1)/(h-1) rows per anchor row, + 2 for rounding
     const int max_rows = (int)(((int64_t)(band + 1) * (H - 1)) / (h - 1)) + 2;
     const size_t shmem = ((size_t)(2 * band + 2) * w + (size_t)(band + 2 + max_rows) * W) * sizeof(float);
-    if (shmem > 160 * 1024 - 256 || (int64_t)(band + 1) * (W / 4) > 1024) {
+    if (shmem > 160 * 1024 - 4096 || (int64_t)(band + 1) * (W / 4) > 1024) {
         vpu_set_error("p2cl_up: band does not fit LDS / one block ((band + 1) * W/4 <= 1024)");
         return VPU_ERR_ARG;
     }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256);
+                                  160 * 1024 - 4096);   // (static: reduction scratch + the anchor tables)
         attr_set = true;
     }
     p2cl_up_kernel<<<(unsigned)(B * S * nband), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
