@@ -227,19 +227,7 @@ __device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, const int f
 // v <- gelu(v), d <- gelu'(v) for 8 values (see the derivation at its use in epilogue_store8)
 __device__ __forceinline__ void gelu_dgelu8(float (&v)[8], float (&d)[8]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {   // explicit fmaf: the file is built with -ffp-contract=off
-        const float x = v[j];
-        const float u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);       // exp(-x^2/2)
-        const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.23164188892868984f, 1.0f));
-        float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-        poly = __builtin_fmaf(t, poly, 1.421413741f);
-        poly = __builtin_fmaf(t, poly, -0.284496736f);
-        poly = __builtin_fmaf(t, poly, 0.254829592f);
-        const float erfa = __builtin_fmaf(-(poly * t), u, 1.0f);       // erf(|x|/sqrt2)
-        const float phi = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);
-        d[j] = __builtin_fmaf(x * 0.3989422804014327f, u, phi);
-        v[j] = x * phi;
-    }
+    for (int j = 0; j < 8; ++j) gelu_pair_fast(v[j], v[j], d[j]);
 }
 struct EpiPre {
     bool has_pre, has_bias;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float t = (v[j] - mu) * rs * ww[r][j] + bv[r][j];
-                    v[j] = gelu ? gelu_f(t) : t;
+                    v[j] = gelu ? gelu_t<T>(t) : t;
                 }
                 store8(y + off, v);
             }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
                     for (int j = 0; j < 8; ++j) {
                         const float xh = (xv[j] - mu) * rs;
                         float d = dv[j];
-                        if (gelu) d *= dgelu_f(xh * ww[r][j] + bv[r][j]);
+                        if (gelu) d *= dgelu_t<T>(xh * ww[r][j] + bv[r][j]);
                         const float g = d * ww[r][j];
                         s1 += g; s2 += g * xh;
                         dwa[r][j] += d * xh; dba[r][j] += d;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ dy
                 for (int j = 0; j < 8; ++j) {
                     const float xh = (xv[j] - mu) * rs;
                     float d = dv[j];
-                    if (gelu) d *= dgelu_f(xh * ww[r][j] + bv[r][j]);
+                    if (gelu) d *= dgelu_t<T>(xh * ww[r][j] + bv[r][j]);
                     dv[j] = rs * (d * ww[r][j] - m1 - xh * m2);
                 }
                 store8(dx + off, dv);

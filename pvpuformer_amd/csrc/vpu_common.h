@@ -81,6 +81,29 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf
 __device__ __forceinline__ float dgelu_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
+// GELU(x) = x Phi(x) and GELU'(x) = Phi(x) + x phi(x) through erf(|x|/sqrt 2) = 1 - (a1 t + .. + a5 t^5) exp(-x^2/2),
+// t = 1 / (1 + p |x| / sqrt 2)   (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7): one v_exp, one v_rcp and ~10 FMAs for the
+// pair, against ~35 instructions per erff() call.  Used where the result is rounded to bf16 (the fp32 parity path keeps erff).
+__device__ __forceinline__ void gelu_pair_fast(float x, float& y, float& dy) {
+    const float u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);       // exp(-x^2/2)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.23164188892868984f, 1.0f));
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    const float erfa = __builtin_fmaf(-(poly * t), u, 1.0f);       // erf(|x|/sqrt2)
+    const float phi = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);
+    dy = __builtin_fmaf(x * 0.3989422804014327f, u, phi);
+    y = x * phi;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {
+    if constexpr (sizeof(T) == 2) { float y, d; gelu_pair_fast(x, y, d); return y; }
+    else return gelu_f(x);
+}
+template <typename T> __device__ __forceinline__ float dgelu_t(float x) {
+    if constexpr (sizeof(T) == 2) { float y, d; gelu_pair_fast(x, y, d); return d; }
+    else return dgelu_f(x);
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // 8 contiguous elements <-> 8 floats
