@@ -450,7 +450,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 //     kernels, same idea with a heavier loop, had measured 37.6 us forward); padding the streaming kernels' LDS to the
 //     same 2 workgroups per CU only costs 22.7 -> 26.6 us, so it is not the occupancy;
 //   * one workgroup of seven waves x two tiles per window problem (keys staged once): 23.6 vs 23.1 us;
-//   * forcing the dQ kernel to 128 VGPRs (4 waves per SIMD, 20 bytes of scratch): 34.0 vs 28.6 us.
+//   * forcing the dQ kernel to 128 VGPRs (4 waves per SIMD, 20 bytes of scratch): 34.0 vs 28.6 us;
+//   * a second register set in the dQ kernel (blocks i + 1 and i + 2 in flight while block i is multiplied): 29.2 vs 28.6 us
+//     on the windows, 60.9 vs 57.9 global -- the steps do not wait for memory.  What is left per SIMD is issue time: ~100
+//     VALU instructions + 16 quarter-rate v_exp_f32 per step and wave, plus a prologue / epilogue of ~600 instructions per
+//     wave (delta, fragment loads, 2-byte stores), at 4.5 waves per SIMD in two rounds.
 // ------------------------------------------------------------------------------------------------
 constexpr float LOG2E = 1.44269504089f, LN2 = 0.69314718056f;
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));

@@ -410,10 +410,23 @@ __device__ __forceinline__ void gemm_bf16_body(const vpu_gemm_desc& p_arg, const
     const int ntiles = GRP ? ga->start[grp + 1] - ga->start[grp] : ntiles0;
     const int kchunk = GRP ? (p.K + BK - 1) / BK * BK : kchunk_arg;
     const int FLG = GEN ? p.flags : (SLAB ? 0 : FL);
-    const int tile_lin = GRP ? work - ga->start[grp] : work % ntiles, rest = GRP ? 0 : work / ntiles;
-    const int split = rest % splitk, z = rest / splitk;
+    int tile_lin = GRP ? work - ga->start[grp] : work % ntiles, rest = GRP ? 0 : work / ntiles;
     int tile_m, tile_n;
-    tile_coords(tile_lin, ntiles, tiles_n, tile_m, tile_n);
+    if (!GRP && splitk > 1) {
+        // split-K: the few output tiles of ONE reduction slice read the same K-range of A and B -- put them on one XCD,
+        // next to each other in its dispatch order, so that they share the panels through that XCD's L2 (in the plain
+        // order the four 128 x 128 tiles of a 256 x 256 weight gradient sat on four XCDs and every panel came from HBM
+        // twice: 308 MB for 154 MB of operands in the FPN's 150528-row reductions).  XCD x takes a contiguous range of
+        // the (slice-major, tile-minor) order.
+        const int xcd = work & 7, q = total_work >> 3, r = total_work & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (work >> 3);
+        tile_lin = v % ntiles; rest = v / ntiles;
+        const int tiles_m = ntiles / tiles_n;
+        tile_n = tile_lin / tiles_m; tile_m = tile_lin - tile_n * tiles_m;
+    } else {
+        tile_coords(tile_lin, ntiles, tiles_n, tile_m, tile_n);
+    }
+    const int split = rest % splitk, z = rest / splitk;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int zo = z / p.inner, zi = z % p.inner;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
