@@ -902,6 +902,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
 // "lean" = 1 (default): the kernels above; 0: the round-1 step kernels (kept for A/B runs and as a second implementation in
 // the tests).  VPU_ATTN_LEAN sets the process default.
 std::atomic<int> g_opt_lean{-1};
+inline bool wide_two() {   // two query tiles per wave also in the 128-column instantiation (head dims 80 / 96: ViT-H, the neck)
+    static const int e0 = [] { const char* e = getenv("VPU_ATTN_WIDE2"); return e ? atoi(e) : 1; }();
+    return e0 != 0;
+}
 inline bool lean_enabled() {
     static const int e0 = [] { const char* e = getenv("VPU_ATTN_LEAN"); return e ? atoi(e) : 1; }();
     const int v = g_opt_lean.load(std::memory_order_relaxed);
@@ -939,9 +943,10 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lean_enabled()) {
         // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
-        const bool two = nq > 64 && hd_image(hd) <= 64;
+        const bool two = nq > 64 && (hd_image(hd) <= 64 || wide_two());
         dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
         switch (hd_image(hd) * 4 + (two ? 2 : 1)) {
+            case 128 * 4 + 2: attn_fwd_lean_kernel<128, 2><<<grid, 256, 0, s>>>(a); break;
             case 32 * 4 + 2: attn_fwd_lean_kernel<32, 2><<<grid, 256, 0, s>>>(a); break;
             case 32 * 4 + 1: attn_fwd_lean_kernel<32, 1><<<grid, 256, 0, s>>>(a); break;
             case 64 * 4 + 2: attn_fwd_lean_kernel<64, 2><<<grid, 256, 0, s>>>(a); break;
@@ -985,9 +990,10 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lean_enabled() && nq % 4 == 0) {
-        const bool q2 = nq > 64 && hd_image(hd) <= 64, k2 = nk > 64 && hd_image(hd) <= 64;
+        const bool q2 = nq > 64 && (hd_image(hd) <= 64 || wide_two()), k2 = nk > 64 && hd_image(hd) <= 64;
         dim3 gq(q2 ? (nq + 127) / 128 : (nq + 63) / 64, nb * H), gk(k2 ? (nk + 127) / 128 : (nk + 63) / 64, nb * H);
         switch (hd_image(hd) * 4 + (q2 ? 2 : 1)) {     // also writes delta
+            case 128 * 4 + 2: attn_bwd_dq_lean_kernel<128, 2><<<gq, 256, 0, s>>>(a); break;
             case 32 * 4 + 2: attn_bwd_dq_lean_kernel<32, 2><<<gq, 256, 0, s>>>(a); break;
             case 32 * 4 + 1: attn_bwd_dq_lean_kernel<32, 1><<<gq, 256, 0, s>>>(a); break;
             case 64 * 4 + 2: attn_bwd_dq_lean_kernel<64, 2><<<gq, 256, 0, s>>>(a); break;
