@@ -659,14 +659,19 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float mrow = __shfl(mref[u], 4 * g + r, 64);
-            const float l = accl[u][r], il = 1.0f / l;
+            const float l = accl[u][r], il = __builtin_amdgcn_rcpf(l);   // (the quotient is rounded to bf16 anyway)
             const int qq = qu + 4 * g + r;
             if (qq < nq) {
                 if (c == 0) a.lse[(int64_t)bh * nq + qq] = (mrow + __builtin_amdgcn_logf(l)) * LN2;
-                bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd;
+                bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd + c;
+                if (hd == HD) {      // (uniform: no per-tile column test on the common path)
 #pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt)
-                    if (dt * 16 < hd) orow[dt * 16 + c] = (bf16_t)(acc[u][dt][r] * il);
+                    for (int dt = 0; dt < HD / 16; ++dt) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt)
+                        if (dt * 16 < hd) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
+                }
             }
         }
     }
@@ -780,10 +785,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
         for (int r = 0; r < 4; ++r) {
             const int qq = q0 + 16 * u + 4 * g + r;
             if (qq < nq) {
-                bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd;
+                bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd + c;
+                if (hd == HD) {
 #pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt)
-                    if (dt * 16 < hd) qr[dt * 16 + c] = (bf16_t)adq[u][dt][r];
+                    for (int dt = 0; dt < HD / 16; ++dt) qr[dt * 16] = (bf16_t)adq[u][dt][r];
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt)
+                        if (dt * 16 < hd) qr[dt * 16] = (bf16_t)adq[u][dt][r];
+                }
             }
         }
 }
@@ -887,14 +897,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
         for (int r = 0; r < 4; ++r) {
             const int kk = key0 + 16 * u + 4 * g + r;
             if (kk < nk) {
-                bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd;
-                bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd;
+                bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd + c;
+                bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd + c;
+                if (hd == HD) {
 #pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt)
-                    if (dt * 16 < hd) {
-                        kr[dt * 16 + c] = (bf16_t)adk[u][dt][r];
-                        vr[dt * 16 + c] = (bf16_t)adv[u][dt][r];
+                    for (int dt = 0; dt < HD / 16; ++dt) {
+                        kr[dt * 16] = (bf16_t)adk[u][dt][r];
+                        vr[dt * 16] = (bf16_t)adv[u][dt][r];
                     }
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < HD / 16; ++dt)
+                        if (dt * 16 < hd) {
+                            kr[dt * 16] = (bf16_t)adk[u][dt][r];
+                            vr[dt * 16] = (bf16_t)adv[u][dt][r];
+                        }
+                }
             }
         }
 }
