@@ -210,7 +210,7 @@ class PromptState:
 
     def __init__(self, B, S, H, W, device, max_rounds=3):
         self.slot_idx = -torch.ones(B, S, dtype=torch.int32, device=device)
-        self.override = torch.zeros(max_rounds * B, H, W, dtype=torch.float32, device=device)
+        self.override = torch.empty(max_rounds * B, H, W, dtype=torch.float32, device=device)   # (only assigned planes are read)
         self.used = 0
 
     def assign(self, b, slot, mask_np):

@@ -54,6 +54,37 @@ class VPUTrainStep:
         self.model, self.opt, self.red = model, optimizer, reducer
         self.max_clicks, self.iter_w, self.ptypes = max_num_next_clicks, tuple(iterloss_weights), tuple(prompt_types)
         self.as_allmask, self.lw = as_allmask, loss_weights
+        # The prompt simulators read results back (component sizes, distance maxima, the chosen pixel): on the training
+        # stream every such read waits for everything queued before it -- the previous step's backward, or this
+        # iteration's.  They run on a stream of their own instead (VPU_SIM_STREAM=0: on the training stream): the
+        # iteration-0 box simulation depends on the batch only, the later ones on the forward output only, so the host
+        # waits for the few small simulator kernels and keeps the training stream fed meanwhile.
+        import os
+        self.sim_stream = None
+        self.use_sim_stream = os.environ.get("VPU_SIM_STREAM", "1") != "0"
+
+    def upload(self, batch_cpu, device):
+        """Host batch -> device on the simulator stream (not behind the previous step's kernels); the returned dict carries
+        the event (``'_ready'``) the training stream has to pass before it touches the tensors."""
+        if not self.use_sim_stream:
+            return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+        side = self._side(device)
+        with torch.cuda.stream(side):
+            out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+            ev = torch.cuda.Event()
+            ev.record(side)
+        main = torch.cuda.current_stream(device)
+        for v in out.values():
+            if torch.is_tensor(v):
+                v.record_stream(main)
+        out['_ready'] = ev
+        out['_host'] = batch_cpu          # (the scribble simulator works on the host copy of the ground truth)
+        return out
+
+    def _side(self, device):
+        if self.sim_stream is None:
+            self.sim_stream = torch.cuda.Stream(device=device)
+        return self.sim_stream
 
     def batch_forward(self, batch, num_iters=None, rng=None, np_rng=None, record=None):
         import random
@@ -64,9 +95,17 @@ class VPUTrainStep:
         rng = rng or random
         np_rng = np_rng or np.random
         eng = self.model._ensure_engine()
-        image, gt, points = batch['images'], batch['instances'].float().contiguous(), batch['points'].float()
-        B, _, H, W = image.shape
+        ready = batch.get('_ready') if isinstance(batch, dict) else None
+        image = batch['images']
         dev = image.device
+        main = torch.cuda.current_stream(dev) if image.is_cuda else None
+        side = self._side(dev) if (self.use_sim_stream and image.is_cuda) else None
+        if ready is not None:
+            main.wait_event(ready)          # the batch was uploaded on the simulator stream (upload())
+        elif side is not None:
+            side.wait_stream(main)          # the batch's producer is unknown: everything queued so far comes first
+        gt, points = batch['instances'].float().contiguous(), batch['points'].float()
+        B, _, H, W = image.shape
         S = 2 * self.model.num_max_points
         net_input = torch.cat([image, torch.zeros(B, 1, H, W, device=dev)], 1).contiguous()   # prev_output = 0 (:324)
         prev = net_input[:, 3:4]
@@ -84,7 +123,14 @@ class VPUTrainStep:
         for it in range(num_iters):
             ptype = self.ptypes[rng.randint(0, len(self.ptypes) - 1)]
             if it == 0:   # boxes from the (empty) previous output; the returned click is discarded (:372-378)
-                _, boxes = get_next_promts(prev, gt, points, None, as_allmask=self.as_allmask, np_rng=np_rng, rng=rng)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        _, boxes = get_next_promts(torch.zeros(B, 1, H, W, device=dev), gt, points, None,
+                                                   as_allmask=self.as_allmask, np_rng=np_rng, rng=rng)
+                    boxes.record_stream(main)
+                    main.wait_stream(side)
+                else:
+                    _, boxes = get_next_promts(prev, gt, points, None, as_allmask=self.as_allmask, np_rng=np_rng, rng=rng)
             mask = None
             if self.model.training and self.model.head.dropout_ratio > 0:
                 keep = 1.0 - self.model.head.dropout_ratio
@@ -98,17 +144,40 @@ class VPUTrainStep:
             if ptype == 2:   # stroke over the ground-truth region, vectors drawn from `rng` (the reference: global random)
                 from ..model.scribble import scribble_curves, scribble_profiles
                 from .prompt_sim import cal_scribble
-                scr, rects = cal_scribble(gt[:, 0].detach().cpu().numpy() > 0.5, rng=rng, np_rng=np_rng)
+                host = batch.get('_host') if isinstance(batch, dict) else None
+                if host is not None:
+                    gt_np = host['instances'].detach().float().numpy()[:, 0]
+                elif side is not None:      # read back on the simulator stream: not behind the queued training kernels
+                    with torch.cuda.stream(side):
+                        gt_np = gt[:, 0].detach().cpu().numpy()
+                else:
+                    gt_np = gt[:, 0].detach().cpu().numpy()
+                scr, rects = cal_scribble(gt_np > 0.5, rng=rng, np_rng=np_rng)
                 scribble = (torch.from_numpy(scribble_curves(scr)), torch.from_numpy(scribble_profiles(scr, rects, H, rng)))
             inst, _ = eng.forward(net_input, points, boxes, ptype, mask, training=True, materialize_aux=False,
                                   scribble=scribble)
             losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, state.slot_idx, state.override,
                                                     iter_weight=float(self.iter_w[it]), w_nfl=self.lw[0],
                                                     w_dice=self.lw[1], w_pcl=self.lw[2], sim_low=eng.sim_low)
+            if side is not None and not last:
+                fwd_done = torch.cuda.Event()       # after the loss kernels: they are the last readers of the slot table
+                fwd_done.record(main)               # and the override masks the simulator is about to update
             eng.backward(d_inst, None, d_sim_low=d_sim)
             for k, v in losses.items():
                 logged[f"{k}_{it}_{self.iter_w[it]}"] = v
-            if not last:
+            if not last and side is not None:
+                # the next prompts need the forward output only: simulated on the side stream while this iteration's
+                # backward (queued above) runs; nothing in backward reads the logits, the previous-mask channel or the
+                # slot table
+                with torch.cuda.stream(side):
+                    side.wait_event(fwd_done)
+                    inst.record_stream(side)
+                    ops.sigmoid_to_channel(inst, net_input, B, H * W, 4, 3)      # prev_output = sigmoid(instances) (:428)
+                    points, boxes = get_next_promts(prev, gt, points, state, as_allmask=self.as_allmask, np_rng=np_rng,
+                                                    rng=rng)
+                points.record_stream(main); boxes.record_stream(main)
+                main.wait_stream(side)
+            elif not last:
                 ops.sigmoid_to_channel(inst, net_input, B, H * W, 4, 3)          # prev_output = sigmoid(instances) (:428)
                 points, boxes = get_next_promts(prev, gt, points, state, as_allmask=self.as_allmask, np_rng=np_rng,
                                                 rng=rng)
@@ -248,7 +317,8 @@ class ISTrainer:
         (loss, losses_logging, batch, outputs) like the reference (outputs: the logged scalars only -- the 38.5-MB/image
         auxiliary tensor is never materialised in training)."""
         self._setup_device_side()
-        batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch_data.items()}
+        batch = self.step_fn.upload(batch_data, self.device) if not validation else \
+            {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch_data.items()}
         if validation:
             with torch.no_grad():
                 image = batch['images']
