@@ -69,6 +69,8 @@ class VPUTrainStep:
         if not self.use_sim_stream:
             return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
         side = self._side(device)
+        if any(torch.is_tensor(v) and v.is_cuda for v in batch_cpu.values()):
+            side.wait_stream(torch.cuda.current_stream(device))     # device tensors: their producer is the current stream
         with torch.cuda.stream(side):
             out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
             ev = torch.cuda.Event()
