@@ -147,7 +147,7 @@ class VPUTrainStep:
                 from ..model.scribble import scribble_curves, scribble_profiles
                 from .prompt_sim import cal_scribble
                 host = batch.get('_host') if isinstance(batch, dict) else None
-                if host is not None:
+                if host is not None and not host['instances'].is_cuda:
                     gt_np = host['instances'].detach().float().numpy()[:, 0]
                 elif side is not None:      # read back on the simulator stream: not behind the queued training kernels
                     with torch.cuda.stream(side):
