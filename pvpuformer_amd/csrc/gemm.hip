@@ -961,23 +961,23 @@ __device__ __forceinline__ void k2_issue(const __amdgpu_buffer_rsrc_t rA, const 
 
 // One K-tile: DMA of a later K-tile into stage `wr`, fragments + MFMAs of the current one from stage `rd` (the stages are
 // __restrict__ parameters of an inlined function for the reason given at ring_step).
-template <int TA, int TB, int WN, bool CS, int WAITN>
+template <int TA, int TB, int WN, bool CS, int WAITN, int RB>
 __device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
                                         const int (&voff)[K2Cfg<WN>::PW], const int soffA, const int soffB, const bool live,
                                         char* __restrict__ wr, const char* __restrict__ rd, const int wave, const int lane,
                                         const int wm, const int wn, const int g, const bool do_cs, const bf16x8_t ones,
-                                        f32x4_t (&acc)[8][4], f32x4_t (&acc_cs)[4]) {
+                                        f32x4_t (&acc)[RB][4], f32x4_t (&acc_cs)[4]) {
     k2_issue<TA, TB, WN>(rA, rB, voff, soffA, soffB, live, wr, wave);
     const char* la = rd + wm * TILE_BYTES;
     const char* lb = rd + (2 + (wn >> 1)) * TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < (K2Cfg<WN>::KG == 2 ? 1 : 2); ++kk) {
         const int ks = K2Cfg<WN>::KG == 2 ? g : kk;
-        bf16x8_t af[8], bfr[4];
+        bf16x8_t af[RB], bfr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(lb, (wn & 1) * 64 + j * 16, ks, lane);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = read_frag<TA>(la, i * 16, ks, lane);
+        for (int i = 0; i < RB; ++i) af[i] = read_frag<TA>(la, i * 16, ks, lane);
         if (WAITN >= 0) {
             // ping-pong: the two K-half groups run one barrier apart, so that on every SIMD one wave is in this load
             // section (DMA issue + fragment reads + waits) while its partner is in the MFMA section below.  The load
@@ -991,11 +991,11 @@ __device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const _
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (CS && do_cs) {   // the two N-halves of the wave grid share the A fragments: each sums four of the eight row blocks
+        if constexpr (CS && RB == 8) if (do_cs) {   // the two N-halves of the wave grid share the A fragments: each sums four of the eight row blocks
             if (wn == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
@@ -1018,7 +1018,8 @@ __device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const _
 // accesses).  Generic form: run-time flags, plain pointer accesses.
 template <bool GEN, int RP>
 __device__ __forceinline__ void k2_epi64(const vpu_gemm_desc& p, const int FLG, const int vec, f32x4_t (&a)[4][4],
-                                         const int mrow0, const int ncol0, float* wl, const int lane) {
+                                         const int mrow0, const int ncol0, float* wl, const int lane,
+                                         const int mend = 0x7FFFFFFF) {   // rows >= mend belong to another wave / tile
     const bool fast = !GEN || vec == 1;
     const bool use_pre = RP == 32 && fast && (FLG & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
                          !((FLG & VPU_EPI_RESID) && (FLG & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
@@ -1052,7 +1053,7 @@ __device__ __forceinline__ void k2_epi64(const vpu_gemm_desc& p, const int FLG, 
             const int row = u >> 3, c8 = (u & 7) * 8;
             const int m = mrow0 + pass * RP + row;
             const int n = ncol0 + c8;
-            if (m < p.M && n < p.N) {
+            if (m < p.M && m < mend && n < p.N) {
                 float v[8];
                 load8(wl + row * 64 + (c8 ^ (((row >> 2) & 3) << 4)), v);
                 if (fast && n + 8 <= p.N) {
@@ -1080,7 +1081,7 @@ template <int FL> struct K2Pre {
 };
 template <int FL>
 __device__ __forceinline__ void k2_prefetch(const vpu_gemm_desc& p, const int mrow0, const int ncol0, const int lane,
-                                            K2Pre<FL>& q) {
+                                            K2Pre<FL>& q, const int npass) {   // passes >= npass: rows of another wave
     constexpr bool IS_RES = (FL & VPU_EPI_RESID) != 0;
     if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DRELU)) != 0) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IS_RES ? p.resid : p.aux), 0, 0x7FFFFFFF, 0x00020000);
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ void k2_prefetch(const vpu_gemm_desc& p, const int mr
                 const int u = lane + 64 * t;
                 const int m = mrow0 + pass * 16 + (u >> 3), n = ncol0 + (u & 7) * 8;
                 const int row = (IS_RES && p.resid_period > 0) ? m % p.resid_period : m;
-                const int off = (m < p.M && n < p.N) ? (row * ld + n) * 2 : OOB_OFFSET;
+                const int off = (pass < npass && m < p.M && n < p.N) ? (row * ld + n) * 2 : OOB_OFFSET;
                 q.x[pass][t] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
             }
     }
@@ -1115,7 +1116,9 @@ __device__ __forceinline__ u32x4v pack_bf16x8(const float (&v)[8]) {
 }
 template <int FL>
 __device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)[4][4], const int mrow0, const int ncol0,
-                                            float* wl, const int lane, const K2Pre<FL>& q) {
+                                            float* wl, const int lane, const K2Pre<FL>& q, const int npass) {
+    // (all four passes issue their stores -- the count is what the next tile's vmcnt is built on; a pass >= npass stores
+    // out of range)
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, 0x7FFFFFFF, 0x00020000);
     const int fr = lane & 15, fq = lane >> 4;
@@ -1137,7 +1140,7 @@ __device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += q.bias[j];
             }
-            const int off = (m < p.M && n < p.N) ? (m * p.ldc + n) * 2 : OOB_OFFSET;
+            const int off = (pass < npass && m < p.M && n < p.N) ? (m * p.ldc + n) * 2 : OOB_OFFSET;
             if constexpr ((FL & VPU_EPI_GELU) != 0) {
                 float d[8];
                 gelu_dgelu8(v, d);
@@ -1168,9 +1171,10 @@ struct K2Tile {   // wave-uniform description of one output tile
     const void* A;
     const void* B;
 };
-template <int WN, bool GRP>
+template <int WN, bool GRP, int RB>
 __device__ __forceinline__ void k2_tile_setup(const int work, const int total_work, const vpu_gemm_desc& p_arg,
                                               const vpu_gemm_group* __restrict__ ga, const int tiles_n_arg, K2Tile& t) {
+    static_assert(!GRP || RB == 8, "grouped form: 256-row tiles");
     int grp = 0, tile_m, tile_n;
     if constexpr (GRP) {
         // one contiguous range of the global tile order per XCD label (work & 7); inside a problem the shorter tile
@@ -1188,27 +1192,28 @@ __device__ __forceinline__ void k2_tile_setup(const int work, const int total_wo
     }
     const vpu_gemm_desc& p = GRP ? ga->d[grp] : p_arg;
     t.grp = grp; t.tile_n = rfl(tile_n);
-    t.m0 = rfl(tile_m * K2_BM); t.n0 = rfl(tile_n * K2Cfg<WN>::BN_);
+    t.m0 = rfl(tile_m * (32 * RB)); t.n0 = rfl(tile_n * K2Cfg<WN>::BN_);
     // (grouped form: the descriptor is picked by a run-time index; pin what the main loop uses to scalar registers)
     t.M = rfl(p.M); t.N = rfl(p.N); t.K = rfl(p.K); t.lda = rfl(p.lda); t.ldb = rfl(p.ldb);
     t.A = rfl_ptr(p.A); t.B = rfl_ptr(p.B);
 }
 // per-lane byte offset of every DMA piece this wave issues per stage, at k = 0 (K % 64 == 0: no k bound inside a tile)
-template <int TA, int TB, int WN>
+template <int TA, int TB, int WN, int RB>
 __device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const int lane, int (&voff)[K2Cfg<WN>::PW]) {
+    static_assert(RB == 8 || TA == 0, "short tiles: row-major A only");
 #pragma unroll
     for (int i = 0; i < K2Cfg<WN>::PW; ++i) {
         const int sub = i >> 1, pis = wave + 8 * (i & 1);
         const bool isA = sub < 2;
         const int tr = isA ? TA : TB;
-        const int x0 = isA ? t.m0 + sub * 128 : t.n0 + (sub - 2) * 128;
+        const int x0 = isA ? t.m0 + sub * (16 * RB) : t.n0 + (sub - 2) * 128;   // (A sub-tile = the rows of one wm)
         const int X = isA ? t.M : t.N;
         const int ld = isA ? t.lda : t.ldb;
         if (tr == 0) {
             const int row = pis * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             const int gx = x0 + row;
-            voff[i] = gx < X ? (gx * ld + chunk * 8) * 2 : OOB_OFFSET;
+            voff[i] = (gx < X && (!isA || row < 16 * RB)) ? (gx * ld + chunk * 8) * 2 : OOB_OFFSET;
         } else {
             const int k = pis * 4 + (lane >> 4);
             const int chunk = (lane & 15) ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
@@ -1218,11 +1223,13 @@ __device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const i
     }
 }
 
-template <int TA, int TB, int WN, bool CS, int FL, bool GRP>
+// RB = 16-row blocks per wave: 8 (256-row tiles) or 7 (224-row tiles: M = 9408 = 42 x 224 fills 252 of 256 CUs per round
+// where 36.75 x 256 fills 222; the LDS layout keeps its 128-row sub-tiles, rows 112-127 of each are dead).
+template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB>
 __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
                                         const int tiles_m_arg, const int tiles_n_arg, const int vec) {
     using Cf = K2Cfg<WN>;
-    static_assert(!CS || (WN == 2 && TA == 1), "fused column sums: weight-gradient form, 256 x 128 tile");
+    static_assert(!CS || (WN == 2 && TA == 1 && RB == 8), "fused column sums: weight-gradient form, 256 x 128 tile");
     constexpr bool PP = WN == 2;       // ping-pong schedule of the two K-half groups + next tile's first stages requested early
     constexpr bool GEN = FL < 0;
     // vector-memory stores one wave issues in the exact-count epilogue of its 64 x 64 quarter
@@ -1240,8 +1247,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
     int voff[Cf::PW];
     bool primed = false;
     if (work < total_work) {
-        k2_tile_setup<WN, GRP>(work, total_work, p_arg, ga, tiles_n_arg, cur);
-        k2_voff<TA, TB, WN>(cur, wave, lane, voff);
+        k2_tile_setup<WN, GRP, RB>(work, total_work, p_arg, ga, tiles_n_arg, cur);
+        k2_voff<TA, TB, WN, RB>(cur, wave, lane, voff);
     }
     while (work < total_work) {
         const vpu_gemm_desc& p = GRP ? ga->d[cur.grp] : p_arg;
@@ -1252,9 +1259,9 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         const int stepA = TA ? cur.lda * (BK * 2) : BK * 2, stepB = TB ? cur.ldb * (BK * 2) : BK * 2;
         const int nk = cur.K / BK;
 
-        f32x4_t acc[8][4];
+        f32x4_t acc[RB][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const bool do_cs = CS && p.colsum != nullptr && cur.tile_n == 0;   // block-uniform
@@ -1279,12 +1286,12 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::PW) : "memory");
             __builtin_amdgcn_s_barrier();
             if (g == 1) __builtin_amdgcn_s_barrier();
-            if (primed) k2_step<TA, TB, WN, CS, W1>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
-            else k2_step<TA, TB, WN, CS, Cf::PW>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+            if (primed) k2_step<TA, TB, WN, CS, W1, RB>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+            else k2_step<TA, TB, WN, CS, Cf::PW, RB>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
             { char* t = s0; s0 = s1; s1 = s2; s2 = t; }
             for (int kt = 1; kt < nk; ++kt) {
                 const int kn = kt + 2;
-                k2_step<TA, TB, WN, CS, Cf::PW>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+                k2_step<TA, TB, WN, CS, Cf::PW, RB>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
                 char* t = s0; s0 = s1; s1 = s2; s2 = t;
             }
             if (g == 0) __builtin_amdgcn_s_barrier();   // the two groups meet again
@@ -1293,7 +1300,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();   // K-tile kt has landed for every wave; every wave is done reading K-tile kt-1
                 const int kn = kt + 1;
-                k2_step<TA, TB, WN, CS, -1>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+                k2_step<TA, TB, WN, CS, -1, RB>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
                 char* t = s0; s0 = s2; s2 = t;
             }
         }
@@ -1309,14 +1316,16 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             __syncthreads();
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
             if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
         } else if constexpr (Cf::KG == 2) {
-            const int mq = m0 + wm * 128 + g * 64, nq = n0 + wn * 64;   // this wave's 64 x 64 quarter
+            // this wave's quarter: 64 x 64 (group 0: row blocks 0-3 of the wave tile; group 1: blocks 4 .. RB-1, 48 rows when RB = 7)
+            const int mq = m0 + wm * (16 * RB) + g * 64, nq = n0 + wn * 64;
+            const int npass = g == 0 ? 4 : RB - 4;
             K2Pre<GEN ? 0 : FL> q;
-            if constexpr (!GEN) k2_prefetch<FL>(p, mq, nq, lane, q);   // lands while the halves are exchanged
+            if constexpr (!GEN) k2_prefetch<FL>(p, mq, nq, lane, q, npass);   // lands while the halves are exchanged
             __syncthreads();
             // the two K-half groups exchange half of their 128 x 64 partial tile: group 0 finishes rows 0-63, group 1 rows
             // 64-127 of it.  Fragment layouts are identical in both waves, so the registers travel as they are (16-byte LDS
@@ -1328,7 +1337,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * 64] = g == 0 ? acc[4 + i][j] : acc[i][j];
+                for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * 64] = g == 0 ? acc[4 + i < RB ? 4 + i : 0][j] : acc[i][j];
             if (CS && do_cs && fr == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -1341,12 +1350,12 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fin[i][j] = (g == 0 ? acc[i][j] : acc[4 + i][j]) + theirs[(i * 4 + j) * 64];
+                for (int j = 0; j < 4; ++j) fin[i][j] = (g == 0 ? acc[i][j] : acc[4 + i < RB ? 4 + i : 0][j]) + theirs[(i * 4 + j) * 64];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();   // every wave has taken its partner's half: stages 0 and 1 can receive the next tile
             if (has_next) {
-                k2_tile_setup<WN, GRP>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
-                k2_voff<TA, TB, WN>(nt, wave, lane, nvoff);
+                k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+                k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
                 const int nsA = TA ? nt.lda * (BK * 2) : BK * 2, nsB = TB ? nt.ldb * (BK * 2) : BK * 2;
@@ -1354,8 +1363,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
             }
             float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
-            if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane);
-            else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q);
+            if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
+            else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q, npass);
         } else {
             __syncthreads();
             float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
@@ -1365,8 +1374,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fin[i][j] = acc[h * 4 + i][j];
-                k2_epi64<GEN, 32>(p, FLG, vec, fin, m0 + wm * 128 + h * 64, n0 + wn * 64, wl, lane);
+                    for (int j = 0; j < 4; ++j) fin[i][j] = acc[h * 4 + i < RB ? h * 4 + i : 0][j];
+                k2_epi64<GEN, 32>(p, FLG, vec, fin, m0 + wm * (16 * RB) + h * 64, n0 + wn * 64, wl, lane, m0 + (wm + 1) * (16 * RB));
             }
         }
         // every wave is done with its epilogue LDS before the next tile's DMA / fragment reads touch it (raw barrier: the
@@ -1374,8 +1383,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         __builtin_amdgcn_s_barrier();
         primed = PP && has_next && vec != 9;
         if (has_next && !primed) {
-            k2_tile_setup<WN, GRP>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
-            k2_voff<TA, TB, WN>(nt, wave, lane, nvoff);
+            k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+            k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
         }
         cur = nt;
 #pragma unroll
@@ -1384,17 +1393,17 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
     }
 }
 
-template <int TA, int TB, int WN, int FL>
+template <int TA, int TB, int WN, int FL, int RB>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
                                                            const int vec) {
-    k2_body<TA, TB, WN, false, FL, false>(p, nullptr, tiles_m, tiles_n, vec);
+    k2_body<TA, TB, WN, false, FL, false, RB>(p, nullptr, tiles_m, tiles_n, vec);
 }
 template <int TA, int TB, bool CS>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
     // the descriptors are read where they already are, in the kernel-argument segment (scalar loads with a run-time
     // index); taking the address of the by-value parameter makes hipcc copy all 3.5 KB of it to scratch first
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
-    k2_body<TA, TB, 2, CS, -1, true>(ga->d[0], ga, 0, 0, vec);
+    k2_body<TA, TB, 2, CS, -1, true, 8>(ga->d[0], ga, 0, 0, vec);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1838,19 +1847,31 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 const int vec2 = noepi2 ? 9 : 1;
                 const int ncu = cu_count();
                 bool done = true;
-#define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_)                                                                             \
+                // tile height: 256 rows, or 224 when that needs less time per CU (rounds of tiles x rows per tile): M = 9408
+                // is 36.75 x 256 -- 222 / 666 / 444 tiles, 87 % of the CUs busy in the last round -- but 42 x 224 exactly
+                // (252 / 756 / 504 tiles).  VPU_GEMM_K2_RB=8 keeps 256 (A/B runs).
+                static const int rb_env = [] { const char* e = getenv("VPU_GEMM_K2_RB"); return e ? atoi(e) : 0; }();
+                auto cost = [&](int bm, int bn) {
+                    const int64_t tiles = (int64_t)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
+                    return ((tiles + ncu - 1) / ncu) * bm;
+                };
+                const int bn_sel = wide ? 256 : 128;
+                const bool short_tile = rb_env != 8 && (rb_env == 7 || cost(224, bn_sel) < cost(256, bn_sel));
+#define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_)                                                                     \
     do {                                                                                                             \
         static bool attr_ = false;                                                                                   \
-        auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_>;                                                         \
+        auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_, RB_>;                                                    \
         if (!attr_) {                                                                                                \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<WN_>::LDS); \
             attr_ = true;                                                                                            \
         }                                                                                                            \
         const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
-        const int tot_ = tm2 * tn_;                                                                                  \
-        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d>", TA_, TB_, WN_, FL_);                                        \
-        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS, s>>>(*d, tm2, tn_, vec2);      \
+        const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
+        const int tot_ = tm_ * tn_;                                                                                  \
+        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d>", TA_, TB_, WN_, FL_, RB_);                               \
+        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS, s>>>(*d, tm_, tn_, vec2);      \
     } while (0)
+#define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_) do { if (short_tile) VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 7); else VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 8); } while (0)
 #define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2(TA_, TB_, 2, FL_); else done = false; } while (0)
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
                 else if (key == 0 && f == F_BR) VPU_K2_BOTH(0, 0, F_BR);
@@ -1860,6 +1881,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 else done = false;
 #undef VPU_K2_BOTH
 #undef VPU_LAUNCH_K2
+#undef VPU_LAUNCH_K2_RB
                 if (done) return vpu_check_launch("vpu_gemm");
             }
         }
