@@ -119,6 +119,7 @@ class Engine:
         # full-K tiles -- one round of the persistent grid, no split-K slabs, no reduce launches --, the neck's 576-row
         # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
+        self.ride_wgrad = os.environ.get("VPU_WGRAD_RIDE", "1") != "0"      # small long-reduction gradients ride with the big groups
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
         self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
@@ -291,7 +292,15 @@ class Engine:
                 self._frozen.add(tt.data_ptr())
             # a full group of one kind (short reductions / this reduction length) is launched at once; the other kinds stay
             kind = 0 if M <= 2048 else M
-            if sum(1 for e in self._wq if (0 if e[3] <= 2048 else e[3]) == kind) >= 8:
+            same = [e for e in self._wq if (0 if e[3] <= 2048 else e[3]) == kind]
+            if kind and self.ride_wgrad:
+                # long reductions: the big problems ("anchors": a ViT block's four gradients are 216 tiles of 256 x 128 on
+                # 256 CUs) are launched once they fill a round; the small ones queued meanwhile (the neck's 768 x 384
+                # projections over the same 9408 rows) ride in the CUs such a launch leaves idle
+                anchors = [e for e in same if not self._is_rider(e)]
+                if sum(self._k2_tiles(e) for e in anchors) >= 200 or len(anchors) >= 8:
+                    self.flush_wgrads(kind, ride=True)
+            elif len(same) >= 8:
                 self.flush_wgrads(kind)
             return
         if not self.use_side:
@@ -952,22 +961,48 @@ class Engine:
         hi = self.total if next_name is None else self.names[next_name][0]
 
         def marker():
-            self.flush_wgrads()
+            # (no reducer attached: nobody needs the range to be final here, the small long-reduction problems wait for a
+            # ride with the next big group)
+            self.flush_wgrads(keep_riders=self.ride_wgrad and self.grad_ready_hook is None)
             if self.grad_ready_hook is not None:
                 self.flush_colsums()       # the range must be final before it is handed to the reducer
                 self.join_side()
                 self.grad_ready_hook(lo, hi)
         self.tape.append(marker)
 
-    def flush_wgrads(self, only_kind=None):
+    @staticmethod
+    def _k2_tiles(e):
+        """256 x 128 output tiles of a queued weight gradient (args: dy, x, g, N, K, M, ...: the gradient is [N, K])."""
+        return ((e[0][3] + 255) // 256) * ((e[0][4] + 127) // 128)
+
+    def _is_rider(self, e):
+        return e[3] > 2048 and self._k2_tiles(e) <= 16
+
+    def flush_wgrads(self, only_kind=None, ride=False, keep_riders=False, touching=None):
         """Launches the queued weight gradients (``only_kind``: just the entries of that kind, 0 = short reductions, else a
         reduction length).  Short reductions (<= 2048 rows) go into one grouped launch; long ones are grouped per reduction
-        length when that beats one split-K launch + reduce each, otherwise they are launched one by one."""
+        length when that beats one split-K launch + reduce each, otherwise they are launched one by one.
+        ``ride``: the kind's big problems plus as many of its queued small ones as fit one round of 256 tiles and one
+        launch's 16 descriptors; ``keep_riders``: the small long-reduction problems stay queued (for a later ride);
+        ``touching``: only the entries that read the buffer at that address (it is about to be modified in place)."""
         kind_of = lambda e: 0 if e[3] <= 2048 else e[3]
         q = [e for e in self._wq if only_kind is None or kind_of(e) == only_kind]
+        if touching is not None:
+            ptr_of = lambda t: (t[0] if isinstance(t, tuple) else t).data_ptr()
+            q = [e for e in q if touching in (ptr_of(e[0][0]), ptr_of(e[0][1]))]
+        if ride:
+            anchors = [e for e in q if not self._is_rider(e)]
+            room, slots, take = 256 - sum(self._k2_tiles(e) for e in anchors), 16 - len(anchors), []
+            for e in q:
+                if self._is_rider(e) and slots > 0 and self._k2_tiles(e) <= room:
+                    take.append(e); slots -= 1; room -= self._k2_tiles(e)
+            q = anchors + take
+        elif keep_riders:
+            q = [e for e in q if not self._is_rider(e)]
         if not q:
             return
-        self._wq = [e for e in self._wq if not (only_kind is None or kind_of(e) == only_kind)]
+        chosen = set(id(e) for e in q)
+        self._wq = [e for e in self._wq if id(e) not in chosen]
         parts = {}   # kind -> entries
         for e in q:
             parts.setdefault(kind_of(e), []).append(e)
@@ -1041,9 +1076,13 @@ class Engine:
         self._frozen.clear()
 
     def _writable(self, t):
-        """Call before modifying gradient buffer ``t`` in place: if a queued side-stream GEMM still reads it, wait."""
+        """Call before modifying gradient buffer ``t`` in place: a queued weight gradient that still reads it is launched
+        first (the rest of the queue stays); with the side stream, the streams are joined."""
         if t is not None and t.data_ptr() in self._frozen:
-            self.join_side()
+            if self.use_side:
+                self.join_side()
+            else:
+                self.flush_wgrads(touching=t.data_ptr())
 
     def backward(self, d_inst, d_aux, d_sim_low=None, tape=None):
         """Runs a recorded tape (``tape``: the one ``forward`` left in ``last_tape`` at that call; default: the most recent

@@ -97,7 +97,7 @@ def test_get_next_promts_gpu_equals_host(ops, as_allmask, gpu_cc, monkeypatch):
     assert ua == ub and ua > 0
     for (pa, ba), (pb, bb) in zip(ta, tb):
         assert torch.equal(pa, pb) and torch.equal(ba, bb)
-    assert torch.equal(sa, sb) and torch.equal(oa, ob)
+    assert torch.equal(sa, sb) and torch.equal(oa[:ua], ob[:ub])      # (planes beyond `used` are never read: uninitialised)
 
 
 def test_cc_roots_equal_scipy_components(ops):
