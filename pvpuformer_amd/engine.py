@@ -587,7 +587,8 @@ class Engine:
                 dt = self._new(M, 4 * Cout)
                 ops.pixel_shuffle2(y.g, dt, None, B, h, w, Cout, inverse=True)
                 self._colsum_to(y.g, Cout, prefix + ".bias", B * 4 * h * w, Cout)
-                # dW[Cin, 4Cout] += x^T dt
+                # dW[Cin, 4Cout] += x^T dt   (launched directly: as a 36-tile rider of the grouped launches it displaced
+                # the neck's small problems and cost more than it saved, 858 vs 864 images/s)
                 ops.gemm(x.t, dt, self.G(prefix + ".weight"), Cin, 4 * Cout, M, Cin, 4 * Cout, 4 * Cout, self.dt,
                          transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
                 f = 0
@@ -1018,12 +1019,18 @@ class Engine:
             etiles = sum(e[2] for e in elig)
             if self.split_wgrad and 2048 < red <= 16384 and len(elig) >= 2 and etiles < 200:
                 self._wgrad_sliced(elig, red, etiles)
-                part = [e for e in part if e[0][8] != e[0][4]]
+                taken = set(id(e) for e in elig)
+                part = [e for e in part if id(e) not in taken]
                 tiles -= etiles
             if not part:
                 pass
             elif len(part) >= 2 and (red == 0 or tiles >= 200 or nk * 0.6 < len(part) * 35.0):
-                ops.gemm_grouped([(e[0], e[1]) for e in part])
+                for i in range(0, len(part), 16):        # (one launch holds 16 descriptors)
+                    chunk = part[i:i + 16]
+                    if len(chunk) == 1:
+                        ops.gemm(*chunk[0][0], **chunk[0][1])
+                    else:
+                        ops.gemm_grouped([(e[0], e[1]) for e in chunk])
             else:
                 for args, kw, _, _ in part:
                     ops.gemm(*args, **kw)
@@ -1104,7 +1111,7 @@ class Engine:
         if tape is self.last_tape:
             self.last_tape = None
         self.tape = Tape()
-        self.flush_colsums()
-        self.join_side()
+        self.join_side()          # every queued weight gradient is launched ...
+        self.flush_colsums()      # ... before the batched column sums (norm-layer partials, slabs of the sliced reductions)
         if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0
             self.grad_ready_hook(0, self.names["backbone.blocks.0.norm1.weight"][0])
