@@ -1724,12 +1724,6 @@ inline int k2_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_K2"); return e ? atoi(e) : 2; }();
     return v;
 }
-std::atomic<int> g_opt_k2pp{-1};
-inline int k2pp_opt() {
-    static const int e0 = [] { const char* e = getenv("VPU_GEMM_K2PP"); return e ? atoi(e) : 1; }();
-    const int v = g_opt_k2pp.load(std::memory_order_relaxed);
-    return v >= 0 ? v : e0;
-}
 inline int k2_opt() { const int v = g_opt_k2.load(std::memory_order_relaxed); return v >= 0 ? v : k2_env0(); }
 // CUs the persistent launches leave unclaimed (vpu_gemm_set_option("reserve_cus")): room for the channel kernels of a
 // collective that runs beside backward (pvpuformer_amd/parallel.py)
@@ -2070,10 +2064,6 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     }
     if (name && !strcmp(name, "reserve_cus") && value >= 0 && value <= 128) {
         g_opt_reserve.store(value, std::memory_order_relaxed);
-        return VPU_OK;
-    }
-    if (name && !strcmp(name, "k2pp") && value >= -1 && value <= 1) {
-        g_opt_k2pp.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
     if (name && !strcmp(name, "splitk_inlaunch") && value >= -1 && value <= 4096) {

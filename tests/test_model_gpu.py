@@ -380,6 +380,37 @@ def test_train_step_multi_iteration_matches_oracle(golden_dir):
     assert not bad, bad[:8]
 
 
+def test_train_step_simulator_stream_equals_training_stream(golden_dir):
+    """The prompt simulators on their own stream (the default; batch uploaded through VPUTrainStep.upload) == the same
+    three-iteration step with everything on the training stream: identical prompts, slot tables, losses and gradients
+    (same host random draws, same kernels; only the stream the simulator kernels and their read-backs run on differs)."""
+    import random
+    from pvpuformer_amd.isegm.engine.trainer import VPUTrainStep
+    got = {}
+    for mode in (False, True):
+        fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+        step = VPUTrainStep(model)
+        step.use_sim_stream = mode
+        rng, np_rng = random.Random(11), np.random.RandomState(12)
+        rec = []
+        if mode:
+            dev_batch = step.upload({k: v.pin_memory() for k, v in batch.items()}, "cuda")
+            assert "_ready" in dev_batch
+        else:
+            dev_batch = {k: v.cuda() for k, v in batch.items()}
+        logged, pts = step.batch_forward(dev_batch, num_iters=3, rng=rng, np_rng=np_rng, record=rec)
+        torch.cuda.synchronize()
+        eng = model._ensure_engine()
+        got[mode] = (rec, {k: (v.item() if torch.is_tensor(v) else v) for k, v in logged.items()}, pts.cpu().clone(),
+                     eng.gflat.clone())
+    (ra, la, pa, ga), (rb, lb, pb, gb) = got[False], got[True]
+    assert la == lb and torch.equal(pa, pb) and torch.equal(ga, gb)
+    for x, y in zip(ra, rb):
+        assert x["ptype"] == y["ptype"] and torch.equal(x["points"].cpu(), y["points"].cpu())
+        assert torch.equal(x["boxes"].cpu(), y["boxes"].cpu()) and torch.equal(x["slot_idx"].cpu(), y["slot_idx"].cpu())
+        assert torch.equal(x["net_input"].cpu(), y["net_input"].cpu())
+
+
 @pytest.mark.parametrize("zoom", [None, dict(skip_clicks=-1, target_size=(448, 448))])
 def test_nobrs_click_loop_iou_parity(golden_dir, zoom):
     """a18 / config 3: the NoBRS evaluation loop (oracle clicks from the Clicker, flip TTA, prev-mask feedback,

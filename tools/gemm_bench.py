@@ -41,10 +41,8 @@ NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
 
 
 def set_k2(opt):
-    """'k2' or 'k2:pp' (pp = ping-pong schedule of the 256 x 128 form, 0 / 1)"""
-    a = opt.split(":")
-    ops.gemm_set_option("k2", int(a[0]))
-    ops.gemm_set_option("k2pp", int(a[1]) if len(a) > 1 else -1)
+    """k2 option value: 0 the 128 x 128 kernel, 1 the 256 x 128 form, 2 the default rule, 3 the 256 x 256 form wherever legal"""
+    ops.gemm_set_option("k2", int(opt.split(":")[0]))
 
 
 def group_bench(reps):
