@@ -103,6 +103,19 @@ __device__ __forceinline__ void load_rows_as_b(const bf16_t* __restrict__ base, 
         f[ks] = __builtin_bit_cast(bf16x8_t, v);
     }
 }
+// the same for the first NK 32-column groups only
+template <int NK>
+__device__ __forceinline__ void load_rows_as_bn(const bf16_t* __restrict__ base, int ld, int row0, int n, int lane,
+                                                bf16x8_t (&f)[NK], int hd) {
+    const int row = row0 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int col = ks * 32 + (lane >> 4) * 8;
+        if (row < n && col < hd) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + col);
+        f[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+}
 __device__ __forceinline__ bf16x8_t pack_pair(const f32x4_t& a, const f32x4_t& b) {
     bf16x8_t f;
 #pragma unroll
@@ -515,8 +528,9 @@ __device__ __forceinline__ float max8(const f32x4_t& a, const f32x4_t& b) {
 
 constexpr float RESCALE_TH = 8.0f;   // log2 units: probabilities relative to the reference maximum stay below 2^8
 
-template <int HD, int QT>
+template <int HD, int QT, int HC>
 __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
+    constexpr int KS = HC / 32, DT = HC / 16;   // computed width HC <= image width HD (head dim 80 / 96: 96 of the 128 columns)
     using S = Stg<HD>;
     __shared__ __attribute__((aligned(16))) char ldsK[2][CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsV[2][CH * HD * 2];
@@ -528,16 +542,16 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
     const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
     const float sc2 = a.scale * LOG2E;
-    bf16x8_t qf[QT][HD / 32];
+    bf16x8_t qf[QT][KS];
     float mref[QT];
-    f32x4_t acc[QT][HD / 16], accl[QT];
+    f32x4_t acc[QT][DT], accl[QT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
-        load_rows_as_b<HD>(q, a.ldq, q0 + 16 * u, nq, lane, qf[u], hd);
+        load_rows_as_bn<KS>(q, a.ldq, q0 + 16 * u, nq, lane, qf[u], hd);
         mref[u] = -INFINITY;
         accl[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) acc[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     bf16x8_t ones;
 #pragma unroll
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kfr = frag_rc<HD>(sK, 16 * t, ks, lane);
 #pragma unroll
                 for (int u = 0; u < QT; ++u)
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
                 const float ar = __shfl(alpha, 4 * g + r, 64);
                 accl[u][r] *= ar;
 #pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt) acc[u][dt][r] *= ar;
+                for (int dt = 0; dt < DT; ++dt) acc[u][dt][r] *= ar;
             }
         }
     };
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
             accl[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], ones, accl[u], 0, 0, 0);
         }
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const bf16x8_t vfr = frag_tr_perm<HD>(sV, dt, lane);
 #pragma unroll
             for (int u = 0; u < QT; ++u) acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], vfr, acc[u][dt], 0, 0, 0);
@@ -664,12 +678,12 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
             if (qq < nq) {
                 if (c == 0) a.lse[(int64_t)bh * nq + qq] = (mrow + __builtin_amdgcn_logf(l)) * LN2;
                 bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd + c;
-                if (hd == HD) {      // (uniform: no per-tile column test on the common path)
+                if (hd == HC) {      // (uniform: no per-tile column test on the common path)
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
+                    for (int dt = 0; dt < DT; ++dt) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
                 } else {
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
                         if (dt * 16 < hd) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
                 }
             }
@@ -678,8 +692,9 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
 }
 
 // dQ (and delta): QT query tiles per wave, keys streamed
-template <int HD, int QT>
+template <int HD, int QT, int HC>
 __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a) {
+    constexpr int KS = HC / 32, DT = HC / 16;
     using S = Stg<HD>;
     __shared__ __attribute__((aligned(16))) char ldsKr[2][CH * HD * 2], ldsKt[2][CH * HD * 2], ldsVr[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -691,22 +706,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
     const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
     const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
     const float sc2 = a.scale * LOG2E;
-    bf16x8_t qf[QT][HD / 32], dof[QT][HD / 32];
+    bf16x8_t qf[QT][KS], dof[QT][KS];
     float nl2[QT], nds[QT];    // -lse * log2 e, -delta * scale of query q0 + 16 u + c
-    f32x4_t adq[QT][HD / 16];
+    f32x4_t adq[QT][DT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const int qu = q0 + 16 * u;
         const bool q_ok = qu + c < nq;
         nl2[u] = q_ok ? -a.lse[(int64_t)bh * nq + qu + c] * LOG2E : 0.f;
-        load_rows_as_b<HD>(q, a.ldq, qu, nq, lane, qf[u], hd);
-        load_rows_as_b<HD>(d_o, a.ldo, qu, nq, lane, dof[u], hd);
+        load_rows_as_bn<KS>(q, a.ldq, qu, nq, lane, qf[u], hd);
+        load_rows_as_bn<KS>(d_o, a.ldo, qu, nq, lane, dof[u], hd);
         // delta[q] = sum_d dO[q][d] * O[q][d] from the dO fragments the wave holds anyway; published for the dK/dV kernel
-        bf16x8_t of[HD / 32];
-        load_rows_as_b<HD>(a.o + rbq * a.ldo + h * hd, a.ldo, qu, nq, lane, of, hd);
+        bf16x8_t of[KS];
+        load_rows_as_bn<KS>(a.o + rbq * a.ldo + h * hd, a.ldo, qu, nq, lane, of, hd);
         float dl = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < HD / 32; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) dl += (float)dof[u][ks][j] * (float)of[ks][j];
         dl += __shfl_xor(dl, 16, 64);
@@ -714,7 +729,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
         if (q_ok && g == 0) a.delta[(int64_t)bh * nq + qu + c] = dl;
         nds[u] = -dl * a.scale;
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) adq[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) adq[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     S st;
     st.init(tid);
@@ -745,7 +760,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
 #pragma unroll
             for (int u = 0; u < QT; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
 #pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kfr = frag_rc<HD>(sKr, 16 * t, ks, lane), vfr = frag_rc<HD>(sVr, 16 * t, ks, lane);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
@@ -773,7 +788,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
 #pragma unroll
         for (int u = 0; u < QT; ++u) dsf[u] = pack_pair(dS[u][0], dS[u][1]);
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const bf16x8_t ktf = frag_tr_perm<HD>(sKt, dt, lane);
 #pragma unroll
             for (int u = 0; u < QT; ++u) adq[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[u], ktf, adq[u][dt], 0, 0, 0);
@@ -786,12 +801,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
             const int qq = q0 + 16 * u + 4 * g + r;
             if (qq < nq) {
                 bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd + c;
-                if (hd == HD) {
+                if (hd == HC) {
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt) qr[dt * 16] = (bf16_t)adq[u][dt][r];
+                    for (int dt = 0; dt < DT; ++dt) qr[dt * 16] = (bf16_t)adq[u][dt][r];
                 } else {
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
                         if (dt * 16 < hd) qr[dt * 16] = (bf16_t)adq[u][dt][r];
                 }
             }
@@ -800,8 +815,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
 
 // dK, dV: KT key tiles per wave, queries streamed (needs nq % 4 == 0: the log-sum-exp / delta values of four consecutive
 // queries are one 16-byte buffer load, zeros past the end)
-template <int HD, int KT>
+template <int HD, int KT, int HC>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnArgs a) {
+    constexpr int KS = HC / 32, DT = HC / 16;
     using S = Stg<HD>;
     __shared__ __attribute__((aligned(16))) char ldsQr[2][CH * HD * 2], ldsQt[2][CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsOr[2][CH * HD * 2], ldsOt[2][CH * HD * 2];
@@ -814,14 +830,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
     const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
     const int key0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
     const float sc2 = a.scale * LOG2E;
-    bf16x8_t kf[KT][HD / 32], vf[KT][HD / 32];
-    f32x4_t adk[KT][HD / 16], adv[KT][HD / 16];
+    bf16x8_t kf[KT][KS], vf[KT][KS];
+    f32x4_t adk[KT][DT], adv[KT][DT];
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
-        load_rows_as_b<HD>(k, a.ldk, key0 + 16 * u, nk, lane, kf[u], hd);
-        load_rows_as_b<HD>(v, a.ldk, key0 + 16 * u, nk, lane, vf[u], hd);
+        load_rows_as_bn<KS>(k, a.ldk, key0 + 16 * u, nk, lane, kf[u], hd);
+        load_rows_as_bn<KS>(v, a.ldk, key0 + 16 * u, nk, lane, vf[u], hd);
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
+        for (int dt = 0; dt < DT; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
     }
     S st;
     st.init(tid);
@@ -861,7 +877,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
 #pragma unroll
             for (int u = 0; u < KT; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
 #pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t qfr = frag_rc<HD>(ldsQr[b], 16 * t, ks, lane), ofr = frag_rc<HD>(ldsOr[b], 16 * t, ks, lane);
 #pragma unroll
                 for (int u = 0; u < KT; ++u) {
@@ -882,7 +898,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
 #pragma unroll
         for (int u = 0; u < KT; ++u) { pf[u] = pack_pair(P[u][0], P[u][1]); dsf[u] = pack_pair(dS[u][0], dS[u][1]); }
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const bf16x8_t otf = frag_tr_perm<HD>(ldsOt[b], dt, lane), qtf = frag_tr_perm<HD>(ldsQt[b], dt, lane);
 #pragma unroll
             for (int u = 0; u < KT; ++u) {
@@ -899,15 +915,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
             if (kk < nk) {
                 bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd + c;
                 bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd + c;
-                if (hd == HD) {
+                if (hd == HC) {
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt) {
+                    for (int dt = 0; dt < DT; ++dt) {
                         kr[dt * 16] = (bf16_t)adk[u][dt][r];
                         vr[dt * 16] = (bf16_t)adv[u][dt][r];
                     }
                 } else {
 #pragma unroll
-                    for (int dt = 0; dt < HD / 16; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
                         if (dt * 16 < hd) {
                             kr[dt * 16] = (bf16_t)adk[u][dt][r];
                             vr[dt * 16] = (bf16_t)adv[u][dt][r];
@@ -964,12 +980,18 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
         const bool two = nq > 64 && (hd_image(hd) <= 64 || wide_two());
         dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
         switch (hd_image(hd) * 4 + (two ? 2 : 1)) {
-            case 128 * 4 + 2: attn_fwd_lean_kernel<128, 2><<<grid, 256, 0, s>>>(a); break;
-            case 32 * 4 + 2: attn_fwd_lean_kernel<32, 2><<<grid, 256, 0, s>>>(a); break;
-            case 32 * 4 + 1: attn_fwd_lean_kernel<32, 1><<<grid, 256, 0, s>>>(a); break;
-            case 64 * 4 + 2: attn_fwd_lean_kernel<64, 2><<<grid, 256, 0, s>>>(a); break;
-            case 64 * 4 + 1: attn_fwd_lean_kernel<64, 1><<<grid, 256, 0, s>>>(a); break;
-            default: attn_fwd_lean_kernel<128, 1><<<grid, 256, 0, s>>>(a); break;
+            case 128 * 4 + 2:
+                if (hd <= 96) attn_fwd_lean_kernel<128, 2, 96><<<grid, 256, 0, s>>>(a);   // head dim 80 / 96: 3 of 4 k-steps, 6 of 8 d-tiles
+                else attn_fwd_lean_kernel<128, 2, 128><<<grid, 256, 0, s>>>(a);
+                break;
+            case 32 * 4 + 2: attn_fwd_lean_kernel<32, 2, 32><<<grid, 256, 0, s>>>(a); break;
+            case 32 * 4 + 1: attn_fwd_lean_kernel<32, 1, 32><<<grid, 256, 0, s>>>(a); break;
+            case 64 * 4 + 2: attn_fwd_lean_kernel<64, 2, 64><<<grid, 256, 0, s>>>(a); break;
+            case 64 * 4 + 1: attn_fwd_lean_kernel<64, 1, 64><<<grid, 256, 0, s>>>(a); break;
+            default:
+                if (hd <= 96) attn_fwd_lean_kernel<128, 1, 96><<<grid, 256, 0, s>>>(a);
+                else attn_fwd_lean_kernel<128, 1, 128><<<grid, 256, 0, s>>>(a);
+                break;
         }
         return vpu_check_launch("vpu_xattn_fwd");
     }
@@ -1011,19 +1033,28 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
         const bool q2 = nq > 64 && (hd_image(hd) <= 64 || wide_two()), k2 = nk > 64 && hd_image(hd) <= 64;
         dim3 gq(q2 ? (nq + 127) / 128 : (nq + 63) / 64, nb * H), gk(k2 ? (nk + 127) / 128 : (nk + 63) / 64, nb * H);
         switch (hd_image(hd) * 4 + (q2 ? 2 : 1)) {     // also writes delta
-            case 128 * 4 + 2: attn_bwd_dq_lean_kernel<128, 2><<<gq, 256, 0, s>>>(a); break;
-            case 32 * 4 + 2: attn_bwd_dq_lean_kernel<32, 2><<<gq, 256, 0, s>>>(a); break;
-            case 32 * 4 + 1: attn_bwd_dq_lean_kernel<32, 1><<<gq, 256, 0, s>>>(a); break;
-            case 64 * 4 + 2: attn_bwd_dq_lean_kernel<64, 2><<<gq, 256, 0, s>>>(a); break;
-            case 64 * 4 + 1: attn_bwd_dq_lean_kernel<64, 1><<<gq, 256, 0, s>>>(a); break;
-            default: attn_bwd_dq_lean_kernel<128, 1><<<gq, 256, 0, s>>>(a); break;
+            case 128 * 4 + 2:
+                if (hd <= 96) attn_bwd_dq_lean_kernel<128, 2, 96><<<gq, 256, 0, s>>>(a);
+                else attn_bwd_dq_lean_kernel<128, 2, 128><<<gq, 256, 0, s>>>(a);
+                break;
+            case 32 * 4 + 2: attn_bwd_dq_lean_kernel<32, 2, 32><<<gq, 256, 0, s>>>(a); break;
+            case 32 * 4 + 1: attn_bwd_dq_lean_kernel<32, 1, 32><<<gq, 256, 0, s>>>(a); break;
+            case 64 * 4 + 2: attn_bwd_dq_lean_kernel<64, 2, 64><<<gq, 256, 0, s>>>(a); break;
+            case 64 * 4 + 1: attn_bwd_dq_lean_kernel<64, 1, 64><<<gq, 256, 0, s>>>(a); break;
+            default:
+                if (hd <= 96) attn_bwd_dq_lean_kernel<128, 1, 96><<<gq, 256, 0, s>>>(a);
+                else attn_bwd_dq_lean_kernel<128, 1, 128><<<gq, 256, 0, s>>>(a);
+                break;
         }
         switch (hd_image(hd) * 4 + (k2 ? 2 : 1)) {
-            case 32 * 4 + 2: attn_bwd_dkdv_lean_kernel<32, 2><<<gk, 256, 0, s>>>(a); break;
-            case 32 * 4 + 1: attn_bwd_dkdv_lean_kernel<32, 1><<<gk, 256, 0, s>>>(a); break;
-            case 64 * 4 + 2: attn_bwd_dkdv_lean_kernel<64, 2><<<gk, 256, 0, s>>>(a); break;
-            case 64 * 4 + 1: attn_bwd_dkdv_lean_kernel<64, 1><<<gk, 256, 0, s>>>(a); break;
-            default: attn_bwd_dkdv_lean_kernel<128, 1><<<gk, 256, 0, s>>>(a); break;
+            case 32 * 4 + 2: attn_bwd_dkdv_lean_kernel<32, 2, 32><<<gk, 256, 0, s>>>(a); break;
+            case 32 * 4 + 1: attn_bwd_dkdv_lean_kernel<32, 1, 32><<<gk, 256, 0, s>>>(a); break;
+            case 64 * 4 + 2: attn_bwd_dkdv_lean_kernel<64, 2, 64><<<gk, 256, 0, s>>>(a); break;
+            case 64 * 4 + 1: attn_bwd_dkdv_lean_kernel<64, 1, 64><<<gk, 256, 0, s>>>(a); break;
+            default:
+                if (hd <= 96) attn_bwd_dkdv_lean_kernel<128, 1, 96><<<gk, 256, 0, s>>>(a);
+                else attn_bwd_dkdv_lean_kernel<128, 1, 128><<<gk, 256, 0, s>>>(a);
+                break;
         }
         return vpu_check_launch("vpu_xattn_bwd");
     }
