@@ -297,8 +297,12 @@ class Engine:
                 # long reductions: the big problems ("anchors": a ViT block's four gradients are 216 tiles of 256 x 128 on
                 # 256 CUs) are launched once they fill a round; the small ones queued meanwhile (the neck's 768 x 384
                 # projections over the same 9408 rows) ride in the CUs such a launch leaves idle
+                # (launched when the rounds of 256 tiles they need are at least 80 % full -- ViT-B's 216 tiles per block are,
+                # ViT-L's 384 / ViT-H's 600 wait for the next block's: 768 = 3 full rounds, 1200 = 94 % of 5 -- or when the
+                # group holds eight problems)
                 anchors = [e for e in same if not self._is_rider(e)]
-                if sum(self._k2_tiles(e) for e in anchors) >= 200 or len(anchors) >= 8:
+                T = sum(self._k2_tiles(e) for e in anchors)
+                if (T >= 200 and T >= 0.8 * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
                     self.flush_wgrads(kind, ride=True)
             elif len(same) >= 8:
                 self.flush_wgrads(kind)
@@ -962,9 +966,12 @@ class Engine:
         hi = self.total if next_name is None else self.names[next_name][0]
 
         def marker():
-            # (no reducer attached: nobody needs the range to be final here, the small long-reduction problems wait for a
-            # ride with the next big group)
-            self.flush_wgrads(keep_riders=self.ride_wgrad and self.grad_ready_hook is None)
+            if self.ride_wgrad and self.grad_ready_hook is None and self.group_wgrad and self.dt == BF16 and not self.use_side:
+                # no reducer attached: nobody needs the range final here -- the long-reduction queue launches itself when
+                # its rounds are full (_wgrad), the short reductions go now
+                self.flush_wgrads(0)
+                return
+            self.flush_wgrads()
             if self.grad_ready_hook is not None:
                 self.flush_colsums()       # the range must be final before it is handed to the reducer
                 self.join_side()
@@ -993,7 +1000,8 @@ class Engine:
             q = [e for e in q if touching in (ptr_of(e[0][0]), ptr_of(e[0][1]))]
         if ride:
             anchors = [e for e in q if not self._is_rider(e)]
-            room, slots, take = 256 - sum(self._k2_tiles(e) for e in anchors), 16 - len(anchors), []
+            T = sum(self._k2_tiles(e) for e in anchors)
+            room, slots, take = 256 * ((T + 255) // 256) - T, 16 - len(anchors), []
             for e in q:
                 if self._is_rider(e) and slots > 0 and self._k2_tiles(e) <= room:
                     take.append(e); slots -= 1; room -= self._k2_tiles(e)
