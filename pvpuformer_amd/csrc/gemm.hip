@@ -1418,12 +1418,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gem
 constexpr int SK_T = 64;
 
 template <int TB>
-__global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const vpu_gemm_desc p, const int tiles_n, const int kw,
-                                                               const int vec) {
+__device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int tile_m, const int tile_n, const int kw,
+                                            const int vec) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // per wave: one K-contiguous image (+ one K-major image, TB = 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
     const int m0 = tile_m * SK_T, n0 = tile_n * SK_T;
     const int kbeg = wave * kw, kend = (kbeg + kw < p.K) ? kbeg + kw : p.K;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
@@ -1531,6 +1530,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const vpu_gemm_de
             }
         }
     }
+}
+
+template <int TB>
+__global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const vpu_gemm_desc p, const int tiles_n, const int kw,
+                                                               const int vec) {
+    const int tile_m = blockIdx.x / tiles_n;
+    skinny_body<TB>(p, tile_m, blockIdx.x - tile_m * tiles_n, kw, vec);
+}
+// Grouped form: the 64 x 64 tiles of up to 16 independent skinny problems in one launch (ga.start[] = first tile of each
+// problem; the q / k / v projections of the neck's prompt-token attentions and their dgrads: three 576-row problems took
+// ~24 us as 128 x 128 tiles walking all of K in the general grouped kernel, or three launches of ~8 us each).
+template <int TB>
+__global__ __launch_bounds__(256) void gemm_bf16_skinny_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
+    const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
+    int grp = 0;
+    while (grp + 1 < ga->n && (int)blockIdx.x >= ga->start[grp + 1]) ++grp;
+    grp = __builtin_amdgcn_readfirstlane(grp);
+    const vpu_gemm_desc& p = ga->d[grp];
+    const int local = blockIdx.x - ga->start[grp];
+    const int tiles_n = (p.N + SK_T - 1) / SK_T;
+    const int tile_m = local / tiles_n;
+    const int kw = ((p.K + 3) / 4 + 63) / 64 * 64;
+    skinny_body<TB>(p, tile_m, local - tile_m * tiles_n, kw, vec);
 }
 
 template <typename T>
@@ -2126,6 +2148,33 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     }
     for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) ga.start[i] = total;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // skinny form: every problem few rows, moderate N / K, plain or K-major B (the single-launch rule of vpu_gemm)
+    static const int sk_grp_env = [] { const char* e = getenv("VPU_GEMM_SKINNY_GROUP"); return e ? atoi(e) : 1; }();
+    if (sk_grp_env && key <= 1 && n >= 2) {
+        bool ok = true;
+        int total64 = 0;
+        vpu_gemm_group g3 = ga;
+        for (int i = 0; i < n; ++i) {
+            const vpu_gemm_desc* d = descs + i;
+            ok = ok && d->M <= 2560 && d->N <= 4096 && d->K >= 64 && d->K <= 4096 && !d->colsum && d->alpha == 1.0f &&
+                 (int64_t)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN) < 192;
+            g3.start[i] = total64;
+            total64 += ((d->M + SK_T - 1) / SK_T) * ((d->N + SK_T - 1) / SK_T);
+        }
+        for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g3.start[i] = total64;
+        if (ok && total64 <= 2048) {
+            static bool attr_skg = false;
+            if (!attr_skg) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
+                attr_skg = true;
+            }
+            NOTE_KERNEL("gemm_bf16_skinny_grouped_kernel<%d>", key);
+            if (key == 1) gemm_bf16_skinny_grouped_kernel<1><<<dim3((unsigned)total64), dim3(256), 8 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
+            else gemm_bf16_skinny_grouped_kernel<0><<<dim3((unsigned)total64), dim3(256), 4 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
+            return vpu_check_launch("vpu_gemm_grouped");
+        }
+    }
     // K2 form: weight-gradient groups over a long reduction whose 256 x 128 tiles fill most of the chip
     if (key == 3 && k2_opt() > 0 && vec) {
         bool ok = true;

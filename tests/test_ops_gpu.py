@@ -1166,6 +1166,42 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
         assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("tB", [0, 1])
+def test_gemm_grouped_skinny_form(ops, tB):
+    """Groups whose problems are all skinny (<= 2560 rows, K <= 4096) run as 64 x 64 tiles with the four waves splitting K
+    (gemm_bf16_skinny_grouped_kernel): bit-exact vs fp32 matmul on exact-integer operands -- fp32 accumulate output, bf16
+    output with bias, ragged M / N / K, both B layouts."""
+    g = torch.Generator().manual_seed(29)
+    shapes = [(576, 768, 768), (576, 384, 768), (200, 136, 72), (96, 1024, 384), (50, 72, 200)]
+    problems, checks = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        Kp = (K + 7) // 8 * 8
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+        ldb = (N + 7) // 8 * 8 if tB else Kp
+        Ah = torch.zeros(M, Kp); Ah[:, :K] = A
+        Bh = torch.zeros((K, ldb) if tB else (N, ldb))
+        if tB: Bh[:, :N] = Bm.t()
+        else: Bh[:, :K] = Bm
+        ldc = (N + 7) // 8 * 8
+        if i % 2 == 0:
+            Cd = torch.full((M, ldc), float(i + 1), device="cuda")
+            kw = dict(transB=bool(tB), flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM)
+            ref = A @ Bm.t() + float(i + 1)
+        else:
+            bias = torch.randint(-3, 4, (ldc,), generator=g).float()
+            Cd = torch.zeros(M, ldc, device="cuda", dtype=torch.bfloat16)
+            kw = dict(transB=bool(tB), flags=ops.EPI_BIAS, bias=dev(bias))
+            ref = A @ Bm.t() + bias[:N]
+        problems.append(((dev(Ah).to(torch.bfloat16), dev(Bh).to(torch.bfloat16), Cd, M, N, K, Kp, ldb, ldc, 0), kw))
+        checks.append((Cd, ref, N))
+    ops.gemm_grouped(problems)
+    assert "skinny_grouped" in ops.gemm_last_kernel()
+    torch.cuda.synchronize()
+    for Cd, ref, N in checks:
+        assert torch.equal(Cd[:, :N].float().cpu(), ref)
+
+
 def test_gemm_k2_grouped_wgrad(ops):
     """Weight-gradient groups over a long reduction in the K2 form (vpu_gemm_grouped: one global tile order cut into a
     contiguous range per XCD): bit-exact accumulation into pre-filled fp32 outputs + the fused bias-gradient column sums,
