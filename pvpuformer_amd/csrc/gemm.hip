@@ -1417,9 +1417,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gem
 // ------------------------------------------------------------------------------------------------
 constexpr int SK_T = 64;
 
-template <int TB>
+template <int TA, int TB>
 __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int tile_m, const int tile_n, const int kw,
                                             const int vec) {
+    static_assert(TA == 0 || TB == 1, "K-major A (weight-gradient form) comes with a K-major B");
     extern __shared__ __attribute__((aligned(16))) char lds[];   // per wave: one K-contiguous image (+ one K-major image, TB = 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1437,8 +1438,18 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
     // 128-byte row segments (8 rows x 8 chunks per wave-instruction); fragment-shaped loads straight from global memory
     // (16 rows x 64 B) measured 9.7 us against 7.3 us for the 576 x 768 x 768 problem.  Wave-local: a wave's LDS
     // operations complete in order, so no barrier is needed inside the loop.
-    char* imgK = lds + wave * (TB ? 2 : 1) * TILE_BYTES;     // [128 rows][64 k]: rows 0..63 = A, rows 64..127 = B (TB = 0)
+    char* imgK = lds + wave * (TB ? 2 : 1) * TILE_BYTES;     // [128 rows][64 k]: rows 0..63 = A, rows 64..127 = B (TB = 0);
+                                                             // TA = 1: [64 k][128 cols] K-major image of A, columns 0..63
     char* imgB = imgK + TILE_BYTES;                          // TB = 1: [64 k][128 cols] K-major image of B, columns 0..63
+    // fused bias gradient of the weight-gradient form: column sums of A = one more MFMA per A fragment against a fragment
+    // whose column 0 is all ones (the n = 0 tiles only)
+    const bool do_cs = TA == 1 && p.colsum != nullptr && tile_n == 0;
+    f32x4_t acc_cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
     // piece pc of a K-contiguous operand: rows 8 pc .. + 8, lane -> (row 8 pc + lane / 8, 16-byte chunk lane % 8)
     auto ldKC = [&](__amdgpu_buffer_rsrc_t r, int ld, int x0, int X, int pc, int k0) -> u32x4v {
         const int gx = x0 + pc * 8 + (lane >> 3), gk = k0 + (lane & 7) * 8;
@@ -1451,12 +1462,18 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
         const int off = (gk < kend && gn < p.N) ? (gk * p.ldb + gn) * 2 : OOB_OFFSET;
         return __builtin_amdgcn_raw_buffer_load_b128(rB, off, 0, 0);
     };
+    // piece pc of a K-major A (TA = 1)
+    auto ldKMa = [&](int pc, int k0) -> u32x4v {
+        const int gk = k0 + pc * 8 + (lane >> 3), gm = m0 + (lane & 7) * 8;
+        const int off = (gk < kend && gm < p.M) ? (gk * p.lda + gm) * 2 : OOB_OFFSET;
+        return __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0);
+    };
     const int nsteps = kend > kbeg ? (kend - kbeg + 63) / 64 : 0;
     u32x4v na[8], nb[8];
     if (nsteps > 0) {
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) {
-            na[pc] = ldKC(rA, p.lda, m0, p.M, pc, kbeg);
+            na[pc] = TA ? ldKMa(pc, kbeg) : ldKC(rA, p.lda, m0, p.M, pc, kbeg);
             nb[pc] = TB ? ldKM(pc, kbeg) : ldKC(rB, p.ldb, n0, p.N, pc, kbeg);
         }
     }
@@ -1464,7 +1481,8 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) {
             const int r8 = pc * 8 + (lane >> 3);
-            *reinterpret_cast<u32x4v*>(imgK + kc_off(r8, lane & 7)) = na[pc];
+            if (TA) *reinterpret_cast<u32x4v*>(imgK + km_off(r8, (lane & 7) * 2)) = na[pc];
+            else *reinterpret_cast<u32x4v*>(imgK + kc_off(r8, lane & 7)) = na[pc];
             if (TB) *reinterpret_cast<u32x4v*>(imgB + km_off(r8, (lane & 7) * 2)) = nb[pc];
             else *reinterpret_cast<u32x4v*>(imgK + kc_off(64 + r8, lane & 7)) = nb[pc];
         }
@@ -1472,7 +1490,7 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
             const int k1 = kbeg + (st + 1) * 64;
 #pragma unroll
             for (int pc = 0; pc < 8; ++pc) {
-                na[pc] = ldKC(rA, p.lda, m0, p.M, pc, k1);
+                na[pc] = TA ? ldKMa(pc, k1) : ldKC(rA, p.lda, m0, p.M, pc, k1);
                 nb[pc] = TB ? ldKM(pc, k1) : ldKC(rB, p.ldb, n0, p.N, pc, k1);
             }
         }
@@ -1480,7 +1498,7 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<0>(imgK, i * 16, ks, lane);
+            for (int i = 0; i < 4; ++i) af[i] = TA ? read_frag<1>(imgK, i * 16, ks, lane) : read_frag<0>(imgK, i * 16, ks, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = TB ? read_frag<1>(imgB, j * 16, ks, lane) : read_frag<0>(imgK, 64 + j * 16, ks, lane);
 #pragma unroll
@@ -1488,6 +1506,12 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if constexpr (TA == 1) {
+                if (do_cs) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's fragment reads are done before the images are rewritten
     }
@@ -1503,7 +1527,20 @@ __device__ __forceinline__ void skinny_body(const vpu_gemm_desc& p, const int ti
                 const int row = i * 16 + fq * 4 + r;
                 wl[row * 64 + ((j * 16 + fr) ^ (fq << 4))] = acc[i][j][r];
             }
+    float* csl = reinterpret_cast<float*>(lds) + 4 * (SK_T * SK_T);   // [wave][64]: the waves' partial column sums (TA = 1)
+    if constexpr (TA == 1) {
+        if (do_cs && fr == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csl[wave * 64 + i * 16 + fq * 4 + r] = acc_cs[i][r];
+        }
+    }
     __syncthreads();
+    if constexpr (TA == 1) {
+        if (do_cs && tid < SK_T && m0 + tid < p.M)
+            p.colsum[m0 + tid] += ((csl[tid] + csl[64 + tid]) + csl[128 + tid]) + csl[192 + tid];
+    }
     // thread -> row tid / 4, 16 columns (tid % 4) * 16: two groups of 8, summed over the waves in wave order
     const float* all = reinterpret_cast<const float*>(lds);
     const int row = tid >> 2;
@@ -1536,12 +1573,12 @@ template <int TB>
 __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const vpu_gemm_desc p, const int tiles_n, const int kw,
                                                                const int vec) {
     const int tile_m = blockIdx.x / tiles_n;
-    skinny_body<TB>(p, tile_m, blockIdx.x - tile_m * tiles_n, kw, vec);
+    skinny_body<0, TB>(p, tile_m, blockIdx.x - tile_m * tiles_n, kw, vec);
 }
 // Grouped form: the 64 x 64 tiles of up to 16 independent skinny problems in one launch (ga.start[] = first tile of each
 // problem; the q / k / v projections of the neck's prompt-token attentions and their dgrads: three 576-row problems took
 // ~24 us as 128 x 128 tiles walking all of K in the general grouped kernel, or three launches of ~8 us each).
-template <int TB>
+template <int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_bf16_skinny_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
     int grp = 0;
@@ -1552,7 +1589,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_grouped_kernel(const vpu
     const int tiles_n = (p.N + SK_T - 1) / SK_T;
     const int tile_m = local / tiles_n;
     const int kw = ((p.K + 3) / 4 + 63) / 64 * 64;
-    skinny_body<TB>(p, tile_m, local - tile_m * tiles_n, kw, vec);
+    skinny_body<TA, TB>(p, tile_m, local - tile_m * tiles_n, kw, vec);
 }
 
 template <typename T>
@@ -1741,6 +1778,7 @@ std::atomic<int> g_opt_inlaunch{-1};
 std::atomic<int> g_opt_skinny{-1};
 // K2 kernels (256-row tiles, 128 x 64 per wave): -1 environment default (VPU_GEMM_K2, 2 if unset), 0 off, 1 the 256 x 128
 // form only, 2 also the 256 x 256 form where its tile count fills the chip, 3 the 256 x 256 form wherever it is legal
+std::atomic<int> g_opt_skinny_group{-1};
 std::atomic<int> g_opt_k2{-1};
 inline int k2_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_K2"); return e ? atoi(e) : 2; }();
@@ -2084,6 +2122,10 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_k2.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
+    if (name && !strcmp(name, "skinny_group") && value >= -1 && value <= 2) {
+        g_opt_skinny_group.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
     if (name && !strcmp(name, "reserve_cus") && value >= 0 && value <= 128) {
         g_opt_reserve.store(value, std::memory_order_relaxed);
         return VPU_OK;
@@ -2149,14 +2191,18 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) ga.start[i] = total;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // skinny form: every problem few rows, moderate N / K, plain or K-major B (the single-launch rule of vpu_gemm)
-    static const int sk_grp_env = [] { const char* e = getenv("VPU_GEMM_SKINNY_GROUP"); return e ? atoi(e) : 1; }();
-    if (sk_grp_env && key <= 1 && n >= 2) {
+    // skinny_group option / VPU_GEMM_SKINNY_GROUP: 0 off, 1 (default) forward / dgrad orientations, 2 also the weight-gradient
+    // orientation (measured: 852 / 855 / 848 images/s for 0 / 1 / 2 on one box -- for the 576-row weight gradients eight
+    // problems of 128 x 128 tiles in the general grouped kernel beat 64 x 64 tiles with a four-way K split)
+    static const int sk_grp_env0 = [] { const char* e = getenv("VPU_GEMM_SKINNY_GROUP"); return e ? atoi(e) : 1; }();
+    const int sk_grp_env = g_opt_skinny_group.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny_group.load(std::memory_order_relaxed) : sk_grp_env0;
+    if (sk_grp_env && (key <= 1 || (key == 3 && sk_grp_env >= 2)) && n >= 2) {
         bool ok = true;
         int total64 = 0;
         vpu_gemm_group g3 = ga;
         for (int i = 0; i < n; ++i) {
             const vpu_gemm_desc* d = descs + i;
-            ok = ok && d->M <= 2560 && d->N <= 4096 && d->K >= 64 && d->K <= 4096 && !d->colsum && d->alpha == 1.0f &&
+            ok = ok && d->M <= 2560 && d->N <= 4096 && d->K >= 64 && d->K <= 4096 && d->alpha == 1.0f &&
                  (int64_t)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN) < 192;
             g3.start[i] = total64;
             total64 += ((d->M + SK_T - 1) / SK_T) * ((d->N + SK_T - 1) / SK_T);
@@ -2165,13 +2211,15 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         if (ok && total64 <= 2048) {
             static bool attr_skg = false;
             if (!attr_skg) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
                 attr_skg = true;
             }
-            NOTE_KERNEL("gemm_bf16_skinny_grouped_kernel<%d>", key);
-            if (key == 1) gemm_bf16_skinny_grouped_kernel<1><<<dim3((unsigned)total64), dim3(256), 8 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
-            else gemm_bf16_skinny_grouped_kernel<0><<<dim3((unsigned)total64), dim3(256), 4 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
+            NOTE_KERNEL("gemm_bf16_skinny_grouped_kernel<%d, %d>", key >> 1, key & 1);
+            if (key == 3) gemm_bf16_skinny_grouped_kernel<1, 1><<<dim3((unsigned)total64), dim3(256), 8 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
+            else if (key == 1) gemm_bf16_skinny_grouped_kernel<0, 1><<<dim3((unsigned)total64), dim3(256), 8 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
+            else gemm_bf16_skinny_grouped_kernel<0, 0><<<dim3((unsigned)total64), dim3(256), 4 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
             return vpu_check_launch("vpu_gemm_grouped");
         }
     }
