@@ -120,6 +120,7 @@ class Engine:
         # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
         self.ride_wgrad = os.environ.get("VPU_WGRAD_RIDE", "1") != "0"      # small long-reduction gradients ride with the big groups
+        self.wgrad_fill = 0.8     # a big group is launched once its rounds of 256 tiles are this full
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
         self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
@@ -302,7 +303,7 @@ class Engine:
                 # group holds eight problems)
                 anchors = [e for e in same if not self._is_rider(e)]
                 T = sum(self._k2_tiles(e) for e in anchors)
-                if (T >= 200 and T >= 0.8 * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
+                if (T >= 200 and T >= self.wgrad_fill * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
                     self.flush_wgrads(kind, ride=True)
             elif len(same) >= 8:
                 self.flush_wgrads(kind)

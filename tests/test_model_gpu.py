@@ -939,6 +939,39 @@ def test_bench_shape_bf16_step_matches_oracle(golden_dir):
     assert len(worst) >= 14 and all(c > 0.98 and r < 0.1 for _, c, r in worst), sorted(worst, key=lambda t: t[1])[:4]
 
 
+@pytest.mark.parametrize("fill", [0.8, 0.9])
+def test_riding_weight_gradients_equal_separate_launches(golden_dir, fill):
+    """The queueing rules of the long-reduction weight gradients (small problems riding in a ViT block's grouped launch; big
+    groups held back until their rounds of tiles are `fill` full: 0.9 makes ViT-B wait for two blocks, the rule ViT-L / ViT-H
+    run under) change WHEN and in which launch a gradient is computed, not its value: the flat gradient buffer of a B = 12
+    step equals the one with riding off (every tensor within 1e-4 of its largest entry: the riders replace a sliced
+    reduction + slab sum by one un-split reduction)."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    from pvpuformer_amd.synth import synth_batch
+    big = synth_batch(12, 448, seed=5, device="cuda")
+    x4 = torch.cat([big["images"], torch.zeros(12, 1, 448, 448, device="cuda")], 1).contiguous()
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    out = {}
+    for ride in (False, True):
+        eng.ride_wgrad, eng.wgrad_fill = ride, fill
+        eng.zero_grad()
+        inst, _ = eng.forward(x4, big["points"].float(), None, 0, None, training=True, materialize_aux=False)
+        losses, d_inst, d_sim = vpu_step_losses(inst, None, big["instances"].float(), None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
+        torch.cuda.synchronize()
+        out[ride] = eng.gflat.clone()
+    eng.ride_wgrad, eng.wgrad_fill = True, 0.8
+    bad = []
+    for n, (off, shape, numel) in eng.names.items():
+        a, b = out[False][off:off + numel], out[True][off:off + numel]
+        scale = float(a.abs().max())
+        if scale > 0 and float((a - b).abs().max()) > 1e-4 * scale:
+            bad.append((n, float((a - b).abs().max()) / scale))
+    assert not bad, bad[:6]
+
+
 def test_bf16_error_budget_per_stage(golden_dir):
     """WHERE the bf16 path's ~1e-2 logit error comes from: the same ViT-B forward in the exact-fp32 engine mode and in the
     bf16 mode, stage by stage (taps).  Every tensor between kernels is stored in bf16 (one rounding of relative size
