@@ -58,7 +58,7 @@ def cpu_baseline(batch_size):
     img4 = torch.cat([b["images"], torch.zeros(batch_size, 1, cfg["img"], cfg["img"])], 1)
     ed = vo.ed_mask_label(b["instances"])
     times, t_begin = [], time.perf_counter()
-    for it in range(4):
+    for it in range(7):                 # 1 warm-up + up to 6 timed steps inside the ~25-s budget (~1.5 s per step at 2 images)
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
