@@ -60,7 +60,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             *reinterpret_cast<float4*>(p + base) = make_float4(pv[0], pv[1], pv[2], pv[3]);
             *reinterpret_cast<float4*>(m + base) = make_float4(mv[0], mv[1], mv[2], mv[3]);
             *reinterpret_cast<float4*>(v + base) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-            if (shadow) for (int j = 0; j < 4; ++j) shadow[base + j] = (bf16_t)pv[j];
+            if (shadow) {   // one 8-byte store (tensors start on 8-element boundaries: base * 2 bytes is 8-byte aligned)
+                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t sv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sv[j] = (bf16_t)pv[j];
+                *reinterpret_cast<bf16x4_t*>(shadow + base) = sv;
+            }
         } else {
             for (int j = 0; j < 4; ++j)
                 if (base + j < n) {
