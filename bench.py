@@ -173,6 +173,8 @@ def main():
     if world > 1:
         backend = os.environ.get("VPU_DIST_BACKEND", "nccl")
         if backend == "nccl":
+            from pvpuformer_amd.parallel import configure_rccl_env
+            configure_rccl_env()      # channel count = the CUs the persistent GEMM grids leave free (before the communicator exists)
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)

@@ -103,6 +103,22 @@ class GradReducer:
         return 1.0 / self.world
 
 
+def configure_rccl_env(channels=None):
+    """Call BEFORE the RCCL communicator is created (``init_process_group``).  An RCCL collective runs as one workgroup per
+    channel, each on a CU of its own for the whole collective; the persistent GEMM launches of the backward pass own one
+    workgroup per CU with static tile lists, so a collective that takes more CUs than ``GradReducer.reserve_cus`` leaves
+    free pushes the last GEMM workgroups into a second round.  The channel count is therefore capped at the reserve
+    (``NCCL_MAX_NCHANNELS``, honoured by RCCL; an explicit setting in the environment wins).  16 channels move the 856 MB a
+    ViT-B step puts on the wire per GPU well inside the backward pass (needed: ~110 GB/s of the 7 x 153 GB/s links).
+    UNMEASURED on hardware, like the reserve itself."""
+    import os
+    if channels is None:
+        channels = int(os.environ.get("VPU_DIST_RESERVE_CUS", "16"))
+    if channels > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(channels))
+    return os.environ.get("NCCL_MAX_NCHANNELS")
+
+
 def broadcast_parameters(flat_param, src=0, group=None):
     """Identical replicas at start (DDP ctor broadcast, trainer.py:118-120): one collective over the flat buffer."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
