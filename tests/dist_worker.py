@@ -57,6 +57,8 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     if mode == "nccl1":
+        from pvpuformer_amd.parallel import configure_rccl_env
+        assert configure_rccl_env() is not None          # NCCL_MAX_NCHANNELS set before the communicator exists (as bench.py does)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         cfg, model, eng = build("bf16")
         b = vo.synth_batch(2, cfg["img"], seed=5)
