@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""What a collective's channel workgroups do to the persistent one-workgroup-per-CU GEMM launches, measured on ONE GPU:
+N single-workgroup spin kernels (torch.cuda._sleep, one stream each) stand in for N RCCL channels; 20 GEMMs of the fc1-dgrad
+shape run on the main stream meanwhile, with and without the reserve.  usage: python tools/reserve_cus_experiment.py"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pvpuformer_amd import ops
+
+M, N, K = 9408, 768, 3072
+A = (torch.rand(M, K, device="cuda") - 0.5).to(torch.bfloat16)
+W = (torch.rand(K, N, device="cuda") - 0.5).to(torch.bfloat16)       # dgrad orientation: B is [K, N]
+C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+streams = [torch.cuda.Stream() for _ in range(64)]
+
+def gemms(n=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.gemm(A, W, C, M, N, K, K, N, N, 0, transB=True)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+for _ in range(3): gemms(5)
+base = gemms()
+print(f"no other work:                                  {base:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
+for nsleep in (16, 32):
+    for reserve in (0, 16, 32):
+        ops.gemm_set_option("reserve_cus", reserve)
+        torch.cuda.synchronize()
+        for s in streams[:nsleep]:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(12_000_000)          # ~5 ms: outlasts the 20 GEMMs
+        t = gemms()
+        torch.cuda.synchronize()
+        print(f"{nsleep:2d} spinning workgroups, reserve_cus = {reserve:2d}:        {t:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
+ops.gemm_set_option("reserve_cus", 0)
