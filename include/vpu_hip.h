@@ -170,6 +170,9 @@ int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* o
 int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst,
                int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
 int vpu_fill_f32(float* p, float v, int64_t n, void* stream);
+/* Diagnostic only (tools/reserve_cus_experiment.py): `wgs` workgroups of 512 threads, ~96 registers per thread, 16 KiB of
+ * LDS, spinning for ~`cycles` shader cycles -- the footprint of a collective's channel workgroups. */
+int vpu_debug_spin(float* sink, int32_t wgs, int64_t cycles, void* stream);
 /* out[b][channel][:] = sigmoid(logits[b][:]) for an fp32 [B][channels][HW] tensor: the previous-mask channel of the next
  * click iteration's input (isegm/engine/trainer.py:428, :384) */
 int vpu_sigmoid_to_channel(const float* logits, float* out, int32_t B, int64_t HW, int32_t channels, int32_t channel,

@@ -740,6 +740,33 @@ extern "C" int vpu_sigmoid_to_channel(const float* logits, float* out, int32_t B
                                                                              (int64_t)channel * HW, total);
     return vpu_check_launch("vpu_sigmoid_to_channel");
 }
+// Diagnostic: `wgs` workgroups of 512 threads that hold ~96 registers per thread and 16 KiB of LDS and spin for `cycles`
+// clock cycles -- the footprint of a collective's channel workgroup, for measuring what such workgroups do to the persistent
+// GEMM launches on ONE GPU (tools/reserve_cus_experiment.py).  Every wave leaves after the same bounded wait.
+namespace {
+__global__ __launch_bounds__(512) void debug_spin_kernel(float* sink, long long cycles) {
+    __shared__ float pad[4096];
+    float r[80];
+#pragma unroll
+    for (int i = 0; i < 80; ++i) r[i] = (float)(threadIdx.x + i);
+    pad[threadIdx.x] = r[3];
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles / 24) {   // wall_clock64 ticks at 100 MHz: ~24 shader cycles per tick
+#pragma unroll
+        for (int i = 0; i < 80; ++i) r[i] = r[i] * 1.0001f + pad[(threadIdx.x + i) & 4095];
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 80; ++i) t += r[i];
+    if (t == 1.2345e30f) sink[0] = t;      // keeps the registers live
+}
+}  // namespace
+extern "C" int vpu_debug_spin(float* sink, int32_t wgs, int64_t cycles, void* stream) {
+    vpu_clear_stale_error();
+    if (wgs < 1 || wgs > 256 || cycles < 0 || cycles > 240000000LL) { vpu_set_error("debug_spin: 1 <= wgs <= 256, cycles <= 2.4e8"); return VPU_ERR_ARG; }
+    debug_spin_kernel<<<wgs, 512, 0, ST>>>(sink, (long long)cycles);
+    return vpu_check_launch("vpu_debug_spin");
+}
 extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
     vpu_clear_stale_error();
     fill_kernel<<<vpu_grid_for(n, 256, 4096), 256, 0, ST>>>(p, v, n);

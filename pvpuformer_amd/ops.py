@@ -232,6 +232,11 @@ def sigmoid_to_channel(logits, out, B, HW, channels, channel):
     _lib.call("vpu_sigmoid_to_channel", ptr(logits), ptr(out), B, HW, channels, channel, _stream())
 
 
+def debug_spin(sink, wgs, cycles):
+    """diagnostic: `wgs` channel-sized workgroups spinning for ~`cycles` shader cycles on the current stream"""
+    _lib.call("vpu_debug_spin", ptr(sink), int(wgs), int(cycles), _stream())
+
+
 def fill_f32(t, v, n=None):
     _lib.call("vpu_fill_f32", ptr(t), v, t.numel() if n is None else n, _stream())
 

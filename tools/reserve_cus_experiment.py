@@ -12,6 +12,8 @@ A = (torch.rand(M, K, device="cuda") - 0.5).to(torch.bfloat16)
 W = (torch.rand(K, N, device="cuda") - 0.5).to(torch.bfloat16)       # dgrad orientation: B is [K, N]
 C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
 streams = [torch.cuda.Stream() for _ in range(64)]
+side = torch.cuda.Stream()
+sink = torch.zeros(16, device="cuda")
 
 def gemms(n=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,4 +37,14 @@ for nsleep in (16, 32):
         t = gemms()
         torch.cuda.synchronize()
         print(f"{nsleep:2d} spinning workgroups, reserve_cus = {reserve:2d}:        {t:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
+print("channel-sized workgroups (512 threads, ~96 registers, 16 KiB LDS: vpu_debug_spin), ONE launch on a second stream:")
+for nsleep in (16, 32, 64):
+    for reserve in (0, 16, 32, 64):
+        ops.gemm_set_option("reserve_cus", reserve)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            ops.debug_spin(sink, nsleep, 12_000_000)      # ~5 ms
+        t = gemms()
+        torch.cuda.synchronize()
+        print(f"{nsleep:2d} channel workgroups, reserve_cus = {reserve:2d}:         {t:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
 ops.gemm_set_option("reserve_cus", 0)
