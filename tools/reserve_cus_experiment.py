@@ -48,3 +48,15 @@ for nsleep in (16, 32, 64):
         torch.cuda.synchronize()
         print(f"{nsleep:2d} channel workgroups, reserve_cus = {reserve:2d}:         {t:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
 ops.gemm_set_option("reserve_cus", 0)
+print("the 128 x 128 kernel (two workgroups per CU, 444 tiles) beside the same channel workgroups, no reserve:")
+ops.gemm_set_option("k2", 0)
+base0 = gemms()
+print(f"alone:                                           {base0:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
+for nsleep in (16, 32, 64):
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        ops.debug_spin(sink, nsleep, 12_000_000)
+    t = gemms()
+    torch.cuda.synchronize()
+    print(f"{nsleep:2d} channel workgroups:                           {t:6.1f} us per GEMM  ({ops.gemm_last_kernel()})")
+ops.gemm_set_option("k2", -1)
