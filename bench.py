@@ -151,13 +151,23 @@ def main():
     # neither inherit a profiler preload nor keep the other ranks waiting inside a collective.  Rank 0 builds, the others
     # poll the file's freshness.
     import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
+    srcdir = os.path.join(ROOT, "pvpuformer_amd", "csrc")
+    lib = os.path.join(ROOT, "pvpuformer_amd", "libvpu_hip.so")
+    failed = lib + ".build_failed"          # rank 0's verdict for the ranks that poll (build.sh renames the finished
+    if rank == 0:                           # library into place, so a fresh file is a complete file)
+        if os.path.exists(failed):
+            os.remove(failed)
+        try:
+            ge.build()
+        except BaseException as e:
+            with open(failed, "w") as f:
+                f.write(f"{type(e).__name__}: {e}\n")
+            raise
     else:
-        srcdir = os.path.join(ROOT, "pvpuformer_amd", "csrc")
-        lib = os.path.join(ROOT, "pvpuformer_amd", "libvpu_hip.so")
         t_wait = time.time()
         while ge._stale(lib, srcdir):
+            if os.path.exists(failed) and os.path.getmtime(failed) >= t_wait - 5:
+                raise SystemExit("bench.py: rank 0 failed to build libvpu_hip.so: " + open(failed).read().strip())
             if time.time() - t_wait > 900:
                 raise SystemExit("bench.py: rank 0 did not finish building libvpu_hip.so within 15 minutes")
             time.sleep(1.0)

@@ -29,12 +29,20 @@ def install(reference_root=None):
     * the mirror packages' ``__path__`` is extended with the matching directories of the next ``isegm`` package on
       ``sys.path`` (or under ``reference_root``), so modules the mirror does not ship -- ``isegm.utils.exp``,
       ``isegm.utils.vis``, ``isegm.utils.log``, ``isegm.model.losses``, ``isegm.data`` ... -- are imported from there,
-      as sub-modules of the same ``isegm`` package (their relative imports keep working).
+      as sub-modules of the same ``isegm`` package (their relative imports keep working);
+    * a mirror module that hides a file of that tree (``isegm.utils.misc``, ``isegm.inference.utils``,
+      ``isegm.utils.serialization`` ...) offers the file's public surface itself and, for any other name, falls through
+      to the hidden file (``pvpuformer_amd._overlay``).
 
     Call it before the first ``import isegm``: if the reference's own package is already imported it is left alone and
-    returned.  Idempotent."""
+    returned.  Idempotent.  In a job launched with ``WORLD_SIZE`` > 1 it also caps RCCL's channel count to the CUs the
+    persistent GEMM grids leave free (``parallel.configure_rccl_env``) -- ``install()`` runs before the reference's
+    ``init_experiment`` creates the process group (exp.py:29-32), which is when that has to be in the environment."""
     import importlib
     import os
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        from .parallel import configure_rccl_env
+        configure_rccl_env()
     import pkgutil
     import sys
     cur = sys.modules.get("isegm")
@@ -53,10 +61,14 @@ def install(reference_root=None):
             d = os.path.join(other, *rel.split(".")) if rel else other
             if os.path.isdir(d) and d not in list(mod.__path__):
                 mod.__path__.append(d)
+        from ._overlay import attach, shadowed_file
         extend(pkg, "")
         for name in names:
             mod = sys.modules["isegm." + name]
             if hasattr(mod, "__path__"):
                 extend(mod, name)
+            path, is_pkg = shadowed_file(other, name)
+            if path is not None and "__getattr__" not in vars(mod):
+                attach(mod, "isegm." + name, path, is_pkg)
     pkg.__vpu_overlay__ = other
     return pkg

@@ -16,5 +16,9 @@ done
 $HIPCC $FLAGS -c common.cpp -o build/common.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libvpu_hip.so build/*.o
+# link beside the target and rename: a rename is atomic, so a process that polls for the library (bench.py, ranks > 0) or
+# dlopens it while another one builds sees the old file or the complete new one, never a half-written ELF
+TMP=../libvpu_hip.so.tmp.$$
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $TMP build/*.o
+mv -f $TMP ../libvpu_hip.so
 echo "built $(cd .. && pwd)/libvpu_hip.so"

@@ -4,6 +4,7 @@ engine's tape.  (The full trainer mirror -- click simulation loop, optimizer, DD
 import torch
 
 from pvpuformer_amd import ops
+from .prompt_sim import cal_box, cal_scribble, get_iou, max_connected_regions   # noqa: F401  (module-level names of trainer.py:1045-1243)
 
 
 def vpu_step_losses(inst, aux, gt, slot_idx=None, override=None, iter_weight=1.0, w_nfl=1.0, w_dice=1.0, w_pcl=2.0,
@@ -88,7 +89,11 @@ class VPUTrainStep:
             self.sim_stream = torch.cuda.Stream(device=device)
         return self.sim_stream
 
-    def batch_forward(self, batch, num_iters=None, rng=None, np_rng=None, record=None):
+    def batch_forward(self, batch, num_iters=None, rng=None, np_rng=None, record=None, zero_grad=True, step=True,
+                      grad_scale=1.0):
+        """``zero_grad`` / ``step`` = False: gradient accumulation (trainer.py:188-202) -- the flat gradient buffer keeps
+        what earlier batches left in it, the exchange and the optimizer step happen on the batch that closes the group;
+        ``grad_scale`` multiplies into the optimizer's gradient scale (1 / accumulate_grad under ``cfg.amp``)."""
         import random
 
         import numpy as np
@@ -104,9 +109,13 @@ class VPUTrainStep:
         side = self._side(dev) if (self.use_sim_stream and image.is_cuda) else None
         if ready is not None:
             main.wait_event(ready)          # the batch was uploaded on the simulator stream (upload())
-        elif side is not None:
-            side.wait_stream(main)          # the batch's producer is unknown: everything queued so far comes first
+        # dtype / layout conversions (uint8 or float64 masks, integer points) are kernels on the training stream: they come
+        # BEFORE the hand-over to the simulator stream, whose iteration-0 box simulation reads gt and points
         gt, points = batch['instances'].float().contiguous(), batch['points'].float()
+        converted = gt is not batch['instances'] or points is not batch['points']
+        if side is not None and (ready is None or converted):
+            side.wait_stream(main)          # producer unknown, or converted just now: everything queued so far comes first
+            gt.record_stream(side); points.record_stream(side)
         B, _, H, W = image.shape
         S = 2 * self.model.num_max_points
         net_input = torch.cat([image, torch.zeros(B, 1, H, W, device=dev)], 1).contiguous()   # prev_output = 0 (:324)
@@ -119,8 +128,9 @@ class VPUTrainStep:
             # an external optimizer stepped the fp32 master parameters: the bf16 shadow and the derived operands are stale
             # (the fused optimizer writes the shadow itself and refreshes the rest)
             eng.shadow_valid = False
-        eng.zero_grad()
-        if self.red is not None:
+        if zero_grad:
+            eng.zero_grad()
+        if self.red is not None and step:
             self.red.begin()
         for it in range(num_iters):
             ptype = self.ptypes[rng.randint(0, len(self.ptypes) - 1)]
@@ -141,7 +151,7 @@ class VPUTrainStep:
                 record.append(dict(points=points.clone(), boxes=boxes.clone(), ptype=ptype, net_input=net_input.clone(),
                                    slot_idx=state.slot_idx.clone(), override=state.override.clone()))
             last = it == num_iters - 1
-            eng.grad_ready_hook = self.red.ready if (self.red is not None and last) else None
+            eng.grad_ready_hook = self.red.ready if (self.red is not None and last and step) else None
             scribble = None
             if ptype == 2:   # stroke over the ground-truth region, vectors drawn from `rng` (the reference: global random)
                 from ..model.scribble import scribble_curves, scribble_profiles
@@ -183,9 +193,11 @@ class VPUTrainStep:
                 ops.sigmoid_to_channel(inst, net_input, B, H * W, 4, 3)          # prev_output = sigmoid(instances) (:428)
                 points, boxes = get_next_promts(prev, gt, points, state, as_allmask=self.as_allmask, np_rng=np_rng,
                                                 rng=rng)
-        scale = self.red.finish() if self.red is not None else 1.0
-        if self.opt is not None:
-            self.opt.step(grad_scale=scale)
+        self.last_instances = inst          # the last iteration's logits (what the reference feeds its train metrics)
+        if step:
+            scale = self.red.finish() if self.red is not None else 1.0
+            if self.opt is not None:
+                self.opt.step(grad_scale=scale * grad_scale)
         logged["num_iters"] = num_iters
         return logged, points
 
@@ -207,6 +219,64 @@ def get_next_points(pred, gt, points, pred_thresh=0.49, np_rng=None):
     return torch.from_numpy(new_pts).to(points.device)
 
 
+def _with_dense_label(pred, gt, points, ed_mask_label, pred_thresh, np_rng):
+    """One simulated click per sample plus the reference's in-place label update: the slot that received the click now
+    predicts this round's false-negative (positive click) / false-positive mask (trainer.py:756,764)."""
+    import numpy as np
+
+    from .prompt_sim import next_click
+    pred_np = pred.detach().float().cpu().numpy()[:, 0]
+    gt_np = (gt.detach().cpu().numpy() if torch.is_tensor(gt) else np.asarray(gt))[:, 0] > 0.5
+    new_pts, picks, fn, fp = next_click(pred_np, gt_np, points.detach().float().cpu().numpy(), pred_thresh,
+                                        np_rng or np.random, device=pred.device if pred.is_cuda else None)
+    if ed_mask_label is not None:
+        for b, pk in enumerate(picks):
+            if pk is not None:
+                mask = torch.from_numpy((fn if pk[1] else fp)[b].astype(np.int32))
+                ed_mask_label[b, pk[0]] = mask.type_as(ed_mask_label).to(ed_mask_label.device)
+    return torch.from_numpy(new_pts).to(points.device), gt_np, fn, fp
+
+
+def get_next_points_and_mask(pred, gt, points, ed_mask_label, pred_thresh=0.49, np_rng=None):
+    """trainer.py:656-700: ``get_next_points`` that also rewrites the clicked slot of the dense P2CL label."""
+    new_pts, _, _, _ = _with_dense_label(pred, gt, points, ed_mask_label, pred_thresh, np_rng)
+    return new_pts, ed_mask_label
+
+
+def get_next_promts(pred, gt, points, ed_mask_label=None, pred_thresh=0.49, as_allmask=False, jitter_box=True):
+    """The reference's call shape (trainer.py:703-768) over ``prompt_sim``: box from the state BEFORE the new click,
+    scribble stroke of the ground truth, then the click; returns ``(points, boxes int32 [B,5], [scribbles, rectangles]``
+    ``[, ed_mask_label])``.  Draw order of the generators as in the reference: ``random`` for the box jitter and the
+    stroke, ``np.random`` for the stroke's coin and the click.  (The hot path calls ``prompt_sim.get_next_promts``, which
+    keeps the label factored and everything on the device; this adapter serves drivers written against the reference.)"""
+    import random
+
+    import numpy as np
+
+    from .prompt_sim import cal_box, cal_scribble
+    pred_np = pred.detach().float().cpu().numpy()[:, 0]
+    gt_np = (gt.detach().cpu().numpy() if torch.is_tensor(gt) else np.asarray(gt))
+    gt_np = (gt_np[None] if len(gt_np) != len(pred_np) else gt_np[:, 0]) > 0.5        # trainer.py:708-712
+    fn0 = np.logical_and(gt_np, pred_np < pred_thresh)
+    fp0 = np.logical_and(np.logical_not(gt_np), pred_np > pred_thresh)
+    boxes = cal_box(gt_np, fn0, fp0, points.detach().float().cpu().numpy(), as_allmask=as_allmask, jitter_box=jitter_box,
+                    rng=random)
+    scribbles = cal_scribble(gt_np, min_p=3, max_p=10, num_samples=1000, rng=random, np_rng=np.random)
+    gt_t = torch.from_numpy(gt_np[:, None].astype(np.float32))
+    new_pts, _, _, _ = _with_dense_label(pred, gt_t, points, ed_mask_label, pred_thresh, np.random)
+    boxes = torch.from_numpy(boxes).to(points.device)
+    if ed_mask_label is not None:
+        return new_pts, boxes, scribbles, ed_mask_label
+    return new_pts, boxes, scribbles
+
+
+def load_weights(model, path_to_weights):
+    """Partial load (``--weights``, trainer.py:1054-1058): keys present in the file replace the model's, the rest stay."""
+    state = model.state_dict()
+    state.update(torch.load(path_to_weights, map_location='cpu', weights_only=False)['state_dict'])
+    model.load_state_dict(state)
+
+
 class ISTrainer:
     """Constructor- and method-compatible mirror of the reference's trainer for the VPU configuration
     (isegm/engine/trainer.py:25-308; built exactly as models/iSegNet/vpu_base448_cocolvis.py:163-179 does), over
@@ -215,8 +285,11 @@ class ISTrainer:
     What it does per batch is ``VPUTrainStep.batch_forward`` (1-3 click iterations, iteration-weighted NFL + Dice + P2CL,
     backward, gradient exchange, fused optimizer step); per epoch the learning-rate schedule and the checkpoint rule
     (``checkpoint_interval`` int or [(from_epoch, every)]).  Experiment logging, TensorBoard, image dumps, tqdm and the
-    AMP grad scaler of the reference are outside the hot path and are not mirrored (bf16 needs no scaler); metrics
-    objects are accepted and, when they offer ``update`` / ``reset_epoch_stats``, fed.  Only the configuration the
+    AMP grad scaler of the reference are outside the hot path and are not mirrored (bf16 needs no scaler);
+    ``cfg.accumulate_grad`` groups batches the way trainer.py:188-202 does (optimizer step and gradient reset on every
+    n-th batch and on the epoch's last one; the loss is divided by n only under ``cfg.amp``, like there); train metrics are
+    reset per epoch and, on the master rank, updated after every batch with the last click iteration's logits and the
+    ground truth (``m.update(instances, gt)``, trainer.py:483-487).  Only the configuration the
     reference can actually run is accepted: ``ed_loss`` with ``as_multi_prompts_ed_loss`` (its other two branches call
     ``_forward`` with too few arguments, trainer.py:395,397)."""
 
@@ -265,6 +338,14 @@ class ISTrainer:
             self.net, optimizer, dict(optimizer_params or {}))
         self.lr = (optimizer_params or {}).get('lr')
         self.distributed, self.reducer, self._ready = distributed, None, False
+        self._zero_next, self._step_now, self._grad_scale = True, True, 1.0
+        if distributed:
+            # the persistent GEMM grids leave `reserve_cus` CUs to RCCL's channel kernels while buckets are in flight; the
+            # channel cap has to be in the environment before the communicator exists (the reference initialises it in
+            # init_experiment, exp.py:29-32, i.e. before this constructor in a launched job -- then this is too late and
+            # only warns)
+            from pvpuformer_amd.parallel import configure_rccl_env
+            configure_rccl_env()
         weights = (1, 2, 3) if not use_iterloss or not iterloss_weights else tuple(iterloss_weights)
         lw = (float(loss_cfg.get('instance_loss_weight', 1.0)), float(loss_cfg.get('instance_aux_loss_weight', 1.0)),
               float(loss_cfg.get('instance_aux3_loss_weight', 2.0)))
@@ -332,7 +413,14 @@ class ISTrainer:
                                                sim_low=eng.sim_low, w_nfl=self.step_fn.lw[0], w_dice=self.step_fn.lw[1],
                                                w_pcl=self.step_fn.lw[2])
             return losses["total"], dict(losses), batch, {"instances": inst}
-        logged, _ = self.step_fn.batch_forward(batch)
+        logged, _ = self.step_fn.batch_forward(batch, zero_grad=self._zero_next, step=self._step_now,
+                                               grad_scale=self._grad_scale)
+        if self.is_master and self.train_metrics:
+            with torch.no_grad():
+                inst, gt = self.step_fn.last_instances.float(), batch['instances'].float()
+                for m in self.train_metrics:
+                    if hasattr(m, "update"):
+                        m.update(inst, gt)
         n = logged.pop("num_iters")
         loss = sum(v for k, v in logged.items() if k.startswith("total_"))
         logged["num_iters"] = n
@@ -347,8 +435,13 @@ class ISTrainer:
                 m.reset_epoch_stats()
         self.net.train()
         self.last_train_loss = None
+        acc = max(1, int(self._get("accumulate_grad", 1) or 1))
+        self._grad_scale = 1.0 / acc if self._get("amp", False) else 1.0          # trainer.py:191-192 vs :199
+        self._zero_next = True
         for i, batch_data in enumerate(self.train_data):
+            self._step_now = (i + 1) % acc == 0 or i + 1 == len(self.train_data)    # trainer.py:188-189
             loss, logged, _, _ = self.batch_forward(batch_data)
+            self._zero_next = self._step_now
             scal = {k: v for k, v in logged.items() if torch.is_tensor(v)}
             scal['overall'] = loss
             self.last_train_loss = reduce_loss_dict(scal)['overall']

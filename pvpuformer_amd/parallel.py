@@ -112,10 +112,14 @@ def configure_rccl_env(channels=None):
     ViT-B step puts on the wire per GPU well inside the backward pass (needed: ~110 GB/s of the 7 x 153 GB/s links).
     UNMEASURED on hardware, like the reserve itself."""
     import os
+    import warnings
     if channels is None:
         channels = int(os.environ.get("VPU_DIST_RESERVE_CUS", "16"))
-    if channels > 0:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(channels))
+    if channels > 0 and "NCCL_MAX_NCHANNELS" not in os.environ:
+        if dist.is_available() and dist.is_initialized():
+            warnings.warn("configure_rccl_env() after init_process_group: a communicator that already exists keeps its "
+                          "channel count; call pvpuformer_amd.install() (or this function) before the process group is created")
+        os.environ["NCCL_MAX_NCHANNELS"] = str(channels)
     return os.environ.get("NCCL_MAX_NCHANNELS")
 
 

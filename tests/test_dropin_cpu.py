@@ -45,11 +45,26 @@ REST = {
         from isegm.utils import misc                           # mirror's misc through the shared package
         class NormalizedFocalLossSigmoid:
             def __init__(self, **k): self.k = k
+            def __call__(self, pred, label):                   # what losses.py:80-83,128-131,176 ask of misc
+                return pred.sum(dim=misc.get_dims_with_exclusion(pred.dim(), 0))
         class DiceLoss(NormalizedFocalLossSigmoid): pass
         class SigmoidBinaryCrossEntropyLoss(NormalizedFocalLossSigmoid): pass
         __all__ = ['NormalizedFocalLossSigmoid', 'DiceLoss', 'SigmoidBinaryCrossEntropyLoss']
         """),
-    "isegm/model/metrics.py": "class AdaptiveIoU:\n    name = 'aiou'\n    def reset_epoch_stats(self):\n        pass\n",
+    "isegm/model/metrics.py": textwrap.dedent("""
+        from isegm.utils import misc
+        class AdaptiveIoU:
+            name = 'aiou'
+            def reset_epoch_stats(self):
+                pass
+            def update(self, pred, gt):                        # metrics.py:90
+                return misc.get_dims_with_exclusion(gt.dim(), 0)
+        """),
+    # files the mirror HIDES: the mirror's modules win, names only these files have are served by the fall-through
+    "isegm/utils/misc.py": "from .log import logger\ndef only_in_the_other_tree():\n    return logger.name\n"
+                           "def get_dims_with_exclusion(dim, exclude=None):\n    raise RuntimeError('mirror must win')\n",
+    "isegm/inference/__init__.py": "",
+    "isegm/inference/utils.py": "from isegm.data.datasets import ToyDataset\ndef get_dataset_legacy(name):\n    return ToyDataset()\n",
     "isegm/data/__init__.py": "",
     "isegm/data/datasets.py": textwrap.dedent("""
         import torch
@@ -119,6 +134,23 @@ DRIVER = textwrap.dedent("""
     from isegm.inference.clicker import Clicker
     import isegm.model.losses
     assert isegm.model.losses.misc is isegm.utils.misc              # the other tree's import landed on the mirror's module
+    # ... and USING it works: the other tree's loss / metric call the mirror's helpers (VERDICT r2 weak #1)
+    x = torch.ones(2, 1, 4, 4)
+    assert isegm.model.losses.SigmoidBinaryCrossEntropyLoss()(x, x).tolist() == [16.0, 16.0]
+    from isegm.model.metrics import AdaptiveIoU
+    assert AdaptiveIoU().update(x, x) == [1, 2, 3]
+    assert utils.get_dataset('NoSuchSet', None) is None and callable(utils.load_is_model) and callable(utils.find_checkpoint)
+    assert utils.get_time_metrics([[0.5, 0.9]], 4.0) == (2.0, 4.0)
+    # names only the hidden files define come from those files (pvpuformer_amd._overlay)
+    assert isegm.utils.misc.only_in_the_other_tree() == 'root'
+    assert type(utils.get_dataset_legacy('x')).__name__ == 'ToyDataset'
+    assert isegm.utils.misc.get_dims_with_exclusion(3, 1) == [0, 2]         # the mirror's definition wins
+    try:
+        isegm.utils.misc.no_such_name
+    except AttributeError as e:
+        assert 'neither' in str(e)
+    else:
+        raise AssertionError('a name neither tree has must raise AttributeError')
     # ---- a reference-style model script, loaded the way train.py:97-102 loads it
     spec = importlib.util.spec_from_file_location('model_script', {rest!r} + '/model_script.py')
     ms = importlib.util.module_from_spec(spec); spec.loader.exec_module(ms)

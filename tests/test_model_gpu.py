@@ -657,6 +657,70 @@ def test_istrainer_mirror_runs_epochs_and_evaluate_dataset(golden_dir, tmp_path)
     assert secs > 0
 
 
+def test_istrainer_accumulate_grad_and_metric_feed(golden_dir):
+    """``cfg.accumulate_grad`` (trainer.py:188-202): the optimizer steps and the gradients are reset on every n-th batch and
+    on the epoch's last one -- 5 batches with n = 2 are groups of 2, 2, 1 --; in between the flat gradient buffer keeps
+    accumulating.  Train metrics get ``update(last iteration's logits, gt)`` after every batch (trainer.py:483-487)."""
+    from types import SimpleNamespace
+    from pvpuformer_amd.isegm.engine.trainer import ISTrainer
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "bf16")
+    big = vo.synth_batch(10, cfg["img"], seed=22)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 10
+
+        def __getitem__(self, i):
+            return {"images": big["images"][i], "instances": (big["instances"][i] * 255).to(torch.uint8) // 255,   # uint8 masks:
+                    "points": big["points"][i].double()}                                    # converted on the training stream
+
+    class Metric:
+        name = "spy"
+
+        def __init__(self):
+            self.calls, self.resets = [], 0
+
+        def reset_epoch_stats(self):
+            self.resets += 1
+
+        def update(self, pred, gt):
+            assert pred.shape == gt.shape == (2, 1, cfg["img"], cfg["img"]) and pred.dtype == gt.dtype == torch.float32
+            self.calls.append(float(((pred > 0) == (gt > 0.5)).float().mean()))
+    for amp in (False, True):
+        tcfg = SimpleNamespace(batch_size=2, val_batch_size=2, distributed=False, workers=0, device="cuda", start_epoch=0,
+                               local_rank=0, CHECKPOINTS_PATH=None, accumulate_grad=2, amp=amp)
+        tcfg.get = lambda k, d=None, c=tcfg: getattr(c, k, d)
+        metric = Metric()
+        import random
+        random.seed(5); np.random.seed(6)
+        tr = ISTrainer(model, tcfg, SimpleNamespace(num_max_points=24), dict(), DS(), None, optimizer="adam",
+                       optimizer_params={"lr": 1e-4, "betas": (0.9, 0.999), "eps": 1e-8}, metrics=[metric],
+                       max_interactive_points=24, max_num_next_clicks=3, use_iterloss=True, iterloss_weights=[1, 2, 3],
+                       ed_loss=True, as_multi_prompts_ed_loss=True, as_allmask=False)
+        eng = model._ensure_engine()
+        zeroed, seen = [], []
+        orig_zero, orig_step = eng.zero_grad, tr.optim.step
+        eng.zero_grad = lambda *a, **k: (zeroed.append(len(seen)), orig_zero(*a, **k))[1]
+
+        def step(grad_scale=1.0):
+            seen.append((float(grad_scale), float(eng.gflat.abs().sum())))
+            return orig_step(grad_scale=grad_scale)
+        tr.optim.step = step
+        norms = []
+        orig_bf = tr.step_fn.batch_forward
+        tr.step_fn.batch_forward = lambda *a, **k: (orig_bf(*a, **k), norms.append(float(eng.gflat.abs().sum())))[0]
+        try:
+            tr.run(num_epochs=1, validation=False)
+        finally:
+            eng.zero_grad = orig_zero
+        assert tr.optim.step_count == 3 and len(seen) == 3 and len(norms) == 5
+        assert zeroed == [0, 1, 2], zeroed                        # one reset per group, before its first batch
+        assert [s for s, _ in seen] == [0.5 if amp else 1.0] * 3
+        assert norms[1] > norms[0] > 0 and norms[3] > norms[2] > 0   # the second batch of a group adds to the first's gradient
+        assert seen[0][1] == norms[1] and seen[1][1] == norms[3] and seen[2][1] == norms[4]
+        assert metric.resets == 1 and len(metric.calls) == 5 and all(0.0 <= c <= 1.0 for c in metric.calls)
+
+
 def test_scribble_prompt_rows_and_polyline_bit_exact(golden_dir):
     """a9 + a3 (prompt type 2) at the kernel level: the PuE rows after the scribble-row overwrite equal the REFERENCE's
     float64 rows bit for bit (scribble.npz: crafted clicks incl. a sample without a valid positive row; tiny_scribble.npz:

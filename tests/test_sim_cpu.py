@@ -137,3 +137,35 @@ def test_cal_scribble_stays_inside_the_region_box():
     assert not out[2].any()
     a, _ = ps.cal_scribble(m, rng=_r.Random(3), np_rng=np.random.RandomState(4), num_samples=200)
     assert np.array_equal(a, out)
+
+
+def test_reference_shaped_get_next_promts_adapter(golden_dir, monkeypatch):
+    """``isegm.engine.trainer.get_next_promts`` under the reference's own signature and return shape (trainer.py:703-768:
+    dense ``ed_mask_label`` rewritten in place, ``(points, boxes, scribbles, label)``) against the same reference-recorded
+    rounds.  The fixture was recorded with the stroke simulator switched off (bezier is absent here), so it is switched off
+    for the comparison as well -- the draws of ``random`` / ``np.random`` then line up."""
+    from pvpuformer_amd.isegm.engine import trainer as tr
+    fx = np.load(os.path.join(golden_dir, "sim.npz"))
+    B, H = 4, 448
+    gt = vo.synth_batch(B, H, seed=int(fx["gt_seed"]))["instances"]
+    monkeypatch.setattr(ps, "cal_scribble", lambda gt_mask, **k: [np.zeros((len(gt_mask), 1, 1000, 2)), np.zeros((len(gt_mask), 1, 4), np.int64)])
+    for r in range(3):
+        pred = np.unpackbits(fx[f"r{r}_pred"])[:B * H * H].reshape(B, 1, H, H).astype(np.float32) * 0.9
+        pts = torch.from_numpy(fx[f"r{r}_points_in"])
+        label = vo.ed_mask_label(gt).clone()
+        np.random.seed(100 + r); random.seed(200 + r)
+        new_pts, boxes, scribbles, label_out = tr.get_next_promts(torch.from_numpy(pred), gt, pts, label, as_allmask=False,
+                                                                  jitter_box=bool(fx[f"r{r}_jitter"]))
+        assert label_out is label and len(scribbles) == 2
+        assert np.array_equal(new_pts.numpy(), fx[f"r{r}_points_out"]) and np.array_equal(boxes.numpy(), fx[f"r{r}_boxes"])
+        changed = ~(label == vo.ed_mask_label(gt)).flatten(2).all(2).numpy()
+        assert np.array_equal(changed, fx[f"r{r}_changed_slots"])
+        np.testing.assert_array_equal(label.sum(dim=(2, 3)).numpy() * changed, fx[f"r{r}_changed_sums"])
+        # without a label: three results, the same click
+        np.random.seed(100 + r); random.seed(200 + r)
+        out3 = tr.get_next_promts(torch.from_numpy(pred), gt, pts, as_allmask=False, jitter_box=bool(fx[f"r{r}_jitter"]))
+        assert len(out3) == 3 and torch.equal(out3[0], new_pts)
+        np.random.seed(100 + r)
+        p2, l2 = tr.get_next_points_and_mask(torch.from_numpy(pred), gt, pts, vo.ed_mask_label(gt).clone())
+        assert torch.equal(l2, label)
+    assert tr.cal_box is ps.cal_box and tr.max_connected_regions is ps.max_connected_regions and callable(tr.load_weights)
