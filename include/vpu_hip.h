@@ -151,6 +151,10 @@ int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
  * with hardware zero fill, thresholded running maximum, two tiles per wave), 0 the round-1 32-key-step kernels,
  * -1 = environment default (VPU_ATTN_LEAN).  Same results within bf16 rounding; both are covered by the tests. */
 int vpu_attn_set_option(const char* name, int32_t value);
+/* Name(s), as rocprofv3 prints them and separated by one space, of the kernel instantiation(s) the calling host thread's
+ * last vpu_(x)attn_fwd / vpu_(x)attn_bwd call launched (the backward launches a dQ and a dK/dV kernel).  "" before the
+ * first call.  Lets a test assert which head-dim path ran (ViT-H: head dim 80 in the 128-column image, 96 computed). */
+const char* vpu_attn_last_kernel(void);
 /* General form (the DMA neck's Attention, transformer.py:484-521): queries are rows [b*nq, (b+1)*nq) of a matrix with
  * row stride ldq, keys / values rows [b*nk, (b+1)*nk) of matrices with row stride ldk; hd % 16 == 0, hd <= 128;
  * lse / delta fp32 [nb*H][nq]; dq has row stride ldgq, dk / dv ldgk. */

@@ -3,7 +3,9 @@ run-time stand-ins of oracle/ref_import.py) and, in the same run, checks the ora
 (oracle/vpu_oracle.py) against it.  Build-container only; the fixtures it writes are data (inputs +
 expected outputs), never reference source.
 
-    python oracle/make_golden.py            # writes tests/golden/{pue,disk,tiny,vitb}.npz
+    python oracle/make_golden.py            # writes tests/golden/{pue,disk,tiny,vitb,...}.npz
+    python oracle/make_golden.py vitl vith  # the full-size ViT-L / ViT-H fixtures (minutes of CPU, ~20 GB of memory; not
+                                            # in the default list)
 
 Weights are NOT stored: they are regenerated bit-identically from ``vpu_oracle.synth_state_dict``
 (integer hash), so fixtures stay small.
@@ -64,10 +66,46 @@ def sub(t, step=7):
     return t[..., ::step, ::step].contiguous().numpy()
 
 
-def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_full_small=True):
+def synth_scribbles(gt, P=200, seed=17):
+    """Seeded strokes across each sample's ground-truth box (float (x, y) samples + the box as (xc, yc, w, h)), the layout
+    ``forward(as_prompt_type=2)`` takes (is_vpu_model.py:294-352)."""
+    B = gt.shape[0]
+    rs = np.random.RandomState(seed)
+    t = np.linspace(0, 1, P)
+    scr = np.zeros((B, 1, P, 2), np.float64)
+    rects = np.zeros((B, 1, 4), np.int64)
+    for b in range(B):
+        ys, xs = np.nonzero(gt[b, 0].numpy() > 0.5)
+        x0, x1, y0, y1 = xs.min(), xs.max(), ys.min(), ys.max()
+        scr[b, 0, :, 0] = x0 + (x1 - x0) * t + rs.uniform(-1.5, 1.5, P)
+        scr[b, 0, :, 1] = (y0 + y1) / 2 + 0.35 * (y1 - y0) * np.sin(5 * t + b) + rs.uniform(-1.5, 1.5, P)
+        rects[b, 0] = ((x0 + x1) // 2, (y0 + y1) // 2, x1 - x0, y1 - y0)
+    return scr, rects
+
+
+def patch_scribble_rasteriser(model):
+    """cv2 is absent: the reference's draw_scribble goes through the oracle's poly-line rasteriser (same arrangement as the
+    box outline); its debug ``ops.draw_scribble`` (cv2.imwrite to a hard-coded path, ops.py:409-419) becomes a no-op."""
+    import isegm.model.ops as ref_ops
+    ref_ops.draw_scribble = lambda *a, **k: None
+
+    def draw_scribble(image_, scribble_, bounding_rectangle_, gt_mask=None):
+        arr = vo.polyline_raster(image_.cpu().numpy().copy(), np.asarray(scribble_[0]))
+        image_[:] = torch.from_numpy(arr)
+        return image_
+    model.draw_scribble = draw_scribble
+
+
+SCRIBBLE_SEED = 321
+
+
+def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_full_small=True,
+                      modes=(("click", 0), ("box", 1))):
+    import random
     t0 = time.time()
     model, sd = build_reference(cfg, ref_vpu)
     patch_box_rasteriser(model)
+    patch_scribble_rasteriser(model)
     batch = vo.synth_batch(B, cfg["img"], seed=3)
     img4 = torch.cat([batch["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1)
     # a non-trivial previous mask for sample 0 (as in click iteration > 0)
@@ -75,8 +113,11 @@ def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_
     pts, boxes, gt = batch["points"], batch["boxes"], batch["instances"]
     fx = {"cfg_" + k: np.asarray(v) for k, v in cfg.items()}
     fx["B"] = np.asarray(B)
+    scr, rects = synth_scribbles(gt)
+    if any(pt == 2 for _, pt in modes):
+        fx.update(scribbles=scr, rects=rects, scribble_seed=np.asarray(SCRIBBLE_SEED))
 
-    for mode, ptype in (("click", 0), ("box", 1)):
+    for mode, ptype in modes:
         taps_ref = {}
         hooks = []
         hooks.append(model.backbone.register_forward_hook(lambda m_, i, o: None))
@@ -105,7 +146,8 @@ def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_
         params = [p for p in model.parameters()]
         for p in params:
             p.grad = None
-        prompts = [pts, boxes, [None, None]] if ptype else None
+        prompts = [pts, boxes, [scr, rects] if ptype == 2 else [None, None]] if ptype else None
+        random.seed(SCRIBBLE_SEED)          # the scribble vectors draw from the global ``random`` state (ops.py:274,290)
         out = model(img4.clone(), pts.clone(), prompts, ptype, True, False)
         model.backbone.forward_backbone, model.neck.forward, model.head.forward_feat = orig_fb, orig_neck, orig_head
         for h in hooks:
@@ -121,8 +163,10 @@ def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_
             with torch.no_grad():
                 pue_ref = model._guassinvector_box(pts, boxes)
             assert np.abs(vo.pue_box(pts.numpy(), boxes.numpy()) - pue_ref.numpy()).max() <= 2e-7
+        okw = dict(scribbles=(scr, rects)) if ptype == 2 else {}
         with torch.no_grad():
-            o_or = vo.vpu_forward(sd, cfg, img4, pts, boxes, ptype, taps=taps, pue_override=pue_ref)
+            o_or = vo.vpu_forward(sd, cfg, img4, pts, boxes, ptype, taps=taps, pue_override=pue_ref,
+                                  rng=random.Random(SCRIBBLE_SEED), **okw)
         for k in ("instances", "instances_aux"):
             err = (o_or[k] - out[k]).abs().max().item()
             ref_mag = out[k].abs().max().item()
@@ -168,7 +212,7 @@ def run_model_fixture(name, cfg, B, ref_vpu, ref_losses, with_grads=True, store_
             assert no_grad == sorted(vo.unused_param_names(cfg)), no_grad
             # oracle backward vs reference backward
             sd_g = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
-            o2 = vo.vpu_forward(sd_g, cfg, img4, pts, boxes, ptype, pue_override=pue_ref)
+            o2 = vo.vpu_forward(sd_g, cfg, img4, pts, boxes, ptype, pue_override=pue_ref, rng=random.Random(SCRIBBLE_SEED), **okw)
             t2, _ = vo.step_loss(o2, gt, ed)
             t2.backward()
             worst = 0.0
@@ -523,6 +567,11 @@ def main():
         run_model_fixture("vitl8", vo.make_cfg(embed_dim=1024, depth=8, num_heads=16), 2, ref_vpu, ref_losses)
     if "vitb" in which:
         run_model_fixture("vitb", vo.make_cfg(), 2, ref_vpu, ref_losses)
+    if "vitl" in which:    # config 4's own model: ViT-L at its full depth 24 (models_vit.py:310-313), click / box / scribble
+        run_model_fixture("vitl", vo.make_cfg(embed_dim=1024, depth=24, num_heads=16), 2, ref_vpu, ref_losses,
+                          modes=(("click", 0), ("box", 1), ("scribble", 2)))
+    if "vith" in which:    # config 5's own model: ViT-H, D = 1280, depth 32, 16 heads of 80, patch 14 (models_vit.py:315-319)
+        run_model_fixture("vith", vo.make_cfg(embed_dim=1280, depth=32, num_heads=16, patch=14), 2, ref_vpu, ref_losses)
 
 
 if __name__ == "__main__":

@@ -100,12 +100,13 @@ SIGNATURES = {
     "vpu_adam_step_hyper": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P],
     "vpu_gemm_set_option": [C.c_char_p, _I],
     "vpu_gemm_last_kernel": [],
+    "vpu_attn_last_kernel": [],
     "vpu_attn_set_option": [C.c_char_p, _I],
     "vpu_gemm_grouped": [C.POINTER(GemmDesc), _I, _P],
     "vpu_last_error": [],
     "vpu_abi_version": [],
 }
-_RET = {"vpu_last_error": C.c_char_p, "vpu_gemm_last_kernel": C.c_char_p}
+_RET = {"vpu_last_error": C.c_char_p, "vpu_gemm_last_kernel": C.c_char_p, "vpu_attn_last_kernel": C.c_char_p}
 
 _lib = None
 

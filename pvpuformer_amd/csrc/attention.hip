@@ -20,6 +20,7 @@
 //   backward: the same trick with the roles swapped: dK/dV kernel keeps 16 keys per wave and sums over queries,
 //   dQ kernel keeps 16 queries per wave and sums over keys (probabilities are recomputed from the saved
 //   log-sum-exp; no atomics, bitwise reproducible).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -949,8 +950,15 @@ inline bool lean_enabled() {
 inline bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int hd_image(int hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : 128); }
+int hd_computed(int hd) { return hd_image(hd) == 128 && hd <= 96 ? 96 : hd_image(hd); }   // the HC template argument
+
+// name(s) of the instantiation(s) the calling thread's last launch dispatched to, as rocprofv3 prints them
+// (vpu_attn_last_kernel): lets a test assert that e.g. the head-dim-80 path of ViT-H really ran
+thread_local char g_last_attn[192] = "";
 
 }  // namespace
+
+extern "C" const char* vpu_attn_last_kernel(void) { return g_last_attn; }
 
 extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
     vpu_clear_stale_error();
@@ -979,6 +987,7 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
         // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
         const bool two = nq > 64 && (hd_image(hd) <= 64 || wide_two());
         dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
+        snprintf(g_last_attn, sizeof(g_last_attn), "attn_fwd_lean_kernel<%d, %d, %d>", hd_image(hd), two ? 2 : 1, hd_computed(hd));
         switch (hd_image(hd) * 4 + (two ? 2 : 1)) {
             case 128 * 4 + 2:
                 if (hd <= 96) attn_fwd_lean_kernel<128, 2, 96><<<grid, 256, 0, s>>>(a);   // head dim 80 / 96: 3 of 4 k-steps, 6 of 8 d-tiles
@@ -998,6 +1007,7 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     static const int qt2 = [] { const char* e = getenv("VPU_ATTN_QT"); return e ? atoi(e) : 2; }();
     const bool two = qt2 == 2 && nq > 64 && nk <= 256 && hd_image(hd) <= 64;
     dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
+    snprintf(g_last_attn, sizeof(g_last_attn), "attn_fwd_kernel<%d, 1, %d>", hd_image(hd), two ? 2 : 1);
     if (two) {
         if (hd_image(hd) == 32) attn_fwd_kernel<32, 1, 2><<<grid, 256, 0, s>>>(a);
         else attn_fwd_kernel<64, 1, 2><<<grid, 256, 0, s>>>(a);
@@ -1032,6 +1042,8 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     if (lean_enabled() && nq % 4 == 0) {
         const bool q2 = nq > 64 && (hd_image(hd) <= 64 || wide_two()), k2 = nk > 64 && hd_image(hd) <= 64;
         dim3 gq(q2 ? (nq + 127) / 128 : (nq + 63) / 64, nb * H), gk(k2 ? (nk + 127) / 128 : (nk + 63) / 64, nb * H);
+        snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_dq_lean_kernel<%d, %d, %d> attn_bwd_dkdv_lean_kernel<%d, %d, %d>",
+                 hd_image(hd), q2 ? 2 : 1, hd_computed(hd), hd_image(hd), k2 ? 2 : 1, hd_computed(hd));
         switch (hd_image(hd) * 4 + (q2 ? 2 : 1)) {     // also writes delta
             case 128 * 4 + 2:
                 if (hd <= 96) attn_bwd_dq_lean_kernel<128, 2, 96><<<gq, 256, 0, s>>>(a);
@@ -1059,6 +1071,7 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
         return vpu_check_launch("vpu_xattn_bwd");
     }
     dim3 gk((nk + 63) / 64, nb * H), gq((nq + 63) / 64, nb * H);
+    snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_dq_kernel<%d, 1> attn_bwd_dkdv_kernel<%d, 1>", hd_image(hd), hd_image(hd));
     switch (hd_image(hd)) {
         case 32:
             attn_bwd_dq_kernel<32, 1><<<gq, 256, 0, s>>>(a);     // also writes delta

@@ -112,6 +112,11 @@ def gemm_last_kernel():
     return _lib.load().vpu_gemm_last_kernel().decode()
 
 
+def attn_last_kernel():
+    """rocprofv3 name(s) of the kernel instantiation(s) the last attention call of this thread launched."""
+    return _lib.load().vpu_attn_last_kernel().decode()
+
+
 def attn_set_option(name, value):
     _lib.call("vpu_attn_set_option", name.encode(), int(value))
 
