@@ -133,6 +133,7 @@ struct AttnArgs {
     int ldq, ldk, ldo;         // row strides of q, of k/v, of o/d_o/out
     int ldgq, ldgk;            // row strides of dq and of dk/dv
     float scale;
+    int gx, nbh;               // see wg_problem
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -527,6 +528,18 @@ __device__ __forceinline__ float max8(const f32x4_t& a, const f32x4_t& b) {
     return max3(max3(a[0], a[1], a[2]), max3(a[3], b[0], b[1]), max3(b[2], b[3], b[3]));
 }
 
+// Workgroup -> (problem bh, block x of it).  a.gx == 0: the 2-D grid (blockIdx.y = problem).  a.gx > 0: a 1-D grid whose
+// workgroups of ONE problem are eight ids apart -- consecutive ids go to consecutive XCDs, so all blocks of a (window,
+// head) problem share an XCD and its L2: the K / V (or Q / dO) rows every block of the problem streams are fetched from
+// HBM once instead of once per block (window problems have two blocks: 81 -> 58 MB read in the forward).
+__device__ __forceinline__ void wg_problem(int gx, int nbh, int& bh, int& xb) {
+    if (gx == 0) { bh = blockIdx.y; xb = blockIdx.x; return; }
+    const int id = blockIdx.x, per = 8 * gx, grp = id / per, r = id - grp * per;
+    const int cnt = min(8, nbh - grp * 8);          // problems in this group (the last group may be short)
+    bh = grp * 8 + r % cnt;
+    xb = r / cnt;
+}
+
 constexpr float RESCALE_TH = 8.0f;   // log2 units: probabilities relative to the reference maximum stay below 2^8
 
 template <int HD, int QT, int HC>
@@ -536,12 +549,14 @@ __global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char ldsK[2][CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsV[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    int bh, xb;
+    wg_problem(a.gx, a.nbh, bh, xb);
+    const int bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
-    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int q0 = xb * (64 * QT) + wave * (16 * QT);
     const float sc2 = a.scale * LOG2E;
     bf16x8_t qf[QT][KS];
     float mref[QT];
@@ -699,13 +714,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
     using S = Stg<HD>;
     __shared__ __attribute__((aligned(16))) char ldsKr[2][CH * HD * 2], ldsKt[2][CH * HD * 2], ldsVr[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    int bh, xb;
+    wg_problem(a.gx, a.nbh, bh, xb);
+    const int bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
     const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
-    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int q0 = xb * (64 * QT) + wave * (16 * QT);
     const float sc2 = a.scale * LOG2E;
     bf16x8_t qf[QT][KS], dof[QT][KS];
     float nl2[QT], nds[QT];    // -lse * log2 e, -delta * scale of query q0 + 16 u + c
@@ -823,13 +840,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
     __shared__ __attribute__((aligned(16))) char ldsQr[2][CH * HD * 2], ldsQt[2][CH * HD * 2];
     __shared__ __attribute__((aligned(16))) char ldsOr[2][CH * HD * 2], ldsOt[2][CH * HD * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
+    int bh, xb;
+    wg_problem(a.gx, a.nbh, bh, xb);
+    const int bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
     const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
     const bf16_t* d_o = a.d_o + rbq * a.ldo + h * hd;
-    const int key0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
+    const int key0 = xb * (64 * KT) + wave * (16 * KT);
     const float sc2 = a.scale * LOG2E;
     bf16x8_t kf[KT][KS], vf[KT][KS];
     f32x4_t adk[KT][DT], adv[KT][DT];
@@ -934,9 +953,229 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
         }
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass backward
+// Window-sized self-attention problems (n <= 256 tokens, head dim 64: the ViT-B / ViT-L blocks, 196 tokens): the two kernels
+// above compute S and dP twice (once per orientation) and fetch Q, K, V, dO twice each -- and their two workgroups per
+// (window, head) land on different XCDs, so the second fetch is not an L2 hit (measured 207 MB read for 72 MB of operands).
+// Here ONE workgroup of eight waves owns a (window, head) problem and every score is computed once:
+//   * the whole problem is resident: Q, dO and K (100 KB at 196 tokens) are requested in the prologue -- every global load
+//     of the workgroup is in flight at once, the loop itself touches LDS only (the first version streamed 32-query blocks
+//     with a two-block look-ahead like the kernels above: with one workgroup per CU nothing covers the latency a block
+//     arrives with, 2 us per block against 0.7 us of work; 65 us per launch, no faster than the two kernels);
+//   * wave w owns one or two 16-key tiles (13 tiles for 196 keys: 2,2,2,2,2,1,1,1), K / V fragments in registers, and
+//     accumulates dK / dV for them over the 32-query blocks (as attn_bwd_dkdv_lean does);
+//   * S = Q K^T comes out as [query 4g+r][key c]: P and dS in that layout are the A operands of dV += P^T dO and
+//     dK += dS^T Q for free.  dQ += dS K sums over KEYS, i.e. over the lane index of that layout, so dS goes through
+//     LDS once: each lane writes its four consecutive queries of one key as ONE 8-byte unit of a [key][32 queries] image
+//     and the dQ product reads it back with ds_read_b64_tr_b16 as the A fragment [query][32 keys];
+//   * after the block's barrier all keys' dS are there, so wave w computes the whole sum over keys for ONE of the eight
+//     16 x 16 tiles of the block's dQ (2 query tiles x 4 column tiles; its K fragments stay in registers) and stores it:
+//     no cross-wave reduction, no atomics.  The dQ of block i - 1 is computed in iteration i: one barrier per block.
+//   * delta = rowsum(dO * O) is computed while dO is staged (the same threads fetch the matching O piece).
+// One image per matrix, in the transposing-read layout; the row-fragment reads (ds_read_b128) of the score products use it
+// too (two-way bank conflicts there instead of none: the LDS is not what bounds this kernel).
+constexpr int WIN_MAX_KB = 8;                                   // 32-row blocks: n <= 256
+constexpr int WIN_ROWS = WIN_MAX_KB * 32;
+constexpr int WIN_LDS_M = WIN_ROWS * 64 * 2;                    // one [256][64] bf16 image
+constexpr int WIN_LDS_S = 2 * (WIN_ROWS + 16) * 32 * 2;         // two [256 keys + 16 spare rows][32 queries] dS images
+constexpr int WIN_LDS = 3 * WIN_LDS_M + WIN_LDS_S + 2 * WIN_ROWS * 4;
+
+// A fragment (16 rows x 32 columns, ds_read_b128) out of an image in the transposing-read layout
+template <int HD> __device__ __forceinline__ bf16x8_t frag_rc_tr(const char* lds, int row16, int ks, int lane) {
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + tr_off<HD>(row16 + (lane & 15), 2 * (ks * 4 + (lane >> 4))));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KS = 2, DT = 4, NP = WIN_ROWS * 8 / 512;   // 16-byte pieces per thread and matrix
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    char* const ldsQ = wlds;
+    char* const ldsO = wlds + WIN_LDS_M;      // dO
+    char* const ldsK = wlds + 2 * WIN_LDS_M;
+    char* const ldsS = wlds + 3 * WIN_LDS_M;  // [2][keys][32 queries] bf16, transposing-read layout (HD = 32 image)
+    float* const ldsD = reinterpret_cast<float*>(ldsS + WIN_LDS_S);   // -delta * scale per query
+    float* const ldsL = ldsD + WIN_ROWS;                              // -lse * log2 e per query
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.x, bw = bh / a.H, h = bh % a.H, n = a.nq;
+    const int64_t rb = (int64_t)bw * n;
+    const bf16_t* q = a.q + rb * a.ldq + h * HD;
+    const bf16_t* k = a.k + rb * a.ldk + h * HD;
+    const bf16_t* v = a.v + rb * a.ldk + h * HD;
+    const bf16_t* o = a.o + rb * a.ldo + h * HD;
+    const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
+    const float sc2 = a.scale * LOG2E;
+    const int NT = (n + 15) >> 4, NKB = (NT + 1) >> 1, nch = (n + CH - 1) / CH, rows = 32 * nch;
+    // key tiles of this wave: NT = 8 base + rem, the first rem waves take one more
+    const int base = NT >> 3, rem = NT & 7;
+    const int nu = base + (wave < rem ? 1 : 0), tile0 = wave * base + (wave < rem ? wave : rem);
+    const int my_t = wave >> 2, my_dt = wave & 3;     // this wave's tile of a block's dQ: queries 16 my_t.., columns 16 my_dt..
+    // ---- prologue: every global load of the problem is requested before the first wait
+    bf16x8_t kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int key0 = (u < nu) ? (tile0 + u) * 16 : n;     // (an unowned slot reads nothing: rows >= n are zeros)
+        load_rows_as_bn<KS>(k, a.ldk, key0, n, lane, kf[u], HD);
+        load_rows_as_bn<KS>(v, a.ldk, key0, n, lane, vf[u], HD);
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rsQ = rows_rsrc(q, n, a.ldq, HD, 2), rsK = rows_rsrc(k, n, a.ldk, HD, 2);
+        const __amdgpu_buffer_rsrc_t rsG = rows_rsrc(d_o, n, a.ldo, HD, 2), rsO = rows_rsrc(o, n, a.ldo, HD, 2);
+        const __amdgpu_buffer_rsrc_t rsL = rows_rsrc(reinterpret_cast<const char*>(a.lse + (int64_t)bh * n), 1, 0, n, 4);
+        u32x4v pq[NP], pk[NP], pg[NP], po[NP];
+        const int ch = tid & 7, row0 = tid >> 3;      // piece i: row row0 + 64 i, 16-byte chunk ch
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = row0 + 64 * i;
+            const bool live = row < rows;
+            pq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, live ? (row * a.ldq + ch * 8) * 2 : 0x40000000, 0, 0);
+            pk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, live ? (row * a.ldk + ch * 8) * 2 : 0x40000000, 0, 0);
+            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsG, live ? (row * a.ldo + ch * 8) * 2 : 0x40000000, 0, 0);
+            po[i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, live ? (row * a.ldo + ch * 8) * 2 : 0x40000000, 0, 0);
+        }
+        const float pl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, tid < WIN_ROWS ? tid * 4 : 0x40000000, 0, 0));
+#pragma unroll
+        for (int i = 0; i < (WIN_LDS_S / 16 + 511) / 512; ++i)
+            if (tid + i * 512 < WIN_LDS_S / 16) *reinterpret_cast<u32x4v*>(ldsS + (tid + i * 512) * 16) = (u32x4v){0u, 0u, 0u, 0u};
+        if (tid < WIN_ROWS) ldsL[tid] = -pl * LOG2E;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = row0 + 64 * i;
+            if (row < rows) {      // (wave-uniform for whole waves: a wave covers 8 consecutive rows)
+                const int off = tr_off<HD>(row, ch * 2);
+                *reinterpret_cast<u32x4v*>(ldsQ + off) = pq[i];
+                *reinterpret_cast<u32x4v*>(ldsK + off) = pk[i];
+                *reinterpret_cast<u32x4v*>(ldsO + off) = pg[i];
+                // delta of the row: eight consecutive lanes hold one row of dO and of O
+                const bf16x8_t x = __builtin_bit_cast(bf16x8_t, pg[i]), y = __builtin_bit_cast(bf16x8_t, po[i]);
+                float dl = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)x[j] * (float)y[j];
+                dl += __shfl_xor(dl, 1, 64);
+                dl += __shfl_xor(dl, 2, 64);
+                dl += __shfl_xor(dl, 4, 64);
+                if (ch == 0) ldsD[row] = -dl * a.scale;
+            }
+        }
+    }
+    // where this lane's dS of slot u goes: key row 16 (tile0 + u) + c of the [key][32 queries] image -- an unowned slot (the
+    // loop has no divergent branches: every wave computes two tiles, an unowned one on zero K / V) writes to spare rows
+    int srow[2], smask[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int krow = (u < nu ? (tile0 + u) * 16 : WIN_ROWS) + c;
+        srow[u] = krow * 64;
+        smask[u] = (((krow >> 1) & 3) << 2) & 7;          // tr_off<32>(krow, unit) = krow * 64 + ((unit ^ mask) << 3)
+    }
+    f32x4_t adk[2][DT], adv[2][DT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
+    __syncthreads();                 // the images are complete
+    bf16x8_t ktf[WIN_MAX_KB];        // K[32 keys of block kb][16 columns of my_dt] as the B operand of the dQ product
+#pragma unroll
+    for (int kb = 0; kb < WIN_MAX_KB; ++kb)
+        if (kb < NKB) ktf[kb] = frag_tr_perm<HD>(ldsK + kb * 32 * HD * 2, my_dt, lane);
+    // dQ tile of block j from the dS image of that block
+    auto dq_block = [&](int j) {
+        const char* sS = ldsS + (j & 1) * (WIN_LDS_S / 2);
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < WIN_MAX_KB; ++kb)
+            if (kb < NKB) {
+                const bf16x8_t af = frag_tr_perm<32>(sS + kb * 32 * 64, my_t, lane);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ktf[kb], acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = j * CH + 16 * my_t + 4 * g + r;
+            if (qq < n) a.dq[(rb + qq) * a.ldgq + h * HD + 16 * my_dt + c] = (bf16_t)acc[r];
+        }
+    };
+    for (int i = 0; i < nch; ++i) {
+        const int b = i & 1, qc = i * CH;
+        const char* sQ = ldsQ + qc * HD * 2;
+        const char* sO = ldsO + qc * HD * 2;
+        char* const sS = ldsS + b * (WIN_LDS_S / 2);
+        {
+            f32x4_t P[2][2], dS[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4_t nl2 = *reinterpret_cast<const f32x4_t*>(ldsL + qc + 16 * t + 4 * g);
+                const f32x4_t nds = *reinterpret_cast<const f32x4_t*>(ldsD + qc + 16 * t + 4 * g);
+                f32x4_t s[2], dp[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8_t qfr = frag_rc_tr<HD>(sQ, 16 * t, ks, lane), ofr = frag_rc_tr<HD>(sO, 16 * t, ks, lane);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], s[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[u][ks], dp[u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {   // element [query = qc + 16 t + 4 g + r][key = 16 (tile0 + u) + c]
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sc2, nl2[r]));
+                            P[u][t][r] = p;
+                            dS[u][t][r] = p * __builtin_fmaf(dp[u][r], a.scale, nds[r]);
+                        }
+                        // this lane's four queries of key row 16 (tile0 + u) + c: one 8-byte unit of the [key][query] image
+                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                        bf16x4_t w4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) w4[r] = (bf16_t)dS[u][t][r];
+                        *reinterpret_cast<bf16x4_t*>(sS + srow[u] + ((4 * t + g) ^ smask[u]) * 8) = w4;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                    const bf16x8_t pf = pack_pair(P[u][0], P[u][1]), dsf = pack_pair(dS[u][0], dS[u][1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16x8_t otf = frag_tr_perm<HD>(sO, dt, lane), qtf = frag_tr_perm<HD>(sQ, dt, lane);
+                        adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, otf, adv[u][dt], 0, 0, 0);
+                        adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, qtf, adk[u][dt], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();     // the dS image of block i is complete (and everybody has finished reading the image of block i - 1)
+        dq_block(i);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (u < nu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = (tile0 + u) * 16 + 4 * g + r;
+                if (kk < n) {
+                    bf16_t* kr = a.dk + (rb + kk) * a.ldgk + h * HD + c;
+                    bf16_t* vr = a.dv + (rb + kk) * a.ldgk + h * HD + c;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        kr[dt * 16] = (bf16_t)adk[u][dt][r];
+                        vr[dt * 16] = (bf16_t)adv[u][dt][r];
+                    }
+                }
+            }
+        }
+}
+
 // "lean" = 1 (default): the kernels above; 0: the round-1 step kernels (kept for A/B runs and as a second implementation in
 // the tests).  VPU_ATTN_LEAN sets the process default.
-std::atomic<int> g_opt_lean{-1};
+std::atomic<int> g_opt_lean{-1}, g_opt_onepass{-1};
+inline bool xcd_map_enabled() {   // VPU_ATTN_XCDMAP=0: the plain 2-D grid (A/B runs)
+    static const int e0 = [] { const char* e = getenv("VPU_ATTN_XCDMAP"); return e ? atoi(e) : 1; }();
+    return e0 != 0;
+}
+inline bool onepass_enabled() {   // "onepass": the one-workgroup-per-(window, head) backward for n <= 256, head dim 64
+    static const int e0 = [] { const char* e = getenv("VPU_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
+    const int v = g_opt_onepass.load(std::memory_order_relaxed);
+    return (v >= 0 ? v : e0) != 0;
+}
 inline bool wide_two() {   // two query tiles per wave also in the 128-column instantiation (head dims 80 / 96: ViT-H, the neck)
     static const int e0 = [] { const char* e = getenv("VPU_ATTN_WIDE2"); return e ? atoi(e) : 1; }();
     return e0 != 0;
@@ -966,7 +1205,12 @@ extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
         g_opt_lean.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
-    vpu_set_error("vpu_attn_set_option: known options: lean (-1 environment default VPU_ATTN_LEAN, 0 round-1 step kernels, 1 lean kernels)");
+    if (name && !strcmp(name, "onepass") && value >= -1 && value <= 1) {
+        g_opt_onepass.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
+    vpu_set_error("vpu_attn_set_option: known options: lean (-1 environment default VPU_ATTN_LEAN, 0 round-1 step kernels, 1 lean kernels), "
+                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems)");
     return VPU_ERR_ARG;
 }
 
@@ -987,6 +1231,7 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
         // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
         const bool two = nq > 64 && (hd_image(hd) <= 64 || wide_two());
         dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
+        if (xcd_map_enabled() && grid.x > 1) { a.gx = grid.x; a.nbh = nb * H; grid = dim3(grid.x * grid.y); }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_fwd_lean_kernel<%d, %d, %d>", hd_image(hd), two ? 2 : 1, hd_computed(hd));
         switch (hd_image(hd) * 4 + (two ? 2 : 1)) {
             case 128 * 4 + 2:
@@ -1039,9 +1284,22 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+            attr = true;
+        }
+        snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_win_kernel");
+        attn_bwd_win_kernel<<<dim3(nb * H), 512, WIN_LDS, s>>>(a);
+        return vpu_check_launch("vpu_xattn_bwd");
+    }
     if (lean_enabled() && nq % 4 == 0) {
         const bool q2 = nq > 64 && (hd_image(hd) <= 64 || wide_two()), k2 = nk > 64 && hd_image(hd) <= 64;
         dim3 gq(q2 ? (nq + 127) / 128 : (nq + 63) / 64, nb * H), gk(k2 ? (nk + 127) / 128 : (nk + 63) / 64, nb * H);
+        AttnArgs ak = a;      // (the two kernels may have different block counts)
+        if (xcd_map_enabled() && gq.x > 1) { a.gx = gq.x; a.nbh = nb * H; gq = dim3(gq.x * gq.y); }
+        if (xcd_map_enabled() && gk.x > 1) { ak.gx = gk.x; ak.nbh = nb * H; gk = dim3(gk.x * gk.y); }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_dq_lean_kernel<%d, %d, %d> attn_bwd_dkdv_lean_kernel<%d, %d, %d>",
                  hd_image(hd), q2 ? 2 : 1, hd_computed(hd), hd_image(hd), k2 ? 2 : 1, hd_computed(hd));
         switch (hd_image(hd) * 4 + (q2 ? 2 : 1)) {     // also writes delta
@@ -1059,13 +1317,13 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
                 break;
         }
         switch (hd_image(hd) * 4 + (k2 ? 2 : 1)) {
-            case 32 * 4 + 2: attn_bwd_dkdv_lean_kernel<32, 2, 32><<<gk, 256, 0, s>>>(a); break;
-            case 32 * 4 + 1: attn_bwd_dkdv_lean_kernel<32, 1, 32><<<gk, 256, 0, s>>>(a); break;
-            case 64 * 4 + 2: attn_bwd_dkdv_lean_kernel<64, 2, 64><<<gk, 256, 0, s>>>(a); break;
-            case 64 * 4 + 1: attn_bwd_dkdv_lean_kernel<64, 1, 64><<<gk, 256, 0, s>>>(a); break;
+            case 32 * 4 + 2: attn_bwd_dkdv_lean_kernel<32, 2, 32><<<gk, 256, 0, s>>>(ak); break;
+            case 32 * 4 + 1: attn_bwd_dkdv_lean_kernel<32, 1, 32><<<gk, 256, 0, s>>>(ak); break;
+            case 64 * 4 + 2: attn_bwd_dkdv_lean_kernel<64, 2, 64><<<gk, 256, 0, s>>>(ak); break;
+            case 64 * 4 + 1: attn_bwd_dkdv_lean_kernel<64, 1, 64><<<gk, 256, 0, s>>>(ak); break;
             default:
-                if (hd <= 96) attn_bwd_dkdv_lean_kernel<128, 1, 96><<<gk, 256, 0, s>>>(a);
-                else attn_bwd_dkdv_lean_kernel<128, 1, 128><<<gk, 256, 0, s>>>(a);
+                if (hd <= 96) attn_bwd_dkdv_lean_kernel<128, 1, 96><<<gk, 256, 0, s>>>(ak);
+                else attn_bwd_dkdv_lean_kernel<128, 1, 128><<<gk, 256, 0, s>>>(ak);
                 break;
         }
         return vpu_check_launch("vpu_xattn_bwd");

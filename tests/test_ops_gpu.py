@@ -1027,6 +1027,43 @@ def test_flash_attention_fwd_bwd(ops, attn_form, hd, n, nb):
         assert (got[i] - ref_g).abs().max().item() < tol, (name, (got[i] - ref_g).abs().max().item(), tol)
 
 
+@pytest.mark.parametrize("n,nb,H", [(196, 5, 3), (256, 2, 2), (208, 1, 1), (100, 3, 2), (64, 2, 4), (16, 3, 1), (4, 2, 1), (132, 2, 12), (50, 2, 2), (197, 1, 2)])
+def test_one_pass_window_backward(ops, n, nb, H):
+    """The one-workgroup-per-(window, head) backward (attn_bwd_win_kernel: head dim 64, n <= 256) against torch fp32 on the
+    bf16-rounded inputs AND against the two-kernel backward it replaces: key-tile counts 13 (2,2,2,2,2,1,1,1 tiles per
+    wave), 16, 13 exact, 7 (ragged last tile), 4, 1 and a quarter tile; every gradient within 2e-2 of its scale and within
+    bf16 rounding of the two-kernel result; the launch really was the one-pass kernel."""
+    hd = 64
+    D = H * hd
+    qkv = dev(rnd(nb * n, 3 * D, seed=160 + n, scale=1.5)).to(torch.bfloat16)
+    O = torch.zeros(nb * n, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(nb * H, n, device="cuda")
+    scale = hd ** -0.5
+    ops.attn_fwd(qkv, (qkv, D), (qkv, 2 * D), O, lse, nb, H, n, hd, 3 * D, D, scale)
+    x = qkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+    ref = torch.softmax((x[0] @ x[1].transpose(-1, -2)) * scale, -1) @ x[2]
+    dO = dev(rnd(nb * n, D, seed=161 + n)).to(torch.bfloat16)
+    ref.backward(dO.float().view(nb, n, H, hd).transpose(1, 2))
+    res = {}
+    try:
+        for onepass in (1, 0):
+            ops.attn_set_option("onepass", onepass)
+            dqkv = torch.full_like(qkv, float("nan"))
+            delta = torch.zeros(nb * H, n, device="cuda")
+            ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, delta, dqkv, (dqkv, D), (dqkv, 2 * D), nb, H, n, hd, 3 * D, D,
+                         3 * D, scale)
+            assert (ops.attn_last_kernel() == "attn_bwd_win_kernel") == bool(onepass), ops.attn_last_kernel()
+            res[onepass] = dqkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4)
+    finally:
+        ops.attn_set_option("onepass", -1)
+    for i, name in enumerate("qkv"):
+        ref_g = x.grad[i]
+        sc = ref_g.abs().max().item()
+        assert torch.isfinite(res[1][i]).all(), name
+        assert (res[1][i] - ref_g).abs().max().item() < 2e-2 * sc, (name, (res[1][i] - ref_g).abs().max().item(), sc)
+        assert (res[1][i] - res[0][i]).abs().max().item() < 1e-2 * sc, (name, (res[1][i] - res[0][i]).abs().max().item(), sc)
+
+
 def test_attention_large_scores_raise_the_reference(ops, attn_form):
     """Scores with a spread of ~ +-60 (inputs scaled by 4): the running maximum of the forward is raised several times
     along the 784 keys (the lean kernels only do so when a step exceeds the reference by more than 2^8) and rows are close
