@@ -25,7 +25,7 @@ def run_smoke():
     img4 = torch.cat([b["images"], torch.zeros(2, 1, 448, 448)], 1)
     with torch.no_grad():
         ref = vo.vpu_forward(sd, cfg, img4, b["points"])
-    for dtype, tol in (("f32", 1e-3), ("bf16", 5e-2)):
+    for dtype, tol in (("f32", 1e-3), ("bf16", 2e-2)):      # bf16: measured 1.08e-2 (bound = 1.85 x that)
         model.set_compute_dtype(dtype)
         eng = model._ensure_engine()
         eng.refresh_weights()

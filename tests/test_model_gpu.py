@@ -33,6 +33,13 @@ def _setup(golden_dir, name, dtype):
     return fx, cfg, sd, model, batch, img4
 
 
+def _within(tag, value, bound):
+    """bf16 bounds are set at 1.5-2x the value measured on MI355X (printed with -s) so that a kernel regression that
+    doubles an error trips them; the fp32 engine mode carries the 1e-3 parity bound."""
+    print(f"[bf16-bound] {tag}: measured {float(value):.4g} bound {bound:.4g}")
+    assert float(value) < bound, (tag, float(value), bound)
+
+
 def _relerr(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
@@ -98,19 +105,23 @@ def test_tiny_fp32_forward_backward_matches_reference(golden_dir, mode, ptype, f
                                atol=1e-3 * np.abs(g).max() + 1e-9)
 
 
+# logits, aux, loss, gradient norms -- measured on MI355X: tiny 9.3e-3 / 8.1e-3 / 1.9e-4 / 3.4e-2, tinyh 1.41e-2 / 7.0e-3 / 5.6e-5 / 2.3e-2
+TOL = {"tiny.npz": (1.8e-2, 1.6e-2, 2e-3, 6e-2), "tinyh.npz": (2.6e-2, 1.4e-2, 2e-3, 4.5e-2)}
+
+
 @pytest.mark.parametrize("fixture", ["tiny.npz", "tinyh.npz"])
 def test_tiny_bf16_close_to_reference(golden_dir, fixture):
-    """bf16 MFMA mode: bf16 activations / weights, fp32 accumulate.  Bound: 3e-2 of the logit range (bf16 has 8
+    """bf16 MFMA mode: bf16 activations / weights, fp32 accumulate.  Bounds (TOL) at ~1.8x the measured values (bf16 has 8
     significant bits; ~60 layers deep), gradients within 6 % in norm and cosine > 0.99 on the checked tensors.
     tinyh runs the fused attention in its 128-column instantiation (head dim 80) and the padded patch-14 im2col."""
     fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
     model.zero_grad()
     out = _run(model, img4, batch, 0)
-    assert _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["click_instances_sub"]) < 3e-2
-    assert _relerr(out["instances_aux"][:, ::6, ::7, ::7].detach().cpu().numpy(), fx["click_instances_aux_sub"]) < 3e-2
+    _within(f"{fixture} logits", _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["click_instances_sub"]), TOL[fixture][0])
+    _within(f"{fixture} aux", _relerr(out["instances_aux"][:, ::6, ::7, ::7].detach().cpu().numpy(), fx["click_instances_aux_sub"]), TOL[fixture][1])
     gt = batch["instances"].cuda()
     total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
-    assert abs(total.item() - fx["click_loss"][0]) < 2e-2 * abs(fx["click_loss"][0])
+    _within(f"{fixture} loss", abs(total.item() - fx["click_loss"][0]) / abs(fx["click_loss"][0]), TOL[fixture][2])
     total.backward()
     params = dict(model.named_parameters())
     names = [str(n) for n in fx["click_grad_names"]]
@@ -119,13 +130,35 @@ def test_tiny_bf16_close_to_reference(golden_dir, fixture):
     for n in names:
         if norms[n] > 1e-4:
             worst = max(worst, abs(float(params[n].grad.norm()) - norms[n]) / norms[n])
-    assert worst < 6e-2, worst
+    _within(f"{fixture} grad norms", worst, TOL[fixture][3])
     for k in fx.files:
         if k.startswith("click_grad::"):
             n = k.split("::")[1]
             a, b = params[n].grad.flatten().cpu().double(), torch.from_numpy(fx[k]).flatten().double()
             if b.norm() > 1e-6:
                 assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99, n
+
+
+@pytest.mark.parametrize("fixture", ["tiny.npz", "vitb.npz"])
+def test_bf16_path_is_as_accurate_as_torch_autocast(golden_dir, fixture):
+    """WHICH reference mode the bf16 path corresponds to: the reference's mixed-precision option (``--amp``: fp16 autocast +
+    GradScaler, trainer.py:156-157,191-197,525-527; bf16 here, no scaler).  The oracle run under
+    ``torch.autocast(bfloat16)`` on the CPU IS that mode -- torch keeps the residual stream, LayerNorm and softmax in fp32
+    and rounds only the GEMM / convolution operands and results to bf16 -- and its mask logits sit ~1e-2 off the fp32
+    reference on ViT-B: the error of this build's bf16 path (everything between kernels stored in bf16) is asserted to be
+    no worse than 1.5x that.  This is also the measurement of what an fp32 residual stream would buy:
+    autocast HAS one and lands at the same error, so the operand roundings, not the stream's, set the floor."""
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
+    with torch.no_grad():
+        out = _run(model, img4, batch, 0)["instances"].float().cpu()
+        ref = vo.vpu_forward(sd, cfg, img4, batch["points"], batch["boxes"], 0)["instances"]
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            amp = vo.vpu_forward(sd, cfg, img4, batch["points"], batch["boxes"], 0)["instances"].float()
+    scale = float(ref.abs().max())
+    e_hip, e_amp = float((out - ref).abs().max()) / scale, float((amp - ref).abs().max()) / scale
+    print(f"[bf16-bound] {fixture}: HIP bf16 path {e_hip:.4g}, torch autocast(bf16) oracle {e_amp:.4g} (relative to the logit range)")
+    assert e_amp > 1e-3, "autocast must actually have rounded something"
+    assert e_hip < 1.5 * e_amp + 2e-3, (e_hip, e_amp)
 
 
 def test_fused_loss_kernels_match_torch_losses(golden_dir):
@@ -176,7 +209,8 @@ def test_vitb_forward_matches_reference(golden_dir):
         outb = _run(model, img4, batch, 1)
     e1 = _relerr(outb["instances"][..., ::7, ::7].cpu().numpy(), fx["box_instances_sub"])
     e2 = _relerr(outb["instances_aux"][:, ::6, ::7, ::7].cpu().numpy(), fx["box_instances_aux_sub"])
-    assert e1 < 5e-2 and e2 < 5e-2, (e1, e2)
+    _within("vitb box logits", e1, 2.5e-2)
+    _within("vitb box aux", e2, 6e-3)          # measured 1.34e-2 (logits) / 2.8e-3 (aux)
 
 
 def test_vitb_bf16_backward_grad_norms(golden_dir):
@@ -185,7 +219,7 @@ def test_vitb_bf16_backward_grad_norms(golden_dir):
     out = _run(model, img4, batch, 0)
     gt = batch["instances"].cuda()
     total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
-    assert abs(total.item() - fx["click_loss"][0]) < 2e-2 * abs(fx["click_loss"][0])
+    _within("vitb loss", abs(total.item() - fx["click_loss"][0]) / abs(fx["click_loss"][0]), 1e-3)          # measured 1.8e-5
     total.backward()
     params = dict(model.named_parameters())
     names = [str(n) for n in fx["click_grad_names"]]
@@ -194,7 +228,7 @@ def test_vitb_bf16_backward_grad_norms(golden_dir):
     # q/k projections of the near-uniform query self-attention (3e-5) -- and are not compared
     rel = {n: abs(float(params[n].grad.norm()) - norms[n]) / norms[n] for n in names if norms[n] > 1e-3}
     worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
-    assert worst[0][1] < 0.1, worst
+    _within("vitb grad norms " + worst[0][0], worst[0][1], 4e-2)      # measured 2.1e-2
 
 
 def test_vitb_bf16_grouped_weight_gradients_equal_ungrouped(golden_dir):
@@ -840,7 +874,11 @@ def test_nobrs_vitb_20_clicks_config3(golden_dir):
     same = 0
     while same < 20 and ch[same] == co[same]:
         same += 1
-    assert same >= 3, (ch[:4], co[:4])
+    print(f"[bf16-bound] config 3: {same} of 20 clicks coincide with the fp32 oracle's before the two series diverge; "
+          f"max IoU {float(ih.max()):.4f} (HIP bf16) vs {float(io_.max()):.4f} (oracle)")
+    # (a click is the arg-max of a distance map: once bf16 noise flips one pixel of the thresholded mask the two series
+    # are different experiments; the measured coincidence count is printed above and recorded in DESIGN section 2)
+    assert same >= 3, f"only {same} leading clicks coincide: {ch[:4]} vs {co[:4]}"
     assert np.all(np.abs(ih[:same] - io_[:same]) <= 0.1), (ih[:same], io_[:same])
     assert abs(float(ih.max()) - float(io_.max())) <= 0.1
 
@@ -927,22 +965,22 @@ def test_vitl_width_bf16_close_to_reference(golden_dir):
     fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitl8.npz", "bf16")
     model.zero_grad()
     out = _run(model, img4, batch, 1)
-    assert _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["box_instances_sub"]) < 5e-2
+    _within("vitl8 box logits", _relerr(out["instances"][..., ::7, ::7].detach().cpu().numpy(), fx["box_instances_sub"]), 3.3e-2)   # measured 1.79e-2
     gt = batch["instances"].cuda()
     total, _ = vo.step_loss(out, gt, vo.ed_mask_label(gt))
-    assert abs(total.item() - fx["box_loss"][0]) < 2e-2 * abs(fx["box_loss"][0])
+    _within("vitl8 loss", abs(total.item() - fx["box_loss"][0]) / abs(fx["box_loss"][0]), 1e-3)      # measured 2.1e-5
     total.backward()
     params = dict(model.named_parameters())
     norms = dict(zip([str(n) for n in fx["box_grad_names"]], fx["box_grad_norms"]))
     rel = {n: abs(float(params[n].grad.norm()) - v) / v for n, v in norms.items() if v > 1e-3}
-    assert max(rel.values()) < 0.1, sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+    _within("vitl8 grad norms " + max(rel, key=rel.get), max(rel.values()), 0.1)      # measured 6.0e-2
 
 
 def test_bench_shape_bf16_step_matches_oracle(golden_dir):
     """The TIMED path at the benchmark's own shapes: ViT-B, B = 12 (M = 9408 token rows: the 256-row-tile GEMM kernels, the
     grouped weight-gradient launch over 216 tiles, the sliced neck gradients -- instantiations the B = 2 fixtures never
     select), bf16, one training step exactly as bench.py runs it (fused upsample + P2CL, no materialised aux), against the
-    CPU oracle on the same batch.  Bounds (bf16 has 8 significant bits, ~60 layers deep): mask logits within 3e-2 of their
+    CPU oracle on the same batch.  Bounds (bf16 has 8 significant bits, ~60 layers deep): mask logits within 2.6e-2 of their
     range, the three loss scalars within 2e-2, every compared gradient within 10 % in norm and cosine > 0.98 element-wise."""
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
     from pvpuformer_amd import ops
@@ -981,10 +1019,10 @@ def test_bench_shape_bf16_step_matches_oracle(golden_dir):
     total.backward()
     ref_inst = out["instances"].detach()
     err = float((inst.cpu() - ref_inst).abs().max()) / float(ref_inst.abs().max())
-    assert err < 3e-2, err
+    _within("bench-shape B=12 logits", err, 2.6e-2)      # measured 1.41e-2
     for k in ("total", "nfl", "dice", "p2cl"):
         a, b = float(losses[k]), float(total if k == "total" else parts[k])
-        assert abs(a - b) < 2e-2 * abs(b), (k, a, b)
+        _within(f"bench-shape loss {k}", abs(a - b) / abs(b), 2e-3)      # measured <= 3.8e-4
     worst = []
     for n in ["backbone.blocks.0.attn.qkv.weight", "backbone.blocks.5.mlp.fc1.weight", "backbone.blocks.11.mlp.fc2.weight",
               "backbone.blocks.6.attn.proj.weight", "backbone.blocks.11.norm2.weight", "backbone.patch_embed.proj.weight",
@@ -1069,5 +1107,5 @@ def test_bf16_error_budget_per_stage(golden_dir):
     # the fp32 engine mode against the reference (fixtures): the parity bound, three orders of magnitude below
     assert _relerr(taps["f32"]["instances"][..., ::7, ::7].cpu().numpy(), fx["click_instances_sub"]) < 1e-4
     e_final = _relerr(taps["bf16"]["instances"][..., ::7, ::7].cpu().numpy(), fx["click_instances_sub"])
-    assert e_final < 3e-2, e_final
+    _within("vitb click logits (budget test)", e_final, 2.3e-2)      # measured 1.25e-2
     print("bf16 error budget (relative L2 vs fp32 mode, random-walk estimate):", {k: (round(a, 5), round(b, 5)) for k, (a, b) in report.items()})
