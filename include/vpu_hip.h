@@ -230,6 +230,13 @@ int vpu_masked_argmax(const float* dist, const uint8_t* keep, uint64_t* out, int
  * pixel -- the label order of the reference's skimage.measure.label(connectivity=2) in max_connected_regions
  * (trainer.py:1175-1190). */
 int vpu_cc_roots(const uint8_t* mask, int32_t* roots, int32_t B, int32_t H, int32_t W, void* stream);
+/* Per-component table over the labels of vpu_cc_roots (what max_connected_regions / cal_box need of a labelling,
+ * trainer.py:1061-1131,1175-1190: component sizes and bounding boxes -- no label image crosses to the host).
+ * table: int32 [kmax][6] rows (root = smallest linear pixel index of the component, pixel count, ymin, ymax, xmin, xmax)
+ * in no particular order, followed by ONE int32 = the number of components found (rows beyond kmax are dropped: the
+ * caller compares the count with kmax).  slots: int32 scratch [B*H*W].  Integer atomics: exact, order-free. */
+int vpu_cc_table(const int32_t* roots, int32_t* slots, int32_t* table, int32_t kmax, int32_t B, int32_t H, int32_t W,
+                 void* stream);
 
 /* DistMaps disks (ops.py:347-379, use_disks, spatial_scale 1) + optional draw_box outline (is_model.py:97-121).
  * out fp32 [B][2][H][W] in {0,1}. */

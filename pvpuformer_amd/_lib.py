@@ -64,6 +64,7 @@ SIGNATURES = {
     "vpu_act_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
     "vpu_pue_encode": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_cc_roots": [_P, _P, _I, _I, _I, _P],
+    "vpu_cc_table": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_edt": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_pue_scribble_rows": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_draw_polyline": [_P, _P, _I, _I, _I, _I, _P],

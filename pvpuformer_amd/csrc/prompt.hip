@@ -411,6 +411,47 @@ __global__ __launch_bounds__(256) void cc_flatten_kernel(int* __restrict__ lab, 
     }
 }
 
+// ---- per-component table over the labels of cc_roots: (root, pixel count, ymin, ymax, xmin, xmax) per component, in
+// no particular order (the host sorts the few rows by root = label order).  Integer atomics only: exact, order-free.
+__global__ __launch_bounds__(256) void cc_table_roots_kernel(const int* __restrict__ roots, int* __restrict__ slots,
+                                                             int* __restrict__ table, int* __restrict__ counter, int64_t n, int kmax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && roots[i] == (int)i) {
+        const int s = atomicAdd(counter, 1);
+        slots[i] = s < kmax ? s : -1;
+        if (s < kmax) {
+            int* t = table + 6 * s;
+            t[0] = (int)i; t[1] = 0; t[2] = 0x7FFFFFFF; t[3] = -1; t[4] = 0x7FFFFFFF; t[5] = -1;
+        }
+    }
+}
+// one wave per 64 consecutive pixels of a row: a run of one component (the common case) costs five atomics per wave
+__global__ __launch_bounds__(256) void cc_table_accum_kernel(const int* __restrict__ roots, const int* __restrict__ slots,
+                                                             int* __restrict__ table, int H, int W) {
+    const int y = blockIdx.y, b = blockIdx.z, x = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)b * H + y) * W + x;
+    const int r = x < W ? roots[i] : -1;
+    const int s = r >= 0 ? slots[r] : -1;
+    const unsigned long long fg = __builtin_amdgcn_ballot_w64(s >= 0);
+    if (fg == 0) return;
+    const int first = __builtin_ctzll(fg), last = 63 - __builtin_clzll(fg);
+    const int s0 = __shfl(s, first, 64);
+    const bool uniform = __builtin_amdgcn_ballot_w64(s >= 0 && s != s0) == 0;
+    if (uniform) {
+        if (lane == first) {
+            int* t = table + 6 * s0;
+            atomicAdd(t + 1, __builtin_popcountll(fg));
+            atomicMin(t + 2, y); atomicMax(t + 3, y);
+            atomicMin(t + 4, x); atomicMax(t + 5, x - first + last);
+        }
+    } else if (s >= 0) {
+        int* t = table + 6 * s;
+        atomicAdd(t + 1, 1);
+        atomicMin(t + 2, y); atomicMax(t + 3, y);
+        atomicMin(t + 4, x); atomicMax(t + 5, x);
+    }
+}
+
 }  // namespace
 
 extern "C" int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, void* out, double* out64,
@@ -514,4 +555,20 @@ extern "C" int vpu_cc_roots(const uint8_t* mask, int32_t* roots, int32_t B, int3
     cc_merge_kernel<<<dim3((W + 255) / 256, H, B), 256, 0, s>>>(mask, roots, H, W);
     cc_flatten_kernel<<<g, 256, 0, s>>>(roots, n);
     return vpu_check_launch("vpu_cc_roots");
+}
+
+extern "C" int vpu_cc_table(const int32_t* roots, int32_t* slots, int32_t* table, int32_t kmax, int32_t B, int32_t H, int32_t W,
+                            void* stream) {
+    vpu_clear_stale_error();
+    const int64_t n = (int64_t)B * H * W;
+    if (!roots || !slots || !table || kmax < 1 || B < 1 || H < 1 || W < 1 || n >= 0x7FFFFFFFLL || B > 65535 || H > 65535) {
+        vpu_set_error("cc_table: null pointer, kmax < 1, or sizes out of range");
+        return VPU_ERR_ARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int32_t* counter = table + 6 * (int64_t)kmax;     // the component count lives behind the last row
+    if (hipMemsetAsync(counter, 0, sizeof(int32_t), s) != hipSuccess) { vpu_set_error("cc_table: memset"); return VPU_ERR_LAUNCH; }
+    cc_table_roots_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(roots, slots, table, counter, n, kmax);
+    cc_table_accum_kernel<<<dim3((W + 255) / 256, H, B), 256, 0, s>>>(roots, slots, table, H, W);
+    return vpu_check_launch("vpu_cc_table");
 }

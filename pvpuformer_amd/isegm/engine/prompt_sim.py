@@ -17,12 +17,11 @@ import torch
 from scipy import ndimage
 
 _EIGHT = np.ones((3, 3), dtype=bool)
-# VPU_SIM_GPU_CC=1: the connected components of cal_box on the GPU too (ops.cc_roots + a per-component table), so that no
-# mask crosses to the host.  Identical results (tests), but slower today: the table is built with torch.unique /
-# scatter_reduce over ~10^6 foreground pixels (39 ms per training step at bs 12 against 22.8 ms with the host labelling
-# inside the bounding box) -- it wants its own reduction kernel.
+# The connected components of cal_box on the GPU too (ops.cc_roots + ops.cc_table: union-find labels, then one reduction
+# pass to a per-component size / bounding-box table), so that no mask crosses to the host.  Identical results (tests).
+# VPU_SIM_GPU_CC=0: one uint8 mask per sample goes to the host and is labelled there (scipy) inside its bounding box.
 import os as _os
-GPU_CC = _os.environ.get("VPU_SIM_GPU_CC", "0") == "1"
+GPU_CC = _os.environ.get("VPU_SIM_GPU_CC", "1") == "1"
 
 
 def distance_transform(mask_u8):
@@ -296,7 +295,7 @@ def _get_next_promts_gpu(pred, gt, points, state, pred_thresh, as_allmask, jitte
         chosen = torch.where(sel[:, None, None], fn, fp).to(torch.uint8)
         if GPU_CC:
             bbox = _kept_region_boxes(chosen)
-        else:   # one uint8 mask per sample to the host, labelled there inside its bounding box (faster today, see GPU_CC)
+        else:   # VPU_SIM_GPU_CC=0: one uint8 mask per sample to the host, labelled there inside its bounding box
             bbox = []
             for m in chosen.cpu().numpy():
                 region = max_connected_regions(m > 0) == 1
@@ -354,33 +353,33 @@ def _get_next_promts_gpu(pred, gt, points, state, pred_thresh, as_allmask, jitte
     return torch.from_numpy(new_pts).to(dev), torch.from_numpy(boxes).to(dev)
 
 
-def _kept_region_boxes(masks):
+def _kept_region_boxes(masks, kmax=4096):
     """Bounding box (y0, y1, x0, x1) of ``max_connected_regions(mask) == 1`` for every mask of a uint8 CUDA batch
-    [B,H,W] (None where the mask is empty).  Components by union-find on the GPU; ordered by their smallest pixel index
-    they are in scipy's / skimage's label order, so the host scan over the component SIZES (largest-so-far, merge
-    everything above 10 % of the foreground) is the one of the reference (trainer.py:1175-1190)."""
+    [B,H,W] (None where the mask is empty).  Components by union-find on the GPU (``vpu_cc_roots``) and their sizes /
+    boxes by one reduction pass (``vpu_cc_table``): what crosses to the host is six integers per component.  Sorted by
+    root (= smallest pixel index) the components are in scipy's / skimage's label order, so the host scan over the
+    component SIZES (largest-so-far, merge everything above 10 % of the foreground) is the one of the reference
+    (trainer.py:1175-1190).  More than ``kmax`` components (salt-and-pepper masks): the host labelling takes over."""
     from pvpuformer_amd import ops
     B, H, W = masks.shape
-    roots = ops.cc_roots(masks)
-    idx = (roots >= 0).nonzero()                                   # [N, 3] = (b, y, x), raster order
-    out = [None] * B
-    if idx.shape[0] == 0:
+    flat = ops.cc_table(ops.cc_roots(masks), kmax).cpu().numpy()
+    K = int(flat[-1])
+    if K > kmax:
+        out = []
+        for m in masks.cpu().numpy():
+            region = max_connected_regions(m > 0) == 1
+            rows, cols = np.flatnonzero(region.any(1)), np.flatnonzero(region.any(0))
+            out.append(None if len(rows) == 0 else (int(rows[0]), int(rows[-1]), int(cols[0]), int(cols[-1])))
         return out
-    r = roots[idx[:, 0], idx[:, 1], idx[:, 2]].long()
-    uniq, inv, counts = torch.unique(r, return_inverse=True, return_counts=True)     # ascending roots = label order
-    K = uniq.shape[0]
-    big = torch.iinfo(torch.int64).max
-
-    def red(v, mode):
-        init = torch.full((K,), big if mode == "amin" else -1, dtype=torch.int64, device=masks.device)
-        return init.scatter_reduce(0, inv, v, reduce=mode, include_self=True)
-    table = torch.stack([uniq // (H * W), counts, red(idx[:, 1], "amin"), red(idx[:, 1], "amax"), red(idx[:, 2], "amin"),
-                         red(idx[:, 2], "amax")]).cpu().numpy()                        # [6, K]
+    table = flat[:6 * K].reshape(K, 6)
+    table = table[np.argsort(table[:, 0], kind="stable")]          # ascending roots = label order
+    owner = table[:, 0] // (H * W)
+    out = [None] * B
     for b in range(B):
-        comp = np.flatnonzero(table[0] == b)
+        comp = table[owner == b]
         if len(comp) == 0:
             continue
-        cnts = table[1, comp]
+        cnts = comp[:, 1]
         total = int(cnts.sum())
         target = np.arange(len(comp))
         max_num, max_pixel = 0, -1
@@ -391,5 +390,5 @@ def _kept_region_boxes(masks):
             if c > 0.1 * total:
                 target[j] = max_pixel
         keep = comp[target == max_pixel]
-        out[b] = (int(table[2, keep].min()), int(table[3, keep].max()), int(table[4, keep].min()), int(table[5, keep].max()))
+        out[b] = (int(keep[:, 2].min()), int(keep[:, 3].max()), int(keep[:, 4].min()), int(keep[:, 5].max()))
     return out

@@ -159,6 +159,16 @@ def cc_roots(mask_u8):
     return roots
 
 
+def cc_table(roots, kmax=4096):
+    """Per-component (root, pixel count, ymin, ymax, xmin, xmax) of a cc_roots labelling (vpu_cc_table) -> int32
+    [kmax * 6 + 1] on the device: kmax rows in no particular order, then the component count."""
+    B, H, W = roots.shape
+    slots = torch.empty(B, H, W, device=roots.device, dtype=torch.int32)
+    table = torch.empty(kmax * 6 + 1, device=roots.device, dtype=torch.int32)
+    _lib.call("vpu_cc_table", ptr(roots), ptr(slots), ptr(table), kmax, B, H, W, _stream())
+    return table
+
+
 def colsum_batched(jobs):
     """jobs: list of (in fp32 [rows, C], out fp32 [C] (tensor or (tensor, offset)), rows, C): out += column sums, 64 per
     launch."""

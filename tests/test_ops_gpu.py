@@ -61,7 +61,7 @@ def test_edt_bit_exact_vs_scipy(ops, shape, border):
         assert np.array_equal(got[b], ref), (b, np.abs(got[b] - ref).max())
 
 
-@pytest.mark.parametrize("as_allmask,gpu_cc", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("as_allmask,gpu_cc", [(False, True), (False, False), (True, True)])      # gpu_cc = True is the default
 def test_get_next_promts_gpu_equals_host(ops, as_allmask, gpu_cc, monkeypatch):
     """The device path of get_next_promts (masks, distance transforms, maxima and the k-th-candidate lookup on the GPU)
     against the host path (numpy + scipy) on the same inputs and the same random streams, three rounds deep: identical
@@ -134,6 +134,45 @@ def test_cc_roots_equal_scipy_components(ops):
             members = flat[rr == u]
             assert members.min() == u
             assert (lab.ravel()[members] == k + 1).all()
+
+
+def test_cc_table_and_kept_region_boxes(ops):
+    """vpu_cc_table over the labels of vpu_cc_roots: per component the exact pixel count and bounding box (against
+    scipy.ndimage on noise, blobs, a 300-pixel-wide run that spans several waves, a full and an empty mask), the component
+    count behind the last row, the overflow signal (count > kmax); and ``_kept_region_boxes`` -- what cal_box takes of
+    max_connected_regions -- equal to the host function on the same masks, with and without the overflow fallback."""
+    from scipy import ndimage
+    from pvpuformer_amd.isegm.engine import prompt_sim as ps
+    g = np.random.RandomState(12)
+    H, W = 120, 333
+    masks = [g.rand(H, W) < d for d in (0.05, 0.4, 0.62)]
+    masks.append(ndimage.binary_opening(g.rand(H, W) < 0.65, iterations=2))
+    wide = np.zeros((H, W), bool); wide[40:44, 10:310] = True; wide[80:100, 200:230] = True; wide[5, 5] = True
+    masks += [wide, np.ones((H, W), bool), np.zeros((H, W), bool)]
+    m = np.stack(masks).astype(np.uint8)
+    md = dev(torch.from_numpy(m))
+    roots = ops.cc_roots(md)
+    kmax = 1 << 14
+    flat = ops.cc_table(roots, kmax).cpu().numpy()
+    K = int(flat[-1])
+    table = flat[:6 * K].reshape(K, 6)
+    table = table[np.argsort(table[:, 0])]
+    want = []
+    for b, mk in enumerate(masks):
+        lab, n = ndimage.label(mk, structure=np.ones((3, 3), bool))
+        for k, sl in enumerate(ndimage.find_objects(lab)):
+            ys, xs = np.nonzero(lab == k + 1)
+            want.append((b * H * W + int((ys * W + xs).min()), len(ys), ys.min(), ys.max(), xs.min(), xs.max()))
+    want = np.array(sorted(want), np.int64)
+    assert K == len(want) and K < kmax and np.array_equal(table, want)
+    assert int(ops.cc_table(roots, 8).cpu().numpy()[-1]) == K          # more components than rows: the count says so
+    host = []
+    for mk in masks:
+        region = ps.max_connected_regions(mk) == 1
+        rows, cols = np.flatnonzero(region.any(1)), np.flatnonzero(region.any(0))
+        host.append(None if len(rows) == 0 else (rows[0], rows[-1], cols[0], cols[-1]))
+    assert ps._kept_region_boxes(md, kmax) == host
+    assert ps._kept_region_boxes(md, 8) == host                          # overflow: the host labelling takes over
 
 
 def test_colsum_batched(ops):
