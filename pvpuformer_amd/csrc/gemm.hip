@@ -2235,7 +2235,12 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128);
         }
         for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g2.start[i] = total2;
-        if (ok && total2 >= 192) {
+        // (a tile of this kernel walks its whole K on a CU of its own: fewer than 192 tiles leave CUs idle, but over a very
+        // long reduction -- the leftover of a step's packed weight-gradient launches, 147 K-tiles -- 96+ tiles still beat
+        // the 128 x 128 grouped kernel's two tiles per CU: 165 vs 236 us)
+        bool very_long = true;
+        for (int i = 0; i < n; ++i) very_long = very_long && descs[i].K >= 8192;
+        if (ok && (total2 >= 192 || (very_long && total2 >= 96))) {
             static bool attr_ = false;
             auto kern_ = gemm_bf16_k2_grouped_kernel<1, 1, true>;
             if (!attr_) {

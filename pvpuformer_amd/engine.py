@@ -121,6 +121,21 @@ class Engine:
         self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
         self.ride_wgrad = os.environ.get("VPU_WGRAD_RIDE", "1") != "0"      # small long-reduction gradients ride with the big groups
         self.wgrad_fill = 0.8     # a big group is launched once its rounds of 256 tiles are this full
+        # VPU_WGRAD_PACK (default 1): the queued long-reduction gradients leave in launches of ONE FULL ROUND of 256-row x
+        # 128-column tiles: every tile of a reduction length costs the same (147 K-tiles at 9408 rows), so a launch takes as
+        # long as one tile whatever its tile count -- a ViT-B block's four gradients are 216 tiles on 256 CUs (84 %), 12
+        # such launches per step.  Packed, a launch takes whole problems in queue order and the leading row / column blocks
+        # of the next one (a sub-matrix of the gradient: pointer offsets, no kernel change), the rest stays queued:
+        # 2592 backbone tiles = 10.1 full launches instead of 12 (-0.3 ms per step).  Not with a reducer attached (a block's
+        # range must be final at its marker).
+        # Only where a block's four gradients under-fill one round (216 of 256 tiles at D = 768): at D = 1024 the fill rule's
+        # groups are whole rounds already (128 + 128, 32 + 96 + 128 tiles) and cutting them costs 1.7 % (ViT-L 340 -> 334
+        # images/s); at D = 1280 (450 / 750-tile groups) it is neutral.  VPU_WGRAD_PACK=0 / 1 forces it off / on.
+        hid = self.D * c["mlp_ratio"]
+        blk = sum(((n + 255) // 256) * ((k + 127) // 128) for n, k in ((3 * self.D, self.D), (self.D, self.D), (hid, self.D), (self.D, hid)))
+        pk = os.environ.get("VPU_WGRAD_PACK", "")
+        self.pack_wgrad = pk == "1" or (pk != "0" and blk < 0.95 * 256)
+        self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
         self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
@@ -303,7 +318,14 @@ class Engine:
                 # group holds eight problems)
                 anchors = [e for e in same if not self._is_rider(e)]
                 T = sum(self._k2_tiles(e) for e in anchors)
-                if (T >= 200 and T >= self.wgrad_fill * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
+                if self.pack_wgrad and self.grad_ready_hook is None:
+                    self._pack_seen[kind] = self._pack_seen.get(kind, 0) + self._k2_tiles(self._wq[-1])
+                    budget = self.pack_tiles(self._pack_total.get(kind))
+                    T = sum(self._k2_tiles(e) for e in same)          # riders count: they are packed like everything else
+                    while T >= budget:
+                        self.flush_wgrads(kind, ride=True, budget=budget)
+                        T = sum(self._k2_tiles(e) for e in self._wq if e[3] == kind)
+                elif (T >= 200 and T >= self.wgrad_fill * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
                     self.flush_wgrads(kind, ride=True)
             elif len(same) >= 8:
                 self.flush_wgrads(kind)
@@ -987,7 +1009,45 @@ class Engine:
     def _is_rider(self, e):
         return e[3] > 2048 and self._k2_tiles(e) <= 16
 
-    def flush_wgrads(self, only_kind=None, ride=False, keep_riders=False, touching=None):
+    @staticmethod
+    def pack_tiles(total=None):
+        """Tiles per packed launch: one full round of the persistent 256 x 128 grid (one workgroup per CU) -- or, once the
+        previous backward pass has shown how many tiles of this reduction length a pass queues, that total spread evenly
+        over the ceil(total / 256) launches it needs anyway (2672 tiles: 11 launches of 243 instead of 10 of 256 and a
+        leftover launch that takes as long as a full one)."""
+        if not total or total < 256:
+            return 256
+        launches = (total + 255) // 256
+        return (total + launches - 1) // launches
+
+    @staticmethod
+    def _split_entry(e, budget):
+        """Cuts a queued weight gradient G[N, K] += dy[:, :N]^T x[:, :K] into (head, tail): head = the leading 256-row blocks
+        of G (columns of dy) or the leading 128-column blocks of G (columns of x), whichever gives more tiles <= ``budget``;
+        both are ordinary problems of the grouped launch (same operands at an offset, same leading dimensions).  The fused
+        bias column sums belong to the tiles of G's first column block: a column cut keeps them in the head.  None if no
+        block fits."""
+        args, kw, _, red = e
+        dy, x, g, N, K, M, ld_dy, ld_x, ldc, dt = args
+        R, Cn = (N + 255) // 256, (K + 127) // 128
+        rows, cols = min(R - 1, budget // Cn), min(Cn - 1, budget // R)     # (a cut leaves something on both sides)
+        if max(rows * Cn, cols * R) <= 0:
+            return None
+        adv = lambda t, n: (t[0], t[1] + n) if isinstance(t, tuple) else (t, n)
+        t128 = lambda n_, k_: ((n_ + 127) // 128) * ((k_ + 127) // 128)
+        cs = kw.get("colsum")
+        if rows * Cn >= cols * R:
+            r = rows * 256
+            head = ((dy, x, g, r, K, M, ld_dy, ld_x, ldc, dt), kw, t128(r, K), red)
+            tail = ((adv(dy, r), x, adv(g, r * ldc), N - r, K, M, ld_dy, ld_x, ldc, dt),
+                    dict(kw, colsum=None if cs is None else adv(cs, r)), t128(N - r, K), red)
+        else:
+            c = cols * 128
+            head = ((dy, x, g, N, c, M, ld_dy, ld_x, ldc, dt), kw, t128(N, c), red)
+            tail = ((dy, adv(x, c), adv(g, c), N, K - c, M, ld_dy, ld_x, ldc, dt), dict(kw, colsum=None), t128(N, K - c), red)
+        return head, tail
+
+    def flush_wgrads(self, only_kind=None, ride=False, keep_riders=False, touching=None, budget=None):
         """Launches the queued weight gradients (``only_kind``: just the entries of that kind, 0 = short reductions, else a
         reduction length).  Short reductions (<= 2048 rows) go into one grouped launch; long ones are grouped per reduction
         length when that beats one split-K launch + reduce each, otherwise they are launched one by one.
@@ -999,7 +1059,24 @@ class Engine:
         if touching is not None:
             ptr_of = lambda t: (t[0] if isinstance(t, tuple) else t).data_ptr()
             q = [e for e in q if touching in (ptr_of(e[0][0]), ptr_of(e[0][1]))]
-        if ride:
+        if ride and budget is not None:
+            # one full round: whole problems in queue order (the small "riders" of this reduction length included), then the
+            # leading row / column blocks of the first one that does not fit; what is cut off stays at its place in the queue
+            take, room = [], budget
+            for e in q:
+                t = self._k2_tiles(e)
+                if t <= room and len(take) < 16:
+                    take.append(e); room -= t
+                    continue
+                cut = self._split_entry(e, room) if len(take) < 16 else None
+                if cut is not None:
+                    head, tail = cut
+                    self._wq[[id(w) for w in self._wq].index(id(e))] = tail
+                    self._wq.insert(0, head)      # (leaves the queue with this launch: `chosen` below goes by identity)
+                    take.append(head)
+                break
+            q = take
+        elif ride:
             anchors = [e for e in q if not self._is_rider(e)]
             T = sum(self._k2_tiles(e) for e in anchors)
             room, slots, take = 256 * ((T + 255) // 256) - T, 16 - len(anchors), []
@@ -1113,8 +1190,10 @@ class Engine:
         self.attach_grads()
         tape.out_grads[:] = [None if d_inst is None else d_inst.contiguous(), None if d_aux is None else d_aux.contiguous(),
                              None if d_sim_low is None else d_sim_low.contiguous()]
+        self._pack_seen = {}
         for fn in reversed(tape.fns):
             fn()
+        self._pack_total = self._pack_seen      # what a backward pass queues per reduction length: the next pass's launch sizes
         tape.fns = []
         tape.done = True
         if tape is self.last_tape:

@@ -7,9 +7,8 @@ reference itself at full depth (tests/golden/vitl.npz, vith.npz: oracle/make_gol
 (b) bf16 at the benchmark's per-GPU batch (ViT-L B = 8 -> M = 6272 token rows, ViT-H B = 12 -> M = 12288): samples 0-1 of
     the batch are the fixture's, so their logits are compared with the reference's (samples are independent); the flat
     gradient of the B-sample step equals the sum of its B / 2 two-sample micro-batches (other tile shapes, other kernels);
-    a spy asserts that the grouped weight-gradient launches this configuration's fill rule produces (whole rounds of 256
-    tiles: 256-tile groups for ViT-L, 450 / 750-tile groups for ViT-H) and the head-dim-80 attention instantiation really
-    ran;
+    a spy asserts that the long-reduction weight gradients leave in groups that fill their rounds of 256 tiles (256-tile
+    groups for ViT-L, 450 / 750 for ViT-H) and that the head-dim-80 attention instantiation really ran;
 (c) one mixed click / box / scribble ``VPUTrainStep`` on the ViT-L model."""
 import os
 import random
@@ -87,8 +86,8 @@ def _step(eng, x, pts, gt, ptype=0, boxes=None):
     return inst, losses
 
 
-@pytest.mark.parametrize("fixture,B,tiles,logit_tol", [("vitl.npz", 8, 256, 3.5e-2), ("vith.npz", 12, 450, 6e-2)])
-def test_bench_batch_bf16_step(golden_dir, fixture, B, tiles, logit_tol):
+@pytest.mark.parametrize("fixture,B,logit_tol", [("vitl.npz", 8, 3.5e-2), ("vith.npz", 12, 6e-2)])
+def test_bench_batch_bf16_step(golden_dir, fixture, B, logit_tol):
     from pvpuformer_amd import ops
     fx, cfg, model, batch, img4 = _model(golden_dir, fixture)
     model.set_compute_dtype("bf16")
@@ -131,11 +130,15 @@ def test_bench_batch_bf16_step(golden_dir, fixture, B, tiles, logit_tol):
     used = set(gemms)
     assert "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
     assert any(k.startswith("gemm_bf16_k2_kernel<0, 0,") for k in used) and any(k.startswith("gemm_bf16_k2_kernel<0, 1,") for k in used)
-    # the long-reduction weight gradients are launched in groups that fill their rounds of 256 tiles to >= 80 % (engine
-    # _wgrad): ViT-L's 128 / 128 / 32 / 96-tile problems leave as exact 256-tile groups (fc2 + fc1; proj + qkv + the next
-    # block's fc2; ...), ViT-H's 200 / 200 / 50 / 150 as 450 and 750; only the flush at the end of backward may be emptier
+    # the long-reduction weight gradients (M = 6272 / 12288 token rows: 147+ K-tiles per output tile) leave in groups that
+    # fill their rounds of 256 CU-sized tiles (Engine._wgrad): a ViT-L block queues 128 / 128 / 32 / 96 tiles, which go
+    # as exact 256-tile groups (fc2 + fc1; proj + qkv + the next block's fc2; ...); a ViT-H block 200 / 200 / 50 / 150,
+    # which go as 450- and 750-tile groups (>= 88 % of their rounds).  (At D = 768 a block's 216 tiles under-fill a round
+    # and the queue is packed instead: tests/test_model_gpu.py::test_riding_weight_gradients_equal_separate_launches.)
+    per_block = {1024: 384, 1280: 600}[D]
     big = [t for t in descs if t >= 200]
-    assert len(big) >= depth and max(big) >= tiles, (sorted(set(descs)), tiles)
+    assert sum(big) >= per_block * (depth - 1), (sorted(set(descs)), per_block * depth)
+    assert max(big) >= {1024: 256, 1280: 450}[D]
     assert sum(t >= 0.8 * 256 * -(-t // 256) for t in big) >= len(big) - 1, sorted(set(big))
     hd = D // cfg["num_heads"]
     if hd == 80:
