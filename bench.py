@@ -77,12 +77,14 @@ def cpu_baseline(batch_size):
 
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of the dominant GEMM variant from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
-    WRITE_SIZE, separate passes: tools/run_pmc_bench.sh + tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json).  Counters
+    WRITE_SIZE, separate passes: tools/run_pmc_bench.sh + tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json).  Counters
     cannot be read from inside this process, so the number is the one measured for the default workload; any other
     workload reports null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path) or args.model != "vitb" or args.batch != 12 or args.dtype != "bf16":
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))     # the newest round's
+    if not found or args.model != "vitb" or args.batch != 12 or args.dtype != "bf16":
         return None
+    path = found[-1]
     tab = json.load(open(path))
     v = tab.get(kernel)
     if not v:

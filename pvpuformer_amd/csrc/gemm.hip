@@ -1871,7 +1871,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const int ring_env = g_opt_ring.load(std::memory_order_relaxed) >= 0 ? g_opt_ring.load(std::memory_order_relaxed) : ring_env0();
         static const int ring_min = [] { const char* e = getenv("VPU_GEMM_RING_MIN"); return e ? atoi(e) : 96; }();
         const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= ring_min && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
-        if (!ring && d->workspace && tiles < 192 && d->K >= 8 * BK) {
+        // (192 ... 256 tiles walking a long K -- the FPN's 2352-row convolution over K = 3072: 228 tiles, 48 K-tiles each on
+        // half of the 512 workgroup slots -- are cut in two as well: 55 -> ~35 us with the reduce)
+        if (!ring && d->workspace && (tiles < 192 || (tiles <= 256 && d->K >= 32 * BK)) && d->K >= 8 * BK) {
             int64_t want = (384 + tiles - 1) / tiles;
             const int64_t max_by_k = d->K / (4 * BK);
             const int64_t max_by_ws = (d->workspace_bytes - CNT_BYTES) / ((int64_t)d->batch * d->M * (d->N + 1) * 4);

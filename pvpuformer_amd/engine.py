@@ -815,9 +815,15 @@ class Engine:
                 def bwd_gate(xg=xg, qi=qi, ki=ki, cg=cg, sg=sg, aq=aq, ac=ac):
                     if xg.g is None:
                         return
-                    for v in (qi, ki):
-                        if v.g is None:
-                            v.g = torch.zeros_like(v.t)
+                    if any(v.g is None for v in (qi, ki)):
+                        # the gate gradients are scattered at arg-max positions into zeroed buffers: ONE fill for the
+                        # buffers of all three gates (their backward closures run back to back), not one per tensor
+                        pend = [v for pair in hs for v in pair if v.g is None]
+                        pool = torch.zeros(sum(v.t.numel() for v in pend), device=self.dev, dtype=self.td)
+                        o_ = 0
+                        for v in pend:
+                            v.g = pool[o_:o_ + v.t.numel()].view_as(v.t)
+                            o_ += v.t.numel()
                     accum = xr.g is not None
                     if not accum:
                         xr.g = torch.empty_like(xr.t)
