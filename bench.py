@@ -318,6 +318,7 @@ def main():
     # is enqueued -- an event pair then brackets the kernel alone instead of the kernel plus the host's lag.
     graph[0] = None                    # the instrumented step is enqueued eagerly (HIP events around every GEMM launch)
     # what the host needs to enqueue ONE step when nothing holds it back (empty queue: no back-pressure from the GPU)
+    step()                             # (the first eager step after a graph capture re-allocates its workspaces: not timed)
     sync()
     t1 = time.perf_counter()
     step()
