@@ -245,7 +245,7 @@ def main():
     def step_body():
         if not mode["overlap"]:
             eng.zero_grad()
-        mask = torch.bernoulli(torch.full((B, model.head.channels), keep, device=dev)) / keep
+        mask = ops.dropout_mask(B, model.head.channels, keep, dev)
         inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
         losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
         if mode["overlap"]:

@@ -173,6 +173,12 @@ int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* o
 /* dst[r][c] (dtype_dst, ld_dst) = src[r][c] (fp32/bf16, ld_src), zero-filling columns [cols, cols_pad) */
 int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst,
                int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
+/* Dropout2d channel mask of the segmentation head (reference: transformer_helper/decode_head.py:82-86,210-215,
+ * nn.Dropout2d(0.1) in train mode): out[i] = Bernoulli(keep) / keep for n = B * channels entries, from a counter-based
+ * generator keyed by (seed, call number, i); the call number lives in state[0] (one uint64 in device memory, zeroed by the
+ * caller once) and is advanced by the launch itself, so the call is capturable in a hipGraph and every replay draws a new
+ * mask.  Same (seed, call number) -> same mask. */
+int vpu_dropout_mask(float* out, int32_t n, float keep, uint64_t seed, uint64_t* state, void* stream);
 int vpu_fill_f32(float* p, float v, int64_t n, void* stream);
 /* Diagnostic only (tools/reserve_cus_experiment.py): `wgs` workgroups of 512 threads, ~96 registers per thread, 16 KiB of
  * LDS, spinning for ~`cycles` shader cycles -- the footprint of a collective's channel workgroups. */

@@ -58,6 +58,7 @@ SIGNATURES = {
     "vpu_add_bcast": [_P, _P, _P, _L, _L, _I, _P],
     "vpu_add4": [_P, _P, _P, _P, _P, _L, _I, _P],
     "vpu_cast2d": [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P],
+    "vpu_dropout_mask": [_P, _I, _F, C.c_uint64, _P, _P],
     "vpu_fill_f32": [_P, _F, _L, _P],
     "vpu_debug_spin": [_P, _I, _L, _P],
     "vpu_sigmoid_to_channel": [_P, _P, _I, _L, _I, _I, _P],

@@ -563,8 +563,36 @@ __global__ __launch_bounds__(256) void sigmoid_to_channel_kernel(const float* __
         out[b * batch_stride + ch_off + r] = 1.0f / (1.0f + expf(-logits[i]));
     }
 }
+// Dropout2d channel mask (decode_head.py:82-86,210-215: one Bernoulli(keep) draw per (sample, channel), scaled by 1 / keep):
+// a counter-based generator -- splitmix64 of (seed, call number, element) -- with the call number kept in device memory
+// and advanced by the kernel itself, so a hipGraph replay of the step draws a fresh mask every time without host work.
+// One workgroup: every thread reads the call number before the barrier, thread 0 advances it after.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, int n, float keep, float inv_keep,
+                                                           unsigned long long seed, unsigned long long* __restrict__ state) {
+    const unsigned long long call = state[0];
+    __syncthreads();
+    if (threadIdx.x == 0) state[0] = call + 1;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        unsigned long long x = seed + call * 0x9E3779B97F4A7C15ULL + (unsigned long long)(i + 1) * 0xD1B54A32D192ED03ULL;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+        x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+        x ^= x >> 31;
+        const float u = (float)(x >> 40) * (1.0f / 16777216.0f);      // 24 uniform bits in [0, 1)
+        out[i] = u < keep ? inv_keep : 0.f;
+    }
+}
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+    // 16-byte stores over the aligned body (the 489-MB gradient buffer is cleared with this every step: 63 us), scalar
+    // stores for the unaligned head / tail
+    const int64_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2;
+    const int64_t h = head < n ? head : n, n4 = (n - h) >> 2;
+    float4* q = reinterpret_cast<float4*>(p + h);
+    const float4 v4 = make_float4(v, v, v, v);
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    for (int64_t i = tid; i < n4; i += nth) q[i] = v4;
+    if (tid < h) p[tid] = v;
+    const int64_t tail = h + 4 * n4;
+    if (tail + tid < n) p[tail + tid] = v;
 }
 
 }  // namespace
@@ -766,6 +794,15 @@ extern "C" int vpu_debug_spin(float* sink, int32_t wgs, int64_t cycles, void* st
     if (wgs < 1 || wgs > 256 || cycles < 0 || cycles > 240000000LL) { vpu_set_error("debug_spin: 1 <= wgs <= 256, cycles <= 2.4e8"); return VPU_ERR_ARG; }
     debug_spin_kernel<<<wgs, 512, 0, ST>>>(sink, (long long)cycles);
     return vpu_check_launch("vpu_debug_spin");
+}
+extern "C" int vpu_dropout_mask(float* out, int32_t n, float keep, uint64_t seed, uint64_t* state, void* stream) {
+    vpu_clear_stale_error();
+    if (!out || !state || n < 1 || n > (1 << 22) || !(keep > 0.f && keep <= 1.f)) {
+        vpu_set_error("dropout_mask: non-null out / state, 1 <= n <= 2^22, 0 < keep <= 1");
+        return VPU_ERR_ARG;
+    }
+    dropout_mask_kernel<<<1, 256, 0, ST>>>(out, n, keep, 1.0f / keep, (unsigned long long)seed, reinterpret_cast<unsigned long long*>(state));
+    return vpu_check_launch("vpu_dropout_mask");
 }
 extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
     vpu_clear_stale_error();

@@ -236,7 +236,7 @@ class Engine:
         return k
 
     def zero_grad(self):
-        self.gflat.zero_()
+        ops.zero_(self.gflat)
 
     def attach_grads(self):
         """``param.grad`` must be the views of the flat gradient buffer the kernels accumulate into.  A caller that ran
@@ -819,7 +819,7 @@ class Engine:
                         # the gate gradients are scattered at arg-max positions into zeroed buffers: ONE fill for the
                         # buffers of all three gates (their backward closures run back to back), not one per tensor
                         pend = [v for pair in hs for v in pair if v.g is None]
-                        pool = torch.zeros(sum(v.t.numel() for v in pend), device=self.dev, dtype=self.td)
+                        pool = ops.zero_(torch.empty(sum(v.t.numel() for v in pend), device=self.dev, dtype=self.td))
                         o_ = 0
                         for v in pend:
                             v.g = pool[o_:o_ + v.t.numel()].view_as(v.t)
@@ -1142,7 +1142,7 @@ class Engine:
         S = (red + kchunk - 1) // kchunk
         slab = self._new(sum(S * e[0][3] * e[0][4] for e in part), dtype=torch.float32)
         nb = sum(S * e[0][3] for e in part if e[1].get("colsum") is not None)
-        bslab = torch.zeros(max(nb, 1), device=self.dev, dtype=torch.float32)   # the fused column sums accumulate
+        bslab = ops.zero_(torch.empty(max(nb, 1), device=self.dev, dtype=torch.float32))   # the fused column sums accumulate
         sub, jobs, so, bo = [], [], 0, 0
         adv = lambda t, n: (t[0], t[1] + n) if isinstance(t, tuple) else (t, n)
         for args, kw, _, _ in part:

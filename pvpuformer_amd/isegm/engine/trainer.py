@@ -31,8 +31,8 @@ def vpu_step_losses(inst, aux, gt, slot_idx=None, override=None, iter_weight=1.0
         ops.p2cl_fwd_bwd(aux, gt, slot_idx, override, part, d_aux, gs, B, S, H, W)
     else:
         d_aux = torch.empty_like(sim_low) if want_grads else None
-        ops.p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, part, d_aux, gs, B, S, sim_low.shape[2], sim_low.shape[3],
-                            H, W)
+        part = ops.p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, None, d_aux, gs, B, S, sim_low.shape[2],
+                                   sim_low.shape[3], H, W)
     res = torch.empty(4, device=dev)
     ops.loss_finalize(out, part, B, part.numel(), 1.0 / (B * S * H * W), w_nfl, w_dice, w_pcl, iter_weight, res)
     return {"total": res[0], "nfl": res[1], "dice": res[2], "p2cl": res[3]}, d_inst, d_aux
@@ -146,7 +146,7 @@ class VPUTrainStep:
             mask = None
             if self.model.training and self.model.head.dropout_ratio > 0:
                 keep = 1.0 - self.model.head.dropout_ratio
-                mask = torch.bernoulli(torch.full((B, self.model.head.channels), keep, device=dev)) / keep
+                mask = ops.dropout_mask(B, self.model.head.channels, keep, dev)
             if record is not None:
                 record.append(dict(points=points.clone(), boxes=boxes.clone(), ptype=ptype, net_input=net_input.clone(),
                                    slot_idx=state.slot_idx.clone(), override=state.override.clone()))

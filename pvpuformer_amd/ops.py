@@ -252,6 +252,29 @@ def debug_spin(sink, wgs, cycles):
     _lib.call("vpu_debug_spin", ptr(sink), int(wgs), int(cycles), _stream())
 
 
+_drop_state = {}
+
+
+def dropout_mask(B, channels, keep, device, seed=None):
+    """Dropout2d mask [B, channels] fp32 (values 0 or 1 / keep) from vpu_dropout_mask: one launch, capturable; the stream of
+    masks is a function of ``seed`` (default: torch.initial_seed() at the first call on that device) and the call count."""
+    key = torch.device(device)
+    if key not in _drop_state:
+        _drop_state[key] = (torch.zeros(1, dtype=torch.int64, device=key), int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1))
+    state, sd = _drop_state[key]
+    out = torch.empty(B, channels, device=key, dtype=torch.float32)
+    _lib.call("vpu_dropout_mask", ptr(out), B * channels, float(keep), sd, ptr(state), _stream())
+    return out
+
+
+def zero_(t):
+    """t <- 0 through vpu_fill_f32 (any dtype whose size in bytes is a multiple of 4 per buffer: zero bits are zero bits)."""
+    nbytes = t.numel() * t.element_size()
+    assert t.is_contiguous() and nbytes % 4 == 0
+    _lib.call("vpu_fill_f32", ptr(t), 0.0, nbytes // 4, _stream())
+    return t
+
+
 def fill_f32(t, v, n=None):
     _lib.call("vpu_fill_f32", ptr(t), v, t.numel() if n is None else n, _stream())
 
@@ -390,12 +413,16 @@ def p2cl_fwd_bwd(prob, gt, slot_idx, override, loss_part, dprob, grad_scale, B, 
 
 
 def p2cl_up_fwd_bwd(sim_low, gt, slot_idx, override, loss_part, dsim_low, grad_scale, B, S, h, w, H, W):
-    """loss_part fp32 [B, S]: per-plane sums (the kernel's per-band partials are summed here)."""
+    """loss_part fp32 [B, S]: per-plane sums (the kernel's per-band partials are summed here); ``loss_part`` None: the
+    per-band partials [B * S, nband] themselves are returned (their total is all vpu_loss_finalize needs: no extra launch)."""
     nband = _lib.load().vpu_p2cl_up_nband(h, w)
     bands = torch.empty(B * S, nband, device=sim_low.device, dtype=torch.float32)
     _lib.call("vpu_p2cl_up_fwd_bwd", ptr(sim_low), ptr(gt), ptr(slot_idx), ptr(override), ptr(bands), ptr(dsim_low),
               grad_scale, B, S, h, w, H, W, _stream())
+    if loss_part is None:
+        return bands
     torch.sum(bands, dim=1, out=loss_part.view(B * S))
+    return loss_part
 
 
 def nfl_dice_fwd_bwd(logits, gt, sums, out, dlogits, w_nfl, w_dice, B, HW):

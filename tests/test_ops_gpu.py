@@ -1335,3 +1335,35 @@ def test_gemm_k2_grouped_wgrad(ops):
         assert torch.equal(Cd.cpu(), ref), (Cd.cpu() - ref).abs().max()
         if cs is not None:
             assert torch.equal(cs.cpu(), csref)
+
+
+def test_dropout_mask_and_fill(ops):
+    """vpu_dropout_mask: values in {0, 1 / keep}, kept fraction ~ keep, a new mask per call (the call number lives on the
+    device and is advanced by the launch -- also inside a replayed hipGraph), the same stream of masks for the same seed;
+    ops.zero_ (vpu_fill_f32 with 16-byte stores) on aligned and unaligned, odd-sized buffers."""
+    from pvpuformer_amd import ops as O
+    O._drop_state.clear()
+    a = [O.dropout_mask(12, 256, 0.9, "cuda", seed=77) for _ in range(3)]
+    assert all(tuple(m.shape) == (12, 256) for m in a)
+    for m in a:
+        vals = set(torch.unique(m).tolist())
+        assert vals <= {0.0, float(torch.tensor(1 / 0.9, dtype=torch.float32))} and len(vals) == 2
+        assert 0.85 < float((m > 0).float().mean()) < 0.95
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[1], a[2])
+    g = torch.cuda.CUDAGraph()
+    out = []
+    with torch.cuda.graph(g):
+        captured = O.dropout_mask(12, 256, 0.9, "cuda")
+    for _ in range(2):
+        g.replay(); torch.cuda.synchronize(); out.append(captured.clone())
+    assert not torch.equal(out[0], out[1])
+    O._drop_state.clear()
+    b = [O.dropout_mask(12, 256, 0.9, "cuda", seed=77) for _ in range(3)]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    O._drop_state.clear()
+    for n, off in ((1 << 20, 0), (1000003, 1), (7, 3), (3, 0)):
+        buf = torch.full((n + 8,), 5.0, device="cuda")
+        O.zero_(buf[off:off + n])
+        assert float(buf[off:off + n].abs().sum()) == 0.0 and float(buf[:off].sum()) == 5.0 * off and float(buf[off + n:].sum()) == 5.0 * (8 - off)
+    h = torch.full((1001,), 3.0, device="cuda", dtype=torch.bfloat16)[:1000]
+    assert float(O.zero_(h).float().abs().sum()) == 0.0
