@@ -1097,6 +1097,7 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
         const char* sQ = ldsQ + qc * HD * 2;
         const char* sO = ldsO + qc * HD * 2;
         char* const sS = ldsS + b * (WIN_LDS_S / 2);
+        bf16x8_t pf[2], dsf[2];
         {
             f32x4_t P[2][2], dS[2][2];
 #pragma unroll
@@ -1132,17 +1133,19 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
                     }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                    const bf16x8_t pf = pack_pair(P[u][0], P[u][1]), dsf = pack_pair(dS[u][0], dS[u][1]);
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const bf16x8_t otf = frag_tr_perm<HD>(sO, dt, lane), qtf = frag_tr_perm<HD>(sQ, dt, lane);
-                        adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, otf, adv[u][dt], 0, 0, 0);
-                        adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, qtf, adk[u][dt], 0, 0, 0);
-                    }
-                }
+            for (int u = 0; u < 2; ++u) { pf[u] = pack_pair(P[u][0], P[u][1]); dsf[u] = pack_pair(dS[u][0], dS[u][1]); }
         }
         __syncthreads();     // the dS image of block i is complete (and everybody has finished reading the image of block i - 1)
+        // everything that does not feed the barrier comes after it: the waves reach it sooner and then have 23 independent
+        // MFMAs (dV, dK and the dQ tile) to issue while the next block's fragment reads are in flight
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8_t otf = frag_tr_perm<HD>(sO, dt, lane), qtf = frag_tr_perm<HD>(sQ, dt, lane);
+                adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], otf, adv[u][dt], 0, 0, 0);
+                adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[u], qtf, adk[u][dt], 0, 0, 0);
+            }
         dq_block(i);
     }
 #pragma unroll
