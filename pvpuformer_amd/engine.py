@@ -136,6 +136,7 @@ class Engine:
         pk = os.environ.get("VPU_WGRAD_PACK", "")
         self.pack_wgrad = pk == "1" or (pk != "0" and blk < 0.95 * 256)
         self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
+        self._pending_reports, self._reporting = [], False    # gradient ranges whose marker has been passed but not reported yet
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
         self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
@@ -318,9 +319,9 @@ class Engine:
                 # group holds eight problems)
                 anchors = [e for e in same if not self._is_rider(e)]
                 T = sum(self._k2_tiles(e) for e in anchors)
-                if self.pack_wgrad and self.grad_ready_hook is None:
+                if self.pack_wgrad:
                     self._pack_seen[kind] = self._pack_seen.get(kind, 0) + self._k2_tiles(self._wq[-1])
-                    budget = self.pack_tiles(self._pack_total.get(kind))
+                    budget = self.pack_tiles(self._pack_total.get(kind), 256 - self._reserved_cus())
                     T = sum(self._k2_tiles(e) for e in same)          # riders count: they are packed like everything else
                     while T >= budget:
                         self.flush_wgrads(kind, ride=True, budget=budget)
@@ -995,16 +996,18 @@ class Engine:
         hi = self.total if next_name is None else self.names[next_name][0]
 
         def marker():
-            if self.ride_wgrad and self.grad_ready_hook is None and self.group_wgrad and self.dt == BF16 and not self.use_side:
-                # no reducer attached: nobody needs the range final here -- the long-reduction queue launches itself when
-                # its rounds are full (_wgrad), the short reductions go now
+            if self.ride_wgrad and self.group_wgrad and self.dt == BF16 and not self.use_side:
+                # the long-reduction queue launches itself when its rounds are full (_wgrad), the short reductions go now;
+                # with a reducer attached the range is reported as soon as nothing queued writes into it any more
                 self.flush_wgrads(0)
+                if self.grad_ready_hook is not None:
+                    self._pending_reports.append((lo, hi))
+                    self._report_ready()
                 return
             self.flush_wgrads()
             if self.grad_ready_hook is not None:
-                self.flush_colsums()       # the range must be final before it is handed to the reducer
-                self.join_side()
-                self.grad_ready_hook(lo, hi)
+                self._pending_reports.append((lo, hi))
+                self._report_ready()
         self.tape.append(marker)
 
     @staticmethod
@@ -1016,15 +1019,47 @@ class Engine:
         return e[3] > 2048 and self._k2_tiles(e) <= 16
 
     @staticmethod
-    def pack_tiles(total=None):
-        """Tiles per packed launch: one full round of the persistent 256 x 128 grid (one workgroup per CU) -- or, once the
-        previous backward pass has shown how many tiles of this reduction length a pass queues, that total spread evenly
-        over the ceil(total / 256) launches it needs anyway (2672 tiles: 11 launches of 243 instead of 10 of 256 and a
-        leftover launch that takes as long as a full one)."""
-        if not total or total < 256:
-            return 256
-        launches = (total + 255) // 256
+    def pack_tiles(total=None, cap=256):
+        """Tiles per packed launch: one full round of the persistent 256 x 128 grid (``cap`` workgroups: one per CU, minus the
+        CUs a reducer keeps free for RCCL) -- or, once the previous backward pass has shown how many tiles of this reduction
+        length a pass queues, that total spread evenly over the ceil(total / cap) launches it needs anyway (2672 tiles: 11
+        launches of 243 instead of 10 of 256 and a leftover launch that takes as long as a full one)."""
+        cap = max(64, cap & ~7)
+        if not total or total < cap:
+            return cap
+        launches = (total + cap - 1) // cap
         return (total + launches - 1) // launches
+
+    def _reserved_cus(self):
+        """CUs the attached reducer keeps out of the persistent GEMM grids while its buckets are in flight."""
+        red = getattr(self.grad_ready_hook, "__self__", None)
+        return int(getattr(red, "reserve_cus", 0) or 0) if self.grad_ready_hook is not None else 0
+
+    def _report_ready(self, final=False):
+        """Hands the finished gradient ranges to the reducer, in the order their markers were passed: a range is final once
+        no queued weight gradient writes into it any more (the queue rules -- packed launches, riders, groups held back for
+        a full round -- may carry the tail of a block's gradients into the next block's launch: its range then goes out one
+        block later, still inside backward).  Launches and collectives share the stream, so "enqueued" is "ordered"."""
+        if self.grad_ready_hook is None:
+            self._pending_reports = []
+            return
+        off_of = lambda t: t[1] if isinstance(t, tuple) else None
+        while self._pending_reports:
+            lo, hi = self._pending_reports[0]
+            if not final:
+                busy = False
+                for args, kw, _, _ in self._wq:
+                    o, c = off_of(args[2]), off_of(kw.get("colsum")) if kw.get("colsum") is not None else None
+                    if (o is not None and lo <= o < hi) or (c is not None and lo <= c < hi) or o is None:
+                        busy = True
+                        break
+                if busy:
+                    return
+            self._pending_reports.pop(0)
+            self.flush_colsums()       # the range must be final before it is handed to the reducer
+            if self.use_side:
+                self.join_side()
+            self.grad_ready_hook(lo, hi)
 
     @staticmethod
     def _split_entry(e, budget):
@@ -1131,6 +1166,12 @@ class Engine:
             for args, _, _, _ in self._wq:   # operands of the entries still queued stay frozen
                 for t in (args[0], args[1]):
                     self._frozen.add((t[0] if isinstance(t, tuple) else t).data_ptr())
+        if self._pending_reports and not self._reporting:
+            self._reporting = True       # (join_side inside _report_ready flushes again)
+            try:
+                self._report_ready()
+            finally:
+                self._reporting = False
 
     def _wgrad_sliced(self, part, red, tiles):
         """Few output tiles over a long reduction (the DMA neck's 768 x 384 projections over the 9408 image tokens: 72
@@ -1207,5 +1248,6 @@ class Engine:
         self.tape = Tape()
         self.join_side()          # every queued weight gradient is launched ...
         self.flush_colsums()      # ... before the batched column sums (norm-layer partials, slabs of the sliced reductions)
+        self._report_ready(final=True)
         if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0
             self.grad_ready_hook(0, self.names["backbone.blocks.0.norm1.weight"][0])
