@@ -173,7 +173,7 @@ class Engine:
         self.b_patch = torch.zeros(D, device=self.dev, dtype=torch.float32)
         self.w_lin1p = torch.zeros(2048, self.Epad, device=self.dev, dtype=self.td)
         self.pos_win = torch.zeros(self.NT, D, device=self.dev, dtype=self.td)
-        self._pos_cache, self._kpe_cache = {}, {}
+        self._pos_cache, self._kpe_cache, self._regrid_cache = {}, {}, {}
         self.shadow_valid = False
         if not self._const_ready:
             self.kpe = pos2d_table(D, self.g, self.g).to(self.dev).to(self.td)
@@ -209,6 +209,20 @@ class Engine:
         ops.window_permute(tmp, self.pos_win, 1, self.g, self.wg, D, to_raster=False)
         self._pos_cache = {self.g: self.pos_win}      # other grids are re-derived from the new weights on demand
         self.shadow_valid = True
+
+    def _regrid_adjoint(self, g):
+        """R^T fp32 [g0^2, g^2] of the bicubic re-gridding of the g0 x g0 position grid onto g x g (row s, column t: the
+        weight of trained position s in re-gridded position t), built once per grid from torch's own interpolate applied
+        to the unit maps on the host -- the same linear map ``_pos_for`` applies to the embedding."""
+        Rt = self._regrid_cache.get(g)
+        if Rt is None:
+            import torch.nn.functional as F
+            g0 = self.g
+            basis = torch.eye(g0 * g0, dtype=torch.float32).view(1, g0 * g0, g0, g0)
+            Rt = F.interpolate(basis, size=(g, g), mode="bicubic", align_corners=False).reshape(g0 * g0, g * g)
+            Rt = Rt.contiguous().to(self.dev)
+            self._regrid_cache[g] = Rt
+        return Rt
 
     def _pos_for(self, g):
         """Window-ordered position embedding for a g x g token grid.  The trained grid is used as it is; any other one
@@ -674,9 +688,6 @@ class Engine:
             raise ValueError(f"input {H}x{W_}: square inputs whose side is a multiple of the {P * self.wg}-pixel window")
         g = H // P
         NT, nw_side = g * g, g // self.wg
-        if training and g != self.g:
-            raise NotImplementedError("training at an input size other than the constructor's (the adjoint of the position "
-                                      "re-gridding is not built); evaluation works at any window multiple")
         pos_win, kpe_tab = self._pos_for(g), self._kpe_for(g)
         M = B * NT
         n = points.shape[1] // 2
@@ -717,7 +728,15 @@ class Engine:
                 r = self._new(NT * D, dtype=torch.float32)
                 ops.window_permute(s, r, 1, g, self.wg, D, to_raster=True)
                 gp = (self.gflat, self.names["backbone.pos_embed"][0] + D)
-                ops.add4(gp, r, None, None, gp, NT * D)
+                if g == self.g:
+                    ops.add4(gp, r, None, None, gp, NT * D)
+                else:
+                    # another input size: the tokens saw the bicubic re-gridding of pos_embed (pos_embed.py:99-128), a fixed
+                    # linear map R of the g0 x g0 grid onto the g x g one; its adjoint takes the gradient back:
+                    # d pos[g0^2, D] += R^T[g0^2, g^2] . d regridded[g^2, D]   (exact-fp32 GEMM into the flat gradient buffer)
+                    g0 = self.g
+                    ops.gemm(self._regrid_adjoint(g), r, gp, g0 * g0, D, NT, NT, D, D, F32, transB=True,
+                             flags=EPI_OUT_F32 | EPI_ACCUM)
             self.tape.append(bwd_patch)
         if taps is not None:
             taps["tokens0_win"] = x.t

@@ -12,6 +12,7 @@ import os
 import torch
 import torch.nn as nn
 
+from pvpuformer_amd import ops
 from ..utils.serialization import serialize
 from .is_model import ISModel
 from .modeling.models_vit import PatchEmbed, VisionTransformer
@@ -189,7 +190,7 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         drop_mask = None
         if self.training and self.head.dropout_ratio > 0:
             keep = 1.0 - self.head.dropout_ratio
-            drop_mask = torch.bernoulli(torch.full((image.shape[0], self.head.channels), keep, device=image.device)) / keep
+            drop_mask = ops.dropout_mask(image.shape[0], self.head.channels, keep, image.device)
         if torch.is_grad_enabled():
             inst, aux = _VPUFunction.apply(self._anchor, self, image, points, boxes, as_prompt_type, drop_mask, scribble)
         elif self.graph_inference and self.weights_frozen and drop_mask is None and image.is_cuda and scribble is None:

@@ -920,6 +920,58 @@ def test_eval_at_672_regrids_the_position_embedding(golden_dir):
         model(torch.zeros(1, 4, 448, 672, device="cuda"), -torch.ones(1, 2, 3, device="cuda"))
 
 
+def test_training_at_672_backpropagates_through_the_regridded_position_embedding(golden_dir):
+    """Training at an input size other than the constructor's (the reference trains at 448 only, but nothing in it forbids
+    another crop size once ``interpolate_pos_embed`` has run): forward + backward at 672^2 (42 x 42 tokens, 9 windows) in
+    the exact-fp32 engine mode against the CPU oracle whose ``pos_embed`` IS torch's differentiable bicubic re-gridding of
+    the trained 28 x 28 grid -- so autograd carries the gradient back to the trained embedding, and the engine's adjoint
+    (R^T applied by an fp32 GEMM, ``Engine._regrid_adjoint``) must give the same tensor.  Every compared gradient within
+    2e-3 of its norm, pos_embed element-wise."""
+    import torch.nn.functional as F
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    S, D, g0 = 672, cfg["embed_dim"], cfg["img"] // cfg["patch"]
+    g = S // cfg["patch"]
+    big = vo.synth_batch(2, S, seed=9)
+    x = torch.cat([big["images"], torch.zeros(2, 1, S, S)], 1)
+    x[0, 3] = torch.sigmoid(4 * (big["instances"][0, 0] - 0.5))
+    pts, gt = big["points"], big["instances"]
+    model.train()
+    model.head.dropout_ratio = 0.0
+    model.zero_grad()
+    out = model(x.cuda(), pts.cuda())
+    total, parts = vo.step_loss(out, gt.cuda(), vo.ed_mask_label(gt.cuda()))
+    total.backward()
+    # ---- oracle: the same forward with pos_embed = regrid(trained pos_embed), differentiable
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    pe = sdg["backbone.pos_embed"]                                        # [1, 1 + g0^2, D]
+    grid = pe[:, 1:].reshape(1, g0, g0, D).permute(0, 3, 1, 2)
+    new = F.interpolate(grid, size=(g, g), mode="bicubic", align_corners=False).permute(0, 2, 3, 1).reshape(1, g * g, D)
+    sd2 = dict(sdg)
+    sd2["backbone.pos_embed"] = torch.cat([pe[:, :1], new], 1)
+    pue = vo.pue_click(pts.numpy(), cfg["num_max_points"], cfg["img"])      # prompt vectors at the constructor's size
+    ref = vo.vpu_forward(sd2, dict(cfg, img=S), x, pts, None, 0, pue_override=pue)
+    tref, _ = vo.step_loss(ref, gt, vo.ed_mask_label(gt))
+    tref.backward()
+    assert abs(total.item() - tref.item()) < 2e-4 * abs(tref.item())
+    assert _relerr(out["instances"].detach().cpu().numpy(), ref["instances"].detach().numpy()) < 1e-3
+    params = dict(model.named_parameters())
+    gpe, rpe = params["backbone.pos_embed"].grad.cpu(), sdg["backbone.pos_embed"].grad
+    assert float(rpe[:, 1:].norm()) > 1e-4 and float(gpe[:, :1].abs().max()) == 0.0          # (the cls slot is unused)
+    np.testing.assert_allclose(gpe[:, 1:].numpy(), rpe[:, 1:].numpy(), rtol=5e-3, atol=2e-3 * float(rpe.abs().max()))
+    for n in ("backbone.patch_embed.proj.weight", "backbone.blocks.0.attn.qkv.weight", "backbone.blocks.7.mlp.fc2.weight",
+              "neck.att.layers.1.cross_attn_image_to_token.q_proj.weight", "neck.down_4.0.weight", "head.conv_seg.weight"):
+        a, b = params[n].grad.cpu(), sdg[n].grad
+        assert abs(float(a.norm()) - float(b.norm())) < 2e-3 * float(b.norm()) + 1e-8, n
+    # ... and the model still trains at its own size afterwards
+    model.zero_grad()
+    out = _run(model, img4, batch, 0)
+    gt0 = batch["instances"].cuda()
+    t0, _ = vo.step_loss(out, gt0, vo.ed_mask_label(gt0))
+    np.testing.assert_allclose(t0.item(), fx["click_loss"][0], rtol=2e-4)
+    model.eval()
+    model.head.dropout_ratio = 0.1
+
+
 def _check_fp32_grads_against_fixture(model, fx, mode, rtol_norm=2e-3):
     """every gradient norm and the stored full gradients / slices of the fixture"""
     names = [str(n) for n in fx[f"{mode}_grad_names"]]
