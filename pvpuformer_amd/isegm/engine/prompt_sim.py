@@ -143,16 +143,17 @@ def cal_scribble(gt_mask, min_p=3, max_p=10, num_samples=1000, rng=random, np_rn
     for b in range(B):
         if not np.any(gt_mask[b]):
             continue
-        rc = np.argwhere(max_connected_regions(gt_mask[b]) == 1)       # (row, col) pixels of the kept region
-        num_p = rng.randint(min_p, max_p)
-        r0, r1, c0, c1 = rc[:, 0].min(), rc[:, 0].max(), rc[:, 1].min(), rc[:, 1].max()
+        region = max_connected_regions(gt_mask[b]) == 1                # the kept region (its pixels in raster order are the
+        num_p = rng.randint(min_p, max_p)                              # reference's point list: a row of it = that row's columns)
+        rows_any, cols_any = np.flatnonzero(region.any(1)), np.flatnonzero(region.any(0))
+        r0, r1, c0, c1 = rows_any[0], rows_any[-1], cols_any[0], cols_any[-1]
         gap = int(r1 - r0) // num_p
         ctrl, lo = [], int(r0)
         for _ in range(num_p):
             row = rng.randint(lo, lo + gap - 1) if gap > 0 else rng.randint(lo, lo + gap)
-            cand = rc[rc[:, 0] == row]
+            cand = np.flatnonzero(region[row]) if 0 <= row < region.shape[0] else ()
             if len(cand):
-                ctrl.append(cand[rng.randint(0, len(cand) - 1)])
+                ctrl.append((row, cand[rng.randint(0, len(cand) - 1)]))
             lo += gap
         if not ctrl:
             continue

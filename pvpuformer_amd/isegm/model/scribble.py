@@ -7,6 +7,7 @@ from the list before the next draw -- so its numbers match the reference only wh
 same generator.  It touches <= 1000 points per sample; the results (2 x img float64 per sample) go to the GPU once
 (``ops.pue_scribble_rows``)."""
 import random as _random
+from bisect import bisect_left
 
 import numpy as np
 
@@ -27,21 +28,31 @@ def scribble_profiles(scribbles, rects, img, rng=None):
             continue
         xc, yc, bw, bh = (min(int(v), img) for v in rect)
         left, top = xc - bw // 2, yc - bh // 2
-        alive = np.ones(len(pts), bool)                # rows still in the list
-        px, py = pts[:, 0], pts[:, 1]
+        # the list of points still alive (ascending original index), how many of them sit in each column / row, and the
+        # copies of each distinct point: the same walk as a mask-and-count per column, without a pass over all points per step
+        px, py = pts[:, 0].tolist(), pts[:, 1].tolist()
+        alive = list(range(len(px)))
+        cx, cy, copies = {}, {}, {}
+        for i, (x, y) in enumerate(zip(px, py)):
+            cx[x] = cx.get(x, 0) + 1
+            cy[y] = cy.get(y, 0) + 1
+            copies.setdefault((x, y), []).append(i)
         for col in range(bw):
-            k = int(np.count_nonzero(alive & (px == col)))
+            k = cx.get(col, 0)
             if k:
-                live = np.flatnonzero(alive)
-                x, y = pts[live[rng.randint(0, k - 1)]]
-                out[b, col] = np.exp(-((int(y) - top) ** 2) / 18)
-                alive &= ~((px == x) & (py == y))      # every copy of the chosen point leaves the list
+                i = alive[rng.randint(0, k - 1)]       # (the drawn number indexes the LIST, not the column's points)
+                x, y = px[i], py[i]
+                out[b, col] = np.exp(-((y - top) ** 2) / 18)
+                gone = copies.pop((x, y))              # every copy of the chosen point leaves the list
+                for j in gone:
+                    del alive[bisect_left(alive, j)]
+                cx[x] -= len(gone)
+                cy[y] -= len(gone)
         for row in range(bh):
-            k = int(np.count_nonzero(alive & (py == row)))
+            k = cy.get(row, 0)
             if k:
-                live = np.flatnonzero(alive)
-                x, _ = pts[live[rng.randint(0, k - 1)]]
-                out[b, img + row] = np.exp(-((int(x) - left) ** 2) / 18)
+                x = px[alive[rng.randint(0, k - 1)]]
+                out[b, img + row] = np.exp(-((x - left) ** 2) / 18)
     return out
 
 
