@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         }
     }
 }
+// one 16-byte group per thread and no grid-stride loop: 8192 workgroups walking the 123 M parameters took 851 us per launch,
+// 32768 took 731, one group per thread (120 k workgroups) 671 (tools/run_stats.sh, VPU_ADAM_GRID)
+inline int adam_grid_cap() {
+    static const int v = [] { const char* e = getenv("VPU_ADAM_GRID"); return e ? atoi(e) : (1 << 22); }();
+    return v;
+}
 }  // namespace
 
 extern "C" int vpu_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
@@ -86,8 +92,7 @@ extern "C" int vpu_adam_step(float* p, const float* g, float* m, float* v, void*
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     const int64_t n4 = (n + 3) / 4;
-    static const int grid_cap = [] { const char* e = getenv("VPU_ADAM_GRID"); return e ? atoi(e) : 8192; }();
-    adam_kernel<<<vpu_grid_for(n4, 256, grid_cap), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    adam_kernel<<<vpu_grid_for(n4, 256, adam_grid_cap()), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         p, g, m, v, (bf16_t*)shadow_bf16, n4, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, nullptr,
         nullptr, nullptr, 0, 0, nullptr);
     return vpu_check_launch("vpu_adam_step");
@@ -105,7 +110,7 @@ extern "C" int vpu_adam_step_groups(float* p, const float* g, float* m, float* v
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     const int64_t n4 = (n + 3) / 4;
-    adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    adam_kernel<<<vpu_grid_for(n4, 256, adam_grid_cap()), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         p, g, m, v, (bf16_t*)shadow_bf16, n4, n, 0.f, beta1, beta2, eps, 0.f, bc1, bc2s, grad_scale, seg_end, seg_lr,
         seg_wd, nseg, decoupled_wd, nullptr);
     return vpu_check_launch("vpu_adam_step_groups");
@@ -121,7 +126,7 @@ extern "C" int vpu_adam_step_hyper(float* p, const float* g, float* m, float* v,
         return VPU_ERR_ARG;
     }
     const int64_t n4 = (n + 3) / 4;
-    adam_kernel<<<vpu_grid_for(n4, 256, 8192), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    adam_kernel<<<vpu_grid_for(n4, 256, adam_grid_cap()), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         p, g, m, v, (bf16_t*)shadow_bf16, n4, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, seg_end, seg_scale,
         seg_wd, nseg > 0 ? nseg : 0, decoupled_wd, hyper);
     return vpu_check_launch("vpu_adam_step_hyper");
