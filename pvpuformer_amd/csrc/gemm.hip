@@ -2225,6 +2225,38 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             return vpu_check_launch("vpu_gemm_grouped");
         }
     }
+    // K2 form for forward / dgrad groups whose 256 x 128 tiles fill most of the chip (the DMA neck's image-side K / V
+    // projections: two 9408 x 384 x 768 problems = 222 tiles; as 128 x 128 tiles in the general grouped kernel 28 us)
+    static const int k2g_fwd = [] { const char* e = getenv("VPU_GEMM_K2G_FWD"); return e ? atoi(e) : 1; }();
+    if (k2g_fwd && key <= 1 && k2_opt() > 0 && vec) {
+        bool ok = true;
+        int total2 = 0;
+        vpu_gemm_group g2 = ga;
+        for (int i = 0; i < n; ++i) {
+            const vpu_gemm_desc* d = descs + i;
+            ok = ok && d->K % BK == 0 && d->K >= 512 && d->N % 8 == 0 && d->alpha == 1.0f && !d->colsum &&
+                 (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL;
+            g2.start[i] = total2;
+            total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128);
+        }
+        for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g2.start[i] = total2;
+        if (ok && total2 >= 192) {
+            const int ncu = cu_count();
+            static bool attr0 = false, attr1 = false;
+            if (key == 0) {
+                auto kern_ = gemm_bf16_k2_grouped_kernel<0, 0, false>;
+                if (!attr0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); attr0 = true; }
+                NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 0, false>");
+                kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
+            } else {
+                auto kern_ = gemm_bf16_k2_grouped_kernel<0, 1, false>;
+                if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); attr1 = true; }
+                NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 1, false>");
+                kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
+            }
+            return vpu_check_launch("vpu_gemm_grouped");
+        }
+    }
     // K2 form: weight-gradient groups over a long reduction whose 256 x 128 tiles fill most of the chip
     if (key == 3 && k2_opt() > 0 && vec) {
         bool ok = true;
