@@ -1,8 +1,9 @@
 """Import harness for the read-only reference at /root/reference (build container only).
 
-TEST INFRASTRUCTURE.  Only ``oracle/make_golden.py`` uses this file; nothing under
-``pvpuformer_amd/``, ``bench.py`` or the ``-m gpu`` tests may import it (``/root/reference``
-does not exist on the GPU box).
+TEST INFRASTRUCTURE.  Only ``oracle/make_golden.py`` (fixture generation) and
+``tests/test_overlay_reference_cpu.py`` (the overlay against the real checkout; skipped where
+``/root/reference`` is absent) use this file; nothing under ``pvpuformer_amd/``, ``bench.py`` or
+the ``-m gpu`` tests may import it (``/root/reference`` does not exist on the GPU box).
 
 The reference imports several third-party packages that are absent from this image
 (cv2, mmcv, timm, easydict, torchvision, tensorboard).  Nothing of their arithmetic is

@@ -1095,6 +1095,16 @@ def test_one_pass_window_backward(ops, n, nb, H):
             res[onepass] = dqkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4)
     finally:
         ops.attn_set_option("onepass", -1)
+    # no atomics, no cross-wave reduction whose order could vary: the same launch gives the same bits every time
+    ops.attn_set_option("onepass", 1)
+    try:
+        for _ in range(4):
+            again = torch.full_like(qkv, float("nan"))
+            ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, torch.zeros(nb * H, n, device="cuda"), again, (again, D),
+                         (again, 2 * D), nb, H, n, hd, 3 * D, D, 3 * D, scale)
+            assert torch.equal(again.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4), res[1])
+    finally:
+        ops.attn_set_option("onepass", -1)
     for i, name in enumerate("qkv"):
         ref_g = x.grad[i]
         sc = ref_g.abs().max().item()
