@@ -492,6 +492,60 @@ def test_nobrs_click_loop_iou_parity(golden_dir, zoom):
         assert np.array_equal(a, b)
 
 
+def test_nobrs_davis_setting_zoom_672(golden_dir):
+    """Config 3 as the evaluation script runs DAVIS (scripts/evaluate_vpumodel.py:125,187-192): position embeddings
+    re-gridded for 672 x 672 (``interpolate_pos_embed_inference``), ZoomIn with ``target_size=(672, 672)``, flip TTA, on a
+    non-square 480 x 854 frame -- six oracle clicks through the predictor mirror on the HIP model (exact-fp32 mode) against
+    the same loop on the CPU oracle network fed the re-gridded embedding: identical click packing, IoU series within 1e-3."""
+    from pvpuformer_amd.isegm.inference.clicker import Clicker
+    from pvpuformer_amd.isegm.inference.predictors import get_predictor
+    from pvpuformer_amd.isegm.inference.utils import get_iou
+    from pvpuformer_amd.isegm.model.modeling.pos_embed import interpolate_pos_embed_inference, regridded_pos_embed
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    S = 672
+    interpolate_pos_embed_inference(model.backbone, (S, S), "cuda")
+    sd2 = dict(sd)
+    sd2["backbone.pos_embed"] = regridded_pos_embed(model.backbone, (S, S)).cpu()
+    cfg2 = dict(cfg, img=S)
+
+    class OracleNet:
+        with_prev_mask = True
+
+        def __call__(self, image, points, prompts=None, as_prompt_type=0):
+            assert tuple(image.shape[-2:]) == (S, S)
+            pue = vo.pue_click(points.cpu().float().numpy(), cfg["num_max_points"], cfg["img"])   # the constructor's size
+            with torch.no_grad():
+                out = vo.vpu_forward(sd2, cfg2, image.cpu().float(), points.cpu().float(), None, 0, pue_override=pue)
+            return {k: v.to(image.device) for k, v in out.items()}
+
+    H, W = 480, 854
+    g = np.random.RandomState(5)
+    image = (g.rand(H, W, 3) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    gt = ((((yy - 260) / 120.0) ** 2 + ((xx - 500) / 210.0) ** 2 <= 1.0) | ((yy > 100) & (yy < 180) & (xx > 300) & (xx < 420))).astype(np.int32)
+    zoom = dict(skip_clicks=-1, target_size=(S, S))
+    series = {}
+    model.weights_frozen = True
+    for name, net in (("oracle", OracleNet()), ("hip", model)):
+        pred = get_predictor(net, "NoBRS", "cuda", with_flip=True, zoom_in_params=zoom)
+        pred.set_input_image(image)
+        clicker = Clicker(gt_mask=gt)
+        mask = np.zeros_like(gt, dtype=bool)
+        ious, packed = [], []
+        for i in range(6):
+            clicker.make_next_click(mask)
+            probs, prompts = pred.get_vqu_prediction(clicker, gt_mask=gt, as_prompt_type=0, click_indx=i)
+            assert probs.shape == gt.shape
+            packed.append(prompts[0].cpu().numpy())
+            mask = probs > 0.49
+            ious.append(float(get_iou(gt, mask)))
+        series[name] = (ious, packed)
+    model.weights_frozen = False
+    for a, b in zip(series["hip"][1], series["oracle"][1]):
+        assert np.array_equal(a, b)
+    assert np.abs(np.array(series["hip"][0]) - np.array(series["oracle"][0])).max() <= 1e-3, series
+
+
 def test_fused_adam_layerwise_decay_step(golden_dir):
     """f3: one optimizer step through get_optimizer_with_layerwise_decay on the tiny model equals torch.optim.Adam with
     the reference's param groups on a copy of the parameters and gradients (weight decay 0.02 on matrices of the
