@@ -281,6 +281,14 @@ class Engine:
     def _new(self, *shape, dtype=None):
         return torch.empty(shape, device=self.dev, dtype=dtype or self.td)
 
+    def _upload(self, t, dtype):
+        """Prompt tensors as contiguous ``dtype`` on the device.  Host tensors (the stroke simulator's curves and profiles)
+        go through pinned memory with an asynchronous copy: a pageable copy blocks the host until everything queued on
+        the stream before it has run -- the whole previous step."""
+        if t.is_cuda:
+            return t.to(dtype=dtype).contiguous()
+        return t.to(dtype).contiguous().pin_memory().to(self.dev, non_blocking=True)
+
     def acc(self, var, g, take=False):
         """var.g += g.  ``take``: g may become var.g itself (caller guarantees g is dead afterwards)."""
         if var.g is None:
@@ -691,14 +699,14 @@ class Engine:
         pos_win, kpe_tab = self._pos_for(g), self._kpe_for(g)
         M = B * NT
         n = points.shape[1] // 2
-        points = points.to(self.dev).contiguous().float()
+        points = self._upload(points, torch.float32)
         use_box = prompt_type == 1
         if use_box:
-            boxes = boxes.to(device=self.dev, dtype=torch.int32).contiguous()
+            boxes = self._upload(boxes, torch.int32)
         use_scr = prompt_type == 2
         if use_scr:
-            curve = scribble[0].to(device=self.dev, dtype=torch.int32).contiguous()
-            prof = scribble[1].to(device=self.dev, dtype=torch.float64).contiguous()
+            curve = self._upload(scribble[0], torch.int32)
+            prof = self._upload(scribble[1], torch.float64)
             assert curve.shape[0] == B and tuple(prof.shape) == (B, 2 * self.img)
         # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
         disks = self._new(B, 2, H, W_, dtype=torch.float32)

@@ -60,8 +60,13 @@ def max_connected_regions(mask):
     labels, n = ndimage.label(mask, structure=_EIGHT)
     if n == 0:
         return labels.astype(np.int64)
-    # the reference relabels the image once per component (O(n * H * W)); the same scan on the component sizes: a label
-    # is evaluated before anything can be merged into it, so its size at that moment is its original size
+    return _kept_labels(labels, n)[labels].astype(np.int8)
+
+
+def _kept_labels(labels, n):
+    """bool [n + 1]: which of the labels 1..n ``max_connected_regions`` keeps.  The reference relabels the image once per
+    component (O(n * H * W)); the same scan on the component sizes: a label is evaluated before anything can be merged
+    into it, so its size at that moment is its original size."""
     counts = np.bincount(labels.ravel(), minlength=n + 1)
     total = int(counts[1:].sum())
     target = np.arange(n + 1)
@@ -74,7 +79,21 @@ def max_connected_regions(mask):
             target[j] = max_pixel
     keep = target == max_pixel
     keep[0] = False
-    return keep[labels].astype(np.int8)
+    return keep
+
+
+def _kept_region_crop(mask):
+    """``max_connected_regions(mask) == 1`` restricted to the bounding box of the foreground: (bool crop, first row, first
+    column), or None for an empty mask -- what the stroke simulator needs, without the full-size passes."""
+    mask = np.asarray(mask)
+    rows = np.flatnonzero(mask.any(1))
+    if len(rows) == 0:
+        return None
+    cols = np.flatnonzero(mask.any(0))
+    crop = mask[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1]
+    labels, n = ndimage.label(crop, structure=_EIGHT)
+    region = (labels > 0) if n == 1 else _kept_labels(labels, n)[labels]
+    return region, int(rows[0]), int(cols[0])
 
 
 def _first_free(points_b, lo, hi, default):
@@ -141,19 +160,20 @@ def cal_scribble(gt_mask, min_p=3, max_p=10, num_samples=1000, rng=random, np_rn
     scr = np.zeros((B, 1, num_samples, 2), np.float64)
     rects = np.zeros((B, 1, 4), np.int64)
     for b in range(B):
-        if not np.any(gt_mask[b]):
-            continue
-        region = max_connected_regions(gt_mask[b]) == 1                # the kept region (its pixels in raster order are the
-        num_p = rng.randint(min_p, max_p)                              # reference's point list: a row of it = that row's columns)
+        kept = _kept_region_crop(gt_mask[b])                            # the kept region inside the foreground's box (its
+        if kept is None:                                                # pixels in raster order are the reference's point
+            continue                                                    # list: a row of it = that row's columns)
+        region, ro, co = kept
+        num_p = rng.randint(min_p, max_p)
         rows_any, cols_any = np.flatnonzero(region.any(1)), np.flatnonzero(region.any(0))
-        r0, r1, c0, c1 = rows_any[0], rows_any[-1], cols_any[0], cols_any[-1]
+        r0, r1, c0, c1 = ro + rows_any[0], ro + rows_any[-1], co + cols_any[0], co + cols_any[-1]
         gap = int(r1 - r0) // num_p
         ctrl, lo = [], int(r0)
         for _ in range(num_p):
             row = rng.randint(lo, lo + gap - 1) if gap > 0 else rng.randint(lo, lo + gap)
-            cand = np.flatnonzero(region[row]) if 0 <= row < region.shape[0] else ()
+            cand = np.flatnonzero(region[row - ro]) if 0 <= row - ro < region.shape[0] else ()
             if len(cand):
-                ctrl.append((row, cand[rng.randint(0, len(cand) - 1)]))
+                ctrl.append((row, co + cand[rng.randint(0, len(cand) - 1)]))
             lo += gap
         if not ctrl:
             continue

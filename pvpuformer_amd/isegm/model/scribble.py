@@ -7,7 +7,7 @@ from the list before the next draw -- so its numbers match the reference only wh
 same generator.  It touches <= 1000 points per sample; the results (2 x img float64 per sample) go to the GPU once
 (``ops.pue_scribble_rows``)."""
 import random as _random
-from bisect import bisect_left
+from bisect import bisect_left, bisect_right
 
 import numpy as np
 
@@ -18,6 +18,9 @@ def scribble_profiles(scribbles, rects, img, rng=None):
     reference's draws).  Faithful to the reference's indexing: the drawn number indexes the point list ITSELF, not the
     list of points in the current column (ops.py:272-275, 288-290); sigma = 3."""
     rng = rng or _random
+    # randint(0, k - 1) IS _randbelow(k) (random.py: randint -> randrange -> istart + _randbelow(width)): the same draws
+    # without two layers of argument checks, ~100 draws per sample
+    below = getattr(getattr(rng, "_inst", rng), "_randbelow", None) or (lambda k: rng.randint(0, k - 1))
     scribbles, rects = np.asarray(scribbles), np.asarray(rects)
     B = scribbles.shape[0]
     out = np.zeros((B, 2 * img), np.float64)
@@ -28,30 +31,35 @@ def scribble_profiles(scribbles, rects, img, rng=None):
             continue
         xc, yc, bw, bh = (min(int(v), img) for v in rect)
         left, top = xc - bw // 2, yc - bh // 2
-        # the list of points still alive (ascending original index), how many of them sit in each column / row, and the
-        # copies of each distinct point: the same walk as a mask-and-count per column, without a pass over all points per step
-        px, py = pts[:, 0].tolist(), pts[:, 1].tolist()
+        # the list of points still alive (ascending original index), how many of them sit in each column / row of the
+        # walk, and the copies of each distinct point (a stable sort of the packed coordinates: one bisect finds them, in
+        # ascending index order): the same walk as a mask-and-count per column, without a pass over all points per step
+        px64, py64 = pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64)
+        px, py = px64.tolist(), py64.tolist()
         alive = list(range(len(px)))
-        cx, cy, copies = {}, {}, {}
-        for i, (x, y) in enumerate(zip(px, py)):
-            cx[x] = cx.get(x, 0) + 1
-            cy[y] = cy.get(y, 0) + 1
-            copies.setdefault((x, y), []).append(i)
+        cx = np.bincount(px64[(px64 >= 0) & (px64 < bw)], minlength=max(bw, 1)).tolist()
+        cy = np.bincount(py64[(py64 >= 0) & (py64 < bh)], minlength=max(bh, 1)).tolist()
+        key = (px64 << 32) + (py64 & 0xFFFFFFFF)
+        order = np.argsort(key, kind="stable")
+        skey, order = key[order].tolist(), order.tolist()
+        key = key.tolist()
         for col in range(bw):
-            k = cx.get(col, 0)
+            k = cx[col]
             if k:
-                i = alive[rng.randint(0, k - 1)]       # (the drawn number indexes the LIST, not the column's points)
+                i = alive[below(k)]                   # (the drawn number indexes the LIST, not the column's points)
                 x, y = px[i], py[i]
                 out[b, col] = np.exp(-((y - top) ** 2) / 18)
-                gone = copies.pop((x, y))              # every copy of the chosen point leaves the list
-                for j in gone:
+                gone = order[bisect_left(skey, key[i]):bisect_right(skey, key[i])]   # every copy of the chosen point
+                for j in gone:                                                       # leaves the list
                     del alive[bisect_left(alive, j)]
-                cx[x] -= len(gone)
-                cy[y] -= len(gone)
+                if 0 <= x < bw:
+                    cx[x] -= len(gone)
+                if 0 <= y < bh:
+                    cy[y] -= len(gone)
         for row in range(bh):
-            k = cy.get(row, 0)
+            k = cy[row]
             if k:
-                x = px[alive[rng.randint(0, k - 1)]]
+                x = px[alive[below(k)]]
                 out[b, img + row] = np.exp(-((x - left) ** 2) / 18)
     return out
 
