@@ -228,9 +228,14 @@ class PromptState:
     """The P2CL label (``ed_mask_label``, trainer.py:329-331) kept in factored form for the fused loss kernel:
     label[b][s] = gt[b] (s < S/2) or 1 - gt[b], unless slot_idx[b][s] >= 0, then override[slot_idx[b][s]]."""
 
-    def __init__(self, B, S, H, W, device, max_rounds=3):
-        self.slot_idx = -torch.ones(B, S, dtype=torch.int32, device=device)
-        self.override = torch.empty(max_rounds * B, H, W, dtype=torch.float32, device=device)   # (only assigned planes are read)
+    def __init__(self, B, S, H, W, device, max_rounds=3, buffers=None):
+        """``buffers`` = (slot_idx, override): tensors at fixed addresses (a captured training pass reads them); the caller
+        has reset ``slot_idx`` to -1."""
+        if buffers is not None:
+            self.slot_idx, self.override = buffers
+        else:
+            self.slot_idx = -torch.ones(B, S, dtype=torch.int32, device=device)
+            self.override = torch.empty(max_rounds * B, H, W, dtype=torch.float32, device=device)   # (only assigned planes are read)
         self.used = 0
 
     def assign(self, b, slot, mask_np):

@@ -63,6 +63,15 @@ class VPUTrainStep:
         import os
         self.sim_stream = None
         self.use_sim_stream = os.environ.get("VPU_SIM_STREAM", "1") != "0"
+        # One click iteration = ~530 kernel launches the host needs 7-9 ms to enqueue -- beside the simulators' host work
+        # that is more than the 13-14 ms the GPU needs for them.  On one GPU the iteration is therefore captured once per
+        # (prompt type, iteration number, batch geometry) as two hipGraphs over static input buffers -- forward + losses,
+        # and backward, so that the next prompts are still simulated beside the backward -- and replayed
+        # (VPU_TRAIN_GRAPH=0: always host-enqueued; with a gradient reducer the step is host-enqueued too: its
+        # collectives are launched from the backward's bucket hook).  First sight of a key runs host-enqueued
+        # (lazily created workspaces and kernel attributes must exist before a capture), the second is captured.
+        self.use_graph = os.environ.get("VPU_TRAIN_GRAPH", "1") != "0"
+        self._static, self._passes, self._pool = {}, {}, None
 
     def upload(self, batch_cpu, device):
         """Host batch -> device on the simulator stream (not behind the previous step's kernels); the returned dict carries
@@ -88,6 +97,72 @@ class VPUTrainStep:
         if self.sim_stream is None:
             self.sim_stream = torch.cuda.Stream(device=device)
         return self.sim_stream
+
+    def _static_buffers(self, B, S, H, W, dev):
+        """The inputs a captured pass reads, at fixed addresses: written before every replay."""
+        from types import SimpleNamespace
+        key = (B, S, H, W, str(dev))
+        st = self._static.get(key)
+        if st is None:
+            st = SimpleNamespace(net_input=torch.zeros(B, 4, H, W, device=dev), points=torch.zeros(B, S, 3, device=dev),
+                                 boxes=torch.zeros(B, 5, dtype=torch.int32, device=dev),
+                                 gt=torch.zeros(B, 1, H, W, device=dev),
+                                 slot_idx=torch.full((B, S), -1, dtype=torch.int32, device=dev),
+                                 override=torch.zeros(self.max_clicks * B, H, W, device=dev), curve=None, prof=None)
+            self._static[key] = st
+        return st
+
+    def _pass_body(self, eng, st, ptype, it):
+        """forward + losses of one click iteration on the static buffers; returns what the backward needs."""
+        B = st.net_input.shape[0]
+        mask = None
+        if self.model.training and self.model.head.dropout_ratio > 0:
+            mask = ops.dropout_mask(B, self.model.head.channels, 1.0 - self.model.head.dropout_ratio, st.net_input.device)
+        inst, _ = eng.forward(st.net_input, st.points, st.boxes, ptype, mask, training=True, materialize_aux=False,
+                              scribble=(st.curve, st.prof) if ptype == 2 else None)
+        losses, d_inst, d_sim = vpu_step_losses(inst, None, st.gt, st.slot_idx, st.override,
+                                                iter_weight=float(self.iter_w[it]), w_nfl=self.lw[0], w_dice=self.lw[1],
+                                                w_pcl=self.lw[2], sim_low=eng.sim_low)
+        return inst, losses, d_inst, d_sim
+
+    def _graph_pass(self, eng, st, ptype, it, after_forward):
+        """One click iteration on the static buffers: host-enqueued the first time its key is seen, captured the second
+        time, replayed from then on.  ``after_forward()`` runs between the forward + loss part and the backward (the
+        event the simulator stream waits for).  Returns (logits, loss dict) -- the logits live in the capture's pool and
+        are overwritten by the next replay of the same key."""
+        from types import SimpleNamespace
+        key = (ptype, it, tuple(st.net_input.shape), tuple(st.points.shape), None if st.curve is None else tuple(st.curve.shape),
+               bool(self.model.training), bool(eng.shadow_valid), id(eng))   # (a stale bf16 shadow is re-cast inside forward)
+        ent = self._passes.get(key)
+        if ent is None or ent is False:
+            if ent is None:
+                self._passes[key] = "seen"
+            inst, losses, d_inst, d_sim = self._pass_body(eng, st, ptype, it)
+            after_forward()
+            eng.backward(d_inst, None, d_sim_low=d_sim)
+            return inst, losses
+        if ent == "seen":
+            try:
+                fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fwd, pool=self._pool):
+                    inst, losses, d_inst, d_sim = self._pass_body(eng, st, ptype, it)
+                if self._pool is None:
+                    self._pool = fwd.pool()      # one pool for every captured pass: they never run beside each other, and
+                with torch.cuda.graph(bwd, pool=self._pool):      # what a pass hands out (logits, losses) stays allocated
+                    eng.backward(d_inst, None, d_sim_low=d_sim)
+                ent = SimpleNamespace(fwd=fwd, bwd=bwd, inst=inst, res=losses["total"]._base)
+                self._passes[key] = ent
+            except Exception as e:               # a capture enqueues nothing: this iteration is host-enqueued instead
+                import warnings
+                warnings.warn(f"VPUTrainStep: hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); this pass stays host-enqueued")
+                torch.cuda.synchronize()
+                self._passes[key] = False
+                return self._graph_pass(eng, st, ptype, it, after_forward)
+        ent.fwd.replay()
+        after_forward()
+        ent.bwd.replay()
+        res = ent.res.clone()                    # (the caller may read the losses after later replays)
+        return ent.inst, {"total": res[0], "nfl": res[1], "dice": res[2], "p2cl": res[3]}
 
     def batch_forward(self, batch, num_iters=None, rng=None, np_rng=None, record=None, zero_grad=True, step=True,
                       grad_scale=1.0):
@@ -118,12 +193,24 @@ class VPUTrainStep:
             gt.record_stream(side); points.record_stream(side)
         B, _, H, W = image.shape
         S = 2 * self.model.num_max_points
-        net_input = torch.cat([image, torch.zeros(B, 1, H, W, device=dev)], 1).contiguous()   # prev_output = 0 (:324)
+        from pvpuformer_amd.optim import FusedAdam
+        # (an optimizer other than the fused one steps the fp32 masters behind the engine's back: host-enqueued)
+        graphed = (self.use_graph and self.red is None and image.is_cuda and record is None
+                   and (self.opt is None or isinstance(self.opt, FusedAdam)))
+        if graphed:     # the captured passes read their inputs from fixed buffers
+            st = self._static_buffers(B, S, H, W, dev)
+            st.net_input[:, :3].copy_(image)
+            st.net_input[:, 3:].zero_()                                                       # prev_output = 0 (:324)
+            st.gt.copy_(gt)
+            st.slot_idx.fill_(-1)
+            net_input = st.net_input
+            state = PromptState(B, S, H, W, dev, max_rounds=self.max_clicks, buffers=(st.slot_idx, st.override))
+        else:
+            net_input = torch.cat([image, torch.zeros(B, 1, H, W, device=dev)], 1).contiguous()   # prev_output = 0 (:324)
+            state = PromptState(B, S, H, W, dev, max_rounds=self.max_clicks)
         prev = net_input[:, 3:4]
-        state = PromptState(B, S, H, W, dev, max_rounds=self.max_clicks)
         num_iters = num_iters or rng.randint(1, self.max_clicks)
         logged, boxes = {}, None
-        from pvpuformer_amd.optim import FusedAdam
         if not isinstance(self.opt, FusedAdam):
             # an external optimizer stepped the fp32 master parameters: the bf16 shadow and the derived operands are stale
             # (the fused optimizer writes the shadow itself and refreshes the rest)
@@ -143,15 +230,7 @@ class VPUTrainStep:
                     main.wait_stream(side)
                 else:
                     _, boxes = get_next_promts(prev, gt, points, None, as_allmask=self.as_allmask, np_rng=np_rng, rng=rng)
-            mask = None
-            if self.model.training and self.model.head.dropout_ratio > 0:
-                keep = 1.0 - self.model.head.dropout_ratio
-                mask = ops.dropout_mask(B, self.model.head.channels, keep, dev)
-            if record is not None:
-                record.append(dict(points=points.clone(), boxes=boxes.clone(), ptype=ptype, net_input=net_input.clone(),
-                                   slot_idx=state.slot_idx.clone(), override=state.override.clone()))
             last = it == num_iters - 1
-            eng.grad_ready_hook = self.red.ready if (self.red is not None and last and step) else None
             scribble = None
             if ptype == 2:   # stroke over the ground-truth region, vectors drawn from `rng` (the reference: global random)
                 from ..model.scribble import scribble_curves, scribble_profiles
@@ -166,15 +245,40 @@ class VPUTrainStep:
                     gt_np = gt[:, 0].detach().cpu().numpy()
                 scr, rects = cal_scribble(gt_np > 0.5, rng=rng, np_rng=np_rng)
                 scribble = (torch.from_numpy(scribble_curves(scr)), torch.from_numpy(scribble_profiles(scr, rects, H, rng)))
-            inst, _ = eng.forward(net_input, points, boxes, ptype, mask, training=True, materialize_aux=False,
-                                  scribble=scribble)
-            losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, state.slot_idx, state.override,
-                                                    iter_weight=float(self.iter_w[it]), w_nfl=self.lw[0],
-                                                    w_dice=self.lw[1], w_pcl=self.lw[2], sim_low=eng.sim_low)
-            if side is not None and not last:
-                fwd_done = torch.cuda.Event()       # after the loss kernels: they are the last readers of the slot table
-                fwd_done.record(main)               # and the override masks the simulator is about to update
-            eng.backward(d_inst, None, d_sim_low=d_sim)
+            fwd_done = [None]
+
+            def after_forward():
+                if side is not None and not last:
+                    fwd_done[0] = torch.cuda.Event()    # after the loss kernels: they are the last readers of the slot table
+                    fwd_done[0].record(main)            # and the override masks the simulator is about to update
+            if graphed:
+                st.points.copy_(points)
+                st.boxes.copy_(boxes)
+                if scribble is not None:
+                    if st.curve is None or st.curve.shape != scribble[0].shape:
+                        st.curve = torch.zeros(scribble[0].shape, dtype=torch.int32, device=dev)
+                        st.prof = torch.zeros(scribble[1].shape, dtype=torch.float64, device=dev)
+                    st.curve.copy_(scribble[0].to(torch.int32).pin_memory(), non_blocking=True)
+                    st.prof.copy_(scribble[1].to(torch.float64).pin_memory(), non_blocking=True)
+                eng.grad_ready_hook = None
+                inst, losses = self._graph_pass(eng, st, ptype, it, after_forward)
+            else:
+                mask = None
+                if self.model.training and self.model.head.dropout_ratio > 0:
+                    keep = 1.0 - self.model.head.dropout_ratio
+                    mask = ops.dropout_mask(B, self.model.head.channels, keep, dev)
+                if record is not None:
+                    record.append(dict(points=points.clone(), boxes=boxes.clone(), ptype=ptype, net_input=net_input.clone(),
+                                       slot_idx=state.slot_idx.clone(), override=state.override.clone()))
+                eng.grad_ready_hook = self.red.ready if (self.red is not None and last and step) else None
+                inst, _ = eng.forward(net_input, points, boxes, ptype, mask, training=True, materialize_aux=False,
+                                      scribble=scribble)
+                losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, state.slot_idx, state.override,
+                                                        iter_weight=float(self.iter_w[it]), w_nfl=self.lw[0],
+                                                        w_dice=self.lw[1], w_pcl=self.lw[2], sim_low=eng.sim_low)
+                after_forward()
+                eng.backward(d_inst, None, d_sim_low=d_sim)
+            fwd_done = fwd_done[0]
             for k, v in losses.items():
                 logged[f"{k}_{it}_{self.iter_w[it]}"] = v
             if not last and side is not None:
@@ -183,7 +287,8 @@ class VPUTrainStep:
                 # slot table
                 with torch.cuda.stream(side):
                     side.wait_event(fwd_done)
-                    inst.record_stream(side)
+                    if not graphed:
+                        inst.record_stream(side)
                     ops.sigmoid_to_channel(inst, net_input, B, H * W, 4, 3)      # prev_output = sigmoid(instances) (:428)
                     points, boxes = get_next_promts(prev, gt, points, state, as_allmask=self.as_allmask, np_rng=np_rng,
                                                     rng=rng)
@@ -193,7 +298,8 @@ class VPUTrainStep:
                 ops.sigmoid_to_channel(inst, net_input, B, H * W, 4, 3)          # prev_output = sigmoid(instances) (:428)
                 points, boxes = get_next_promts(prev, gt, points, state, as_allmask=self.as_allmask, np_rng=np_rng,
                                                 rng=rng)
-        self.last_instances = inst          # the last iteration's logits (what the reference feeds its train metrics)
+        # the last iteration's logits (what the reference feeds its train metrics); a captured pass's live in its pool
+        self.last_instances = inst.clone() if graphed else inst
         if step:
             scale = self.red.finish() if self.red is not None else 1.0
             if self.opt is not None:

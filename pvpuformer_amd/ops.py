@@ -255,16 +255,35 @@ def debug_spin(sink, wgs, cycles):
 _drop_state = {}
 
 
+def _drop_key(device):
+    key = torch.device(device)
+    if key.type == "cuda" and key.index is None:
+        key = torch.device("cuda", torch.cuda.current_device())
+    return key
+
+
 def dropout_mask(B, channels, keep, device, seed=None):
     """Dropout2d mask [B, channels] fp32 (values 0 or 1 / keep) from vpu_dropout_mask: one launch, capturable; the stream of
     masks is a function of ``seed`` (default: torch.initial_seed() at the first call on that device) and the call count."""
-    key = torch.device(device)
+    key = _drop_key(device)
     if key not in _drop_state:
         _drop_state[key] = (torch.zeros(1, dtype=torch.int64, device=key), int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1))
     state, sd = _drop_state[key]
     out = torch.empty(B, channels, device=key, dtype=torch.float32)
     _lib.call("vpu_dropout_mask", ptr(out), B * channels, float(keep), sd, ptr(state), _stream())
     return out
+
+
+def dropout_seed(device, seed):
+    """Restarts the mask stream of ``device``: call count 0 (in place: captured launches keep pointing at the counter)
+    and a new seed (a kernel argument: launches captured before keep the seed they were captured with)."""
+    key = _drop_key(device)
+    sd = int(seed) & (2 ** 63 - 1)
+    if key in _drop_state:
+        _drop_state[key][0].zero_()
+        _drop_state[key] = (_drop_state[key][0], sd)
+    else:
+        _drop_state[key] = (torch.zeros(1, dtype=torch.int64, device=key), sd)
 
 
 def zero_(t):

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import vpu_oracle as vo
+from pvpuformer_amd import ops
 from test_api_cpu import TINY, make_model
 from test_oracle_golden import cfg_from_fixture
 
@@ -443,6 +444,41 @@ def test_train_step_simulator_stream_equals_training_stream(golden_dir):
         assert x["ptype"] == y["ptype"] and torch.equal(x["points"].cpu(), y["points"].cpu())
         assert torch.equal(x["boxes"].cpu(), y["boxes"].cpu()) and torch.equal(x["slot_idx"].cpu(), y["slot_idx"].cpu())
         assert torch.equal(x["net_input"].cpu(), y["net_input"].cpu())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_train_step_graph_replay_equals_host_enqueued(golden_dir, dtype):
+    """The captured click iterations (two hipGraphs per (prompt type, iteration number): forward + losses, backward; static
+    input buffers; simulators beside the backward) == the host-enqueued step: eight optimizer steps of 1-3 iterations with
+    click / box / scribble prompts from the same seeds give the same losses, prompts and parameters -- the same kernels
+    in the same order, so bit for bit --, and passes really were replayed."""
+    import random
+    from pvpuformer_amd.isegm.engine.trainer import VPUTrainStep
+    from pvpuformer_amd.optim import FusedAdam
+    got = {}
+    for mode in (False, True):
+        fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", dtype)
+        model.train()
+        ops.dropout_seed("cuda", 77)            # the same dropout masks in both runs
+        step = VPUTrainStep(model, FusedAdam(model, lr=1e-4), None, prompt_types=(0, 1, 2))
+        step.use_graph = mode
+        rng, np_rng = random.Random(21), np.random.RandomState(22)
+        host = {k: v.pin_memory() for k, v in batch.items()}
+        trace = []
+        for i in range(8):
+            logged, pts = step.batch_forward(step.upload(host, "cuda"), rng=rng, np_rng=np_rng)
+            torch.cuda.synchronize()
+            trace.append(({k: (v.item() if torch.is_tensor(v) else v) for k, v in logged.items()}, pts.cpu().clone(),
+                          step.last_instances.cpu().clone()))
+        eng = model._ensure_engine()
+        replayed = sum(1 for v in step._passes.values() if v not in ("seen", False))
+        got[mode] = (trace, eng.flat.clone(), replayed)
+    (ta, pa, na), (tb, pb, nb) = got[False], got[True]
+    assert na == 0 and nb >= 2, (na, nb)
+    for i, ((la, xa, ia), (lb, xb, ib)) in enumerate(zip(ta, tb)):
+        assert la == lb, (i, la, lb)
+        assert torch.equal(xa, xb) and torch.equal(ia, ib), i
+    assert torch.equal(pa, pb)
 
 
 @pytest.mark.parametrize("zoom", [None, dict(skip_clicks=-1, target_size=(448, 448))])

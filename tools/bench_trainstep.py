@@ -38,10 +38,12 @@ def main():
     if mixed:
         step.ptypes = tuple(int(t) for t in mixed.split(","))
         print("prompt types sampled per iteration:", step.ptypes)
+    # warm-up: every (prompt type, iteration number) pass is host-enqueued the first time and captured the second
+    warm = int(os.environ.get("BENCH_WARMUP", "24"))
     for fixed in (1, None):
         iters = 0
-        for i in range(steps + 2):
-            if i == 2:
+        for i in range(steps + warm):
+            if i == warm:
                 torch.cuda.synchronize(); t0 = time.perf_counter(); iters = 0
             logged, _ = step.batch_forward(step.upload(batch_host, "cuda"), num_iters=fixed, rng=rng, np_rng=np_rng)
             iters += logged["num_iters"]
