@@ -218,8 +218,11 @@ def main():
     # step (measured equal on an idle 256-core box, 858-863 images/s either way: the step is GPU-bound; on a box with a
     # small CPU share the eager loop becomes host-bound, the replay does not).  VPU_BENCH_GRAPH=0 forces the eager loop;
     # a failed capture falls back to it and says so in the JSON line.  Multi-GPU runs launch their RCCL collectives from
-    # the backward tape and run eagerly.
+    # the backward tape: there the step is replayed as a CHAIN of graphs -- zero-grad + forward + losses, then the backward
+    # cut wherever the engine reports a finished gradient range (pvpuformer_amd/graphs.py), the reducer's collectives
+    # launched by the host between two segments, Adam host-enqueued -- ~25 launches per step instead of ~530.
     use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
+    use_chain = world > 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
     opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, capturable=use_graph)
     red = GradReducer(eng.gflat, wire=os.environ.get("VPU_DIST_WIRE", "fp32"))   # VPU_DIST_WIRE=bf16: half the bytes per link
     eng.grad_ready_hook = red.ready if red.enabled else None
@@ -259,13 +262,28 @@ def main():
         last["loss"] = losses["total"]
 
     graph = [None]
+    chain = [None]                     # (head graph, SegmentedBackward) of a data-parallel step
     graph_note = [None]
+    held = {}
+
+    def head_body():
+        eng.zero_grad()
+        mask = ops.dropout_mask(B, model.head.channels, keep, dev)
+        inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
+        losses, held["d_inst"], held["d_sim"] = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        held["loss"] = losses["total"]
 
     def step():
         if use_graph:
             opt.prepare_step(1.0)      # step count, bias corrections, lr -> device scalars read by the captured Adam launch
         if graph[0] is not None:
             graph[0].replay()
+        elif chain[0] is not None:
+            chain[0][0].replay()
+            red.begin()
+            chain[0][1].replay(red.ready if red.enabled else None)
+            opt.step(grad_scale=red.finish())
+            last["loss"] = held["loss"]
         else:
             step_body()
 
@@ -294,6 +312,36 @@ def main():
             graph_note[0] = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:120]})"
             graph[0] = None
             torch.cuda.synchronize()
+    if use_chain and overlap is None:
+        # every rank captures for itself (a capture enqueues nothing and launches no collective); a rank whose capture
+        # fails stays host-enqueued: the same kernels and the same collectives in the same order as the replaying ranks
+        from pvpuformer_amd.graphs import SegmentedBackward
+        if args.warmup == 0:
+            step()
+            sync()
+        try:
+            head = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(head, capture_error_mode="thread_local"):
+                head_body()
+            red.begin()                # (the GEMM grids of a data-parallel backward leave the reducer's CUs free)
+            seg = SegmentedBackward.capture(eng, lambda: eng.backward(held["d_inst"], None, d_sim_low=held["d_sim"]),
+                                            hook_owner=red if red.enabled else None, pool=head.pool())
+            red.finish()
+            chain[0] = (head, seg)
+            graph_note[0] = (f"hipGraph chain: forward graph + {sum(1 for g, _ in seg.segments if g is not None)} backward "
+                             f"segments cut at the {sum(len(r) for _, r in seg.segments)} reported gradient ranges, collectives between them")
+        except Exception as e:
+            graph_note[0] = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:120]})"
+            chain[0] = None
+            try:
+                red.finish()
+            except Exception:
+                pass
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        step()                         # first replay (untimed): graph upload
+        sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -322,6 +370,7 @@ def main():
     # GEMM: three plain steps are queued first (no sync), so that the GPU works off a backlog while the instrumented step
     # is enqueued -- an event pair then brackets the kernel alone instead of the kernel plus the host's lag.
     graph[0] = None                    # the instrumented step is enqueued eagerly (HIP events around every GEMM launch)
+    chain[0] = None
     # what the host needs to enqueue ONE step when nothing holds it back (empty queue: no back-pressure from the GPU)
     step()                             # (the first eager step after a graph capture re-allocates its workspaces: not timed)
     sync()

@@ -144,6 +144,7 @@ class Engine:
         self._gq = []          # deferred small GEMMs of one group (an attention's q / k / v projections or their dgrads)
         self._gq_out = set()   # data_ptr of the outputs the queued GEMMs will write
         self._frozen = set()   # data_ptr of buffers a queued / side-stream GEMM still reads: no in-place writes
+        self._token_rows = 0
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -698,6 +699,7 @@ class Engine:
         NT, nw_side = g * g, g // self.wg
         pos_win, kpe_tab = self._pos_for(g), self._kpe_for(g)
         M = B * NT
+        self._token_rows = M          # the reduction length of the ViT blocks' weight gradients (the packed queue)
         n = points.shape[1] // 2
         points = self._upload(points, torch.float32)
         use_box = prompt_type == 1
@@ -1028,6 +1030,12 @@ class Engine:
                 # with a reducer attached the range is reported as soon as nothing queued writes into it any more
                 self.flush_wgrads(0)
                 if self.grad_ready_hook is not None:
+                    # the other long reductions (the FPN's / head's maps: a handful of problems over 37632 / 150528 rows that
+                    # never fill a round and would wait for the end of backward) go now as well: ranges are reported in
+                    # order, and a gradient of the head still in the queue would hold every block's range back until
+                    # nothing of the backward is left to overlap the exchange with
+                    for k in sorted({e[3] for e in self._wq if e[3] > 2048} - {self._token_rows}):
+                        self.flush_wgrads(k)
                     self._pending_reports.append((lo, hi))
                     self._report_ready()
                 return

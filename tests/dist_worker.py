@@ -52,6 +52,37 @@ def step(eng, img4, pts, gt, red=None):
     return eng.gflat.clone() * scale
 
 
+def chain_step(eng, img4, pts, gt, red, replays=2):
+    """The same step replayed as a chain of hipGraphs (pvpuformer_amd/graphs.py): zero-grad + forward + losses in one graph,
+    the backward cut at the reported gradient ranges, the reducer's collectives launched by the host between the segments."""
+    from pvpuformer_amd.graphs import SegmentedBackward
+    held = {}
+
+    def head_body():
+        eng.zero_grad()
+        inst, _ = eng.forward(img4, pts, None, 0, None, training=True, materialize_aux=False)
+        _, held["d_inst"], held["d_sim"] = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+    head = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(head, capture_error_mode="thread_local"):
+        head_body()
+    red.begin()
+    seg = SegmentedBackward.capture(eng, lambda: eng.backward(held["d_inst"], None, d_sim_low=held["d_sim"]), hook_owner=red,
+                                    pool=head.pool())
+    red.finish()
+    assert eng.grad_ready_hook is None
+    outs = []
+    for _ in range(replays):
+        head.replay()
+        red.begin()
+        seg.replay(red.ready)
+        scale = red.finish()
+        torch.cuda.synchronize()
+        outs.append(eng.gflat.clone() * scale)
+    n_graphs = sum(1 for g, _ in seg.segments if g is not None)
+    n_ranges = sum(len(r) for _, r in seg.segments)
+    return outs, n_graphs, n_ranges
+
+
 def main():
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -69,12 +100,27 @@ def main():
         assert red.enabled and red.world == 1
         with_red = step(eng, img4, pts, gt, red)
         launched = list(red.launched)
+        chain, n_graphs, n_ranges = chain_step(eng, img4, pts, gt, red)
+        chain_launched = list(red.launched)
+        # every block's weight gradients launched at its marker (no queue across blocks): ranges are reported in the middle
+        # of backward, the chain is really cut there
+        eng.group_wgrad = False
+        plain_ng = step(eng, img4, pts, gt)
+        eager_ng = step(eng, img4, pts, gt, red)
+        launched_ng = list(red.launched)
+        chain_ng, n_graphs_ng, n_ranges_ng = chain_step(eng, img4, pts, gt, red)
+        chain_launched_ng = list(red.launched)
+        eng.group_wgrad = True
         red16 = GradReducer(eng.gflat, bucket_bytes=1 << 20, force=True, wire="bf16", reserve_cus=0)
         with_bf16 = step(eng, img4, pts, gt, red16)
         again = step(eng, img4, pts, gt)               # the reserve knob is back to 0: same kernels as the first step
         np.savez(os.path.join(out, "nccl1.npz"), plain=plain.cpu().numpy(), with_red=with_red.cpu().numpy(),
                  with_bf16=with_bf16.cpu().numpy(), again=again.cpu().numpy(), launched=np.asarray(launched),
-                 total=np.asarray(eng.total))
+                 total=np.asarray(eng.total), chain0=chain[0].cpu().numpy(), chain1=chain[1].cpu().numpy(),
+                 chain_launched=np.asarray(chain_launched), chain_graphs=np.asarray([n_graphs, n_ranges]),
+                 plain_ng=plain_ng.cpu().numpy(), eager_ng=eager_ng.cpu().numpy(), chain_ng0=chain_ng[0].cpu().numpy(),
+                 chain_ng1=chain_ng[1].cpu().numpy(), launched_ng=np.asarray(launched_ng),
+                 chain_launched_ng=np.asarray(chain_launched_ng), chain_graphs_ng=np.asarray([n_graphs_ng, n_ranges_ng]))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         cfg, model, eng = build("f32")
@@ -94,6 +140,9 @@ def main():
         mine = step(eng, img4[rank:rank + 1].contiguous(), pts[rank:rank + 1].contiguous(), gt[rank:rank + 1].contiguous(), red)
         res = dict(flat=eng.flat.cpu().numpy(), buf=buf.cpu().numpy(), mine=mine.cpu().numpy(),
                    launched=np.asarray(red.launched))
+        chain, _, _ = chain_step(eng, img4[rank:rank + 1].contiguous(), pts[rank:rank + 1].contiguous(),
+                                 gt[rank:rank + 1].contiguous(), red, replays=1)
+        res["chain"] = chain[0].cpu().numpy()
         if rank == 0:
             res["full"] = step(eng, img4, pts, gt).cpu().numpy()
         np.savez(os.path.join(out, f"gloo2_rank{rank}.npz"), **res)

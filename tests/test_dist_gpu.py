@@ -48,6 +48,15 @@ def test_rccl_world_size_1_reducer_is_the_identity(tmp_path):
     spans = sorted(tuple(x) for x in r["launched"])
     assert len(spans) >= 3 and spans[0][0] == 0 and spans[-1][1] == int(r["total"])
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "the buckets must tile the flat gradient buffer"
+    # the same step as a chain of hipGraphs cut at the reported ranges, collectives launched between the segments
+    assert np.array_equal(r["chain0"], r["plain"]) and np.array_equal(r["chain1"], r["plain"])
+    assert np.array_equal(r["chain_launched"], r["launched"]), "the replayed chain launches the same buckets in the same order"
+    assert r["chain_graphs"][0] >= 1 and r["chain_graphs"][1] >= 3, r["chain_graphs"]
+    # ... and with the ranges reported in the middle of backward (no weight-gradient queue across blocks): really cut
+    assert np.array_equal(r["eager_ng"], r["plain_ng"])
+    assert np.array_equal(r["chain_ng0"], r["plain_ng"]) and np.array_equal(r["chain_ng1"], r["plain_ng"])
+    assert np.array_equal(r["chain_launched_ng"], r["launched_ng"])
+    assert r["chain_graphs_ng"][0] >= 3 and r["chain_graphs_ng"][1] >= 3, r["chain_graphs_ng"]
     ref = r["plain"]
     err = np.abs(r["with_bf16"] - ref)
     assert np.all(err <= 2.0 ** -8 * np.abs(ref) + 1e-30), "bf16 wire format: one rounding to 8 significant bits"
@@ -65,3 +74,4 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
     scale = np.abs(full).max()
     assert np.abs(dp - full).max() <= 2e-5 * scale, np.abs(dp - full).max() / scale
     assert len(r0["launched"]) >= 3 and np.array_equal(r0["launched"], r1["launched"])
+    assert np.array_equal(r0["chain"], r0["mine"]) and np.array_equal(r1["chain"], r1["mine"]), "graph chain == host-enqueued step"

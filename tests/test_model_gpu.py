@@ -1118,6 +1118,79 @@ def test_vitl_width_bf16_close_to_reference(golden_dir):
     _within("vitl8 grad norms " + max(rel, key=rel.get), max(rel.values()), 0.1)      # measured 6.0e-2
 
 
+def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir):
+    """Data parallel at the benchmark's shapes (ViT-B, B = 12, bf16, a reducer attached): the exchange can only overlap the
+    backward if the ranges are reported WHILE it runs -- one per ViT block, each at most two blocks after its marker,
+    although the blocks' weight gradients are packed into full rounds across blocks and the head's long reductions would
+    otherwise sit in the queue until the end (every range was once reported after the last kernel).  Counted in launches
+    of the library.  The same backward captured as a chain of hipGraphs cut at those reports gives the same gradients."""
+    from pvpuformer_amd import _lib
+    from pvpuformer_amd.graphs import SegmentedBackward
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    B = 12
+    big = vo.synth_batch(B, cfg["img"], seed=100)
+    x = torch.cat([big["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1).cuda()
+    pts, gt = big["points"].cuda(), big["instances"].cuda()
+    model.train()
+    model.head.dropout_ratio = 0.0
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+
+    class Red:
+        reserve_cus = 16
+
+        def __init__(self):
+            self.seen = []
+
+        def ready(self, lo, hi):
+            self.seen.append((lo, hi, ncall[0]))
+    red, ncall, orig = Red(), [0], _lib.call
+
+    def counting(name, *a):
+        ncall[0] += 1
+        return orig(name, *a)
+
+    def head_part():
+        eng.zero_grad()
+        inst, _ = eng.forward(x, pts, None, 0, None, training=True, materialize_aux=False)
+        _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        return d_inst, d_sim
+    try:
+        for _ in range(2):                       # (the packing of a pass goes by what the pass before it queued)
+            eng.grad_ready_hook = red.ready
+            d_inst, d_sim = head_part()
+            red.seen, ncall[0] = [], 0
+            _lib.call = counting
+            eng.backward(d_inst, None, d_sim_low=d_sim)
+            _lib.call = orig
+        torch.cuda.synchronize()
+        eager = eng.gflat.clone()
+    finally:
+        _lib.call = orig
+        eng.grad_ready_hook = None
+    total = ncall[0]
+    seen = red.seen
+    assert len(seen) == cfg["depth"] + 2 and seen[0][1] == eng.total and seen[-1][0] == 0
+    at = [c for _, _, c in seen]
+    # head + neck (30 % of the bytes) once block 11's packed launch has taken the neck's riders along; then a block each
+    assert at[0] < 0.7 * total, (at, total)
+    assert at[len(at) // 2] < 0.9 * total and len(set(at)) >= cfg["depth"] - 1, (at, total)
+    late = sum(hi - lo for lo, hi, c in seen if c >= total - 1)
+    assert late < 0.1 * eng.total, f"{late} of {eng.total} gradient elements were reported only when backward had ended"
+    # the chain of graphs cut at those reports: same ranges at the same places, same gradients
+    d_inst, d_sim = head_part()
+    seg = SegmentedBackward.capture(eng, lambda: eng.backward(d_inst, None, d_sim_low=d_sim), hook_owner=red)
+    assert eng.grad_ready_hook is None and _lib.call is orig
+    assert [r for _, rs in seg.segments for r in rs] == [(lo, hi) for lo, hi, _ in seen]
+    assert sum(1 for g, _ in seg.segments if g is not None) >= cfg["depth"] - 2
+    got = []
+    seg.replay(lambda lo, hi: got.append((lo, hi)))
+    torch.cuda.synchronize()
+    assert got == [(lo, hi) for lo, hi, _ in seen]
+    assert torch.equal(eng.gflat, eager)
+
+
 def test_bench_shape_bf16_step_matches_oracle(golden_dir):
     """The TIMED path at the benchmark's own shapes: ViT-B, B = 12 (M = 9408 token rows: the 256-row-tile GEMM kernels, the
     grouped weight-gradient launch over 216 tiles, the sliced neck gradients -- instantiations the B = 2 fixtures never

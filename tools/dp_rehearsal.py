@@ -61,6 +61,40 @@ def main():
         eng.grad_ready_hook = None
         return (time.perf_counter() - t0) / steps * 1e3
 
+    def run_chain(red):
+        """the same step replayed as bench.py replays it at N > 1: forward graph + backward segments cut at the reported
+        ranges, the reducer's collectives launched by the host between two segments, Adam host-enqueued"""
+        from pvpuformer_amd.graphs import SegmentedBackward
+        held = {}
+
+        def head_body():
+            eng.zero_grad()
+            inst, _ = eng.forward(x, b["points"], None, 0, None, training=True, materialize_aux=False)
+            _, held["d_inst"], held["d_sim"] = vpu_step_losses(inst, None, b["instances"], None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        head = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(head, capture_error_mode="thread_local"):
+            head_body()
+        red.begin()
+        seg = SegmentedBackward.capture(eng, lambda: eng.backward(held["d_inst"], None, d_sim_low=held["d_sim"]),
+                                        hook_owner=red, pool=head.pool())
+        red.finish()
+
+        def one():
+            head.replay()
+            red.begin()
+            seg.replay(red.ready)
+            opt.step(grad_scale=red.finish())
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt / steps * 1e3, t_host / steps * 1e3, sum(1 for g, _ in seg.segments if g is not None)
+
     res = {"what": "ViT-B 448 bs=12 bf16 training step on ONE MI355X, eager launch, RCCL world size 1", "steps": steps,
            "NCCL_MAX_NCHANNELS": channels}
     res["ms_no_reducer"] = round(run(None), 3)
@@ -70,6 +104,10 @@ def main():
     res["rccl_kernels_at_world_size_1"] = "none: RCCL returns from an in-place all-reduce over one rank without launching (kernel trace: 0 nccl kernels)"
     res["ms_reducer_bf16_wire_reserve16"] = round(run(GradReducer(eng.gflat, force=True, wire="bf16", reserve_cus=16)), 3)
     res["ms_reducer_fp32_wire_reserve0"] = round(run(GradReducer(eng.gflat, force=True, reserve_cus=0)), 3)
+    ms, host, nseg = run_chain(GradReducer(eng.gflat, force=True, reserve_cus=16))
+    res["ms_reducer_fp32_wire_reserve16_graph_chain"] = round(ms, 3)
+    res["graph_chain_host_ms_per_step"] = round(host, 3)
+    res["graph_chain_backward_segments"] = nseg
     res["ms_no_reducer_again"] = round(run(None), 3)
     print(json.dumps(res))
     if len(sys.argv) > 2:
