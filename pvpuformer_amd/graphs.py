@@ -31,8 +31,9 @@ class _CutHook:
 
 class SegmentedBackward:
     """``capture(eng, run, hook_owner=None, pool=None)`` runs ``run()`` (a callable that executes ``eng.backward(...)``)
-    under capture; ``replay(hook)`` launches the segments and calls ``hook(lo, hi)`` for every range where the engine
-    reported it.  ``segments``: [(graph or None, [(lo, hi), ...])]."""
+    under capture -- ``hook_owner``: the reducer whose ``ready`` the replay will call (None: no reports, one segment) --;
+    ``replay(hook)`` launches the segments and calls ``hook(lo, hi)`` for every range where the engine reported it.
+    ``segments``: [(graph or None, [(lo, hi), ...])]."""
 
     def __init__(self):
         self.segments = []
@@ -72,7 +73,8 @@ class SegmentedBackward:
             state["launched"] = True
             return orig_call(name, *args)
 
-        eng.grad_ready_hook = _CutHook(int(getattr(hook_owner, "reserve_cus", 0) or 0), pending).ready
+        # (no reducer: the engine sees no hook -- it queues and launches as in any single-GPU backward -- and nothing is cut)
+        eng.grad_ready_hook = None if hook_owner is None else _CutHook(int(getattr(hook_owner, "reserve_cus", 0) or 0), pending).ready
         _lib.call = call
         open_()
         try:

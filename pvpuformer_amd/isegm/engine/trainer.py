@@ -71,7 +71,7 @@ class VPUTrainStep:
         # collectives are launched from the backward's bucket hook).  First sight of a key runs host-enqueued
         # (lazily created workspaces and kernel attributes must exist before a capture), the second is captured.
         self.use_graph = os.environ.get("VPU_TRAIN_GRAPH", "1") != "0"
-        self._static, self._passes, self._pool = {}, {}, None
+        self._static, self._passes, self._pool, self._reserving = {}, {}, None, False
 
     def upload(self, batch_cpu, device):
         """Host batch -> device on the simulator stream (not behind the previous step's kernels); the returned dict carries
@@ -125,31 +125,39 @@ class VPUTrainStep:
                                                 w_pcl=self.lw[2], sim_low=eng.sim_low)
         return inst, losses, d_inst, d_sim
 
-    def _graph_pass(self, eng, st, ptype, it, after_forward):
+    def _graph_pass(self, eng, st, ptype, it, after_forward, reducer=None):
         """One click iteration on the static buffers: host-enqueued the first time its key is seen, captured the second
         time, replayed from then on.  ``after_forward()`` runs between the forward + loss part and the backward (the
         event the simulator stream waits for).  Returns (logits, loss dict) -- the logits live in the capture's pool and
-        are overwritten by the next replay of the same key."""
+        are overwritten by the next replay of the same key.  ``reducer``: this backward reports its finished gradient ranges
+        to it (``reducer.begin()`` has been called: the GEMM grids leave its CUs free)."""
         from types import SimpleNamespace
+        from pvpuformer_amd.graphs import SegmentedBackward
+        hook = reducer.ready if reducer is not None else None
         key = (ptype, it, tuple(st.net_input.shape), tuple(st.points.shape), None if st.curve is None else tuple(st.curve.shape),
-               bool(self.model.training), bool(eng.shadow_valid), id(eng))   # (a stale bf16 shadow is re-cast inside forward)
+               bool(self.model.training), bool(eng.shadow_valid), id(eng),   # (a stale bf16 shadow is re-cast inside forward)
+               reducer is not None, int(getattr(self.red, "reserve_cus", 0) or 0) if self._reserving else 0)
         ent = self._passes.get(key)
         if ent is None or ent is False:
             if ent is None:
                 self._passes[key] = "seen"
+            eng.grad_ready_hook = hook
             inst, losses, d_inst, d_sim = self._pass_body(eng, st, ptype, it)
             after_forward()
             eng.backward(d_inst, None, d_sim_low=d_sim)
+            eng.grad_ready_hook = None
             return inst, losses
         if ent == "seen":
             try:
-                fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fwd, pool=self._pool):
+                eng.grad_ready_hook = None
+                fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fwd, pool=self._pool, capture_error_mode="thread_local"):
                     inst, losses, d_inst, d_sim = self._pass_body(eng, st, ptype, it)
                 if self._pool is None:
                     self._pool = fwd.pool()      # one pool for every captured pass: they never run beside each other, and
-                with torch.cuda.graph(bwd, pool=self._pool):      # what a pass hands out (logits, losses) stays allocated
-                    eng.backward(d_inst, None, d_sim_low=d_sim)
+                # what a pass hands out (logits, losses) stays allocated
+                bwd = SegmentedBackward.capture(eng, lambda: eng.backward(d_inst, None, d_sim_low=d_sim), hook_owner=reducer,
+                                                pool=self._pool)      # (no reducer: nothing is reported, one segment)
                 ent = SimpleNamespace(fwd=fwd, bwd=bwd, inst=inst, res=losses["total"]._base)
                 self._passes[key] = ent
             except Exception as e:               # a capture enqueues nothing: this iteration is host-enqueued instead
@@ -157,10 +165,10 @@ class VPUTrainStep:
                 warnings.warn(f"VPUTrainStep: hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); this pass stays host-enqueued")
                 torch.cuda.synchronize()
                 self._passes[key] = False
-                return self._graph_pass(eng, st, ptype, it, after_forward)
+                return self._graph_pass(eng, st, ptype, it, after_forward, reducer)
         ent.fwd.replay()
         after_forward()
-        ent.bwd.replay()
+        ent.bwd.replay(hook)
         res = ent.res.clone()                    # (the caller may read the losses after later replays)
         return ent.inst, {"total": res[0], "nfl": res[1], "dice": res[2], "p2cl": res[3]}
 
@@ -195,7 +203,7 @@ class VPUTrainStep:
         S = 2 * self.model.num_max_points
         from pvpuformer_amd.optim import FusedAdam
         # (an optimizer other than the fused one steps the fp32 masters behind the engine's back: host-enqueued)
-        graphed = (self.use_graph and self.red is None and image.is_cuda and record is None
+        graphed = (self.use_graph and image.is_cuda and record is None
                    and (self.opt is None or isinstance(self.opt, FusedAdam)))
         if graphed:     # the captured passes read their inputs from fixed buffers
             st = self._static_buffers(B, S, H, W, dev)
@@ -217,6 +225,7 @@ class VPUTrainStep:
             eng.shadow_valid = False
         if zero_grad:
             eng.zero_grad()
+        self._reserving = self.red is not None and step          # (begin() keeps the reducer's CUs out of the GEMM grids)
         if self.red is not None and step:
             self.red.begin()
         for it in range(num_iters):
@@ -260,8 +269,8 @@ class VPUTrainStep:
                         st.prof = torch.zeros(scribble[1].shape, dtype=torch.float64, device=dev)
                     st.curve.copy_(scribble[0].to(torch.int32).pin_memory(), non_blocking=True)
                     st.prof.copy_(scribble[1].to(torch.float64).pin_memory(), non_blocking=True)
-                eng.grad_ready_hook = None
-                inst, losses = self._graph_pass(eng, st, ptype, it, after_forward)
+                inst, losses = self._graph_pass(eng, st, ptype, it, after_forward,
+                                                self.red if (self.red is not None and last and step) else None)
             else:
                 mask = None
                 if self.model.training and self.model.head.dropout_ratio > 0:

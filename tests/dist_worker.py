@@ -114,7 +114,30 @@ def main():
         red16 = GradReducer(eng.gflat, bucket_bytes=1 << 20, force=True, wire="bf16", reserve_cus=0)
         with_bf16 = step(eng, img4, pts, gt, red16)
         again = step(eng, img4, pts, gt)               # the reserve knob is back to 0: same kernels as the first step
+        # the reference-faithful training step under the reducer: captured passes (the reporting backward as a graph chain)
+        # against host-enqueued ones, eight optimizer steps of 1-3 click iterations from the same seeds
+        import random
+        from pvpuformer_amd.isegm.engine.trainer import VPUTrainStep
+        from pvpuformer_amd.optim import FusedAdam
+        ts = {}
+        for use_graph in (False, True):
+            _, model_t, eng_t = build("bf16")
+            red_t = GradReducer(eng_t.gflat, bucket_bytes=1 << 20, force=True, reserve_cus=16)
+            st = VPUTrainStep(model_t, FusedAdam(model_t, lr=1e-4), red_t)
+            st.use_graph = use_graph
+            rng, np_rng = random.Random(3), np.random.RandomState(4)
+            dev_batch = {k: v.cuda() for k, v in b.items()}
+            buckets = []
+            for _ in range(8):
+                st.batch_forward(dev_batch, rng=rng, np_rng=np_rng)
+                buckets.append(len(red_t.launched))
+            torch.cuda.synchronize()
+            ts[use_graph] = (eng_t.flat.clone().cpu().numpy(), sum(1 for v in st._passes.values() if v not in ("seen", False)),
+                             buckets)
+        assert ts[False][1] == 0 and ts[True][1] >= 2, (ts[False][1], ts[True][1])
+        assert ts[False][2] == ts[True][2] and min(ts[True][2]) >= 3, (ts[False][2], ts[True][2])
         np.savez(os.path.join(out, "nccl1.npz"), plain=plain.cpu().numpy(), with_red=with_red.cpu().numpy(),
+                 ts_eager=ts[False][0], ts_graph=ts[True][0],
                  with_bf16=with_bf16.cpu().numpy(), again=again.cpu().numpy(), launched=np.asarray(launched),
                  total=np.asarray(eng.total), chain0=chain[0].cpu().numpy(), chain1=chain[1].cpu().numpy(),
                  chain_launched=np.asarray(chain_launched), chain_graphs=np.asarray([n_graphs, n_ranges]),

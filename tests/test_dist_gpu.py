@@ -57,6 +57,8 @@ def test_rccl_world_size_1_reducer_is_the_identity(tmp_path):
     assert np.array_equal(r["chain_ng0"], r["plain_ng"]) and np.array_equal(r["chain_ng1"], r["plain_ng"])
     assert np.array_equal(r["chain_launched_ng"], r["launched_ng"])
     assert r["chain_graphs_ng"][0] >= 3 and r["chain_graphs_ng"][1] >= 3, r["chain_graphs_ng"]
+    # VPUTrainStep under the reducer: captured passes == host-enqueued passes after eight optimizer steps
+    assert np.array_equal(r["ts_graph"], r["ts_eager"])
     ref = r["plain"]
     err = np.abs(r["with_bf16"] - ref)
     assert np.all(err <= 2.0 ** -8 * np.abs(ref) + 1e-30), "bf16 wire format: one rounding to 8 significant bits"
