@@ -64,12 +64,13 @@ class VPUTrainStep:
         self.sim_stream = None
         self.use_sim_stream = os.environ.get("VPU_SIM_STREAM", "1") != "0"
         # One click iteration = ~530 kernel launches the host needs 7-9 ms to enqueue -- beside the simulators' host work
-        # that is more than the 13-14 ms the GPU needs for them.  On one GPU the iteration is therefore captured once per
-        # (prompt type, iteration number, batch geometry) as two hipGraphs over static input buffers -- forward + losses,
-        # and backward, so that the next prompts are still simulated beside the backward -- and replayed
-        # (VPU_TRAIN_GRAPH=0: always host-enqueued; with a gradient reducer the step is host-enqueued too: its
-        # collectives are launched from the backward's bucket hook).  First sight of a key runs host-enqueued
-        # (lazily created workspaces and kernel attributes must exist before a capture), the second is captured.
+        # that is more than the 13-14 ms the GPU needs for them.  The iteration is therefore captured once per (prompt type,
+        # iteration number, batch geometry) as hipGraphs over static input buffers -- forward + losses, and backward, so that
+        # the next prompts are still simulated beside the backward -- and replayed (VPU_TRAIN_GRAPH=0: always
+        # host-enqueued).  Under a gradient reducer the backward that reports the finished gradient ranges -- the last
+        # iteration's -- is a chain of graphs cut at the reports, the reducer's collectives launched by the host between
+        # two segments (pvpuformer_amd/graphs.py).  First sight of a key runs host-enqueued (lazily created workspaces
+        # and kernel attributes must exist before a capture), the second is captured.
         self.use_graph = os.environ.get("VPU_TRAIN_GRAPH", "1") != "0"
         self._static, self._passes, self._pool, self._reserving = {}, {}, None, False
 
