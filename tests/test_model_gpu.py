@@ -1191,16 +1191,17 @@ def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir):
     assert torch.equal(eng.gflat, eager)
 
 
-def test_bench_shape_bf16_step_matches_oracle(golden_dir):
+@pytest.mark.parametrize("B", [12, 4])
+def test_bench_shape_bf16_step_matches_oracle(golden_dir, B):
     """The TIMED path at the benchmark's own shapes: ViT-B, B = 12 (M = 9408 token rows: the 256-row-tile GEMM kernels, the
     grouped weight-gradient launch over 216 tiles, the sliced neck gradients -- instantiations the B = 2 fixtures never
     select), bf16, one training step exactly as bench.py runs it (fused upsample + P2CL, no materialised aux), against the
     CPU oracle on the same batch.  Bounds (bf16 has 8 significant bits, ~60 layers deep): mask logits within 2.6e-2 of their
-    range, the three loss scalars within 2e-2, every compared gradient within 10 % in norm and cosine > 0.98 element-wise."""
+    range, the three loss scalars within 2e-2, every compared gradient within 10 % in norm and cosine > 0.98 element-wise.
+    B = 4: the per-device batch of the reference's 8-GPU recipe (32 / 8; SURVEY 8e: "must work in the build" -- the
+    reference itself crashes there): M = 3136 rows, other tile counts and kernel choices, same bounds."""
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
-    from pvpuformer_amd import ops
     fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
-    B = 12
     big = vo.synth_batch(B, cfg["img"], seed=100)
     x = torch.cat([big["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1)
     x[:, 3] = torch.sigmoid(3 * (big["instances"][:, 0] - 0.4))
@@ -1225,8 +1226,10 @@ def test_bench_shape_bf16_step_matches_oracle(golden_dir):
     finally:
         eng_ops.gemm, eng_ops.gemm_grouped = orig_gemm, orig_grouped
     used = set(kernels)
-    assert any(k.startswith("gemm_bf16_k2_kernel<0, 0, 4") for k in used) and any(k.startswith("gemm_bf16_k2_kernel<0, 1, 2") for k in used)
-    assert "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
+    print(f"[kernels] B={B}:", sorted(used))
+    if B == 12:
+        assert any(k.startswith("gemm_bf16_k2_kernel<0, 0, 4") for k in used) and any(k.startswith("gemm_bf16_k2_kernel<0, 1, 2") for k in used)
+        assert "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
     # oracle on the same batch (fp32, CPU)
     sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
     out = vo.vpu_forward(sdg, cfg, x, big["points"])
@@ -1234,7 +1237,7 @@ def test_bench_shape_bf16_step_matches_oracle(golden_dir):
     total.backward()
     ref_inst = out["instances"].detach()
     err = float((inst.cpu() - ref_inst).abs().max()) / float(ref_inst.abs().max())
-    _within("bench-shape B=12 logits", err, 2.6e-2)      # measured 1.41e-2
+    _within(f"bench-shape B={B} logits", err, 2.6e-2)      # measured 1.41e-2 (B = 12)
     for k in ("total", "nfl", "dice", "p2cl"):
         a, b = float(losses[k]), float(total if k == "total" else parts[k])
         _within(f"bench-shape loss {k}", abs(a - b) / abs(b), 2e-3)      # measured <= 3.8e-4
