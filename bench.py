@@ -301,8 +301,9 @@ def main():
             sync()
         opt.prepare_step(1.0)
         try:
+            from pvpuformer_amd.graphs import capture
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture(g, device=dev):
                 step_body()
             opt.step_count -= 1        # capturing enqueues nothing: that step was not taken
             graph[0] = g
@@ -321,7 +322,8 @@ def main():
             sync()
         try:
             head = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(head, capture_error_mode="thread_local"):
+            from pvpuformer_amd.graphs import capture
+            with capture(head, device=dev):
                 head_body()
             red.begin()                # (the GEMM grids of a data-parallel backward leave the reducer's CUs free)
             seg = SegmentedBackward.capture(eng, lambda: eng.backward(held["d_inst"], None, d_sim_low=held["d_sim"]),

@@ -14,7 +14,27 @@ cut -- a range can be reported later than necessary, never earlier.
 """
 import torch
 
-from . import _lib
+from . import _lib, ops
+
+_capture_streams = {}
+
+
+def capture(g, pool=None, device=None):
+    """``torch.cuda.graph(g, ...)`` on this package's capture stream of ``device``.  The GEMMs' split-K scratch is kept per
+    stream and zero-filled when it is created: created here, before the first capture, the fill is not captured (on torch's
+    own capture stream the 128-MB fill became a node of every graph that was the first to need the scratch).
+    ``thread_local`` error mode: RCCL's watchdog thread polls events while a rank captures."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _capture_streams.get(dev.index)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            ops.split_k_workspace(dev)
+        st.synchronize()
+        _capture_streams[dev.index] = st
+    return torch.cuda.graph(g, pool=pool, stream=st, capture_error_mode="thread_local")
 
 
 class _CutHook:
@@ -48,7 +68,7 @@ class SegmentedBackward:
 
         def open_():
             g = torch.cuda.CUDAGraph()
-            ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local")   # (RCCL's watchdog thread polls events)
+            ctx = capture(g, pool=self.pool, device=eng.dev)
             ctx.__enter__()
             state.update(g=g, ctx=ctx, launched=False)
 

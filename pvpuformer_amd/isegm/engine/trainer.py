@@ -133,7 +133,7 @@ class VPUTrainStep:
         are overwritten by the next replay of the same key.  ``reducer``: this backward reports its finished gradient ranges
         to it (``reducer.begin()`` has been called: the GEMM grids leave its CUs free)."""
         from types import SimpleNamespace
-        from pvpuformer_amd.graphs import SegmentedBackward
+        from pvpuformer_amd.graphs import SegmentedBackward, capture
         hook = reducer.ready if reducer is not None else None
         key = (ptype, it, tuple(st.net_input.shape), tuple(st.points.shape), None if st.curve is None else tuple(st.curve.shape),
                bool(self.model.training), bool(eng.shadow_valid), id(eng),   # (a stale bf16 shadow is re-cast inside forward)
@@ -152,7 +152,7 @@ class VPUTrainStep:
             try:
                 eng.grad_ready_hook = None
                 fwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fwd, pool=self._pool, capture_error_mode="thread_local"):
+                with capture(fwd, pool=self._pool, device=st.net_input.device):
                     inst, losses, d_inst, d_sim = self._pass_body(eng, st, ptype, it)
                 if self._pool is None:
                     self._pool = fwd.pool()      # one pool for every captured pass: they never run beside each other, and

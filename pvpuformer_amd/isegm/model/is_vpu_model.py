@@ -213,8 +213,9 @@ class VitMultiGaussianVector_ed_Model(ISModel):
             s_box = None if boxes is None else boxes.to(device=image.device, dtype=torch.int32).contiguous().clone()
             eng.forward(s_img, s_pts, s_box, ptype, None, training=False)          # eager once: lazily created state
             torch.cuda.synchronize()
+            from pvpuformer_amd.graphs import capture
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture(g, device=image.device):
                 inst, aux = eng.forward(s_img, s_pts, s_box, ptype, None, training=False)
             ent = self._graphs[key] = (g, s_img, s_pts, s_box, inst, aux)
         g, s_img, s_pts, s_box, inst, aux = ent

@@ -55,7 +55,7 @@ def step(eng, img4, pts, gt, red=None):
 def chain_step(eng, img4, pts, gt, red, replays=2):
     """The same step replayed as a chain of hipGraphs (pvpuformer_amd/graphs.py): zero-grad + forward + losses in one graph,
     the backward cut at the reported gradient ranges, the reducer's collectives launched by the host between the segments."""
-    from pvpuformer_amd.graphs import SegmentedBackward
+    from pvpuformer_amd.graphs import SegmentedBackward, capture
     held = {}
 
     def head_body():
@@ -63,7 +63,7 @@ def chain_step(eng, img4, pts, gt, red, replays=2):
         inst, _ = eng.forward(img4, pts, None, 0, None, training=True, materialize_aux=False)
         _, held["d_inst"], held["d_sim"] = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
     head = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(head, capture_error_mode="thread_local"):
+    with capture(head):
         head_body()
     red.begin()
     seg = SegmentedBackward.capture(eng, lambda: eng.backward(held["d_inst"], None, d_sim_low=held["d_sim"]), hook_owner=red,

@@ -64,7 +64,7 @@ def main():
     def run_chain(red):
         """the same step replayed as bench.py replays it at N > 1: forward graph + backward segments cut at the reported
         ranges, the reducer's collectives launched by the host between two segments, Adam host-enqueued"""
-        from pvpuformer_amd.graphs import SegmentedBackward
+        from pvpuformer_amd.graphs import SegmentedBackward, capture
         held = {}
 
         def head_body():
@@ -72,7 +72,7 @@ def main():
             inst, _ = eng.forward(x, b["points"], None, 0, None, training=True, materialize_aux=False)
             _, held["d_inst"], held["d_sim"] = vpu_step_losses(inst, None, b["instances"], None, None, iter_weight=1.0, sim_low=eng.sim_low)
         head = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(head, capture_error_mode="thread_local"):
+        with capture(head):
             head_body()
         red.begin()
         seg = SegmentedBackward.capture(eng, lambda: eng.backward(held["d_inst"], None, d_sim_low=held["d_sim"]),
