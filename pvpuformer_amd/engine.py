@@ -799,12 +799,15 @@ class Engine:
         nQ, nK = B * nq * D, M * D
         q, k = q0, xr
         hs = []
+        qq = None
         for l in range(3):
             p = f"neck.att.layers.{l}"
             if l == 0:
                 q = self.mha(p + ".self_attn", q, q, q, B, nq, nq, D)
             else:
-                qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
+                # (queries + query_pe of the unchanged queries: the sum the previous layer's image-to-token attention
+                # took -- the reference adds it again, transformer.py:439 after :457, :374 after :457; same numbers, one launch less each
+                # way and two gradient accumulations less)
                 q = self.mha(p + ".self_attn", qq, qq, q, B, nq, nq, D, resid=q)
             q = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5)
             qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
@@ -818,8 +821,7 @@ class Engine:
             k = self.layernorm(k2, p + ".norm4", M, D, 1e-5)
             if l != 2:
                 hs.append((q, k))
-        qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
-        kk = self.add_pe(k, kpe_tab, nK, NT * D)
+        kk = self.add_pe(k, kpe_tab, nK, NT * D)            # (qq: the last layer's queries + query_pe, as above)
         q = self.mha("neck.att.final_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
         q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
         hs.append((q, k))
