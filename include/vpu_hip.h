@@ -113,6 +113,17 @@ int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, fl
 int vpu_layernorm_bwd_nblk(int64_t rows);
 int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype, void* stream);
+/* LayerNorm with the position-embedding add that follows it in the DMA neck (TwoWayAttentionBlock.forward,
+ * transformer.py:438-460: queries = norm(queries); q = queries + query_pe -- likewise keys + key_pe) in the same launch:
+ * y = LN(x) and y2 = y + pe[row % pe_rows] (pe: [pe_rows][C]; the sum is taken from the rounded y, as a separate add
+ * would take it).  pe = y2 = NULL: plain vpu_layernorm_fwd.  Its backward: the gradient of the output is dy + dy2
+ * (dy2 may be NULL), summed in fp32. */
+int vpu_layernorm_fwd_pe(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                         int64_t rows, int32_t C, float eps, const void* pe, int64_t pe_rows, void* y2,
+                         int32_t dtype, void* stream);
+int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* w, const float* mean,
+                       const float* rstd, const void* dres, void* dx, float* part, int64_t rows, int32_t C,
+                       int32_t dtype, void* stream);
 /* n (<= VPU_COLSUM_BATCH_MAX) independent fp32 column sums in one launch: out_j[c] += sum_r in_j[r * ncols_j + c].
  * Used for the partial weight / bias gradient rows of every LayerNorm / GroupNorm backward of a step
  * (models_vit.py:72-75, transformer.py:417-426, is_vpu_model.py:55-86 backward). */

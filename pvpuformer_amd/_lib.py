@@ -44,6 +44,8 @@ SIGNATURES = {
     "vpu_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "vpu_layernorm_bwd_nblk": [_L],
     "vpu_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "vpu_layernorm_fwd_pe": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _L, _P, _I, _P],
+    "vpu_layernorm_bwd2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vpu_colsum_batched": [C.POINTER(ColsumJob), _I, _P],
     "vpu_colsum_f32": [_P, _P, _L, _I, _F, _P],
     "vpu_colsum": [_P, _I, _P, _P, _L, _I, _F, _I, _P],

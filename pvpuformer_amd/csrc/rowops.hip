@@ -17,11 +17,15 @@ constexpr int LN_BWD_WAVES = 8;   // part rows: rows / 16, at most 512
 // One row per wave and trip; a wave walks rows with the grid stride and requests the NEXT row before it reduces the
 // current one (the reductions are two dependent cross-lane chains: without the prefetch every row pays a full HBM round
 // trip with nothing in flight).  NCH: 512-column chunks per row.
-template <typename T, int NCH>
+// PE: a second output y2 = y + pe[row % pe_rows] (the position-embedding add every normalised token / image map of the DMA
+// neck goes through before its q / k projections, transformer.py:439-457): the sum is taken from the ROUNDED y, as the
+// separate add launch takes it.
+template <typename T, int NCH, bool PE>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int64_t rows, int C, float eps) {
+                                                            int64_t rows, int C, float eps, const T* __restrict__ pe,
+                                                            int64_t pe_rows, T* __restrict__ y2) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -75,6 +79,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * ww[i][j] + bb[i][j];
                 store8(yr + c, o);
+                if (PE) {
+                    float pv[8];
+                    load8(pe + (row % pe_rows) * C + c, pv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = to_f32(from_f32<T>(o[j])) + pv[j];
+                    store8(y2 + row * C + c, o);
+                }
             }
         }
 #pragma unroll
@@ -86,8 +97,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------- LayerNorm bwd
 // NCH: 512-column chunks per row (C <= 512*NCH); NW waves per workgroup, one row per wave and trip: 16 rows in
 // flight per CU (one 1024-thread workgroup per CU) instead of 4 -- the kernel is a latency-bound stream of 3 KB rows.
-template <typename T, int NCH, int NW, bool PF>
-__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// D2: the gradient of the output is dy + dy2 (the two outputs of the PE form of the forward), summed in fp32.
+template <typename T, int NCH, int NW, bool PF, bool D2>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                            const T* __restrict__ x,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -111,6 +124,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
     const int64_t stride = (int64_t)nblk * NW;
     int64_t row = (int64_t)blockIdx.x * NW + wave;
     Raw8<T> cx[NCH], cd[NCH], cr[NCH], nx[NCH], nd[NCH], nres[NCH];
+    Raw8<T> cd2[D2 ? NCH : 1], nd2[D2 ? NCH : 1];
     float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
     if (PF && row < rows) {
         mu = mean[row]; rs = rstd[row];
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
             if (c < C) {
                 cx[i].load(x + row * C + c);
                 cd[i].load(dy + row * C + c);
+                if (D2) cd2[i].load(dy2 + row * C + c);
                 if (dres) cr[i].load(dres + row * C + c);
             }
         }
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
                 if (c < C) {
                     nx[i].load(x + nr * C + c);
                     nd[i].load(dy + nr * C + c);
+                    if (D2) nd2[i].load(dy2 + nr * C + c);
                     if (dres) nres[i].load(dres + nr * C + c);
                 }
             }
@@ -146,6 +162,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
                 if (c < C) {
                     cx[i].load(x + row * C + c);
                     cd[i].load(dy + row * C + c);
+                    if (D2) cd2[i].load(dy2 + row * C + c);
                     if (dres) cr[i].load(dres + row * C + c);
                 }
             }
@@ -159,6 +176,12 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
                 float xv[8], dv[8];
                 cx[i].get(xv);
                 cd[i].get(dv);
+                if (D2) {
+                    float d2[8];
+                    cd2[i].get(d2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dv[j] += d2[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -190,7 +213,10 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
         if (PF) {
             mu = nmu; rs = nrs;
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nres[i]; }
+            for (int i = 0; i < NCH; ++i) {
+                cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nres[i];
+                if (D2) cd2[i] = nd2[i];
+            }
         }
     }
     // reduce the waves' dw / db and write this block's partial row
@@ -599,37 +625,55 @@ __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n)
 
 #define ST reinterpret_cast<hipStream_t>(stream)
 
-extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
-                                 int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+extern "C" int vpu_layernorm_fwd_pe(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                    int64_t rows, int32_t C, float eps, const void* pe, int64_t pe_rows, void* y2,
+                                    int32_t dtype, void* stream) {
     vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm: C % 8 == 0, C <= 2048"); return VPU_ERR_ARG; }
+    if ((pe != nullptr) != (y2 != nullptr) || (pe && pe_rows <= 0)) {
+        vpu_set_error("layernorm_fwd_pe: pe, pe_rows > 0 and y2 go together");
+        return VPU_ERR_ARG;
+    }
     // balanced persistent grid: at most 2048 workgroups (8 per CU), every wave the same number of rows (+-1)
     const int64_t nb = (rows + 3) / 4, trips = (nb + 2047) / 2048;
     const unsigned grid = (unsigned)((nb + trips - 1) / trips);
-#define VPU_LN_FWD(NCH_) DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps);)
+#define VPU_LN_FWD(NCH_)                                                                                              \
+    if (pe) { DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_, true><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)pe, pe_rows, (T*)y2);) } \
+    else { DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_, false><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)nullptr, 1, (T*)nullptr);) }
     if (C <= 512) { VPU_LN_FWD(1) } else if (C <= 1024) { VPU_LN_FWD(2) } else { VPU_LN_FWD(4) }
 #undef VPU_LN_FWD
     return vpu_check_launch("vpu_layernorm_fwd");
+}
+extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                 int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+    return vpu_layernorm_fwd_pe(x, w, b, y, mean, rstd, rows, C, eps, nullptr, 0, nullptr, dtype, stream);
 }
 extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
     int64_t n = rows / (2 * LN_BWD_WAVES);
     return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));   // two workgroups per CU
 }
-extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype,
-                                 void* stream) {
+extern "C" int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* w, const float* mean,
+                                  const float* rstd, const void* dres, void* dx, float* part, int64_t rows, int32_t C,
+                                  int32_t dtype, void* stream) {
     vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
     const int nblk = vpu_layernorm_bwd_nblk(rows);
 #define VPU_LN_BWD(NCH_, NW_)                                                                                         \
-    DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2)><<<nblk, 64 * NW_, 0, ST>>>(                    \
-                          (const T*)dy, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);)
+    if (dy2) { DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), true><<<nblk, 64 * NW_, 0, ST>>>(   \
+                          (const T*)dy, (const T*)dy2, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);) } \
+    else { DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), false><<<nblk, 64 * NW_, 0, ST>>>(      \
+                          (const T*)dy, (const T*)nullptr, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);) }
     // (C > 1024 keeps 8 waves: its 4 chunks per lane need the 256-register budget)
     // (<= 2 chunks: 4-wave workgroups, ~170 VGPRs with the prefetched row -> three per CU; 4 chunks: no prefetch)
     if (C <= 512) { VPU_LN_BWD(1, 4) } else if (C <= 1024) { VPU_LN_BWD(2, 4) } else { VPU_LN_BWD(4, 8) }
 #undef VPU_LN_BWD
     return vpu_check_launch("vpu_layernorm_bwd");
+}
+extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, float* part, int64_t rows, int32_t C, int32_t dtype,
+                                 void* stream) {
+    return vpu_layernorm_bwd2(dy, nullptr, x, w, mean, rstd, dres, dx, part, rows, C, dtype, stream);
 }
 extern "C" int vpu_colsum_f32(const float* in, float* out, int64_t rows, int32_t C, float beta, void* stream) {
     vpu_clear_stale_error();

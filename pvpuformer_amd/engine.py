@@ -115,6 +115,7 @@ class Engine:
         # CUs, and the fork/join events cost host time (measured: 19.45 ms/step on one stream, 19.9 ms on two)
         self.use_side = os.environ.get("VPU_WGRAD_STREAM", "0") == "1"
         self.side = None
+        self.fuse_ln_pe = os.environ.get("VPU_LN_PE", "1") != "0"   # LayerNorm + position-embedding add in one launch (neck)
         # weight-gradient GEMMs are queued and launched in groups (ops.gemm_grouped): the four of a ViT block are 432
         # full-K tiles -- one round of the persistent grid, no split-K slabs, no reduce launches --, the neck's 576-row
         # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
@@ -482,23 +483,39 @@ class Engine:
             self.tape.append(bwd)
         return y
 
-    def layernorm(self, x, prefix, rows, Cdim, eps):
+    def layernorm(self, x, prefix, rows, Cdim, eps, pe=None, pe_rows=0, pe_var=None):
+        """y = LN(x).  ``pe`` [pe_rows, C]: also yy = y + pe[row % pe_rows] from the same launch -- the position-embedding
+        add of the DMA neck (transformer.py:439-457) -- and (y, yy) is returned; ``pe_var``: the Var behind ``pe`` when it
+        takes a gradient (the prompt tokens).  The backward takes the two outputs' gradients in one launch."""
+        if pe is not None and not self.fuse_ln_pe:       # VPU_LN_PE=0: the separate add launch (A/B runs)
+            y = self.layernorm(x, prefix, rows, Cdim, eps)
+            return y, self.add_pe(y, pe, rows * Cdim, pe_rows * Cdim, pe_var=pe_var)
         y = Var(self._new(rows, Cdim))
+        yy = Var(self._new(rows, Cdim)) if pe is not None else None
         mean, rstd = self._new(rows, dtype=torch.float32), self._new(rows, dtype=torch.float32)
-        ops.layernorm_fwd(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, rows, Cdim, eps)
+        if pe is None:
+            ops.layernorm_fwd(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, rows, Cdim, eps)
+        else:
+            ops.layernorm_fwd_pe(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, rows, Cdim,
+                                 eps, pe, pe_rows, yy.t)
         if self.training:
             def bwd():
-                if y.g is None:
+                dy, dy2 = y.g, (yy.g if yy is not None else None)
+                if dy is None and dy2 is None:
                     return
+                if dy2 is not None and pe_var is not None:
+                    self.acc(pe_var, dy2)
+                if dy is None:
+                    dy, dy2 = dy2, None
                 nblk = ops.layernorm_bwd_nblk(rows)
                 part = self._new(nblk, 2, Cdim, dtype=torch.float32)
                 dres = x.g
                 if x.g is None or x.g.data_ptr() in self._frozen:
                     x.g = torch.empty_like(x.t)   # (a frozen dres is read, the sum goes to a fresh buffer: no wait needed)
-                ops.layernorm_bwd(y.g, x.t, self.Pm(prefix + ".weight"), mean, rstd, dres, x.g, part, rows, Cdim)
+                ops.layernorm_bwd(dy, x.t, self.Pm(prefix + ".weight"), mean, rstd, dres, x.g, part, rows, Cdim, dy2=dy2)
                 self._reduce_wb(part, nblk, prefix, Cdim)
             self.tape.append(bwd)
-        return y
+        return y if pe is None else (y, yy)
 
     def sdpa(self, q, k, v, o, nb, H, nq, nk, hd, scale):
         """softmax(Q K^T * scale) V for nb*H independent (batch, head) problems.  q,k,v,o = (Var, col_off, ld, rows_per_b):
@@ -800,28 +817,25 @@ class Engine:
         q, k = q0, xr
         hs = []
         qq = None
+        kk = self.add_pe(k, kpe_tab, nK, NT * D)
         for l in range(3):
             p = f"neck.att.layers.{l}"
+            # queries + query_pe / keys + key_pe (transformer.py:439-457) come out of the LayerNorm launch that produces the
+            # queries / keys (Engine.layernorm(pe=...)); the sum of unchanged queries is taken once -- the reference adds it
+            # again at the next layer's start (:439 after :457, :374 after :457): same numbers
             if l == 0:
                 q = self.mha(p + ".self_attn", q, q, q, B, nq, nq, D)
             else:
-                # (queries + query_pe of the unchanged queries: the sum the previous layer's image-to-token attention
-                # took -- the reference adds it again, transformer.py:439 after :457, :374 after :457; same numbers, one launch less each
-                # way and two gradient accumulations less)
                 q = self.mha(p + ".self_attn", qq, qq, q, B, nq, nq, D, resid=q)
-            q = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5)
-            qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
-            kk = self.add_pe(k, kpe_tab, nK, NT * D)
+            q, qq = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
             q = self.mha(p + ".cross_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
             q = self.layernorm(q, p + ".norm2", B * nq, D, 1e-5)
             q = self.mlp(q, p + ".mlp.lin1", p + ".mlp.lin2", B * nq, D, 1024, D, "relu", resid=q)
-            q = self.layernorm(q, p + ".norm3", B * nq, D, 1e-5)
-            qq = self.add_pe(q, q0.t, nQ, nQ, pe_var=q0)
+            q, qq = self.layernorm(q, p + ".norm3", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
             k2 = self.mha(p + ".cross_attn_image_to_token", kk, qq, q, B, NT, nq, D // 2, resid=k)
-            k = self.layernorm(k2, p + ".norm4", M, D, 1e-5)
+            k, kk = self.layernorm(k2, p + ".norm4", M, D, 1e-5, pe=kpe_tab, pe_rows=NT)
             if l != 2:
                 hs.append((q, k))
-        kk = self.add_pe(k, kpe_tab, nK, NT * D)            # (qq: the last layer's queries + query_pe, as above)
         q = self.mha("neck.att.final_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
         q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
         hs.append((q, k))

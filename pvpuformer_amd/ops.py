@@ -130,13 +130,24 @@ def layernorm_fwd(x, w, b, y, mean, rstd, rows, Cdim, eps):
               _stream())
 
 
+def layernorm_fwd_pe(x, w, b, y, mean, rstd, rows, Cdim, eps, pe, pe_rows, y2):
+    """y = LN(x), y2 = y + pe[row % pe_rows] in one launch (vpu_layernorm_fwd_pe)."""
+    _lib.call("vpu_layernorm_fwd_pe", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, Cdim, eps, ptr(pe),
+              int(pe_rows), ptr(y2), code_of(x), _stream())
+
+
 def layernorm_bwd_nblk(rows):
     return _lib.load().vpu_layernorm_bwd_nblk(rows)
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, Cdim):
-    _lib.call("vpu_layernorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(part), rows,
-              Cdim, code_of(x), _stream())
+def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, Cdim, dy2=None):
+    """``dy2``: a second gradient of the output, summed with dy in fp32 (vpu_layernorm_bwd2)."""
+    if dy2 is None:
+        _lib.call("vpu_layernorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(part), rows,
+                  Cdim, code_of(x), _stream())
+    else:
+        _lib.call("vpu_layernorm_bwd2", ptr(dy), ptr(dy2), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                  ptr(part), rows, Cdim, code_of(x), _stream())
 
 
 def edt(mask_u8, zero_border=True):

@@ -391,6 +391,49 @@ def test_layernorm(ops, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C,pe_rows", [(768, 333), (768, 37), (1280, 111), (256, 9)])
+def test_layernorm_with_position_embedding_add(ops, dtype, C, pe_rows):
+    """vpu_layernorm_fwd_pe / vpu_layernorm_bwd2 (the DMA neck's LayerNorm -> + position embedding, transformer.py:439-457, in
+    one launch each way): both outputs bit-identical to the LayerNorm launch followed by the broadcast add (the sum is taken
+    from the rounded y); the backward over the two outputs' gradients == the plain backward over their sum -- bit-identical
+    in fp32, within one bf16 rounding of the summed gradient otherwise."""
+    rows = 333
+    td = TD[dtype]
+    x = dev(rnd(rows, C, seed=10, scale=2.0) + 0.3).to(td)
+    w, b = dev(1 + rnd(C, seed=11, scale=0.2)), dev(rnd(C, seed=12, scale=0.2))
+    pe = dev(rnd(pe_rows, C, seed=16)).to(td)
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd_pe(x, w, b, y, mean, rstd, rows, C, 1e-5, pe, pe_rows, y2)
+    y_ref, yy_ref = torch.empty_like(x), torch.empty_like(x)
+    mean_r, rstd_r = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x, w, b, y_ref, mean_r, rstd_r, rows, C, 1e-5)
+    ops.add_bcast(y_ref, pe, yy_ref, rows * C, pe_rows * C)
+    assert torch.equal(y, y_ref) and torch.equal(y2, yy_ref) and torch.equal(mean, mean_r) and torch.equal(rstd, rstd_r)
+    dy, dy2 = dev(rnd(rows, C, seed=13)).to(td), dev(rnd(rows, C, seed=17)).to(td)
+    dres = dev(rnd(rows, C, seed=14)).to(td)
+    nblk = ops.layernorm_bwd_nblk(rows)
+    part, part_r = torch.zeros(nblk, 2, C, device="cuda"), torch.zeros(nblk, 2, C, device="cuda")
+    dx, dx_r = torch.empty_like(x), torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, part, rows, C, dy2=dy2)
+    dsum = torch.empty_like(dy)
+    ops.add4(dy, dy2, None, None, dsum, rows * C)
+    ops.layernorm_bwd(dsum, x, w, mean, rstd, dres, dx_r, part_r, rows, C)
+    if dtype == 1:
+        assert torch.equal(dx, dx_r) and torch.equal(part, part_r)
+    else:
+        torch.testing.assert_close(dx.float(), dx_r.float(), atol=4e-2, rtol=2e-2)
+        torch.testing.assert_close(part.sum(0), part_r.sum(0), atol=0.3, rtol=3e-2)
+        # against the exact sum: closer than the path that rounds the summed gradient
+        xf = x.float().requires_grad_(True)
+        F.layer_norm(xf, (C,), w, b, 1e-5).backward(dy.float() + dy2.float())
+        exact = xf.grad + dres.float()
+        assert (dx.float() - exact).abs().mean() <= (dx_r.float() - exact).abs().mean() * 1.05
+    with pytest.raises(Exception):
+        ops.layernorm_fwd_pe(x, w, b, y, mean, rstd, rows, C, 1e-5, pe, 0, y2)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 def test_colsum_l2norm_add_cast(ops, dtype):
     td = TD[dtype]
     rows, C, ld = 1000, 256, 264
