@@ -104,6 +104,7 @@ def main():
     res["rccl_kernels_at_world_size_1"] = "none: RCCL returns from an in-place all-reduce over one rank without launching (kernel trace: 0 nccl kernels)"
     res["ms_reducer_bf16_wire_reserve16"] = round(run(GradReducer(eng.gflat, force=True, wire="bf16", reserve_cus=16)), 3)
     res["ms_reducer_fp32_wire_reserve0"] = round(run(GradReducer(eng.gflat, force=True, reserve_cus=0)), 3)
+    res["ms_reducer_fp32_wire_reserve0_again"] = round(run(GradReducer(eng.gflat, force=True, reserve_cus=0)), 3)
     ms, host, nseg = run_chain(GradReducer(eng.gflat, force=True, reserve_cus=16))
     res["ms_reducer_fp32_wire_reserve16_graph_chain"] = round(ms, 3)
     res["graph_chain_host_ms_per_step"] = round(host, 3)
