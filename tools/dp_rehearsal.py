@@ -109,6 +109,8 @@ def main():
     res["ms_reducer_fp32_wire_reserve16_graph_chain"] = round(ms, 3)
     res["graph_chain_host_ms_per_step"] = round(host, 3)
     res["graph_chain_backward_segments"] = nseg
+    ms0, host0, nseg0 = run_chain(GradReducer(eng.gflat, force=True, reserve_cus=0))
+    res["ms_reducer_fp32_wire_reserve0_graph_chain"] = round(ms0, 3)
     res["ms_no_reducer_again"] = round(run(None), 3)
     print(json.dumps(res))
     if len(sys.argv) > 2:
