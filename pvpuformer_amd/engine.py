@@ -1054,6 +1054,18 @@ class Engine:
                         self.flush_wgrads(k)
                     self._pending_reports.append((lo, hi))
                     self._report_ready()
+                    if len(self._pending_reports) >= 2:
+                        # the oldest range has waited a whole block: what still writes into it goes now -- the neck's small
+                        # long-reduction gradients wait to ride in a block's launch, and where the blocks' launches are whole
+                        # rounds already (D = 1024: 768 tiles) there is never room for them before the end of backward
+                        lo0, hi0 = self._pending_reports[0]
+                        off_of = lambda t: t[1] if isinstance(t, tuple) else None
+                        late = [e for e in self._wq
+                                if (off_of(e[0][2]) is None or lo0 <= off_of(e[0][2]) < hi0 or
+                                    (e[1].get("colsum") is not None and off_of(e[1]["colsum"]) is not None
+                                     and lo0 <= off_of(e[1]["colsum"]) < hi0))]
+                        if late:
+                            self.flush_wgrads(entries=late)
                 return
             self.flush_wgrads()
             if self.grad_ready_hook is not None:
@@ -1139,7 +1151,7 @@ class Engine:
             tail = ((dy, adv(x, c), adv(g, c), N, K - c, M, ld_dy, ld_x, ldc, dt), dict(kw, colsum=None), t128(N, K - c), red)
         return head, tail
 
-    def flush_wgrads(self, only_kind=None, ride=False, keep_riders=False, touching=None, budget=None):
+    def flush_wgrads(self, only_kind=None, ride=False, keep_riders=False, touching=None, budget=None, entries=None):
         """Launches the queued weight gradients (``only_kind``: just the entries of that kind, 0 = short reductions, else a
         reduction length).  Short reductions (<= 2048 rows) go into one grouped launch; long ones are grouped per reduction
         length when that beats one split-K launch + reduce each, otherwise they are launched one by one.
@@ -1148,6 +1160,9 @@ class Engine:
         ``touching``: only the entries that read the buffer at that address (it is about to be modified in place)."""
         kind_of = lambda e: 0 if e[3] <= 2048 else e[3]
         q = [e for e in self._wq if only_kind is None or kind_of(e) == only_kind]
+        if entries is not None:          # exactly these queued entries
+            ids = set(id(e) for e in entries)
+            q = [e for e in self._wq if id(e) in ids]
         if touching is not None:
             ptr_of = lambda t: (t[0] if isinstance(t, tuple) else t).data_ptr()
             q = [e for e in q if touching in (ptr_of(e[0][0]), ptr_of(e[0][1]))]

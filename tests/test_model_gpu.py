@@ -1118,8 +1118,11 @@ def test_vitl_width_bf16_close_to_reference(golden_dir):
     _within("vitl8 grad norms " + max(rel, key=rel.get), max(rel.values()), 0.1)      # measured 6.0e-2
 
 
-def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir):
-    """Data parallel at the benchmark's shapes (ViT-B, B = 12, bf16, a reducer attached): the exchange can only overlap the
+@pytest.mark.parametrize("fixture,B", [("vitb.npz", 12), ("vitl.npz", 8)])
+def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir, fixture, B):
+    """Data parallel at the benchmark's shapes (ViT-B, B = 12 and ViT-L, B = 8 -- config 4's per-GPU batch, where the blocks'
+    launches are whole rounds and the neck's small gradients never find room to ride: they once held every range back to the
+    end --, bf16, a reducer attached): the exchange can only overlap the
     backward if the ranges are reported WHILE it runs -- one per ViT block, each at most two blocks after its marker,
     although the blocks' weight gradients are packed into full rounds across blocks and the head's long reductions would
     otherwise sit in the queue until the end (every range was once reported after the last kernel).  Counted in launches
@@ -1127,8 +1130,7 @@ def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir):
     from pvpuformer_amd import _lib
     from pvpuformer_amd.graphs import SegmentedBackward
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
-    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
-    B = 12
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
     big = vo.synth_batch(B, cfg["img"], seed=100)
     x = torch.cat([big["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1).cuda()
     pts, gt = big["points"].cuda(), big["instances"].cuda()
