@@ -201,7 +201,7 @@ def main():
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
     from pvpuformer_amd.isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model
     from pvpuformer_amd.optim import FusedAdam
-    from pvpuformer_amd.parallel import GradReducer, broadcast_parameters
+    from pvpuformer_amd.parallel import GradReducer, broadcast_parameters, finish_and_step
     from pvpuformer_amd.synth import synth_batch, vitb_model_kwargs
 
     mk = MODELS[args.model]
@@ -258,7 +258,7 @@ def main():
         else:
             red.begin()
             eng.backward(d_inst, None, d_sim_low=d_sim)
-            opt.step(grad_scale=red.finish())
+            finish_and_step(red, opt)       # (N > 1: Adam on the reduced part while the last collectives are on the wire)
         last["loss"] = losses["total"]
 
     graph = [None]
@@ -282,7 +282,7 @@ def main():
             chain[0][0].replay()
             red.begin()
             chain[0][1].replay(red.ready if red.enabled else None)
-            opt.step(grad_scale=red.finish())
+            finish_and_step(red, opt)
             last["loss"] = held["loss"]
         else:
             step_body()

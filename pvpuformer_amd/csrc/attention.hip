@@ -1232,7 +1232,13 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lean_enabled()) {
         // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
-        const bool two = nq > 64 && (hd_image(hd) <= 64 || wide_two());
+        // The one-tile-per-wave instantiation of the 128-column image (attn_fwd_lean_kernel<128, 1, *>: head dims 80 - 128
+        // with <= 64 queries, i.e. ViT-H's 48 prompt tokens attending to the image) is NOT used: with scores large enough to
+        // leave the common loop (|q.k| scale of a few units: the rescaling path) its output differed from launch to launch
+        // and went NaN at larger ones (tools/xattn_repro.py; the two-tile form on the same inputs is bit-reproducible and
+        // matches torch, as do the 32- / 64-column one-tile forms).  Cause not found; the two-tile form takes these
+        // problems (half of its waves idle on 48 queries: a few microseconds per step).
+        const bool two = hd_image(hd) == 128 || (nq > 64 && hd_image(hd) <= 64);
         dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
         if (xcd_map_enabled() && grid.x > 1) { a.gx = grid.x; a.nbh = nb * H; grid = dim3(grid.x * grid.y); }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_fwd_lean_kernel<%d, %d, %d>", hd_image(hd), two ? 2 : 1, hd_computed(hd));
@@ -1246,9 +1252,8 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
             case 64 * 4 + 2: attn_fwd_lean_kernel<64, 2, 64><<<grid, 256, 0, s>>>(a); break;
             case 64 * 4 + 1: attn_fwd_lean_kernel<64, 1, 64><<<grid, 256, 0, s>>>(a); break;
             default:
-                if (hd <= 96) attn_fwd_lean_kernel<128, 1, 96><<<grid, 256, 0, s>>>(a);
-                else attn_fwd_lean_kernel<128, 1, 128><<<grid, 256, 0, s>>>(a);
-                break;
+                vpu_set_error("xattn_fwd: no kernel for this head dim / query count");
+                return VPU_ERR_ARG;
         }
         return vpu_check_launch("vpu_xattn_fwd");
     }

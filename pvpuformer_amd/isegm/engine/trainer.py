@@ -311,9 +311,10 @@ class VPUTrainStep:
         # the last iteration's logits (what the reference feeds its train metrics); a captured pass's live in its pool
         self.last_instances = inst.clone() if graphed else inst
         if step:
-            scale = self.red.finish() if self.red is not None else 1.0
-            if self.opt is not None:
-                self.opt.step(grad_scale=scale * grad_scale)
+            # (under a reducer the update of everything but the front of the buffer starts while the step's last
+            # collectives are still on the wire: parallel.finish_and_step)
+            from pvpuformer_amd.parallel import finish_and_step
+            finish_and_step(self.red, self.opt, grad_scale)
         logged["num_iters"] = num_iters
         return logged, points
 

@@ -136,8 +136,43 @@ def main():
                              buckets)
         assert ts[False][1] == 0 and ts[True][1] >= 2, (ts[False][1], ts[True][1])
         assert ts[False][2] == ts[True][2] and min(ts[True][2]) >= 3, (ts[False][2], ts[True][2])
+        # the optimizer step started before the last collectives have ended (parallel.finish_and_step) == the plain sequence
+        from pvpuformer_amd.parallel import finish_and_step
+        fs = {}
+        for wire in ("fp32", "bf16"):
+            for split in (False, True):
+                _, model_s, eng_s = build("bf16")
+                red_s = GradReducer(eng_s.gflat, bucket_bytes=1 << 20, force=True, reserve_cus=16, wire=wire)
+                opt_s = FusedAdam(model_s, lr=1e-3)
+                cuts = []
+                for _ in range(3):
+                    eng_s.zero_grad()
+                    red_s.begin()
+                    eng_s.grad_ready_hook = red_s.ready
+                    inst, _ = eng_s.forward(img4, pts, None, 0, None, training=True, materialize_aux=False)
+                    _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng_s.sim_low)
+                    eng_s.backward(d_inst, None, d_sim_low=d_sim)
+                    if split:
+                        finish_and_step(red_s, opt_s, 0.5, keep_last=2)
+                        cuts.append(int(red_s.last_split))
+                        assert not red_s._works and not red_s._staged
+                    else:
+                        opt_s.step(grad_scale=red_s.finish() * 0.5)
+                    eng_s.grad_ready_hook = None
+                torch.cuda.synchronize()
+                if split:       # the update really was cut in two: the front of the buffer waited for the last collectives
+                    assert all(0 < c < eng_s.total for c in cuts), (cuts, eng_s.total)
+                fs[(wire, split)] = (eng_s.flat.clone().cpu().numpy(), opt_s.m.clone().cpu().numpy(), opt_s.v.clone().cpu().numpy(),
+                                     eng_s.shadow.float().cpu().numpy(), opt_s.step_count)
+            for a, b_ in zip(fs[(wire, False)][:4], fs[(wire, True)][:4]):
+                assert np.array_equal(a, b_), f"split optimizer step differs from the plain one ({wire} wire)"
+        fs = {False: fs[("fp32", False)], True: fs[("fp32", True)]}
+        assert fs[False][4] == fs[True][4] == 3
         np.savez(os.path.join(out, "nccl1.npz"), plain=plain.cpu().numpy(), with_red=with_red.cpu().numpy(),
                  ts_eager=ts[False][0], ts_graph=ts[True][0],
+                 fs_plain_p=fs[False][0], fs_split_p=fs[True][0], fs_plain_m=fs[False][1], fs_split_m=fs[True][1],
+                 fs_plain_v=fs[False][2], fs_split_v=fs[True][2], fs_plain_s=fs[False][3], fs_split_s=fs[True][3],
+                 fs_total=np.asarray(eng_s.total),
                  with_bf16=with_bf16.cpu().numpy(), again=again.cpu().numpy(), launched=np.asarray(launched),
                  total=np.asarray(eng.total), chain0=chain[0].cpu().numpy(), chain1=chain[1].cpu().numpy(),
                  chain_launched=np.asarray(chain_launched), chain_graphs=np.asarray([n_graphs, n_ranges]),

@@ -57,6 +57,9 @@ def test_rccl_world_size_1_reducer_is_the_identity(tmp_path):
     assert np.array_equal(r["chain_ng0"], r["plain_ng"]) and np.array_equal(r["chain_ng1"], r["plain_ng"])
     assert np.array_equal(r["chain_launched_ng"], r["launched_ng"])
     assert r["chain_graphs_ng"][0] >= 3 and r["chain_graphs_ng"][1] >= 3, r["chain_graphs_ng"]
+    # Adam started on the reduced part while the last collectives are in flight == one Adam launch after all of them
+    for k in "pmvs":
+        assert np.array_equal(r[f"fs_split_{k}"], r[f"fs_plain_{k}"]), k
     # VPUTrainStep under the reducer: captured passes == host-enqueued passes after eight optimizer steps
     assert np.array_equal(r["ts_graph"], r["ts_eager"])
     ref = r["plain"]

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pvpuformer_amd.parallel import GradReducer, configure_rccl_env                   # noqa: E402
+from pvpuformer_amd.parallel import GradReducer, configure_rccl_env, finish_and_step  # noqa: E402
 
 
 def main():
@@ -50,7 +50,7 @@ def main():
             if red is not None:
                 red.begin()
             eng.backward(d_inst, None, d_sim_low=d_sim)
-            opt.step(grad_scale=red.finish() if red is not None else 1.0)
+            finish_and_step(red, opt)
         for _ in range(3):
             one()
         torch.cuda.synchronize()
@@ -83,7 +83,7 @@ def main():
             head.replay()
             red.begin()
             seg.replay(red.ready)
-            opt.step(grad_scale=red.finish())
+            finish_and_step(red, opt)
         for _ in range(3):
             one()
         torch.cuda.synchronize()
