@@ -518,14 +518,22 @@ template <int HD> struct Stg {
     }
 };
 
-// max of eight MFMA results: v_max3_f32 directly (fmaxf would first canonicalise every operand with a v_max_f32 x, x)
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// max of eight MFMA results: v_max3_f32 directly (fmaxf would first canonicalise every operand with a v_max_f32 x, x).
+// ONE asm block that starts with its own wait states: the compiler's hazard recognizer does not look into inline asm, and an
+// XDL result read by a VALU instruction needs up to 19 wait states after the MFMA was issued (no hardware interlock) --
+// without them the v_max3 directly behind the score MFMAs read the PREVIOUS key chunk's scores some of the time: a running
+// maximum that lags, exp2 of a positive difference, outputs that differ from launch to launch and NaN once the scores are
+// tens apart (seen in the one-tile 128-column form at ViT-H's neck shapes; every form had the pattern in its ISA).
 __device__ __forceinline__ float max8(const f32x4_t& a, const f32x4_t& b) {
-    return max3(max3(a[0], a[1], a[2]), max3(a[3], b[0], b[1]), max3(b[2], b[3], b[3]));
+    float d, t0, t1;
+    asm volatile("s_nop 15\n\ts_nop 3\n\t"
+                 "v_max3_f32 %0, %3, %4, %5\n\t"
+                 "v_max3_f32 %1, %6, %7, %8\n\t"
+                 "v_max3_f32 %2, %9, %10, %10\n\t"
+                 "v_max3_f32 %0, %0, %1, %2"
+                 : "=&v"(d), "=&v"(t0), "=&v"(t1)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    return d;
 }
 
 // Workgroup -> (problem bh, block x of it).  a.gx == 0: the 2-D grid (blockIdx.y = problem).  a.gx > 0: a 1-D grid whose
@@ -1232,13 +1240,8 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lean_enabled()) {
         // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
-        // The one-tile-per-wave instantiation of the 128-column image (attn_fwd_lean_kernel<128, 1, *>: head dims 80 - 128
-        // with <= 64 queries, i.e. ViT-H's 48 prompt tokens attending to the image) is NOT used: with scores large enough to
-        // leave the common loop (|q.k| scale of a few units: the rescaling path) its output differed from launch to launch
-        // and went NaN at larger ones (tools/xattn_repro.py; the two-tile form on the same inputs is bit-reproducible and
-        // matches torch, as do the 32- / 64-column one-tile forms).  Cause not found; the two-tile form takes these
-        // problems (half of its waves idle on 48 queries: a few microseconds per step).
-        const bool two = hd_image(hd) == 128 || (nq > 64 && hd_image(hd) <= 64);
+        // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
+        const bool two = nq > 64 && (hd_image(hd) <= 64 || wide_two());
         dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
         if (xcd_map_enabled() && grid.x > 1) { a.gx = grid.x; a.nbh = nb * H; grid = dim3(grid.x * grid.y); }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_fwd_lean_kernel<%d, %d, %d>", hd_image(hd), two ? 2 : 1, hd_computed(hd));
@@ -1252,8 +1255,9 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
             case 64 * 4 + 2: attn_fwd_lean_kernel<64, 2, 64><<<grid, 256, 0, s>>>(a); break;
             case 64 * 4 + 1: attn_fwd_lean_kernel<64, 1, 64><<<grid, 256, 0, s>>>(a); break;
             default:
-                vpu_set_error("xattn_fwd: no kernel for this head dim / query count");
-                return VPU_ERR_ARG;
+                if (hd <= 96) attn_fwd_lean_kernel<128, 1, 96><<<grid, 256, 0, s>>>(a);
+                else attn_fwd_lean_kernel<128, 1, 128><<<grid, 256, 0, s>>>(a);
+                break;
         }
         return vpu_check_launch("vpu_xattn_fwd");
     }

@@ -186,7 +186,7 @@ def _assert_independent(total, rows, image_tol, report, total_tol=1e-2):
     prompt-token path by direction (cosine > 0.98) for every tensor that is not at its noise floor (norm above 1e-3 of the
     path's largest); the whole buffer within ``total_tol``.  Measured (printed): ViT-L B = 8 0.55 % whole buffer, 3.4 %
     worst image-path tensor (pos_embed), lowest token-path cosine 0.992; ViT-H B = 12 0.41 % / 2.3 % / 0.985 (the same in every
-    process since the 128-column one-tile attention kernel, whose output varied from launch to launch, is no longer used)."""
+    process since the forward attention kernels' running maximum waits for its score MFMAs: csrc/attention.hip, max8)."""
     image = [r for r in rows if not r[2].startswith(TOKEN_PATH) and r[3] > 1e-3]
     token = [r for r in rows if r[2].startswith(TOKEN_PATH)]
     floor = 1e-3 * max(r[3] for r in token)

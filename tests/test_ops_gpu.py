@@ -1225,8 +1225,9 @@ def test_attention_with_large_scores_is_reproducible_and_finite(ops, hd, nq, nk,
     """Scores far apart (|q.k| of tens: the running-maximum rescaling of the streaming softmax is exercised at every key
     chunk) over many key chunks, at the neck's and the backbones' problem shapes: the output matches torch, is finite, and
     six launches on the same inputs -- with different memory around them -- agree bit for bit, forward and backward.  (The
-    one-tile-per-wave instantiation of the 128-column kernels failed all three at 48 queries -- ViT-H's prompt tokens
-    attending to the image -- and is no longer dispatched: csrc/attention.hip, vpu_xattn_fwd.)"""
+    forward kernels' running maximum once read its score MFMAs' results without the wait states an XDL result needs -- inline
+    asm, invisible to the compiler's hazard recognizer --: the one-tile 128-column form failed all three at 48 queries, ViT-H's
+    prompt tokens attending to the image: csrc/attention.hip, max8.)"""
     nb, H = 12, 8
     ld = H * hd
     g = torch.Generator(device="cuda").manual_seed(1234)
