@@ -158,6 +158,41 @@ def test_bench_batch_bf16_step(golden_dir, fixture, B, logit_tol):
     _assert_independent(total, rows, 4e-2, f"{fixture} B={B}:")
 
 
+@pytest.mark.parametrize("fixture,B", [("vitl.npz", 8), ("vith.npz", 12)])
+def test_training_step_is_bitwise_reproducible(golden_dir, fixture, B):
+    """The same step three times (the reference-shaped synthetic weights of the fixtures: scores large enough for the
+    attention kernels' rescaling path), freed memory poisoned with NaNs in between: logits, low-resolution similarities and
+    every gradient agree bit for bit, nothing is NaN -- no kernel depends on timing or reads what it has not written.
+    (This is the check that exposed the attention forward's missing wait states: ViT-H's neck output changed from launch
+    to launch.)"""
+    fx, cfg, model, batch, img4 = _model(golden_dir, fixture)
+    model.set_compute_dtype("bf16")
+    model.train()
+    more = vo.synth_batch(B - 2, cfg["img"], seed=200)
+    x = torch.cat([img4, torch.cat([more["images"], torch.sigmoid(3 * (more["instances"] - 0.4))], 1)], 0).cuda().contiguous()
+    pts = torch.cat([batch["points"], more["points"]], 0).cuda()
+    gt = torch.cat([batch["instances"], more["instances"]], 0).cuda()
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    runs = []
+    for r in range(3):
+        if r:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            junk = [torch.full((1 << 28,), float("nan"), device="cuda") for _ in range(16)]
+            junk += [torch.full((n,), float("nan"), device="cuda") for n in (256, 4096, 65536, 200000) for _ in range(300)]
+            del junk
+        eng.zero_grad()
+        inst, _ = _step(eng, x, pts, gt)
+        torch.cuda.synchronize()
+        runs.append((inst.clone(), eng.sim_low.clone(), eng.gflat.clone()))
+    for t in runs[0]:
+        assert torch.isfinite(t).all()
+    for other in runs[1:]:
+        for name, a, b in zip(("logits", "sim_low", "gradients"), runs[0], other):
+            assert torch.equal(a, b), f"{name} differ between two runs of the same step"
+
+
 TOKEN_PATH = ("neck.att", "neck.ffn_layer", "head.ffn_layer")     # the 48-prompt-token side: q / k projection gradients are small
                                                                   # differences of large terms (near-uniform softmax at random init)
 

@@ -1261,6 +1261,38 @@ def test_bench_shape_bf16_step_matches_oracle(golden_dir, B):
     assert len(worst) >= 14 and all(c > 0.98 and r < 0.1 for _, c, r in worst), sorted(worst, key=lambda t: t[1])[:4]
 
 
+@pytest.mark.parametrize("fixture,B", [("vitb.npz", 12), ("tiny.npz", 4)])
+def test_bench_shape_step_is_bitwise_reproducible(golden_dir, fixture, B):
+    """One training step three times on the same inputs (reference-shaped synthetic weights), the allocator's free memory
+    poisoned with NaNs in between: logits and every gradient bit for bit the same, all finite (see
+    tests/test_configs45_gpu.py::test_training_step_is_bitwise_reproducible for ViT-L / ViT-H)."""
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
+    big = vo.synth_batch(B, cfg["img"], seed=100)
+    x = torch.cat([big["images"], torch.sigmoid(3 * (big["instances"] - 0.4))], 1).cuda().contiguous()
+    pts, gt = big["points"].cuda(), big["instances"].cuda()
+    model.train()
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    runs = []
+    for r in range(3):
+        if r:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            junk = [torch.full((1 << 28,), float("nan"), device="cuda") for _ in range(12)]
+            junk += [torch.full((n,), float("nan"), device="cuda") for n in (256, 4096, 65536, 200000) for _ in range(300)]
+            del junk
+        eng.zero_grad()
+        inst, _ = eng.forward(x, pts, None, 0, None, training=True, materialize_aux=False)
+        _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
+        torch.cuda.synchronize()
+        runs.append((inst.clone(), eng.gflat.clone()))
+    assert all(torch.isfinite(t).all() for t in runs[0])
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][1], other[1])
+
+
 @pytest.mark.parametrize("fill", [0.8, 0.9])
 def test_riding_weight_gradients_equal_separate_launches(golden_dir, fill):
     """The queueing rules of the long-reduction weight gradients (small problems riding in a ViT block's grouped launch; big
