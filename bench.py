@@ -5,6 +5,9 @@ bf16 MFMA, synthetic data, random-init weights (BASELINE.json configs[1]).
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no WORLD_SIZE in the environment: bench.py starts the N ranks itself, as fresh
+                                         child processes, BEFORE anything here has touched the GPU or RCCL -- the
+                                         reference's launch is torch.distributed.launch, train.py:18,74)
 
 One "step" = one ISTrainer.batch_forward iteration with num_iters fixed to 1 (isegm/engine/trainer.py:310-491) on a
 resident batch: zero grads, forward (train mode, Dropout2d on), NFL + Dice + P2CL losses, backward, bucketed gradient
@@ -39,14 +42,43 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="NO GPU, NO model: only the launcher / rendezvous / bucketed reducer / JSON plumbing of an N-rank "
+                         "run over gloo on the CPU with a stand-in gradient buffer (tests/test_bench_launch_cpu.py). "
+                         "Prints value null: never a measurement")
     return ap.parse_args()
 
 
-def cpu_baseline(batch_size):
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: N fresh child processes through torch.distributed.run (one rank
+    per GPU, 127.0.0.1 rendezvous on a free port).  Called before this process has made any HIP / RCCL call -- it never
+    makes one: it waits for the children and exits with their code."""
+    import socket
+    import subprocess
+    if not args.rehearse_launch:
+        import __graft_entry__ as ge
+        ge.build()                     # hipcc only (no GPU): the ranks find a fresh library instead of racing to build it
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"bench.py: no WORLD_SIZE in the environment -- starting {args.gpus} ranks: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(batch_size, gpu_batch=12, keep_ref=None):
     """The CPU oracle (torch-CPU fp32 restatement of the reference, oracle/vpu_oracle.py) timed on this box's host
-    cores on a bounded sample: same step definition (fwd + NFL/Dice/P2CL + bwd), ``batch_size`` images per step."""
+    cores on a bounded sample: same step definition (fwd + NFL/Dice/P2CL + bwd), the FIRST ``batch_size`` images of the
+    batch rank 0's GPU step runs on (pvpuformer_amd.synth.synth_batch(gpu_batch, 448, seed=100), same seed path).
+    ``keep_ref``: a dict that receives the oracle's inputs, weights and mask logits for the parity check below."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vpu_oracle as vo
+    from pvpuformer_amd.synth import synth_batch
     # torch-CPU scales badly past a few dozen threads on this model (256 threads: 233 s/step measured in round 1):
     # use at most 32 and say so.  The sample is bounded to ~30 s: stop as soon as the budget is spent.
     cores = min(os.cpu_count() or 1, 32)
@@ -54,7 +86,8 @@ def cpu_baseline(batch_size):
     cfg = vo.make_cfg()
     sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in
           vo.synth_state_dict(vo.param_shapes(cfg), seed=0).items()}
-    b = vo.synth_batch(batch_size, cfg["img"], seed=1)
+    full = synth_batch(gpu_batch, cfg["img"], seed=100, device="cpu")
+    b = {k: v[:batch_size].contiguous() for k, v in full.items()}
     img4 = torch.cat([b["images"], torch.zeros(batch_size, 1, cfg["img"], cfg["img"])], 1)
     ed = vo.ed_mask_label(b["instances"])
     # 3 warm-up + >= 5 timed steps; bounded to ~30 s of CPU work (~1.4 s per step at 2 images): the warm-up is
@@ -71,13 +104,121 @@ def cpu_baseline(batch_size):
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_begin > BUDGET:
             break
+    if keep_ref is not None:
+        keep_ref.update(sd={k: v.detach() for k, v in sd.items()}, img4=img4, points=b["points"],
+                        logits=out["instances"].detach(), loss=float(total.detach()))
     warm = min(WARM, max(0, len(times) - 1))
     timed = times[warm:]
     t = sum(timed) / len(timed)
     return {"value": round(batch_size / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle/vpu_oracle.py fp32 torch-CPU on {cores} of {os.cpu_count()} host threads (more is slower: 256 "
-                      f"threads took 233 s/step), ViT-B/448, {batch_size} images/step fwd+bwd+losses, mean of {len(timed)} timed "
+                      f"threads took 233 s/step), ViT-B/448, the first {batch_size} images of the GPU step's batch "
+                      f"(synth_batch seed 100) per step, fwd+bwd+losses, mean of {len(timed)} timed "
                       f"step(s) after {warm} warm-up ({t:.2f} s/step, best {min(timed):.2f})"}
+
+
+def parity_vs_oracle(ref, model_kwargs, dev):
+    """Mask logits of the HIP path against the CPU oracle's on the SAME weights (hash-generated, loaded into a second model
+    instance) and the same images -- the first images of the timed batch --, in the exact-fp32 engine mode and in the bf16
+    mode the timed step runs in: max |difference| / max |reference logit| (north_star's 1e-3 is the fp32 figure; the bf16
+    mode is the reference's --amp analogue).  The oracle is the checker here, nothing of it is timed."""
+    from pvpuformer_amd.isegm.model.is_vpu_model import VitMultiGaussianVector_ed_Model
+    m = VitMultiGaussianVector_ed_Model(**model_kwargs).to(dev)
+    m.load_state_dict(ref["sd"], strict=True)
+    m.eval()
+    out = {}
+    for dtype in ("f32", "bf16"):
+        m.set_compute_dtype(dtype)
+        eng = m._ensure_engine()
+        eng.refresh_weights()
+        inst, _ = eng.forward(ref["img4"].to(dev), ref["points"].to(dev), None, 0, None, training=False, materialize_aux=False)
+        err = (inst.float().cpu() - ref["logits"]).abs().max().item() / ref["logits"].abs().max().item()
+        out["fp32_rel" if dtype == "f32" else "bf16_rel"] = float(f"{err:.3e}")
+    out["what"] = (f"max |mask logit - oracle| / max |oracle logit|, ViT-B/448, {ref['img4'].shape[0]} images of the timed batch, "
+                   f"oracle weights loaded into the HIP model (eval mode); the timed step computes in bf16")
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+def rehearse_launch(args, rank, world):
+    """``--rehearse-launch``: the N-rank plumbing of this file WITHOUT a GPU and WITHOUT the model -- launcher, gloo
+    rendezvous, parameter broadcast, the bucketed reducer fed tail-first ranges of a stand-in gradient buffer, barrier +
+    max-over-ranks timing, the data-parallel diagnostics and the JSON line.  ``value`` is null: nothing is measured."""
+    import torch.distributed as dist
+    from pvpuformer_amd.parallel import GradReducer, broadcast_parameters
+    if world > 1:
+        dist.init_process_group("gloo")
+    n = 1 << 20
+    flat = torch.full((n,), float(rank + 1))
+    broadcast_parameters(flat)
+    assert float(flat[0]) == 1.0
+    g = torch.zeros(n)
+    red = GradReducer(g, bucket_bytes=1 << 20)
+    cuts = [n, n * 3 // 4, n // 2, n // 4, n // 8, 0]
+
+    def step(diag=False):
+        g.fill_(float(rank + 1))
+        red.trace = [] if diag else None
+        red.begin()
+        for hi, lo in zip(cuts, cuts[1:]):
+            red.ready(lo, hi)
+        red.mark("bwd_end")
+        scale = red.finish()
+        red.mark("step_end")
+        return scale
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scale = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = bool(torch.all(g == world * (world + 1) / 2)) and scale == 1.0 / world
+    step(diag=True)
+    dp = dp_report(red, world, "gloo", "eager (rehearsal)")
+    if rank == 0:
+        print(json.dumps({"metric": "448x448 images/sec fwd+bwd, ViT-B VPUFormer", "value": None, "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.dtype, "data": "none (launch rehearsal on the CPU: no model, no GPU)",
+                          "config": {"workload": "launch rehearsal", "parallelism": f"dp{world}", "reduced_ok": ok},
+                          "dp": dp}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py --rehearse-launch: the reduced gradient is wrong")
+
+
+def dp_report(red, world, backend, launch_mode):
+    """The data-parallel fields of the JSON line (N > 1): what the run looked like from the inside, so that the first
+    multi-GPU measurement comes with an explanation -- ranks the communicator saw, bytes per step on the wire, where each
+    bucket's collective was launched and completed relative to the end of backward (exposed communication), host time
+    spent waiting, launch mode, the RCCL channel cap / reserved CUs in force."""
+    import torch.distributed as dist
+    d = red.summary() if red.trace is not None else {}
+    ranks = None
+    if world > 1 and dist.is_initialized():
+        one = torch.ones(1, device=red.g.device)
+        dist.all_reduce(one)
+        ranks = int(one.item())
+    d.update({"backend": backend, "ranks_seen_by_all_reduce": ranks, "launch_mode": launch_mode,
+              "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+              "VPU_DIST_RESERVE_CUS": os.environ.get("VPU_DIST_RESERVE_CUS", "16 (default)"),
+              "split_adam": int(os.environ.get("VPU_DIST_SPLIT_ADAM", "0"))})
+    try:
+        d["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:
+        d["rccl_version"] = None
+    return d
 
 
 def pmc_traffic(kernel, args):
@@ -151,9 +292,15 @@ class GemmProbe:
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))    # (this process has not touched the GPU and never will)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.rehearse_launch:
+        return rehearse_launch(args, rank, world)
     # the extension is (re)built BEFORE anything touches the GPU or RCCL: a stale .so means 8 hipcc children, which must
     # neither inherit a profiler preload nor keep the other ranks waiting inside a collective.  Rank 0 builds, the others
     # poll the file's freshness.
@@ -195,7 +342,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from pvpuformer_amd import ops
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
@@ -221,8 +367,11 @@ def main():
     # the backward tape: there the step is replayed as a CHAIN of graphs -- zero-grad + forward + losses, then the backward
     # cut wherever the engine reports a finished gradient range (pvpuformer_amd/graphs.py), the reducer's collectives
     # launched by the host between two segments, Adam host-enqueued -- ~25 launches per step instead of ~530.
+    # (N > 1 default: host-enqueued.  The chain has run under RCCL at world size 1 and over two gloo ranks only, and on a
+    # host that keeps up it is not faster -- 14.23 vs 14.08 ms per step under the forced reducer, DESIGN section 6 --:
+    # VPU_BENCH_DP_GRAPH=1 selects it once it has been seen on a multi-GPU node.)
     use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
-    use_chain = world > 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
+    use_chain = world > 1 and os.environ.get("VPU_BENCH_DP_GRAPH", "0") == "1"
     opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, capturable=use_graph)
     red = GradReducer(eng.gflat, wire=os.environ.get("VPU_DIST_WIRE", "fp32"))   # VPU_DIST_WIRE=bf16: half the bytes per link
     eng.grad_ready_hook = red.ready if red.enabled else None
@@ -386,6 +535,28 @@ def main():
     eng.use_side = side_was
     eng.grad_ready_hook = hook_was
     agg = probe.summary()
+    dp = None
+    if world > 1:
+        # one more untimed, host-enqueued step with every bucket's launch / completion stamped (HIP events on the compute
+        # stream): exposed communication = end of backward -> last bucket complete
+        try:
+            sync()
+            red.trace = []
+            eng.zero_grad()
+            mask = ops.dropout_mask(B, model.head.channels, keep, dev)
+            inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
+            _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+            red.begin()
+            eng.backward(d_inst, None, d_sim_low=d_sim)
+            red.mark("bwd_end")
+            finish_and_step(red, opt)
+            red.mark("step_end")
+            sync()
+            dp = dp_report(red, world, os.environ.get("VPU_DIST_BACKEND", "nccl"),
+                           graph_note[0] or "eager (host-enqueued kernels, collectives from the backward tape's markers)")
+        except Exception as e:         # diagnostics must never cost the measurement
+            dp = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        red.trace = None
     if agg:
         name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
@@ -405,15 +576,23 @@ def main():
                            "flop_per_image_fwd_bwd": FLOP_PER_IMG[args.model],
                            "mfma_roofline_frac_end_to_end":
                                round(value / world * FLOP_PER_IMG[args.model] / (BF16_PEAK_TFLOPS * 1e12), 4),
-                           "launch": graph_note[0] or ("hipGraph replay of the captured step" if use_graph else "eager"),
+                           "launch": graph_note[0] or ("hipGraph replay of the captured step" if use_graph else "eager (host-enqueued)"),
                            "optimizer": "Adam per finished gradient range on a second stream, overlapped with backward"
                                         if overlap is not None else "one Adam launch after backward",
                            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
                            "host_eager_enqueue_ms_unblocked": round(t_host * 1e3, 3),
                            "final_loss": round(loss_val, 5)},
                 "roofline": roof}
+        if dp is not None:
+            line["dp"] = dp
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+            ref = {} if (args.model == "vitb" and args.dtype == "bf16") else None
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, gpu_batch=B, keep_ref=ref)
+            if ref:
+                try:
+                    line["parity"] = parity_vs_oracle(ref, vitb_model_kwargs(), dev)
+                except Exception as e:
+                    line["parity"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -35,12 +35,13 @@ def install(reference_root=None):
       to the hidden file (``pvpuformer_amd._overlay``).
 
     Call it before the first ``import isegm``: if the reference's own package is already imported it is left alone and
-    returned.  Idempotent.  In a job launched with ``WORLD_SIZE`` > 1 it also caps RCCL's channel count to the CUs the
-    persistent GEMM grids leave free (``parallel.configure_rccl_env``) -- ``install()`` runs before the reference's
-    ``init_experiment`` creates the process group (exp.py:29-32), which is when that has to be in the environment."""
+    returned.  Idempotent.  In a job launched with ``WORLD_SIZE`` > 1 AND ``VPU_DIST_RESERVE_CUS`` set explicitly it also
+    caps RCCL's channel count to those CUs (``parallel.configure_rccl_env``, logged on rank 0) -- ``install()`` runs before
+    the reference's ``init_experiment`` creates the process group (exp.py:29-32), which is when that has to be in the
+    environment.  Opt-in: the cap applies to EVERY collective of the process and is unmeasured on a multi-GPU node."""
     import importlib
     import os
-    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and os.environ.get("VPU_DIST_RESERVE_CUS", "") != "":
         from .parallel import configure_rccl_env
         configure_rccl_env()
     import pkgutil

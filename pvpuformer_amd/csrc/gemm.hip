@@ -1407,6 +1407,278 @@ __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gem
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3 (round 4): the K2 wave tile (128 x 64 outputs per wave, 8 x 4 accumulator tiles) in a 256-thread workgroup of
+// 2 (M) x 2 (N) waves -- a 256 x 128 output tile with NO K split -- and TWO such workgroups per CU.
+//   * K2's eight waves are coupled by the workgroup barrier of every K-step: its two K-half groups alternate load and MFMA
+//     sections in lock step ("ping-pong"), so a barrier interval lasts as long as the LONGER of the two sections and the
+//     MFMA pipe is busy Mf / max(L, Mf) of the time (measured 0.45: the load section -- six LDS-DMA issues, twelve
+//     fragment reads, the counted wait -- takes ~1.7-2.4 x the 512 MFMA cycles it is paired with).  Two independent
+//     workgroups are not coupled: each SIMD holds one wave of either, the hardware issues whichever is ready, load sections
+//     overlap each other as well as the other wave's MFMAs (2 Mf / (L + Mf) at best), and one workgroup's prologue / epilogue
+//     runs beside the other's main loop -- no priming of the next tile, no exact-count epilogue, no K-half exchange
+//     (128 KiB through LDS per tile in K2).
+//   * two workgroups must share the 160 KiB of LDS: a K-step is 32 deep (one MFMA k), a stage is 24 KiB (A rows 0-127 |
+//     A rows 128-255 | B), three stages in a ring with a counted s_waitcnt vmcnt + ONE raw s_barrier per K-step
+//     (K2: two).  K-major operands keep K2's image ([k][128 columns], 256-B rows, 4 k-rows per 1-KiB DMA piece);
+//     K-contiguous ones are [128 rows][32 k] with 64-B rows, 16 rows per piece, 16-byte chunk index XOR ((row >> 3) & 1) << 1
+//     (conflict-free for ds_read_b128's lane groups).
+// ------------------------------------------------------------------------------------------------
+constexpr int K3_BK = 32;
+constexpr int K3_SUB = 8192;               // one 128 x 32 / 32 x 128 bf16 sub-tile
+constexpr int K3_STAGE = 3 * K3_SUB;
+constexpr int K3_LDS = 3 * K3_STAGE;       // 72 KiB
+constexpr int K3_PW = 6;                   // DMA pieces per wave per stage (24 pieces / 4 waves)
+
+__device__ __forceinline__ int kc32_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4); }
+
+template <int TRANS>
+__device__ __forceinline__ bf16x8_t k3_frag(const char* lds, int x16, int lane) {
+    if (TRANS == 0) return *reinterpret_cast<const bf16x8_t*>(lds + kc32_off(x16 + (lane & 15), lane >> 4));
+    else return read_frag<1>(lds, x16, 0, lane);
+}
+
+template <int TA, int TB, int RB>
+__device__ __forceinline__ void k3_voff(const K2Tile& t, const int wave, const int lane, int (&voff)[K3_PW]) {
+    static_assert(RB == 8 || TA == 0, "short tiles: row-major A only");
+#pragma unroll
+    for (int i = 0; i < K3_PW; ++i) {
+        const int sub = i >> 1, pis = wave + 4 * (i & 1);
+        const bool isA = sub < 2;
+        const int tr = isA ? TA : TB;
+        const int x0 = isA ? t.m0 + sub * (16 * RB) : t.n0;
+        const int X = isA ? t.M : t.N;
+        const int ld = isA ? t.lda : t.ldb;
+        if (tr == 0) {
+            const int row = pis * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ (((row >> 3) & 1) << 1);
+            const int gx = x0 + row;
+            voff[i] = (gx < X && (!isA || row < 16 * RB)) ? (gx * ld + chunk * 8) * 2 : OOB_OFFSET;
+        } else {
+            const int k = pis * 4 + (lane >> 4);
+            const int chunk = (lane & 15) ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
+            const int gx = x0 + chunk * 8;
+            voff[i] = gx < X ? (k * ld + gx) * 2 : OOB_OFFSET;
+        }
+    }
+}
+
+__device__ __forceinline__ void k3_issue(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB, const int (&voff)[K3_PW],
+                                         const int soffA, const int soffB, const bool live, char* __restrict__ wr, const int wave) {
+#pragma unroll
+    for (int i = 0; i < K3_PW; ++i) {
+        const int sub = i >> 1, pis = wave + 4 * (i & 1);
+        const int vo = live ? voff[i] : OOB_OFFSET;
+        if (sub < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(wr + sub * K3_SUB + pis * 1024), 16, vo, soffA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vptr)(wr + sub * K3_SUB + pis * 1024), 16, vo, soffB, 0, 0);
+    }
+}
+
+// one K-step: the DMA of K-step kt+2 into stage `wr`, the fragments and the 32 MFMAs of K-step kt from stage `rd`
+// (__restrict__ parameters of an inlined function: see ring_step)
+template <int TA, int TB, bool CS, int RB>
+__device__ __forceinline__ void k3_step(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB, const int (&voff)[K3_PW],
+                                        const int soffA, const int soffB, const bool live, char* __restrict__ wr,
+                                        const char* __restrict__ rd, const int wave, const int lane, const int wm, const int wn,
+                                        const bool do_cs, const bf16x8_t ones, f32x4_t (&acc)[RB][4], f32x4_t (&acc_cs)[4]) {
+    k3_issue(rA, rB, voff, soffA, soffB, live, wr, wave);
+    const char* la = rd + wm * K3_SUB;
+    const char* lb = rd + 2 * K3_SUB;
+    bf16x8_t af[RB], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = k3_frag<TB>(lb, wn * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) af[i] = k3_frag<TA>(la, i * 16, lane);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if constexpr (CS && RB == 8) if (do_cs) {   // the two N-halves of the wave grid share the A fragments: each sums four of the eight row blocks
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4 + i], ones, acc_cs[i], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <int FL, int RB, int H>
+__device__ __forceinline__ void k3_epi_half(const vpu_gemm_desc& p, const int FLG, const int vec, f32x4_t (&acc)[RB][4],
+                                            const int mw, const int nq, float* wl, const int lane) {
+    f32x4_t fin[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fin[i][j] = acc[H * 4 + i < RB ? H * 4 + i : 0][j];
+    const int mq = mw + H * 64;
+    constexpr int npass = H == 0 ? 4 : RB - 4;
+    k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
+}
+template <int FL, int RB, int H>
+__device__ __forceinline__ void k3_epi_fast_half(const vpu_gemm_desc& p, f32x4_t (&acc)[RB][4], const int mw, const int nq,
+                                                 float* wl, const int lane, const K2Pre<FL>& q) {
+    f32x4_t fin[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fin[i][j] = acc[H * 4 + i < RB ? H * 4 + i : 0][j];
+    k2_epi_fast<FL>(p, fin, mw + H * 64, nq, wl, lane, q, H == 0 ? 4 : RB - 4);
+}
+
+template <int TA, int TB, bool CS, int FL, bool GRP, int RB>
+__device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
+                                        const int tiles_m_arg, const int tiles_n_arg, const int vec_in) {
+    static_assert(!CS || (TA == 1 && RB == 8), "fused column sums: weight-gradient form");
+    constexpr bool GEN = FL < 0;
+    // exact-count epilogue (compile-time flag sets): the first two K-steps of the NEXT tile are requested before this tile's
+    // epilogue, whose NST unconditional stores per wave are then younger than those DMA pieces -- the counted waits of the
+    // next tile's first two K-steps allow for them
+    constexpr bool PRIME = !GEN;
+    constexpr int NST = GEN ? 0 : 16 * ((FL & VPU_EPI_SAVE_DGELU) ? 2 : 1);
+    constexpr int W1 = K3_PW + NST;
+    static_assert(W1 < 64, "vmcnt is a 6-bit count");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int vec = vec_in & 255;
+    const int total_work = GRP ? ga->start[ga->n] : tiles_m_arg * tiles_n_arg;
+    if ((vec_in >> 8) && (int)blockIdx.x >= (int)(gridDim.x >> 1)) {
+        // VPU_GEMM_K3_STAGGER=c: the second half of the grid (the second workgroup of a CU under round-robin placement) starts
+        // c x 1024 cycles late, so that the two workgroups of a CU are in different phases of their tiles
+        for (int i = 0; i < (vec_in >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    int work = blockIdx.x;
+    K2Tile cur;
+    int voff[K3_PW];
+    bool primed = false;
+    if (work < total_work) {
+        k2_tile_setup<2, GRP, RB>(work, total_work, p_arg, ga, tiles_n_arg, cur);
+        k3_voff<TA, TB, RB>(cur, wave, lane, voff);
+    }
+    while (work < total_work) {
+        const vpu_gemm_desc& p = GRP ? ga->d[cur.grp] : p_arg;
+        const int FLG = GEN ? p.flags : FL;
+        const int m0 = cur.m0, n0 = cur.n0;
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(cur.A), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(cur.B), 0, 0x7FFFFFFF, 0x00020000);
+        const int stepA = TA ? cur.lda * (K3_BK * 2) : K3_BK * 2, stepB = TB ? cur.ldb * (K3_BK * 2) : K3_BK * 2;
+        const int nk = cur.K / K3_BK;
+
+        f32x4_t acc[RB][4];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bool do_cs = CS && p.colsum != nullptr && cur.tile_n == 0;   // block-uniform
+        f32x4_t acc_cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
+
+        char* s0 = lds;
+        char* s1 = lds + K3_STAGE;
+        char* s2 = lds + 2 * K3_STAGE;
+        if (!primed) {
+            k3_issue(rA, rB, voff, 0, 0, true, s0, wave);
+            k3_issue(rA, rB, voff, stepA, stepB, 1 < nk, s1, wave);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's pieces of K-step kt have landed (the six of K-step kt+1 may still fly -- and, in the first two
+            // K-steps of a primed tile, the previous tile's epilogue stores); after the barrier so have everybody's, and
+            // every wave is done reading K-step kt-1, whose stage the next DMA overwrites
+            if (PRIME && primed && kt < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K3_PW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int kn = kt + 2;
+            k3_step<TA, TB, CS, RB>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, do_cs, ones, acc, acc_cs);
+            char* t = s0; s0 = s1; s1 = s2; s2 = t;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the out-of-range tail pieces still write zeros into LDS)
+        __syncthreads();
+        const int nxt = work + gridDim.x;
+        const bool has_next = nxt < total_work;
+        K2Tile nt = cur;
+        int nvoff[K3_PW];
+#pragma unroll
+        for (int i = 0; i < K3_PW; ++i) nvoff[i] = voff[i];
+        float* wl = reinterpret_cast<float*>(lds + 2 * K3_STAGE + wave * 4096);   // 16 rows x 64 fp32 per wave, in stage 2
+        const int mw = m0 + wm * (16 * RB), nq = n0 + wn * 64;
+        if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
+            primed = false;
+        } else if constexpr (GEN) {
+            if constexpr (CS) if (do_cs && (lane & 15) == 0) {
+                const int fq = lane >> 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + wm * 128 + (wn * 4 + i) * 16 + fq * 4 + r;
+                        if (row < cur.M) p.colsum[row] += acc_cs[i][r];
+                    }
+            }
+            // (the two 64-row halves of the wave tile, written out twice: a loop over them that the compiler does not unroll
+            // indexes the accumulators at run time and sends all 128 of them to scratch)
+            k3_epi_half<FL, RB, 0>(p, FLG, vec, acc, mw, nq, wl, lane);
+            k3_epi_half<FL, RB, 1>(p, FLG, vec, acc, mw, nq, wl, lane);
+            primed = false;
+        } else {
+            // everything the epilogue reads from global memory is requested first, then the next tile's first two K-steps,
+            // then the math and the stores
+            K2Pre<GEN ? 0 : FL> q0, q1;
+            k2_prefetch<GEN ? 0 : FL>(p, mw, nq, lane, q0, 4);
+            k2_prefetch<GEN ? 0 : FL>(p, mw + 64, nq, lane, q1, RB - 4);
+            if (has_next) {
+                k2_tile_setup<2, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+                k3_voff<TA, TB, RB>(nt, wave, lane, nvoff);
+                const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
+                const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
+                const int nsA = TA ? nt.lda * (K3_BK * 2) : K3_BK * 2, nsB = TB ? nt.ldb * (K3_BK * 2) : K3_BK * 2;
+                k3_issue(nA, nB, nvoff, 0, 0, true, lds, wave);
+                k3_issue(nA, nB, nvoff, nsA, nsB, K3_BK < nt.K, lds + K3_STAGE, wave);
+            }
+            k3_epi_fast_half<GEN ? 0 : FL, RB, 0>(p, acc, mw, nq, wl, lane, q0);
+            k3_epi_fast_half<GEN ? 0 : FL, RB, 1>(p, acc, mw, nq, wl, lane, q1);
+            primed = has_next;
+        }
+        // every wave is done with its epilogue scratch before the next tile's third K-step lands in stage 2 (raw barrier: the
+        // global stores stay in flight)
+        __builtin_amdgcn_s_barrier();
+        if (has_next && !primed) {
+            k2_tile_setup<2, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+            k3_voff<TA, TB, RB>(nt, wave, lane, nvoff);
+        }
+        cur = nt;
+#pragma unroll
+        for (int i = 0; i < K3_PW; ++i) voff[i] = nvoff[i];
+        work = nxt;
+    }
+}
+
+template <int TA, int TB, int FL, int RB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_k3_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
+                                                              const int vec) {
+    k3_body<TA, TB, false, FL, false, RB>(p, nullptr, tiles_m, tiles_n, vec);
+}
+template <int TA, int TB, bool CS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_k3_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
+    const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
+    k3_body<TA, TB, CS, -1, true, 8>(ga->d[0], ga, 0, 0, vec);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny problems: the DMA neck's prompt-token GEMMs (M = B*48 = 576 rows, N, K <= 2048; at inference M = 96).  With the
 // 128x128 tile they are 15-30 tiles of 12+ K-tiles each, run as split-K slabs + a reduce launch (~16 us per GEMM, 50 of
 // them per training step).  Here a workgroup owns one 64x64 output tile and its FOUR WAVES SPLIT K: every wave walks a
@@ -1780,6 +2052,14 @@ std::atomic<int> g_opt_skinny{-1};
 // form only, 2 also the 256 x 256 form where its tile count fills the chip, 3 the 256 x 256 form wherever it is legal
 std::atomic<int> g_opt_skinny_group{-1};
 std::atomic<int> g_opt_k2{-1};
+// K3 kernels (256 x 128 tiles in 256-thread workgroups, two per CU): bit 0 the grouped weight gradients, bit 1 the
+// forward / dgrad forms of vpu_gemm, bit 2 the grouped forward / dgrad form; -1 environment default (VPU_GEMM_K3)
+std::atomic<int> g_opt_k3{-1};
+inline int k3_env0() {
+    static const int v = [] { const char* e = getenv("VPU_GEMM_K3"); return e ? atoi(e) : 1; }();
+    return v;
+}
+inline int k3_opt() { const int v = g_opt_k3.load(std::memory_order_relaxed); return v >= 0 ? v : k3_env0(); }
 inline int k2_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_K2"); return e ? atoi(e) : 2; }();
     return v;
@@ -1884,6 +2164,47 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 kchunk = (int)(((d->K + want - 1) / want + BK - 1) / BK * BK);
                 splitk = (d->K + kchunk - 1) / kchunk;
             }
+        }
+        // K3 (bit 1 of the k3 option): the same problems as K2 below, 256 x 128 tiles in 256-thread workgroups, two per CU
+        if ((k3_opt() & 2) && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % K3_BK == 0 && d->K >= 256 &&
+            !d->transA && d->alpha == 1.0f && (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL &&
+            (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
+            static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            static const int rb3_env = [] { const char* e = getenv("VPU_GEMM_K2_RB"); return e ? atoi(e) : 0; }();
+            constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
+                          F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
+            const int tn3 = (d->N + 127) / 128;
+            const int64_t t256 = (int64_t)((d->M + 255) / 256) * tn3, t224 = (int64_t)((d->M + 223) / 224) * tn3;
+            const bool short3 = rb3_env != 8 && (rb3_env == 7 || t224 * 224 < t256 * 256);
+            const int64_t tot3 = short3 ? t224 : t256;
+            const int cap3 = 2 * cu_count();
+            bool done3 = tot3 > cu_count();      // (one workgroup per CU: K2's ping-pong is the faster form)
+            static const int stag3 = [] { const char* e = getenv("VPU_GEMM_K3_STAGGER"); return e ? atoi(e) : 0; }();
+            const int vec3 = (noepi3 ? 9 : 1) | (stag3 << 8);
+#define VPU_LAUNCH_K3_RB(TA_, TB_, FL_, RB_)                                                                         \
+    do {                                                                                                             \
+        static bool attr_ = false;                                                                                   \
+        auto kern_ = gemm_bf16_k3_kernel<TA_, TB_, FL_, RB_>;                                                         \
+        if (!attr_) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS); \
+            attr_ = true;                                                                                            \
+        }                                                                                                            \
+        const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
+        const int tot_ = tm_ * tn3;                                                                                  \
+        NOTE_KERNEL("gemm_bf16_k3_kernel<%d, %d, %d, %d>", TA_, TB_, FL_, RB_);                                        \
+        kern_<<<dim3((unsigned)(tot_ < cap3 ? tot_ : cap3)), dim3(256), K3_LDS, s>>>(*d, tm_, tn3, vec3);              \
+    } while (0)
+#define VPU_LAUNCH_K3(TA_, TB_, FL_) do { if (short3) VPU_LAUNCH_K3_RB(TA_, TB_, FL_, 7); else VPU_LAUNCH_K3_RB(TA_, TB_, FL_, 8); } while (0)
+            if (!done3) {}
+            else if (key == 0 && f == F_B) VPU_LAUNCH_K3(0, 0, F_B);
+            else if (key == 0 && f == F_BR) VPU_LAUNCH_K3(0, 0, F_BR);
+            else if (key == 0 && f == F_G) VPU_LAUNCH_K3(0, 0, F_G);
+            else if (key == 1 && f == 0) VPU_LAUNCH_K3(0, 1, 0);
+            else if (key == 1 && f == F_M) VPU_LAUNCH_K3(0, 1, F_M);
+            else done3 = false;
+#undef VPU_LAUNCH_K3
+#undef VPU_LAUNCH_K3_RB
+            if (done3) return vpu_check_launch("vpu_gemm");
         }
         // K2: large problems whose 256 x 128 tiles fill the chip and whose epilogue is one of the ViT-block flag sets
         {
@@ -2124,6 +2445,10 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_k2.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
+    if (name && !strcmp(name, "k3") && value >= -1 && value <= 7) {
+        g_opt_k3.store(value, std::memory_order_relaxed);
+        return VPU_OK;
+    }
     if (name && !strcmp(name, "skinny_group") && value >= -1 && value <= 2) {
         g_opt_skinny_group.store(value, std::memory_order_relaxed);
         return VPU_OK;
@@ -2140,6 +2465,7 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
                   "splitk_inlaunch (-1 environment default, 0 separate reduce launch, 1 last-arriver combine), "
                   "skinny (-1 environment default, 0 off, 1 on), "
                   "k2 (-1 environment default, 0 off, 1 256x128 tiles, 2 + 256x256 where it fills the chip, 3 256x256 wherever legal), "
+                  "k3 (-1 environment default, bit 0 grouped weight gradients, bit 1 forward / dgrad, bit 2 grouped forward / dgrad), "
                   "reserve_cus (0..128 CUs the persistent launches leave unclaimed)");
     return VPU_ERR_ARG;
 }
@@ -2274,6 +2600,21 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         // the 128 x 128 grouped kernel's two tiles per CU: 165 vs 236 us)
         bool very_long = true;
         for (int i = 0; i < n; ++i) very_long = very_long && descs[i].K >= 8192;
+        // (K3: two free-running workgroups per CU -- measured against K2 on grouped weight gradients over 9408 rows: 512 tiles
+        // 246 vs 284 us, 432 tiles 280 vs 299, but 216 tiles -- one workgroup per CU, nobody to overlap with -- 201 vs 149)
+        if (ok && (k3_opt() & 1) && total2 > cu_count()) {
+            static bool attr3_ = false;
+            auto kern_ = gemm_bf16_k3_grouped_kernel<1, 1, true>;
+            if (!attr3_) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
+                attr3_ = true;
+            }
+            const int cap = 2 * cu_count();
+            static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            NOTE_KERNEL("gemm_bf16_k3_grouped_kernel<1, 1, true>");
+            kern_<<<dim3((unsigned)(total2 < cap ? total2 : cap)), dim3(256), K3_LDS, s>>>(g2, noepi3 ? 9 : 1);
+            return vpu_check_launch("vpu_gemm_grouped");
+        }
         if (ok && (total2 >= 192 || (very_long && total2 >= 96))) {
             static bool attr_ = false;
             auto kern_ = gemm_bf16_k2_grouped_kernel<1, 1, true>;

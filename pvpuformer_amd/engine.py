@@ -136,6 +136,10 @@ class Engine:
         blk = sum(((n + 255) // 256) * ((k + 127) // 128) for n, k in ((3 * self.D, self.D), (self.D, self.D), (hid, self.D), (self.D, hid)))
         pk = os.environ.get("VPU_WGRAD_PACK", "")
         self.pack_wgrad = pk == "1" or (pk != "0" and blk < 0.95 * 256)
+        # K3 weight-gradient launches (round 4: 256 x 128 tiles in 256-thread workgroups, TWO per CU, free-running): a full
+        # round is 512 tiles.  VPU_GEMM_K3 (bit 0) selects them in the library; the engine sizes its packed launches for it.
+        self.k3_wgrad = (int(os.environ.get("VPU_GEMM_K3", "1")) & 1) != 0
+        self.wgrad_round = 512 if self.k3_wgrad else 256
         self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
         self._pending_reports, self._reporting = [], False    # gradient ranges whose marker has been passed but not reported yet
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
@@ -345,7 +349,7 @@ class Engine:
                 T = sum(self._k2_tiles(e) for e in anchors)
                 if self.pack_wgrad:
                     self._pack_seen[kind] = self._pack_seen.get(kind, 0) + self._k2_tiles(self._wq[-1])
-                    budget = self.pack_tiles(self._pack_total.get(kind), 256 - self._reserved_cus())
+                    budget = self.pack_tiles(self._pack_total.get(kind), self.wgrad_round - (self.wgrad_round // 256) * self._reserved_cus())
                     T = sum(self._k2_tiles(e) for e in same)          # riders count: they are packed like everything else
                     while T >= budget:
                         self.flush_wgrads(kind, ride=True, budget=budget)

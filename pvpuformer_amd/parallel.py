@@ -50,6 +50,54 @@ class GradReducer:
         self.on_bucket = None     # optional callable(lo, hi, work): called right after a bucket's collective is launched
         self.reduced_from = 0     # see finish(keep_last)
         self.last_split = 0       # where finish_and_step cut the optimizer step in two (0: it did not)
+        self.trace = None         # a list: every launch / completed wait / mark() of the step is stamped (see summary())
+
+    # ---- diagnostics of ONE step (bench.py at N > 1, tools/dp_sweep.py): where the exchange sits relative to backward
+    def _stamp(self):
+        """(host seconds, device event or None): the event is recorded on the CURRENT stream, so for a 'done' stamp --
+        taken right after the stream was made to wait for a collective -- it fires when that collective has completed and
+        everything queued before it on the compute stream has run."""
+        import time
+        ev = None
+        if self.g.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        return (time.perf_counter(), ev)
+
+    def mark(self, name):
+        if self.trace is not None:
+            self.trace.append((name, 0, 0, self._stamp(), 0.0))
+
+    def summary(self):
+        """After the step has been synchronised: per-bucket launch / completion times relative to the 'bwd_end' mark, the
+        exposed communication (end of backward -> last bucket complete, on the compute stream), bytes on the wire."""
+        tr = self.trace or []
+        def at(stamp, ref):
+            (h, e), (h0, e0) = stamp, ref
+            return e0.elapsed_time(e) if (e is not None and e0 is not None) else (h - h0) * 1e3
+        ref = next((t[3] for t in tr if t[0] == "bwd_end"), None)
+        esz = 2 if self.wire == "bf16" else self.g.element_size()
+        buckets, last_done, host_wait = [], 0.0, 0.0
+        launch = {(lo, hi): st for n, lo, hi, st, _ in tr if n == "launch"}
+        for n, lo, hi, st, hw in tr:
+            if n != "done":
+                continue
+            d = at(st, ref) if ref is not None else None
+            l = at(launch[(lo, hi)], ref) if (ref is not None and (lo, hi) in launch) else None
+            buckets.append({"mb": round((hi - lo) * esz / 1e6, 1), "launched_ms_vs_bwd_end": None if l is None else round(l, 3),
+                            "done_ms_vs_bwd_end": None if d is None else round(d, 3), "host_wait_ms": round(hw * 1e3, 3)})
+            host_wait += hw
+            if d is not None:
+                last_done = max(last_done, d)
+        payload = sum((hi - lo) * esz for n, lo, hi, _, _ in tr if n == "launch")
+        step_end = next((t[3] for t in tr if t[0] == "step_end"), None)
+        return {"world_size": self.world, "collectives_per_step": len(launch), "wire_dtype": self.wire,
+                "payload_bytes_per_step": int(payload),
+                "wire_bytes_per_gpu_per_step": int(payload * 2 * (self.world - 1) / max(self.world, 1)),
+                "exposed_comm_ms": round(last_done, 3) if ref is not None else None,
+                "bwd_end_to_step_end_ms": round(at(step_end, ref), 3) if (ref is not None and step_end is not None) else None,
+                "host_wait_ms_total": round(host_wait * 1e3, 3), "reserve_cus": self.reserve_cus,
+                "bucket_mb": round(self.bucket_elems * self.g.element_size() / 1e6, 1), "buckets": buckets}
 
     def begin(self):
         self._pending_hi = self._pending_lo = None
@@ -85,6 +133,8 @@ class GradReducer:
             work = dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(work)
         self.launched.append((lo, hi))
+        if self.trace is not None:
+            self.trace.append(("launch", lo, hi, self._stamp(), 0.0))
         if self.on_bucket is not None:
             self.on_bucket(lo, hi, work)
 
@@ -96,9 +146,23 @@ class GradReducer:
         if self.enabled:
             self._flush()
             n_wait = max(0, len(self._works) - keep_last) if keep_last else len(self._works)
-            done_lo = self.launched[len(self.launched) - len(self._works) + n_wait - 1][0] if n_wait else None
-            for w in self._works[:n_wait]:
+            first = len(self.launched) - len(self._works)          # index in `launched` of the oldest collective in flight
+            if keep_last and n_wait < len(self._works):
+                # [reduced_from, total) may only be called final if the buckets really went out tail-first: every range that
+                # stays in flight must lie wholly below every range that has been waited for.  ready() accepts ranges in any
+                # order (it flushes them separately), so check instead of assuming -- otherwise wait for everything.
+                waited, kept = self.launched[first:first + n_wait], self.launched[first + n_wait:]
+                cut = min((lo for lo, _ in waited), default=None)
+                if cut is None or any(hi > cut for _, hi in kept):
+                    n_wait = len(self._works)
+            done_lo = min(lo for lo, _ in self.launched[first:first + n_wait]) if n_wait else None
+            import time
+            for i, w in enumerate(self._works[:n_wait]):
+                t0 = time.perf_counter()
                 w.wait()
+                if self.trace is not None:
+                    lo, hi = self.launched[first + i]
+                    self.trace.append(("done", lo, hi, self._stamp(), time.perf_counter() - t0))
             self._works = self._works[n_wait:]
             rest = []
             for lo, hi, stage in self._staged:
@@ -116,16 +180,20 @@ class GradReducer:
         return 1.0 / self.world
 
 
-def finish_and_step(red, opt, grad_scale=1.0, keep_last=2):
+def finish_and_step(red, opt, grad_scale=1.0, keep_last=None):
     """``opt.step(grad_scale * red.finish())`` with the optimizer's work started before the exchange has ended: the last
     ``keep_last`` collectives of a step -- block 0, the patch embeddings: ranges the backward can only hand over when it
     ends -- are on the wire when nothing of the backward is left to hide them; the Adam update of everything ELSE (an
     HBM-bound stream over ~90 % of the parameters, 0.55 ms at ViT-B) does not need them.  So: wait for all but the last
     collectives, update [reduced_from, total), wait for the rest, update [0, reduced_from).  Same arithmetic as one launch
     (the update is element-wise).  Falls back to the plain sequence for a per-tensor hyper-parameter table, a capturable
-    optimizer or a disabled reducer."""
+    optimizer or a disabled reducer.  ``keep_last`` None: ``VPU_DIST_SPLIT_ADAM`` (default 0 = the plain sequence: the split
+    has only run at world size 1 on RCCL and over gloo; opt in once it has been measured on a multi-GPU node)."""
     from . import ops
     from .optim import FusedAdam
+    if keep_last is None:
+        import os
+        keep_last = int(os.environ.get("VPU_DIST_SPLIT_ADAM", "0"))
     plain = (red is None or not red.enabled or not isinstance(opt, FusedAdam) or opt.capturable or opt.per_param is not None
              or opt.decoupled or keep_last <= 0)
     if plain:
@@ -168,6 +236,10 @@ def configure_rccl_env(channels=None):
             warnings.warn("configure_rccl_env() after init_process_group: a communicator that already exists keeps its "
                           "channel count; call pvpuformer_amd.install() (or this function) before the process group is created")
         os.environ["NCCL_MAX_NCHANNELS"] = str(channels)
+        if os.environ.get("RANK", "0") == "0":
+            import sys
+            sys.stderr.write(f"pvpuformer_amd: NCCL_MAX_NCHANNELS={channels} (= the CUs the persistent GEMM grids leave to "
+                             f"RCCL; set NCCL_MAX_NCHANNELS or VPU_DIST_RESERVE_CUS to override)\n")
     return os.environ.get("NCCL_MAX_NCHANNELS")
 
 

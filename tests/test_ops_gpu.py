@@ -1340,6 +1340,59 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
 
 
 @pytest.mark.parametrize("tB", [0, 1])
+@pytest.mark.parametrize("shape", [(6001, 1544, 256), (5000, 2304, 640), (9408, 2304, 768)])
+def test_gemm_k3_exact_and_epilogues(ops, tB, shape):
+    """The round-4 kernels (vpu_gemm_set_option("k3", 3): 256 / 224 x 128 tiles in 256-thread workgroups, two per CU, 32-deep
+    K-steps, K-contiguous operands as [128 rows][32 k] images): exact-integer operands must give the fp32 matmul bit for bit
+    (ragged M and N, more tiles than workgroup slots, K of 8, 20 and 24 K-steps); the flag sets of the ViT blocks against
+    the 128 x 128 kernel's output."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(13)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[0, 1] = 3; A[1, 0] = -2; Bm[0, 1] = 1; Bm[1, 0] = -3
+    ref = A @ Bm.t()
+    Ad = dev(A).to(torch.bfloat16)
+    Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+    ldb = N if tB else K
+    bias = dev(torch.randint(-4, 5, (N,), generator=g).float())
+    R = dev(torch.randint(-4, 5, (M, N), generator=g).float()).to(torch.bfloat16)
+    aux = dev(torch.randint(-2, 3, (M, N), generator=g).float()).to(torch.bfloat16)
+
+    def run(k3, flags, A_=None, **kw):
+        Cd = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        pre = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_set_option("k3", k3)
+        if not k3:
+            ops.gemm_set_option("k2", 0)
+        try:
+            ops.gemm(Ad if A_ is None else A_, Bd, Cd, M, N, K, K, ldb, N, 0, transB=bool(tB), flags=flags, preact=pre, **kw)
+            name = ops.gemm_last_kernel()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_set_option("k3", -1)
+            ops.gemm_set_option("k2", -1)
+        assert ("k3_kernel" in name) == bool(k3), name
+        return Cd.float().cpu(), pre.float().cpu()
+
+    if tB == 0:
+        out, _ = run(3, ops.EPI_BIAS, bias=bias)
+        assert torch.equal(out, (ref + bias.cpu()).to(torch.bfloat16).float())
+        out, _ = run(3, ops.EPI_BIAS | ops.EPI_RESID, bias=bias, resid=R, ldr=N)
+        assert torch.equal(out, (ref + bias.cpu() + R.float().cpu()).to(torch.bfloat16).float())
+        fl = ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU
+        As = (Ad.float() * 0.125).to(torch.bfloat16)      # GELU away from saturation
+        o_new, p_new = run(3, fl, A_=As, bias=bias * 0.25)
+        o_old, p_old = run(0, fl, A_=As, bias=bias * 0.25)
+        assert torch.equal(o_new, o_old) and torch.equal(p_new, p_old)
+    else:
+        out, _ = run(3, 0)
+        assert torch.equal(out, ref.to(torch.bfloat16).float())
+        out, _ = run(3, ops.EPI_MULAUX, aux=aux, ldaux=N)
+        assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("tB", [0, 1])
 def test_gemm_grouped_skinny_form(ops, tB):
     """Groups whose problems are all skinny (<= 2560 rows, K <= 4096) run as 64 x 64 tiles with the four waves splitting K
     (gemm_bf16_skinny_grouped_kernel): bit-exact vs fp32 matmul on exact-integer operands -- fp32 accumulate output, bf16
@@ -1428,6 +1481,40 @@ def test_gemm_k2_grouped_wgrad(ops):
         torch.cuda.synchronize()
     finally:
         ops.gemm_set_option("k2", -1)
+    for Cd, cs, ref, csref in checks:
+        assert torch.equal(Cd.cpu(), ref), (Cd.cpu() - ref).abs().max()
+        if cs is not None:
+            assert torch.equal(cs.cpu(), csref)
+
+
+def test_gemm_k3_grouped_wgrad(ops):
+    """The round-4 form of the same groups (vpu_gemm_set_option("k3", 1): 256 x 128 tiles in 256-thread workgroups, two per
+    CU, 32-deep K-steps through a three-stage ring, no K split): bit-exact accumulation into pre-filled fp32 outputs + the
+    fused bias-gradient column sums; ragged edges; more tiles than workgroup slots (a persistent workgroup walks several
+    tiles of different problems: 549 tiles on 512 slots); K of 64 and of 66 K-steps."""
+    g = torch.Generator().manual_seed(29)
+    shapes = [(3072, 768, 2048), (768, 3072, 2048), (2304, 776, 2048), (520, 760, 2048),         # (M, N, K): 72+72+63+18 tiles
+              (3072, 768, 2112), (768, 3072, 2112), (2304, 768, 2112), (2056, 2056, 2112), (3072, 768, 2112),
+              (768, 3072, 2112), (2304, 768, 2112)]                                               # 72+72+54+153+72+72+54 = 549
+    problems, checks = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A = torch.randint(-2, 3, (K, M), generator=g).float()
+        Bm = torch.randint(-2, 3, (K, N), generator=g).float()
+        Ad, Bd = dev(A).to(torch.bfloat16), dev(Bm).to(torch.bfloat16)
+        Cd = torch.full((M, N), float(i + 1), device="cuda")
+        cs = torch.full((M,), 5.0, device="cuda") if i != 1 else None
+        problems.append(((Ad, Bd, Cd, M, N, K, M, N, N, 0),
+                         dict(transA=True, transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)))
+        checks.append((Cd, cs, A.t() @ Bm + float(i + 1), A.sum(0) + 5.0))
+    ops.gemm_set_option("k3", 1)
+    try:
+        ops.gemm_grouped(problems[:4])           # 225 tiles: one workgroup per CU would have nobody to overlap with -> K2
+        assert "k2_grouped" in ops.gemm_last_kernel()
+        ops.gemm_grouped(problems[4:])
+        assert "k3_grouped" in ops.gemm_last_kernel()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_set_option("k3", -1)
     for Cd, cs, ref, csref in checks:
         assert torch.equal(Cd.cpu(), ref), (Cd.cpu() - ref).abs().max()
         if cs is not None:

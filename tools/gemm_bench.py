@@ -41,7 +41,13 @@ NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
 
 
 def set_k2(opt):
-    """k2 option value: 0 the 128 x 128 kernel, 1 the 256 x 128 form, 2 the default rule, 3 the 256 x 256 form wherever legal"""
+    """k2 option value: 0 the 128 x 128 kernel, 1 the 256 x 128 form, 2 the default rule, 3 the 256 x 256 form wherever legal;
+    "k3": the round-4 form (two 256-thread workgroups per CU) where it is legal, the default rule elsewhere"""
+    if opt == "k3":
+        ops.gemm_set_option("k2", -1)
+        ops.gemm_set_option("k3", 3)
+        return
+    ops.gemm_set_option("k3", 0 if opt != "-1" else -1)
     ops.gemm_set_option("k2", int(opt.split(":")[0]))
 
 
