@@ -368,7 +368,7 @@ def main():
     # cut wherever the engine reports a finished gradient range (pvpuformer_amd/graphs.py), the reducer's collectives
     # launched by the host between two segments, Adam host-enqueued -- ~25 launches per step instead of ~530.
     # (N > 1 default: host-enqueued.  The chain has run under RCCL at world size 1 and over two gloo ranks only, and on a
-    # host that keeps up it is not faster -- 14.23 vs 14.08 ms per step under the forced reducer, DESIGN section 6 --:
+    # host that keeps up it is not faster -- 14.23 vs 14.08 ms per step under the forced reducer, HISTORY.md section 6 --:
     # VPU_BENCH_DP_GRAPH=1 selects it once it has been seen on a multi-GPU node.)
     use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
     use_chain = world > 1 and os.environ.get("VPU_BENCH_DP_GRAPH", "0") == "1"
@@ -462,6 +462,7 @@ def main():
             graph_note[0] = f"eager (hipGraph capture failed: {type(e).__name__}: {str(e)[:120]})"
             graph[0] = None
             torch.cuda.synchronize()
+            eng.abort_pass()           # nothing the aborted capture queued may reach the eager steps' launches
     if use_chain and overlap is None:
         # every rank captures for itself (a capture enqueues nothing and launches no collective); a rank whose capture
         # fails stays host-enqueued: the same kernels and the same collectives in the same order as the replaying ranks
@@ -489,6 +490,7 @@ def main():
             except Exception:
                 pass
             torch.cuda.synchronize()
+            eng.abort_pass()
         if world > 1:
             dist.barrier()
         step()                         # first replay (untimed): graph upload

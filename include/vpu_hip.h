@@ -128,7 +128,10 @@ int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const flo
  * Used for the partial weight / bias gradient rows of every LayerNorm / GroupNorm backward of a step
  * (models_vit.py:72-75, transformer.py:417-426, is_vpu_model.py:55-86 backward). */
 #define VPU_COLSUM_BATCH_MAX 64
-typedef struct vpu_colsum_job { const float* in; float* out; int32_t nrows, ncols; } vpu_colsum_job;
+/* row_len > 0: the output is a [ncols / row_len][row_len] block of a wider matrix with leading dimension out_ld -- column c
+ * goes to out[(c / row_len) * out_ld + c % row_len] (the column blocks of the head's fusion weight: its slabs are summed
+ * straight into the strided gradient); row_len = 0: out[c]. */
+typedef struct vpu_colsum_job { const float* in; float* out; int32_t nrows, ncols, row_len, out_ld; } vpu_colsum_job;
 typedef struct vpu_colsum_batch { vpu_colsum_job job[VPU_COLSUM_BATCH_MAX]; } vpu_colsum_batch;
 int vpu_colsum_batched(const vpu_colsum_job* jobs, int32_t n, void* stream);
 /* out[c] = beta*out[c] + sum_r in[r][c]  (fp32 in) */
@@ -228,6 +231,12 @@ int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, int32_t P, 
  * scratch: int32 [B][H][W]. */
 int vpu_edt(const uint8_t* mask, int32_t* scratch, float* dist, int32_t B, int32_t H, int32_t W, int32_t zero_border,
             void* stream);
+/* 5 x 5 chamfer transform = cv2.distanceTransform(mask, DIST_L2, 5) of the training simulators (trainer.py:628-629, 673-674,
+ * 736-737), restated from OpenCV's two-pass fixed-point algorithm (weights 1, 1.4, 2.1969 in 16-bit fixed point); equals
+ * oracle/vpu_oracle.py::chamfer_l2_5x5 bit for bit.  zero_border as in vpu_edt.  scratch: int32 [B][H + 2][W + 2].
+ * W + 2 <= 1024. */
+int vpu_chamfer5(const uint8_t* mask, int32_t* scratch, float* dist, int32_t B, int32_t H, int32_t W, int32_t zero_border,
+                 void* stream);
 /* NoBRS-loop reductions over maps that stay on the device (zoom_in.py:30-165, clicker.py:29-56).
  * vpu_mask_bbox: out[b] = {pixels with prob > thr, rmin, rmax, cmin, cmax} of image b of prob [B][H][W], the box joined
  * with the nclicks positive clicks pos_clicks (int32 (row, col) pairs; zoom_in.py:153-158 sets them in the mask first);

@@ -424,6 +424,49 @@ def polyline_raster(canvas, curve, thickness=3):
     return canvas
 
 
+# weights of OpenCV's 5x5 chamfer mask for DIST_L2 (getDistanceTransformMask: a = 1, b = 1.4, c = 2.1969, float32) in the
+# 16-bit fixed point of distanceTransform_5x5: CV_FLT_TO_FIX(x, 16) = cvRound(x * 65536)
+_CH_A = int(np.rint(np.float32(1.0) * np.float32(65536.0)))        # 65536
+_CH_B = int(np.rint(np.float32(1.4) * np.float32(65536.0)))        # 91750
+_CH_C = int(np.rint(np.float32(2.1969) * np.float32(65536.0)))     # 143976
+
+
+def chamfer_l2_5x5(mask):
+    """cv2.distanceTransform(mask, cv2.DIST_L2, 5) of the training simulators (isegm/engine/trainer.py:628-629,673-674,
+    736-737): the two-pass 5x5 chamfer approximation of the distance to the nearest zero pixel.  OpenCV 4.7.0 (pinned at
+    requirements.txt:88) is not installable here, so this RESTATES its published algorithm (modules/imgproc/src/
+    distransform.cpp, distanceTransform_5x5, the C++ path without IPP): integer distances in 16-bit fixed point, a forward
+    raster pass over the upper half of the mask ((-2,+-1), (-1,+-2) at c; (-1,+-1) at b; (-1,0), (0,-1) at a), a backward
+    pass over the mirrored half, everything outside the image at "infinity", result = float32(t) * 2^-16.  PARITY UNPINNED
+    against real OpenCV (no cv2, no fixture of the reference's): what is pinned is HIP == this function, bit for bit.
+    mask: [H, W] bool / uint8; returns float32 [H, W].  Row recurrences are prefix minima: t[j] = min(cand[j], t[j-1] + a)
+    = a j + min_{k <= j} (cand[k] - a k)."""
+    m = np.asarray(mask) != 0
+    H, W = m.shape
+    INF = np.int64(1) << 40
+    a, b, c = np.int64(_CH_A), np.int64(_CH_B), np.int64(_CH_C)
+    T = np.full((H + 4, W + 4), INF, np.int64)      # two border rows / columns of "infinity" on every side
+    cols = np.arange(W, dtype=np.int64) * a
+
+    def sh(row, d):                                  # row shifted by d columns (image columns live at [2, W + 2))
+        return row[2 + d: 2 + d + W]
+    for i in range(H):                               # forward pass
+        r1, r2 = T[i + 1], T[i]                      # image rows i - 1 and i - 2
+        base = np.minimum.reduce([sh(r2, -1) + c, sh(r2, 1) + c, sh(r1, -2) + c, sh(r1, 2) + c,
+                                  sh(r1, -1) + b, sh(r1, 1) + b, sh(r1, 0) + a])
+        cand = np.where(m[i], base, 0)
+        T[i + 2, 2:W + 2] = np.minimum.accumulate(cand - cols) + cols
+    for i in range(H - 1, -1, -1):                   # backward pass
+        r1, r2 = T[i + 3], T[i + 4]                  # image rows i + 1 and i + 2
+        base = np.minimum.reduce([sh(r2, -1) + c, sh(r2, 1) + c, sh(r1, -2) + c, sh(r1, 2) + c,
+                                  sh(r1, -1) + b, sh(r1, 1) + b, sh(r1, 0) + a])
+        cand = np.minimum(T[i + 2, 2:W + 2], base)
+        rev = (cand + cols)[::-1]                    # t[j] = min(cand[j], t[j+1] + a) = -a j + min_{k >= j} (cand[k] + a k)
+        T[i + 2, 2:W + 2] = np.minimum.accumulate(rev)[::-1] - cols
+    t = np.minimum(T[2:H + 2, 2:W + 2], np.int64(0xFFFFFFFF) - c)       # DIST_MAX saturation (an all-foreground image)
+    return t.astype(np.float32) * np.float32(1.0 / 65536.0)
+
+
 def coord_features(prev_mask, points, boxes=None, prompt_type=0, radius=5, scribbles=None):
     """ISModel.get_coord_features_with_prompt (is_model.py:78-95): cat(prev_mask, disks).  ``scribbles`` (prompt type 2):
     array [B,1,P,2] of (x, y)."""

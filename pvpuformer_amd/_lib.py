@@ -36,7 +36,8 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (every function returns int unless listed in _RET)
 class ColsumJob(C.Structure):
-    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32)]
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32),
+                ("row_len", C.c_int32), ("out_ld", C.c_int32)]
 
 
 SIGNATURES = {
@@ -69,6 +70,7 @@ SIGNATURES = {
     "vpu_cc_roots": [_P, _P, _I, _I, _I, _P],
     "vpu_cc_table": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_edt": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vpu_chamfer5": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_pue_scribble_rows": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_draw_polyline": [_P, _P, _I, _I, _I, _I, _P],
     "vpu_mask_bbox": [_P, _F, _P, _I, _P, _I, _I, _I, _P],

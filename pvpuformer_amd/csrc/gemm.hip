@@ -1019,7 +1019,8 @@ __device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const _
 template <bool GEN, int RP>
 __device__ __forceinline__ void k2_epi64(const vpu_gemm_desc& p, const int FLG, const int vec, f32x4_t (&a)[4][4],
                                          const int mrow0, const int ncol0, float* wl, const int lane,
-                                         const int mend = 0x7FFFFFFF) {   // rows >= mend belong to another wave / tile
+                                         const int mend = 0x7FFFFFFF,     // rows >= mend belong to another wave / tile
+                                         const int64_t coff = 0) {        // element offset of this batch entry's C (K3 grouped slices)
     const bool fast = !GEN || vec == 1;
     const bool use_pre = RP == 32 && fast && (FLG & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)) != 0 &&
                          !((FLG & VPU_EPI_RESID) && (FLG & (VPU_EPI_MULAUX | VPU_EPI_DGELU | VPU_EPI_DRELU)));
@@ -1061,9 +1062,9 @@ __device__ __forceinline__ void k2_epi64(const vpu_gemm_desc& p, const int FLG, 
                     e.has_pre = use_pre; e.has_bias = use_bias8; e.pre = RP == 32 ? pre[pass & 1][t & 3] : make_uint4(0, 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) e.bias[j] = bias8[j];
-                    epilogue_store8(p, FLG, 0, 0, m, n, v, e);
+                    epilogue_store8(p, FLG, coff, 0, m, n, v, e);
                 } else {
-                    for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, 0, 0, m, n + j, v[j]);
+                    for (int j = 0; j < 8 && n + j < p.N; ++j) epilogue_store<bf16_t>(p, coff, 0, m, n + j, v[j]);
                 }
             }
         }
@@ -1168,14 +1169,16 @@ __device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)
 
 struct K2Tile {   // wave-uniform description of one output tile
     int m0, n0, tile_n, grp, M, N, K, lda, ldb;
+    int z;            // batch entry (K3 grouped form: the reduction slices of one weight gradient), else 0
+    int64_t coff;     // element offset of that entry's C
     const void* A;
     const void* B;
 };
-template <int WN, bool GRP, int RB>
+template <int WN, bool GRP, int RB, bool BATCH = false>
 __device__ __forceinline__ void k2_tile_setup(const int work, const int total_work, const vpu_gemm_desc& p_arg,
                                               const vpu_gemm_group* __restrict__ ga, const int tiles_n_arg, K2Tile& t) {
     static_assert(!GRP || RB == 8, "grouped form: 256-row tiles");
-    int grp = 0, tile_m, tile_n;
+    int grp = 0, tile_m, tile_n, z = 0;
     if constexpr (GRP) {
         // one contiguous range of the global tile order per XCD label (work & 7); inside a problem the shorter tile
         // dimension runs fastest, so a range is a compact block of the problem's tile grid
@@ -1183,8 +1186,12 @@ __device__ __forceinline__ void k2_tile_setup(const int work, const int total_wo
         const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (work >> 3);
         while (grp + 1 < ga->n && v >= ga->start[grp + 1]) ++grp;
         grp = rfl(grp);
-        const int local = v - ga->start[grp];
+        int local = v - ga->start[grp];
         const int tm = (ga->d[grp].M + K2_BM - 1) / K2_BM, tn = (ga->d[grp].N + K2Cfg<WN>::BN_ - 1) / K2Cfg<WN>::BN_;
+        if constexpr (BATCH) {   // batch entries (reduction slices) of one problem: entry-major, so that an XCD's range stays within few slices
+            z = local / (tm * tn);
+            local -= z * (tm * tn);
+        }
         if (tn <= tm) { tile_m = local / tn; tile_n = local - tile_m * tn; }
         else { tile_n = local / tm; tile_m = local - tile_n * tm; }
     } else {
@@ -1195,7 +1202,15 @@ __device__ __forceinline__ void k2_tile_setup(const int work, const int total_wo
     t.m0 = rfl(tile_m * (32 * RB)); t.n0 = rfl(tile_n * K2Cfg<WN>::BN_);
     // (grouped form: the descriptor is picked by a run-time index; pin what the main loop uses to scalar registers)
     t.M = rfl(p.M); t.N = rfl(p.N); t.K = rfl(p.K); t.lda = rfl(p.lda); t.ldb = rfl(p.ldb);
-    t.A = rfl_ptr(p.A); t.B = rfl_ptr(p.B);
+    t.z = rfl(z);
+    if constexpr (BATCH) {
+        t.coff = (int64_t)t.z * p.sCo;
+        t.A = rfl_ptr(reinterpret_cast<const bf16_t*>(p.A) + (int64_t)t.z * p.sAo);
+        t.B = rfl_ptr(reinterpret_cast<const bf16_t*>(p.B) + (int64_t)t.z * p.sBo);
+    } else {
+        t.coff = 0;
+        t.A = rfl_ptr(p.A); t.B = rfl_ptr(p.B);
+    }
 }
 // per-lane byte offset of every DMA piece this wave issues per stage, at k = 0 (K % 64 == 0: no k bound inside a tile)
 template <int TA, int TB, int WN, int RB>
@@ -1425,9 +1440,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gem
 // ------------------------------------------------------------------------------------------------
 constexpr int K3_BK = 32;
 constexpr int K3_SUB = 8192;               // one 128 x 32 / 32 x 128 bf16 sub-tile
-constexpr int K3_STAGE = 3 * K3_SUB;
-constexpr int K3_LDS = 3 * K3_STAGE;       // 72 KiB
-constexpr int K3_PW = 6;                   // DMA pieces per wave per stage (24 pieces / 4 waves)
+// NWN = 2: "K3", 2 x 2 waves, 256 x 128 tile, three 24-KiB stages (72 KiB: two workgroups per CU).
+// NWN = 4: "K4", 2 x 4 waves, 256 x 256 tile, FIVE 32-KiB stages (all 160 KiB of one CU, one workgroup): the long-reduction
+// weight gradients are bound by bytes in flight over the latency of an HBM miss (operands that no cache holds: 2 x 24 KiB
+// per workgroup -> ~38 GB/s per CU whatever the schedule, K2 and K3 alike: ~900 TFLOP/s in the step); the wider tile needs
+// 2/3 of the bytes per MFMA and the deeper ring keeps 4 x 32 KiB = 128 KiB in flight.
+// TM = 128 ("K3S", NWN = 2): a 128 x 128 tile, 64 x 64 per wave, ONE A sub-tile; 16-KiB stages, three of them: 48 KiB, three
+// workgroups per CU -- the round-1 128 x 128 kernel's shapes (one round of tiles over a short K, the neck / FPN / head maps)
+// with a ring and a counted wait instead of one K-tile in flight and a drained vmcnt(0) per K-tile.
+template <int NWN, int TM = 256> struct K3Cfg {
+    static constexpr int NSUBA = TM / 128;
+    static constexpr int NSUB = NSUBA + NWN / 2;
+    static constexpr int STAGE = NSUB * K3_SUB;
+    static constexpr int S = NWN == 2 ? 3 : 5;
+    static constexpr int LDS = S * STAGE;
+    static constexpr int NWAVE = 2 * NWN;
+    static constexpr int PW = NSUB * 8 / NWAVE;     // DMA pieces per wave per stage: 6 / 4
+    static constexpr int INFL = (S - 2) * PW;       // pieces that may stay in flight at the top of a K-step: 6 / 12
+    static constexpr int NCS = 8 / NWN;             // row blocks whose column sums one wave takes
+};
+constexpr int K3_LDS = K3Cfg<2>::LDS;
+constexpr int K3_PW = K3Cfg<2>::PW;
 
 __device__ __forceinline__ int kc32_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4); }
 
@@ -1437,22 +1470,27 @@ __device__ __forceinline__ bf16x8_t k3_frag(const char* lds, int x16, int lane) 
     else return read_frag<1>(lds, x16, 0, lane);
 }
 
-template <int TA, int TB, int RB>
-__device__ __forceinline__ void k3_voff(const K2Tile& t, const int wave, const int lane, int (&voff)[K3_PW]) {
-    static_assert(RB == 8 || TA == 0, "short tiles: row-major A only");
+template <int TA, int TB, int RB, int NWN, int TM = 256>
+__device__ __forceinline__ void k3_voff(const K2Tile& t, const int wave, const int lane, int (&voff)[K3Cfg<NWN, TM>::PW]) {
+    using Cf = K3Cfg<NWN, TM>;
+    static_assert(RB == 8 || TA == 0 || TM == 128, "short tiles: row-major A only");
+    constexpr int SUBROWS = TM == 256 ? 16 * RB : 128;   // live rows of an A sub-tile (TM = 256: the rows of one wave row)
 #pragma unroll
-    for (int i = 0; i < K3_PW; ++i) {
-        const int sub = i >> 1, pis = wave + 4 * (i & 1);
-        const bool isA = sub < 2;
+    for (int i = 0; i < Cf::PW; ++i) {
+        // (sub-tile and piece from compile-time arithmetic: `wave` is a run-time value, and a sub-tile index that depends
+        // on it makes every DMA a run-time choice between the A and the B resource)
+        constexpr int PPS = 8 / Cf::NWAVE;      // pieces per sub-tile and wave
+        const int sub = i / PPS, pis = wave + Cf::NWAVE * (i % PPS);
+        const bool isA = sub < Cf::NSUBA;
         const int tr = isA ? TA : TB;
-        const int x0 = isA ? t.m0 + sub * (16 * RB) : t.n0;
+        const int x0 = isA ? t.m0 + sub * SUBROWS : t.n0 + (sub - Cf::NSUBA) * 128;
         const int X = isA ? t.M : t.N;
         const int ld = isA ? t.lda : t.ldb;
         if (tr == 0) {
             const int row = pis * 16 + (lane >> 2);
             const int chunk = (lane & 3) ^ (((row >> 3) & 1) << 1);
             const int gx = x0 + row;
-            voff[i] = (gx < X && (!isA || row < 16 * RB)) ? (gx * ld + chunk * 8) * 2 : OOB_OFFSET;
+            voff[i] = (gx < X && (!isA || row < SUBROWS)) ? (gx * ld + chunk * 8) * 2 : OOB_OFFSET;
         } else {
             const int k = pis * 4 + (lane >> 4);
             const int chunk = (lane & 15) ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
@@ -1462,53 +1500,133 @@ __device__ __forceinline__ void k3_voff(const K2Tile& t, const int wave, const i
     }
 }
 
-__device__ __forceinline__ void k3_issue(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB, const int (&voff)[K3_PW],
-                                         const int soffA, const int soffB, const bool live, char* __restrict__ wr, const int wave) {
+template <int NWN, int TM = 256>
+__device__ __forceinline__ void k3_issue(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
+                                         const int (&voff)[K3Cfg<NWN, TM>::PW], const int soffA, const int soffB, const bool live,
+                                         char* __restrict__ wr, const int wave) {
 #pragma unroll
-    for (int i = 0; i < K3_PW; ++i) {
-        const int sub = i >> 1, pis = wave + 4 * (i & 1);
+    for (int i = 0; i < K3Cfg<NWN, TM>::PW; ++i) {
+        constexpr int PPS = 8 / K3Cfg<NWN, TM>::NWAVE;
+        const int sub = i / PPS, pis = wave + K3Cfg<NWN, TM>::NWAVE * (i % PPS);
         const int vo = live ? voff[i] : OOB_OFFSET;
-        if (sub < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(wr + sub * K3_SUB + pis * 1024), 16, vo, soffA, 0, 0);
+        if (sub < K3Cfg<NWN, TM>::NSUBA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(wr + sub * K3_SUB + pis * 1024), 16, vo, soffA, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vptr)(wr + sub * K3_SUB + pis * 1024), 16, vo, soffB, 0, 0);
     }
 }
 
-// one K-step: the DMA of K-step kt+2 into stage `wr`, the fragments and the 32 MFMAs of K-step kt from stage `rd`
+// one K-step: the DMA of K-step kt+S-1 into stage `wr`, the fragments and the 32 MFMAs of K-step kt from stage `rd`
 // (__restrict__ parameters of an inlined function: see ring_step)
-template <int TA, int TB, bool CS, int RB>
-__device__ __forceinline__ void k3_step(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB, const int (&voff)[K3_PW],
-                                        const int soffA, const int soffB, const bool live, char* __restrict__ wr,
-                                        const char* __restrict__ rd, const int wave, const int lane, const int wm, const int wn,
-                                        const bool do_cs, const bf16x8_t ones, f32x4_t (&acc)[RB][4], f32x4_t (&acc_cs)[4]) {
-    k3_issue(rA, rB, voff, soffA, soffB, live, wr, wave);
-    const char* la = rd + wm * K3_SUB;
-    const char* lb = rd + 2 * K3_SUB;
+template <int TA, int TB, bool CS, int RB, int NWN, int TM = 256>
+__device__ __forceinline__ void k3_step(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
+                                        const int (&voff)[K3Cfg<NWN, TM>::PW], const int soffA, const int soffB, const bool live,
+                                        char* __restrict__ wr, const char* __restrict__ rd, const int wave, const int lane,
+                                        const int wm, const int wn, const bool do_cs, const bf16x8_t ones, f32x4_t (&acc)[RB][4],
+                                        f32x4_t (&acc_cs)[K3Cfg<NWN>::NCS]) {
+    k3_issue<NWN, TM>(rA, rB, voff, soffA, soffB, live, wr, wave);
+    const char* la = rd + (TM == 256 ? wm : 0) * K3_SUB;           // TM = 128: one A sub-tile, this wave's rows at wm * 64
+    const int arow = TM == 256 ? 0 : wm * 64;
+    const char* lb = rd + (K3Cfg<NWN, TM>::NSUBA + (wn >> 1)) * K3_SUB;
     bf16x8_t af[RB], bfr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = k3_frag<TB>(lb, wn * 64 + j * 16, lane);
+    for (int j = 0; j < 4; ++j) bfr[j] = k3_frag<TB>(lb, (wn & 1) * 64 + j * 16, lane);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) af[i] = k3_frag<TA>(la, i * 16, lane);
+    for (int i = 0; i < RB; ++i) af[i] = k3_frag<TA>(la, arow + i * 16, lane);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    if constexpr (CS && RB == 8) if (do_cs) {   // the two N-halves of the wave grid share the A fragments: each sums four of the eight row blocks
-        if (wn == 0) {
+    if constexpr (CS && RB == 8) if (do_cs) {   // the N positions of the wave grid share the A fragments: each sums NCS of the eight row blocks
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, acc_cs[i], 0, 0, 0);
-        } else {
+        for (int w = 0; w < NWN; ++w)
+            if (wn == w) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4 + i], ones, acc_cs[i], 0, 0, 0);
-        }
+                for (int i = 0; i < K3Cfg<NWN>::NCS; ++i)
+                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[w * K3Cfg<NWN>::NCS + i], ones, acc_cs[i], 0, 0, 0);
+            }
     }
     __builtin_amdgcn_s_setprio(0);
 }
 
+// Software-pipelined K-step (round 4, second version), in two halves of 16 MFMAs.  In the plain step the DMA issues, the
+// fragment reads and their wait sit in front of the 32 MFMAs with the matrix pipe idle -- both waves of a SIMD are in the
+// same phase: ~780 of ~1800 cycles per K-step (measured through the per-CU rate: 56 % of the MFMA peak whatever the tile
+// and however many CUs are busy).  Here every MFMA runs from fragments that are already in registers, and the DMA pieces
+// and the NEXT fragments' LDS reads are issued BETWEEN the MFMAs (sched_group_barrier):
+//   half 0: A rows 0-63 (aL) x B of K-step kt   |  reads A rows 64-127 (aH) of K-step kt, issues the DMA of K-step kt+S-1
+//   half 1: aH x B                               |  reads aL and B of K-step kt+1 (landed: the barrier at the top of kt)
+// Two register sets of half the A fragments (2 x 16 registers) and two of the B fragments (2 x 16) instead of one whole set
+// (48): the whole-step double buffer (96) does not fit beside the 128 accumulators.
+template <int TA, int TB, bool CS, int NWN>
+__device__ __forceinline__ void k3_half0(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
+                                         const int (&voff)[K3Cfg<NWN>::PW], const int soffA, const int soffB, const bool live,
+                                         char* __restrict__ wr, const char* __restrict__ rd, const int wave, const int lane,
+                                         const int wm, const int wn, const bool do_cs, const bf16x8_t ones,
+                                         const bf16x8_t (&aL)[4], const bf16x8_t (&bc)[4], bf16x8_t (&aH)[4],
+                                         f32x4_t (&acc)[8][4], f32x4_t (&acc_cs)[K3Cfg<NWN>::NCS]) {
+    k3_issue<NWN>(rA, rB, voff, soffA, soffB, live, wr, wave);
+    const char* la = rd + wm * K3_SUB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aH[i] = k3_frag<TA>(la, (4 + i) * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aL[i], bc[j], acc[i][j], 0, 0, 0);
+    constexpr int NDS = (TA ? 2 : 1) * 4;      // LDS read instructions of this half
+#pragma unroll
+    for (int gI = 0; gI < 4; ++gI) {           // masks: MFMA 0x8, DS read 0x100, VMEM read 0x20
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, (K3Cfg<NWN>::PW + 3) / 4, 0);
+    }
+    if constexpr (CS) if (do_cs) {
+#pragma unroll
+        for (int w = 0; w < NWN / 2; ++w)      // the wave positions whose NCS row blocks lie in rows 0-63
+            if (wn == w) {
+#pragma unroll
+                for (int i = 0; i < K3Cfg<NWN>::NCS; ++i)
+                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aL[w * K3Cfg<NWN>::NCS + i], ones, acc_cs[i], 0, 0, 0);
+            }
+    }
+}
+template <int TA, int TB, bool CS, int NWN>
+__device__ __forceinline__ void k3_half1(const char* __restrict__ rd, const int lane, const int wm, const int wn,
+                                         const bool do_cs, const bf16x8_t ones, const bf16x8_t (&aH)[4], const bf16x8_t (&bc)[4],
+                                         bf16x8_t (&aL)[4], bf16x8_t (&bn)[4], f32x4_t (&acc)[8][4],
+                                         f32x4_t (&acc_cs)[K3Cfg<NWN>::NCS]) {
+    const char* la = rd + wm * K3_SUB;
+    const char* lb = rd + (2 + (wn >> 1)) * K3_SUB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bn[j] = k3_frag<TB>(lb, (wn & 1) * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aL[i] = k3_frag<TA>(la, i * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aH[i], bc[j], acc[4 + i][j], 0, 0, 0);
+    constexpr int NDS = (TA ? 2 : 1) * 4 + (TB ? 2 : 1) * 4;
+#pragma unroll
+    for (int gI = 0; gI < 4; ++gI) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 0);
+    }
+    if constexpr (CS) if (do_cs) {
+#pragma unroll
+        for (int w = NWN / 2; w < NWN; ++w)
+            if (wn == w) {
+#pragma unroll
+                for (int i = 0; i < K3Cfg<NWN>::NCS; ++i)
+                    acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aH[(w - NWN / 2) * K3Cfg<NWN>::NCS + i], ones, acc_cs[i], 0, 0, 0);
+            }
+    }
+}
+
 template <int FL, int RB, int H>
 __device__ __forceinline__ void k3_epi_half(const vpu_gemm_desc& p, const int FLG, const int vec, f32x4_t (&acc)[RB][4],
-                                            const int mw, const int nq, float* wl, const int lane) {
+                                            const int mw, const int nq, float* wl, const int lane, const int64_t coff) {
     f32x4_t fin[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1516,7 +1634,7 @@ __device__ __forceinline__ void k3_epi_half(const vpu_gemm_desc& p, const int FL
         for (int j = 0; j < 4; ++j) fin[i][j] = acc[H * 4 + i < RB ? H * 4 + i : 0][j];
     const int mq = mw + H * 64;
     constexpr int npass = H == 0 ? 4 : RB - 4;
-    k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
+    k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass, coff);
 }
 template <int FL, int RB, int H>
 __device__ __forceinline__ void k3_epi_fast_half(const vpu_gemm_desc& p, f32x4_t (&acc)[RB][4], const int mw, const int nq,
@@ -1529,38 +1647,29 @@ __device__ __forceinline__ void k3_epi_fast_half(const vpu_gemm_desc& p, f32x4_t
     k2_epi_fast<FL>(p, fin, mw + H * 64, nq, wl, lane, q, H == 0 ? 4 : RB - 4);
 }
 
-template <int TA, int TB, bool CS, int FL, bool GRP, int RB>
+template <int TA, int TB, bool CS, int FL, bool GRP, int RB, int NWN = 2, bool PIPE = false, int TM = 256>
 __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
                                         const int tiles_m_arg, const int tiles_n_arg, const int vec_in) {
+    using Cf = K3Cfg<NWN, TM>;
     static_assert(!CS || (TA == 1 && RB == 8), "fused column sums: weight-gradient form");
+    static_assert(TM == 256 || (RB == 4 && NWN == 2 && !GRP && !PIPE && !CS), "128-row tiles: single problems, 64 x 64 per wave");
     constexpr bool GEN = FL < 0;
-    // exact-count epilogue (compile-time flag sets): the first two K-steps of the NEXT tile are requested before this tile's
-    // epilogue, whose NST unconditional stores per wave are then younger than those DMA pieces -- the counted waits of the
-    // next tile's first two K-steps allow for them
-    constexpr bool PRIME = !GEN;
-    constexpr int NST = GEN ? 0 : 16 * ((FL & VPU_EPI_SAVE_DGELU) ? 2 : 1);
-    constexpr int W1 = K3_PW + NST;
-    static_assert(W1 < 64, "vmcnt is a 6-bit count");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NWN == 2 ? wave >> 1 : wave >> 2, wn = wave & (NWN - 1);
     const int vec = vec_in & 255;
     const int total_work = GRP ? ga->start[ga->n] : tiles_m_arg * tiles_n_arg;
     if ((vec_in >> 8) && (int)blockIdx.x >= (int)(gridDim.x >> 1)) {
-        // VPU_GEMM_K3_STAGGER=c: the second half of the grid (the second workgroup of a CU under round-robin placement) starts
-        // c x 1024 cycles late, so that the two workgroups of a CU are in different phases of their tiles
+        // VPU_GEMM_K3_STAGGER=c (diagnostic): the second half of the grid starts c x 1024 cycles late.  Measured on the forward
+        // forms (c = 4, 8, 12): every launch longer by about the delay -- the two workgroups of a CU do not make up for it
         for (int i = 0; i < (vec_in >> 8); ++i) __builtin_amdgcn_s_sleep(16);
     }
-    int work = blockIdx.x;
-    K2Tile cur;
-    int voff[K3_PW];
-    bool primed = false;
-    if (work < total_work) {
-        k2_tile_setup<2, GRP, RB>(work, total_work, p_arg, ga, tiles_n_arg, cur);
-        k3_voff<TA, TB, RB>(cur, wave, lane, voff);
-    }
-    while (work < total_work) {
+    for (int work = blockIdx.x; work < total_work; work += gridDim.x) {
+        K2Tile cur;
+        int voff[Cf::PW];
+        k2_tile_setup<NWN, GRP, RB, GRP>(work, total_work, p_arg, ga, tiles_n_arg, cur);
+        k3_voff<TA, TB, RB, NWN, TM>(cur, wave, lane, voff);
         const vpu_gemm_desc& p = GRP ? ga->d[cur.grp] : p_arg;
         const int FLG = GEN ? p.flags : FL;
         const int m0 = cur.m0, n0 = cur.n0;
@@ -1575,40 +1684,80 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const bool do_cs = CS && p.colsum != nullptr && cur.tile_n == 0;   // block-uniform
-        f32x4_t acc_cs[4];
+        f32x4_t acc_cs[Cf::NCS];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < Cf::NCS; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         bf16x8_t ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
 
-        char* s0 = lds;
-        char* s1 = lds + K3_STAGE;
-        char* s2 = lds + 2 * K3_STAGE;
-        if (!primed) {
-            k3_issue(rA, rB, voff, 0, 0, true, s0, wave);
-            k3_issue(rA, rB, voff, stepA, stepB, 1 < nk, s1, wave);
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            // this wave's pieces of K-step kt have landed (the six of K-step kt+1 may still fly -- and, in the first two
-            // K-steps of a primed tile, the previous tile's epilogue stores); after the barrier so have everybody's, and
-            // every wave is done reading K-step kt-1, whose stage the next DMA overwrites
-            if (PRIME && primed && kt < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K3_PW) : "memory");
+        if constexpr (PIPE) {
+            static_assert(!PIPE || RB == 8, "pipelined form: 256-row tiles");
+            // ring: K-step kt lives in stage kt % S; S - 1 stages are requested up front.  At the top of K-step kt: its aL / B
+            // fragments are in registers, its aH half is still in stage kt (read during half 0), K-step kt+1 has landed,
+            // kt+2 .. kt+S-2 fly, kt+S-1 is issued into the stage K-step kt-1 has left.
+#pragma unroll
+            for (int st = 0; st < Cf::S - 1; ++st)
+                k3_issue<NWN>(rA, rB, voff, st * stepA, st * stepB, st < nk, lds + st * Cf::STAGE, wave);
+            bf16x8_t aL[4], aH[4], b0[4], b1[4];
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Cf::S - 2) * Cf::PW) : "memory");
             __builtin_amdgcn_s_barrier();
-            const int kn = kt + 2;
-            k3_step<TA, TB, CS, RB>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, do_cs, ones, acc, acc_cs);
-            char* t = s0; s0 = s1; s1 = s2; s2 = t;
+            {
+                const char* la = lds + wm * K3_SUB;
+                const char* lb = lds + (2 + (wn >> 1)) * K3_SUB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b0[j] = k3_frag<TB>(lb, (wn & 1) * 64 + j * 16, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aL[i] = k3_frag<TA>(la, i * 16, lane);
+            }
+            int st_c = 0, st_w = Cf::S - 1;      // stage of K-step kt / stage the next DMA goes to
+            for (int kt = 0; kt < nk; kt += 2) {
+                // (two K-steps per iteration: the B register sets swap roles, every index is a compile-time constant)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && kt + 1 >= nk) break;
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Cf::S - 3) * Cf::PW) : "memory");   // K-step kt+1 has landed (mine)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // aL / B of this K-step are in registers
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int st_n = st_c + 1 == Cf::S ? 0 : st_c + 1;
+                    const int kn = kt + u + Cf::S - 1;
+                    __builtin_amdgcn_s_setprio(1);
+                    if (u == 0) k3_half0<TA, TB, CS, NWN>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
+                                                          wave, lane, wm, wn, do_cs, ones, aL, b0, aH, acc, acc_cs);
+                    else k3_half0<TA, TB, CS, NWN>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
+                                                   wave, lane, wm, wn, do_cs, ones, aL, b1, aH, acc, acc_cs);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // aH is in registers
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u == 0) k3_half1<TA, TB, CS, NWN>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b0, aL, b1, acc, acc_cs);
+                    else k3_half1<TA, TB, CS, NWN>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b1, aL, b0, acc, acc_cs);
+                    __builtin_amdgcn_s_setprio(0);
+                    st_w = st_c;
+                    st_c = st_n;
+                }
+            }
+        } else {
+        // ring: K-step kt lives in stage kt % S; S - 1 K-steps are requested ahead
+#pragma unroll
+        for (int st = 0; st < Cf::S - 1; ++st)
+            k3_issue<NWN, TM>(rA, rB, voff, st * stepA, st * stepB, st < nk, lds + st * Cf::STAGE, wave);
+        int rd_i = 0, wr_i = Cf::S - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's pieces of K-step kt have landed (those of the S - 2 later ones may still fly); after the barrier so
+            // have everybody's, and every wave is done reading K-step kt-1, whose stage the next DMA overwrites
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::INFL) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int kn = kt + Cf::S - 1;
+            k3_step<TA, TB, CS, RB, NWN, TM>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + wr_i * Cf::STAGE, lds + rd_i * Cf::STAGE,
+                                             wave, lane, wm, wn, do_cs, ones, acc, acc_cs);
+            rd_i = rd_i + 1 == Cf::S ? 0 : rd_i + 1;
+            wr_i = wr_i + 1 == Cf::S ? 0 : wr_i + 1;
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the out-of-range tail pieces still write zeros into LDS)
         __syncthreads();
-        const int nxt = work + gridDim.x;
-        const bool has_next = nxt < total_work;
-        K2Tile nt = cur;
-        int nvoff[K3_PW];
-#pragma unroll
-        for (int i = 0; i < K3_PW; ++i) nvoff[i] = voff[i];
-        float* wl = reinterpret_cast<float*>(lds + 2 * K3_STAGE + wave * 4096);   // 16 rows x 64 fp32 per wave, in stage 2
+        float* wl = reinterpret_cast<float*>(lds + wave * 4096);   // 16 rows x 64 fp32 per wave
         const int mw = m0 + wm * (16 * RB), nq = n0 + wn * 64;
         if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only
             float t = 0.f;
@@ -1617,53 +1766,32 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
             if (t == 1.2345678e30f) reinterpret_cast<float*>(p.C)[0] = t;
-            primed = false;
         } else if constexpr (GEN) {
             if constexpr (CS) if (do_cs && (lane & 15) == 0) {
                 const int fq = lane >> 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < Cf::NCS; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = m0 + wm * 128 + (wn * 4 + i) * 16 + fq * 4 + r;
-                        if (row < cur.M) p.colsum[row] += acc_cs[i][r];
+                        const int row = m0 + wm * 128 + (wn * Cf::NCS + i) * 16 + fq * 4 + r;
+                        if (row < cur.M) p.colsum[(int64_t)cur.z * cur.M + row] += acc_cs[i][r];   // (a batch entry's sums: colsum + z M)
                     }
             }
             // (the two 64-row halves of the wave tile, written out twice: a loop over them that the compiler does not unroll
             // indexes the accumulators at run time and sends all 128 of them to scratch)
-            k3_epi_half<FL, RB, 0>(p, FLG, vec, acc, mw, nq, wl, lane);
-            k3_epi_half<FL, RB, 1>(p, FLG, vec, acc, mw, nq, wl, lane);
-            primed = false;
+            k3_epi_half<FL, RB, 0>(p, FLG, vec, acc, mw, nq, wl, lane, cur.coff);
+            if constexpr (RB > 4) k3_epi_half<FL, RB, 1>(p, FLG, vec, acc, mw, nq, wl, lane, cur.coff);
         } else {
-            // everything the epilogue reads from global memory is requested first, then the next tile's first two K-steps,
-            // then the math and the stores
+            // everything the epilogue reads from global memory is requested before its first store
             K2Pre<GEN ? 0 : FL> q0, q1;
             k2_prefetch<GEN ? 0 : FL>(p, mw, nq, lane, q0, 4);
-            k2_prefetch<GEN ? 0 : FL>(p, mw + 64, nq, lane, q1, RB - 4);
-            if (has_next) {
-                k2_tile_setup<2, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
-                k3_voff<TA, TB, RB>(nt, wave, lane, nvoff);
-                const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
-                const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
-                const int nsA = TA ? nt.lda * (K3_BK * 2) : K3_BK * 2, nsB = TB ? nt.ldb * (K3_BK * 2) : K3_BK * 2;
-                k3_issue(nA, nB, nvoff, 0, 0, true, lds, wave);
-                k3_issue(nA, nB, nvoff, nsA, nsB, K3_BK < nt.K, lds + K3_STAGE, wave);
-            }
+            if constexpr (RB > 4) k2_prefetch<GEN ? 0 : FL>(p, mw + 64, nq, lane, q1, RB - 4);
             k3_epi_fast_half<GEN ? 0 : FL, RB, 0>(p, acc, mw, nq, wl, lane, q0);
-            k3_epi_fast_half<GEN ? 0 : FL, RB, 1>(p, acc, mw, nq, wl, lane, q1);
-            primed = has_next;
+            if constexpr (RB > 4) k3_epi_fast_half<GEN ? 0 : FL, RB, 1>(p, acc, mw, nq, wl, lane, q1);
         }
-        // every wave is done with its epilogue scratch before the next tile's third K-step lands in stage 2 (raw barrier: the
-        // global stores stay in flight)
+        // every wave is done with its epilogue scratch before the next tile's DMA lands in stage 0 (raw barrier: the global
+        // stores stay in flight)
         __builtin_amdgcn_s_barrier();
-        if (has_next && !primed) {
-            k2_tile_setup<2, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
-            k3_voff<TA, TB, RB>(nt, wave, lane, nvoff);
-        }
-        cur = nt;
-#pragma unroll
-        for (int i = 0; i < K3_PW; ++i) voff[i] = nvoff[i];
-        work = nxt;
     }
 }
 
@@ -1672,10 +1800,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_k3_kernel(const vpu_gemm_des
                                                               const int vec) {
     k3_body<TA, TB, false, FL, false, RB>(p, nullptr, tiles_m, tiles_n, vec);
 }
+template <int TA, int TB, int FL>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_k3s_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
+                                                               const int vec) {
+    k3_body<TA, TB, false, FL, false, 4, 2, false, 128>(p, nullptr, tiles_m, tiles_n, vec);
+}
 template <int TA, int TB, bool CS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_k3_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
     k3_body<TA, TB, CS, -1, true, 8>(ga->d[0], ga, 0, 0, vec);
+}
+template <int TA, int TB, bool CS>
+__global__ __launch_bounds__(512) void gemm_bf16_k4_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
+    const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
+    k3_body<TA, TB, CS, -1, true, 8, 4>(ga->d[0], ga, 0, 0, vec);
+}
+template <int TA, int TB, bool CS>
+__global__ __launch_bounds__(512) void gemm_bf16_k4p_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
+    const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
+    k3_body<TA, TB, CS, -1, true, 8, 4, true>(ga->d[0], ga, 0, 0, vec);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2053,10 +2196,12 @@ std::atomic<int> g_opt_skinny{-1};
 std::atomic<int> g_opt_skinny_group{-1};
 std::atomic<int> g_opt_k2{-1};
 // K3 kernels (256 x 128 tiles in 256-thread workgroups, two per CU): bit 0 the grouped weight gradients, bit 1 the
-// forward / dgrad forms of vpu_gemm, bit 2 the grouped forward / dgrad form; -1 environment default (VPU_GEMM_K3)
+// forward / dgrad forms of vpu_gemm, bit 2 "K3S": the 128 x 128 ring kernel for short-K launches of the round-1 kernel, bit 3
+// "K4": grouped weight gradients as 256 x 256 tiles in one 512-thread workgroup per CU with a five-stage ring, bit 4 its
+// software-pipelined K-step, bit 5 K3S for every K; -1 environment default (VPU_GEMM_K3, 28 if unset)
 std::atomic<int> g_opt_k3{-1};
 inline int k3_env0() {
-    static const int v = [] { const char* e = getenv("VPU_GEMM_K3"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("VPU_GEMM_K3"); return e ? atoi(e) : 28; }();   // K3S + K4 + pipelined K4
     return v;
 }
 inline int k3_opt() { const int v = g_opt_k3.load(std::memory_order_relaxed); return v >= 0 ? v : k3_env0(); }
@@ -2339,6 +2484,40 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             else VPU_LAUNCH_RING(1, 1, false, -1);
         }
 #undef VPU_LAUNCH_RING
+        // K3S (bit 2 of the k3 option): the same flag sets on the 128 x 128 ring kernel, three workgroups per CU
+        // (measured against the two-stage kernel, tools/gemm_bench.py GEMM_BENCH_K2=2,k3s: it wins where K is short -- the FPN /
+        // head maps: 150528 x 128 x 192 23.3 -> 18.5 us, 150528 x 256 x 128 35.4 -> 27.0, 37632 x 256 x 256 16.1 -> 12.8, the
+        // fusion dgrad 57.0 -> 46.8 -- and loses 3-10 % at K = 768 (proj 20.5 -> 21.8): K <= 384 only; "k3" option bit 5 lifts
+        // the bound for tests)
+        if (!launched && spec_ok && (k3_opt() & 4) && (d->K <= 384 || (k3_opt() & 32)) && d->batch == 1 && d->K % K3_BK == 0 && d->K >= 128 && d->alpha == 1.0f &&
+            (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL && (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
+            constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID, F_BL = VPU_EPI_BIAS | VPU_EPI_RELU,
+                          F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX, F_D = VPU_EPI_DRELU;
+            const int cap3s = 3 * cu_count();
+            const int tot3s = tiles_m * tiles_n;
+            launched = true;
+#define VPU_LAUNCH_K3S(TA_, TB_, FL_)                                                                                \
+    do {                                                                                                             \
+        static bool attr_ = false;                                                                                   \
+        auto kern_ = gemm_bf16_k3s_kernel<TA_, TB_, FL_>;                                                             \
+        if (!attr_) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<2, 128>::LDS); \
+            attr_ = true;                                                                                            \
+        }                                                                                                            \
+        NOTE_KERNEL("gemm_bf16_k3s_kernel<%d, %d, %d>", TA_, TB_, FL_);                                                \
+        kern_<<<dim3((unsigned)(tot3s < cap3s ? tot3s : cap3s)), dim3(256), K3Cfg<2, 128>::LDS, s>>>(*d, tiles_m, tiles_n, 1); \
+    } while (0)
+            if (key == 0 && f == F_B) VPU_LAUNCH_K3S(0, 0, F_B);
+            else if (key == 0 && f == F_BR) VPU_LAUNCH_K3S(0, 0, F_BR);
+            else if (key == 0 && f == F_G) VPU_LAUNCH_K3S(0, 0, F_G);
+            else if (key == 0 && f == F_BL) VPU_LAUNCH_K3S(0, 0, F_BL);
+            else if (key == 0 && f == 0) VPU_LAUNCH_K3S(0, 0, 0);
+            else if (key == 1 && f == F_D) VPU_LAUNCH_K3S(0, 1, F_D);
+            else if (key == 1 && f == 0) VPU_LAUNCH_K3S(0, 1, 0);
+            else if (key == 1 && f == F_M) VPU_LAUNCH_K3S(0, 1, F_M);
+            else launched = false;
+#undef VPU_LAUNCH_K3S
+        }
         if (!launched && spec_ok) {
             launched = true;
             constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
@@ -2445,7 +2624,7 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_k2.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
-    if (name && !strcmp(name, "k3") && value >= -1 && value <= 7) {
+    if (name && !strcmp(name, "k3") && value >= -1 && value <= 63) {
         g_opt_k3.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
@@ -2476,14 +2655,23 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     vpu_gemm_group ga;
     ga.n = n;
     int total = 0;
-    bool vec = true;
+    bool vec = true, any_batch = false;
     const int key = (descs[0].transA ? 2 : 0) | (descs[0].transB ? 1 : 0);
     for (int i = 0; i < n; ++i) {
         const vpu_gemm_desc* d = descs + i;
-        if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch != 1 || d->inner != 1 ||
+        if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1 || d->inner != 1 ||
             d->dtype != VPU_BF16 || ((d->transA ? 2 : 0) | (d->transB ? 1 : 0)) != key) {
-            vpu_set_error("vpu_gemm_grouped: every problem bf16, batch 1, non-null operands, the same transA / transB");
+            vpu_set_error("vpu_gemm_grouped: every problem bf16, inner 1, non-null operands, the same transA / transB");
             return VPU_ERR_ARG;
+        }
+        if (d->batch > 1) {
+            // batch entries = the reduction slices of one weight gradient (entry z: A + z sAo, B + z sBo, C + z sCo, colsum +
+            // z M): only the K3 weight-gradient form walks them
+            any_batch = true;
+            if (key != 3 || d->sAo % 8 || d->sBo % 8 || d->sCo % 8 || (int64_t)d->batch * d->M * d->N >= 0x7FFFFFFFLL) {
+                vpu_set_error("vpu_gemm_grouped: batch > 1 needs transA = transB = 1 and batch strides that are multiples of 8 elements");
+                return VPU_ERR_ARG;
+            }
         }
         const int f = d->flags;
         if (((f & VPU_EPI_BIAS) && !d->bias) || ((f & VPU_EPI_RESID) && !d->resid) ||
@@ -2524,7 +2712,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     // problems of 128 x 128 tiles in the general grouped kernel beat 64 x 64 tiles with a four-way K split)
     static const int sk_grp_env0 = [] { const char* e = getenv("VPU_GEMM_SKINNY_GROUP"); return e ? atoi(e) : 1; }();
     const int sk_grp_env = g_opt_skinny_group.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny_group.load(std::memory_order_relaxed) : sk_grp_env0;
-    if (sk_grp_env && (key <= 1 || (key == 3 && sk_grp_env >= 2)) && n >= 2) {
+    if (!any_batch && sk_grp_env && (key <= 1 || (key == 3 && sk_grp_env >= 2)) && n >= 2) {
         bool ok = true;
         int total64 = 0;
         vpu_gemm_group g3 = ga;
@@ -2592,7 +2780,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             const vpu_gemm_desc* d = descs + i;
             ok = ok && d->K % BK == 0 && d->K >= 2048 && d->N % 8 == 0 && d->M % 8 == 0;
             g2.start[i] = total2;
-            total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128);
+            total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128) * d->batch;
         }
         for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g2.start[i] = total2;
         // (a tile of this kernel walks its whole K on a CU of its own: fewer than 192 tiles leave CUs idle, but over a very
@@ -2602,17 +2790,43 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         for (int i = 0; i < n; ++i) very_long = very_long && descs[i].K >= 8192;
         // (K3: two free-running workgroups per CU -- measured against K2 on grouped weight gradients over 9408 rows: 512 tiles
         // 246 vs 284 us, 432 tiles 280 vs 299, but 216 tiles -- one workgroup per CU, nobody to overlap with -- 201 vs 149)
-        if (ok && (k3_opt() & 1) && total2 > cu_count()) {
+        if (ok && (k3_opt() & 8)) {
+            // K4: 256 x 256 tiles, one 512-thread workgroup per CU, five-stage ring
+            vpu_gemm_group g4 = ga;
+            int total4 = 0;
+            for (int i = 0; i < n; ++i) {
+                g4.start[i] = total4;
+                total4 += ((descs[i].M + 255) / 256) * ((descs[i].N + 255) / 256) * descs[i].batch;
+            }
+            for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g4.start[i] = total4;
+            static bool attr4_ = false;
+            const bool pipe = (k3_opt() & 16) != 0;
+            if (!attr4_) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4p_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
+                attr4_ = true;
+            }
+            const int ncu = cu_count();
+            static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true>", pipe ? "p" : "");
+            if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+            else gemm_bf16_k4_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+            return vpu_check_launch("vpu_gemm_grouped");
+        }
+        if (any_batch && !ok) {
+            vpu_set_error("vpu_gemm_grouped: batch > 1 needs K % 64 == 0, K >= 2048, M % 8 == 0, N % 8 == 0 and aligned operands");
+            return VPU_ERR_ARG;
+        }
+        if (ok && (any_batch || ((k3_opt() & 1) && total2 > cu_count()))) {
             static bool attr3_ = false;
-            auto kern_ = gemm_bf16_k3_grouped_kernel<1, 1, true>;
             if (!attr3_) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k3_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
                 attr3_ = true;
             }
             const int cap = 2 * cu_count();
             static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k3_grouped_kernel<1, 1, true>");
-            kern_<<<dim3((unsigned)(total2 < cap ? total2 : cap)), dim3(256), K3_LDS, s>>>(g2, noepi3 ? 9 : 1);
+            gemm_bf16_k3_grouped_kernel<1, 1, true><<<dim3((unsigned)(total2 < cap ? total2 : cap)), dim3(256), K3_LDS, s>>>(g2, noepi3 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
         }
         if (ok && (total2 >= 192 || (very_long && total2 >= 96))) {
@@ -2629,6 +2843,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             return vpu_check_launch("vpu_gemm_grouped");
         }
     }
+    if (any_batch) { vpu_set_error("vpu_gemm_grouped: batch > 1 is only implemented for 16-byte-addressable weight-gradient groups"); return VPU_ERR_ARG; }
     static const int persist_env = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
     const int persist_cap = persist_env > 0 ? persist_env : 2 * cu_count();
     dim3 grid((unsigned)(total < persist_cap ? total : persist_cap)), block(256);

@@ -542,6 +542,116 @@ extern "C" int vpu_edt(const uint8_t* mask, int32_t* scratch, float* dist, int32
     return vpu_check_launch("vpu_edt");
 }
 
+// ------------------------------------------------------------------------------------------------
+// 5 x 5 chamfer distance transform: cv2.distanceTransform(mask, DIST_L2, 5) of the TRAINING simulators
+// (isegm/engine/trainer.py:628-629, 673-674, 736-737), restated from OpenCV's published two-pass algorithm
+// (distanceTransform_5x5: 16-bit fixed point, a = 65536, b = 91750, c = 143976; see oracle/vpu_oracle.py::chamfer_l2_5x5, which
+// this kernel equals bit for bit).  One workgroup per mask, one thread per column; the rows of a pass are sequential, a row
+// is t[j] = min(cand[j], t[j-1] + a) = a j + prefix-min(cand[k] - a k): a block-wide min-scan per row.
+// ------------------------------------------------------------------------------------------------
+constexpr int CH_A = 65536, CH_B = 91750, CH_C = 143976, CH_INF = 0x3FFFFFFF;
+
+__device__ __forceinline__ int block_scan_min(int v, int* wsum /* [16] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v = v < t ? v : t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int pre = CH_INF * 2;
+    for (int w = 0; w < wave; ++w) pre = pre < wsum[w] ? pre : wsum[w];
+    __syncthreads();
+    return v < pre ? v : pre;
+}
+
+// rows live in LDS as [Wp + 4] ints with two "infinite" columns on either side
+__global__ __launch_bounds__(1024) void chamfer5_kernel(const uint8_t* __restrict__ mask, int* __restrict__ scratch,
+                                                        float* __restrict__ dist, int H, int W, int pad) {
+    extern __shared__ int sm[];          // r1 | r2 | cur, each Wp + 4
+    __shared__ int wsum[16];
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, LD = Wp + 4;
+    int* r1 = sm;                        // the previous row of the pass (i - 1 forward, i + 1 backward)
+    int* r2 = sm + LD;                   // the one before it
+    int* cur = sm + 2 * LD;
+    const int b = blockIdx.x, j = threadIdx.x;
+    const uint8_t* m = mask + (int64_t)b * H * W;
+    int* T = scratch + (int64_t)b * Hp * Wp;
+    for (int i = j; i < 3 * LD; i += blockDim.x) sm[i] = CH_INF;
+    __syncthreads();
+    // ---- forward pass
+    for (int i = 0; i < Hp; ++i) {
+        int v = CH_INF * 2;              // (threads beyond the row do not disturb the scan)
+        const bool live = j < Wp;
+        if (live) {
+            const int y = i - pad, x = j - pad;
+            const bool fg = y >= 0 && y < H && x >= 0 && x < W && m[(int64_t)y * W + x] != 0;
+            int cand = 0;
+            if (fg) {
+                const int* p1 = r1 + 2 + j;
+                const int* p2 = r2 + 2 + j;
+                int t = p2[-1] + CH_C, u = p2[1] + CH_C;
+                t = t < u ? t : u; u = p1[-2] + CH_C; t = t < u ? t : u; u = p1[2] + CH_C; t = t < u ? t : u;
+                u = p1[-1] + CH_B; t = t < u ? t : u; u = p1[1] + CH_B; t = t < u ? t : u; u = p1[0] + CH_A; t = t < u ? t : u;
+                cand = t;
+            }
+            v = cand - CH_A * j;
+        }
+        v = block_scan_min(v, wsum);
+        if (live) {
+            const int t = v + CH_A * j;
+            cur[2 + j] = t;
+            T[(int64_t)i * Wp + j] = t;
+        }
+        __syncthreads();
+        int* tmp = r2; r2 = r1; r1 = cur; cur = tmp;          // rotate: cur becomes the previous row
+    }
+    // ---- backward pass (rows bottom-up, columns right-to-left: thread j handles column Wp - 1 - j)
+    for (int i = threadIdx.x; i < 3 * LD; i += blockDim.x) sm[i] = CH_INF;
+    __syncthreads();
+    r1 = sm; r2 = sm + LD; cur = sm + 2 * LD;
+    for (int i = Hp - 1; i >= 0; --i) {
+        int v = CH_INF * 2;
+        const bool live = j < Wp;
+        const int col = Wp - 1 - j;
+        if (live) {
+            const int* p1 = r1 + 2 + col;
+            const int* p2 = r2 + 2 + col;
+            int t = T[(int64_t)i * Wp + col], u = p2[-1] + CH_C;
+            t = t < u ? t : u; u = p2[1] + CH_C; t = t < u ? t : u; u = p1[-2] + CH_C; t = t < u ? t : u; u = p1[2] + CH_C; t = t < u ? t : u;
+            u = p1[-1] + CH_B; t = t < u ? t : u; u = p1[1] + CH_B; t = t < u ? t : u; u = p1[0] + CH_A; t = t < u ? t : u;
+            v = t - CH_A * j;            // suffix scan over columns = prefix scan over j: t[col] = min(cand, t[col+1] + a)
+        }
+        v = block_scan_min(v, wsum);
+        if (live) {
+            const int t = v + CH_A * j;
+            cur[2 + col] = t;
+            const int y = i - pad, x = col - pad;
+            // (no zero pixel anywhere: OpenCV's DIST_MAX saturation, UINT_MAX - c, as the oracle has it)
+            const unsigned tu = t >= CH_INF ? 0xFFFFFFFFu - (unsigned)CH_C : (unsigned)t;
+            if (y >= 0 && y < H && x >= 0 && x < W) dist[(int64_t)b * H * W + (int64_t)y * W + x] = (float)tu * (1.0f / 65536.0f);
+        }
+        __syncthreads();
+        int* tmp = r2; r2 = r1; r1 = cur; cur = tmp;
+    }
+}
+
+extern "C" int vpu_chamfer5(const uint8_t* mask, int32_t* scratch, float* dist, int32_t B, int32_t H, int32_t W,
+                            int32_t zero_border, void* stream) {
+    vpu_clear_stale_error();
+    const int pad = zero_border ? 1 : 0;
+    if (!mask || !scratch || !dist || B < 1 || H < 1 || W < 1 || W + 2 * pad > 1024 || H > 16000) {
+        vpu_set_error("chamfer5: null pointer, or size out of range (W + border <= 1024, H <= 16000)");
+        return VPU_ERR_ARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int Wp = W + 2 * pad;
+    const int threads = ((Wp + 63) / 64) * 64;
+    chamfer5_kernel<<<B, threads, (size_t)3 * (Wp + 4) * sizeof(int), s>>>(mask, scratch, dist, H, W, pad);
+    return vpu_check_launch("vpu_chamfer5");
+}
+
 extern "C" int vpu_cc_roots(const uint8_t* mask, int32_t* roots, int32_t B, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
     const int64_t n = (int64_t)B * H * W;

@@ -1,5 +1,6 @@
 // Row-wise and element-wise kernels: LayerNorm, softmax, L2 normalise, column sums, broadcasts, casts.
 // All HBM-bound; 16-byte vector accesses, one wave (64 lanes) per row, fp32 math.
+#include <stdlib.h>
 #include "vpu_common.h"
 #include "../../include/vpu_hip.h"
 
@@ -276,14 +277,18 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const vpu_colsum_ba
     const int C = j.ncols;
     const int64_t rows = j.nrows;
     const float* __restrict__ in = j.in;
-    if (rows <= 16 && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(j.out)) & 15) == 0) {
+    if (rows <= 16 && (C & 3) == 0 && !(j.row_len > 0 && ((j.row_len | j.out_ld) & 3)) &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(j.out)) & 15) == 0) {
         // few rows over many columns (the split-K style slabs of Engine._wgrad_sliced: 2-8 rows x ~300k columns): one
         // lane per 4 columns, 16-byte accesses, rows in order (deterministic); block-uniform branch, no barrier below
         const int C4 = C >> 2;
+        const int rl = j.row_len;      // (> 0: a strided output block; row_len and out_ld are multiples of 4 here, host-checked)
         for (int c4 = blockIdx.x * 256 + threadIdx.x; c4 < C4; c4 += gridDim.x * 256) {
-            f32x4_t a = *reinterpret_cast<const f32x4_t*>(j.out + 4 * (int64_t)c4);
-            for (int64_t r = 0; r < rows; ++r) a += *reinterpret_cast<const f32x4_t*>(in + r * C + 4 * (int64_t)c4);
-            *reinterpret_cast<f32x4_t*>(j.out + 4 * (int64_t)c4) = a;
+            const int64_t c = 4 * (int64_t)c4;
+            float* o = j.out + (rl > 0 ? (c / rl) * j.out_ld + c % rl : c);
+            f32x4_t a = *reinterpret_cast<const f32x4_t*>(o);
+            for (int64_t r = 0; r < rows; ++r) a += *reinterpret_cast<const f32x4_t*>(in + r * C + c);
+            *reinterpret_cast<f32x4_t*>(o) = a;
         }
         return;
     }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const vpu_colsum_ba
             float t = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) t += red[g][cl];
-            j.out[c] += t;
+            j.out[j.row_len > 0 ? (int64_t)(c / j.row_len) * j.out_ld + c % j.row_len : c] += t;
         }
     }
 }
@@ -651,7 +656,9 @@ extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, 
 extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
     int64_t n = rows / (2 * LN_BWD_WAVES);
-    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));   // two workgroups per CU
+    // workgroups per CU: 2 (round 1), VPU_LN_BWD_WGS = 3: the 4-wave form's ~170 registers allow three
+    static const int cap = [] { const char* e = getenv("VPU_LN_BWD_WGS"); const int v = e ? atoi(e) : 2; return 256 * (v < 1 ? 1 : (v > 4 ? 4 : v)); }();
+    return (int)(n < 1 ? 1 : (n > cap ? cap : n));
 }
 extern "C" int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* w, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* part, int64_t rows, int32_t C,
@@ -690,9 +697,14 @@ extern "C" int vpu_colsum_batched(const vpu_colsum_job* jobs, int32_t n, void* s
             vpu_set_error("colsum_batched: null pointer or empty job");
             return VPU_ERR_ARG;
         }
+        if (jobs[i].row_len < 0 || (jobs[i].row_len > 0 && (jobs[i].ncols % jobs[i].row_len || jobs[i].out_ld < jobs[i].row_len))) {
+            vpu_set_error("colsum_batched: row_len must divide ncols and out_ld >= row_len");
+            return VPU_ERR_ARG;
+        }
         jb.job[i] = jobs[i];
+        // the 16-byte few-row form needs every output row start 16-byte aligned: otherwise the job runs as the generic form
         // blocks this job can use: 32 columns each, or (few-row form, same test as in the kernel) 1024 columns each
-        const bool few = jobs[i].nrows <= 16 && (jobs[i].ncols & 3) == 0 &&
+        const bool few = jobs[i].nrows <= 16 && (jobs[i].ncols & 3) == 0 && !(jobs[i].row_len > 0 && ((jobs[i].row_len | jobs[i].out_ld) & 3)) &&
                          ((reinterpret_cast<uintptr_t>(jobs[i].in) | reinterpret_cast<uintptr_t>(jobs[i].out)) & 15) == 0;
         const int need = few ? (jobs[i].ncols + 1023) / 1024 : (jobs[i].ncols + 31) / 32;
         cmax = need > cmax ? need : cmax;

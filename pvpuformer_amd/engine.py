@@ -135,11 +135,23 @@ class Engine:
         hid = self.D * c["mlp_ratio"]
         blk = sum(((n + 255) // 256) * ((k + 127) // 128) for n, k in ((3 * self.D, self.D), (self.D, self.D), (hid, self.D), (self.D, hid)))
         pk = os.environ.get("VPU_WGRAD_PACK", "")
-        self.pack_wgrad = pk == "1" or (pk != "0" and blk < 0.95 * 256)
+        # (round 4: with the K4 launches -- 256 x 256 tiles, rounds cut exactly, small problems riding -- every geometry packs)
+        k4_default = (int(os.environ.get("VPU_GEMM_K3", "28")) & 8) != 0
+        self.pack_wgrad = pk == "1" or (pk != "0" and (blk < 0.95 * 256 or k4_default))
         # K3 weight-gradient launches (round 4: 256 x 128 tiles in 256-thread workgroups, TWO per CU, free-running): a full
         # round is 512 tiles.  VPU_GEMM_K3 (bit 0) selects them in the library; the engine sizes its packed launches for it.
-        self.k3_wgrad = (int(os.environ.get("VPU_GEMM_K3", "1")) & 1) != 0
-        self.wgrad_round = 512 if self.k3_wgrad else 256
+        k3 = int(os.environ.get("VPU_GEMM_K3", "28"))
+        self.k3_wgrad = (k3 & 1) != 0
+        self.k4_wgrad = (k3 & 8) != 0          # 256 x 256 tiles, one workgroup per CU
+        self.wgrad_round = 256 if (self.k4_wgrad or not self.k3_wgrad) else 512
+        self.wgrad_tn = 256 if self.k4_wgrad else 128      # tile width of the long-reduction weight-gradient launches
+        # VPU_WGRAD_UNIFY (default 1, with the packed queue): every weight gradient over a multiple of the token rows -- the
+        # FPN's and the head's maps: 4 x / 16 x the 9408 rows of a ViT block -- is cut into reduction slices of exactly the
+        # token rows, given to the launch as BATCH ENTRIES of one problem (one descriptor), each writing its own fp32 slab; the
+        # slices are tiles of the same cost as a ViT block's, so they pack into the same launches, and one batched column
+        # sum adds the slabs to the gradients.  Before: a split-K launch + a reduce launch per problem, most of them at the
+        # end of backward with the chip a quarter full (0.47 ms per step).
+        self.unify_wgrad = os.environ.get("VPU_WGRAD_UNIFY", "1") != "0"
         self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
         self._pending_reports, self._reporting = [], False    # gradient ranges whose marker has been passed but not reported yet
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
@@ -331,7 +343,24 @@ class Engine:
             ldc_ = K if ldc is None else ldc
             args = (dy, x, gout, N, K, M, ld_dy, ld_x, ldc_, self.dt)
             kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
-            self._wq.append((args, kw, ((N + 127) // 128) * ((K + 127) // 128), M))   # (the queue keeps dy and x alive)
+            L = self._token_rows
+            if (self.unify_wgrad and self.pack_wgrad and (self.k3_wgrad or self.k4_wgrad) and L > 2048 and M > L and M % L == 0
+                    and L % 64 == 0 and N % 8 == 0 and K % 8 == 0 and ld_dy % 8 == 0 and ld_x % 8 == 0 and ldc_ % 4 == 0):
+                # S = M / L reduction slices as the batch entries of one problem: entry z reads rows [z L, (z + 1) L) of dy and
+                # x and writes slab z (and its slice of the fused bias column sums); "_post": the column-sum jobs that add the
+                # slabs to the gradient once the launch that holds the entry has been enqueued, "_target": where they end up
+                S = M // L
+                slab = self._new(S * N * K, dtype=torch.float32)
+                post = [((slab, 0), gout, S, N * K, K, ldc_)]
+                cs = None
+                if fuse:
+                    cs = (ops.zero_(self._new(S * N, dtype=torch.float32)), 0)       # (the kernel accumulates into it)
+                    post.append((cs, self.G(bias), S, N))
+                args = (dy, x, (slab, 0), N, K, L, ld_dy, ld_x, K, self.dt)
+                kw = dict(transA=True, transB=True, flags=EPI_OUT_F32, colsum=cs, batch=S, sA=(L * ld_dy, 0), sB=(L * ld_x, 0),
+                          sC=(N * K, 0), _post=post, _target=[gout] + ([self.G(bias)] if fuse else []))
+                M = L
+            self._wq.append((args, kw, ((N + 127) // 128) * ((K + 127) // 128) * kw.get("batch", 1), M))   # (the queue keeps dy and x alive)
             for t in (dy, x):
                 tt = t[0] if isinstance(t, tuple) else t
                 self._frozen.add(tt.data_ptr())
@@ -349,14 +378,25 @@ class Engine:
                 T = sum(self._k2_tiles(e) for e in anchors)
                 if self.pack_wgrad:
                     self._pack_seen[kind] = self._pack_seen.get(kind, 0) + self._k2_tiles(self._wq[-1])
-                    budget = self.pack_tiles(self._pack_total.get(kind), self.wgrad_round - (self.wgrad_round // 256) * self._reserved_cus())
+                    # (full rounds: with the round cut exactly, the even spread of round 3 only risks a leftover launch)
+                    budget = self.pack_tiles(None, self.wgrad_round - (self.wgrad_round // 256) * self._reserved_cus())
                     T = sum(self._k2_tiles(e) for e in same)          # riders count: they are packed like everything else
-                    while T >= budget:
+                    # a launch leaves when it would be FULL: up to 9 small problems (the neck's projections, the reduction slices
+                    # of the head / FPN gradients: ~10 tiles each -- 16 descriptors of them alone fill half a round) plus big
+                    # ones, the last of them cut so that the round is filled to the brim; or when two rounds have piled up
+                    while True:
+                        mine = [e for e in self._wq if e[3] == kind]
+                        T = sum(self._k2_tiles(e) for e in mine)
+                        t_small = sum(self._k2_tiles(e) for e in [e for e in mine if self._pack_small(e)][:9])
+                        t_big = sum(self._k2_tiles(e) for e in mine if not self._pack_small(e))
+                        if not (T >= budget and (t_small + t_big >= budget or T >= 2 * budget)):
+                            break
                         self.flush_wgrads(kind, ride=True, budget=budget)
-                        T = sum(self._k2_tiles(e) for e in self._wq if e[3] == kind)
+                        if sum(self._k2_tiles(e) for e in self._wq if e[3] == kind) >= T:
+                            break
                 elif (T >= 200 and T >= self.wgrad_fill * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
                     self.flush_wgrads(kind, ride=True)
-            elif len(same) >= 8:
+            elif len(same) >= 16:       # (one launch holds 16 descriptors; round 3 launched them in eights)
                 self.flush_wgrads(kind)
             return
         if not self.use_side:
@@ -661,8 +701,13 @@ class Engine:
                 self._colsum_to(y.g, Cout, prefix + ".bias", B * 4 * h * w, Cout)
                 # dW[Cin, 4Cout] += x^T dt   (launched directly: as a 36-tile rider of the grouped launches it displaced
                 # the neck's small problems and cost more than it saved, 858 vs 864 images/s)
-                ops.gemm(x.t, dt, self.G(prefix + ".weight"), Cin, 4 * Cout, M, Cin, 4 * Cout, 4 * Cout, self.dt,
-                         transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
+                if self.unify_wgrad and self.pack_wgrad and self.dt == BF16 and self.group_wgrad and not self.use_side:
+                    # (round 4: queued like every other long reduction -- in the packed launches every tile counts, so it
+                    # displaces nobody; a 37632-row one goes as four reduction slices)
+                    self._wgrad(x.t, Cin, dt, 4 * Cout, prefix + ".weight", Cin, 4 * Cout, M)
+                else:
+                    ops.gemm(x.t, dt, self.G(prefix + ".weight"), Cin, 4 * Cout, M, Cin, 4 * Cout, 4 * Cout, self.dt,
+                             transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM)
                 f = 0
                 if x.g is None:
                     x.g = torch.empty_like(x.t)
@@ -1065,9 +1110,7 @@ class Engine:
                         lo0, hi0 = self._pending_reports[0]
                         off_of = lambda t: t[1] if isinstance(t, tuple) else None
                         late = [e for e in self._wq
-                                if (off_of(e[0][2]) is None or lo0 <= off_of(e[0][2]) < hi0 or
-                                    (e[1].get("colsum") is not None and off_of(e[1]["colsum"]) is not None
-                                     and lo0 <= off_of(e[1]["colsum"]) < hi0))]
+                                if any(off_of(t) is None or lo0 <= off_of(t) < hi0 for t in self._targets(e))]
                         if late:
                             self.flush_wgrads(entries=late)
                 return
@@ -1077,10 +1120,15 @@ class Engine:
                 self._report_ready()
         self.tape.append(marker)
 
-    @staticmethod
-    def _k2_tiles(e):
-        """256 x 128 output tiles of a queued weight gradient (args: dy, x, g, N, K, M, ...: the gradient is [N, K])."""
-        return ((e[0][3] + 255) // 256) * ((e[0][4] + 127) // 128)
+    def _pack_small(self, e):
+        """Small problems of the packed long-reduction queue: at most 24 tiles, or given as reduction slices (never cut)."""
+        return self._k2_tiles(e) <= 24 or e[1].get("batch", 1) > 1
+
+    def _k2_tiles(self, e):
+        """Output tiles (256 x 128, or 256 x 256 for the K4 form) of a queued weight gradient (args: dy, x, g, N, K, M, ...: the
+        gradient is [N, K]), times its batch entries (reduction slices)."""
+        tn = self.wgrad_tn
+        return ((e[0][3] + 255) // 256) * ((e[0][4] + tn - 1) // tn) * e[1].get("batch", 1)
 
     def _is_rider(self, e):
         return e[3] > 2048 and self._k2_tiles(e) <= 16
@@ -1115,10 +1163,13 @@ class Engine:
             lo, hi = self._pending_reports[0]
             if not final:
                 busy = False
-                for args, kw, _, _ in self._wq:
-                    o, c = off_of(args[2]), off_of(kw.get("colsum")) if kw.get("colsum") is not None else None
-                    if (o is not None and lo <= o < hi) or (c is not None and lo <= c < hi) or o is None:
-                        busy = True
+                for e in self._wq:
+                    for t in self._targets(e):
+                        o = off_of(t)
+                        if o is None or lo <= o < hi:
+                            busy = True
+                            break
+                    if busy:
                         break
                 if busy:
                     return
@@ -1128,16 +1179,18 @@ class Engine:
                 self.join_side()
             self.grad_ready_hook(lo, hi)
 
-    @staticmethod
-    def _split_entry(e, budget):
+    def _split_entry(self, e, budget):
         """Cuts a queued weight gradient G[N, K] += dy[:, :N]^T x[:, :K] into (head, tail): head = the leading 256-row blocks
         of G (columns of dy) or the leading 128-column blocks of G (columns of x), whichever gives more tiles <= ``budget``;
         both are ordinary problems of the grouped launch (same operands at an offset, same leading dimensions).  The fused
         bias column sums belong to the tiles of G's first column block: a column cut keeps them in the head.  None if no
         block fits."""
         args, kw, _, red = e
+        if kw.get("batch", 1) > 1:
+            return None                    # (a sliced problem goes whole or waits)
         dy, x, g, N, K, M, ld_dy, ld_x, ldc, dt = args
-        R, Cn = (N + 255) // 256, (K + 127) // 128
+        tn = self.wgrad_tn
+        R, Cn = (N + 255) // 256, (K + tn - 1) // tn
         rows, cols = min(R - 1, budget // Cn), min(Cn - 1, budget // R)     # (a cut leaves something on both sides)
         if max(rows * Cn, cols * R) <= 0:
             return None
@@ -1150,7 +1203,7 @@ class Engine:
             tail = ((adv(dy, r), x, adv(g, r * ldc), N - r, K, M, ld_dy, ld_x, ldc, dt),
                     dict(kw, colsum=None if cs is None else adv(cs, r)), t128(N - r, K), red)
         else:
-            c = cols * 128
+            c = cols * tn
             head = ((dy, x, g, N, c, M, ld_dy, ld_x, ldc, dt), kw, t128(N, c), red)
             tail = ((dy, adv(x, c), adv(g, c), N, K - c, M, ld_dy, ld_x, ldc, dt), dict(kw, colsum=None), t128(N, K - c), red)
         return head, tail
@@ -1171,21 +1224,38 @@ class Engine:
             ptr_of = lambda t: (t[0] if isinstance(t, tuple) else t).data_ptr()
             q = [e for e in q if touching in (ptr_of(e[0][0]), ptr_of(e[0][1]))]
         if ride and budget is not None:
-            # one full round: whole problems in queue order (the small "riders" of this reduction length included), then the
-            # leading row / column blocks of the first one that does not fit; what is cut off stays at its place in the queue
+            # one full round.  A launch holds 16 descriptors, and the small problems (the neck's projections, the reduction
+            # slices of the head / FPN gradients: a dozen tiles each) would use them up with the round half empty (measured:
+            # 157 of 256 tiles in the first launch of a backward pass, 114 left over for a launch of their own at its end).
+            # So: first the BIG problems in queue order (whole, then the leading row / column blocks of the first one that does
+            # not fit; what is cut off stays at its place in the queue), at most 10 descriptors of them; then small ones, whole,
+            # in queue order, while tiles and descriptors last.
+            smalls = [e for e in q if self._pack_small(e)][:9]
             take, room = [], budget
-            for e in q:
+            for e in smalls:
+                t = self._k2_tiles(e)
+                if t <= room:
+                    take.append(e); room -= t
+            nbig = 0
+            for e in [e for e in q if not self._pack_small(e)]:
                 t = self._k2_tiles(e)
                 if t <= room and len(take) < 16:
-                    take.append(e); room -= t
+                    take.append(e); room -= t; nbig += 1
                     continue
                 cut = self._split_entry(e, room) if len(take) < 16 else None
                 if cut is not None:
                     head, tail = cut
                     self._wq[[id(w) for w in self._wq].index(id(e))] = tail
                     self._wq.insert(0, head)      # (leaves the queue with this launch: `chosen` below goes by identity)
-                    take.append(head)
+                    take.append(head); room -= self._k2_tiles(head)
                 break
+            if room > 0:                          # no (more) big problems: further small ones, whole, while descriptors last
+                for e in [e for e in q if self._pack_small(e)][9:]:
+                    t = self._k2_tiles(e)
+                    if len(take) >= 16:
+                        break
+                    if t <= room:
+                        take.append(e); room -= t
             q = take
         elif ride:
             anchors = [e for e in q if not self._is_rider(e)]
@@ -1212,7 +1282,7 @@ class Engine:
             tiles = sum(e[2] for e in part)
             # (reductions beyond ~16k rows -- the head / FPN maps -- keep the per-problem split-K launch with up to 128
             # slices: measured 18.5 vs 17.9 ms per step when they were cut into 8 slices here)
-            elig = [e for e in part if e[0][8] == e[0][4]]     # slabs are summed into contiguous gradients only
+            elig = [e for e in part if e[0][8] == e[0][4] and e[1].get("batch", 1) == 1]     # slabs are summed into contiguous gradients only
             etiles = sum(e[2] for e in elig)
             if self.split_wgrad and 2048 < red <= 16384 and len(elig) >= 2 and etiles < 200:
                 self._wgrad_sliced(elig, red, etiles)
@@ -1224,13 +1294,18 @@ class Engine:
             elif len(part) >= 2 and (red == 0 or tiles >= 200 or nk * 0.6 < len(part) * 35.0):
                 for i in range(0, len(part), 16):        # (one launch holds 16 descriptors)
                     chunk = part[i:i + 16]
-                    if len(chunk) == 1:
-                        ops.gemm(*chunk[0][0], **chunk[0][1])
+                    if len(chunk) == 1 and chunk[0][1].get("batch", 1) == 1:
+                        ops.gemm(*chunk[0][0], **self._pub(chunk[0][1]))
                     else:
-                        ops.gemm_grouped([(e[0], e[1]) for e in chunk])
+                        ops.gemm_grouped([(e[0], self._pub(e[1])) for e in chunk])
             else:
                 for args, kw, _, _ in part:
-                    ops.gemm(*args, **kw)
+                    if kw.get("batch", 1) > 1:
+                        ops.gemm_grouped([(args, self._pub(kw))])     # (reduction slices: the grouped K3 / K4 form walks them)
+                    else:
+                        ops.gemm(*args, **self._pub(kw))
+            for e in part:                               # the slabs of a sliced problem are added to its gradient by the
+                self._csq.extend(e[1].get("_post", ()))  # batched column sums (flush_colsums: after this launch, same stream)
         if not self.use_side:
             self._frozen = set()
             for args, _, _, _ in self._wq:   # operands of the entries still queued stay frozen
@@ -1242,6 +1317,22 @@ class Engine:
                 self._report_ready()
             finally:
                 self._reporting = False
+
+    @staticmethod
+    def _pub(kw):
+        """The keyword arguments of a queued GEMM without the queue's own annotations ("_post", "_target")."""
+        return {k: v for k, v in kw.items() if not k.startswith("_")} if any(k.startswith("_") for k in kw) else kw
+
+    @staticmethod
+    def _targets(e):
+        """(tensor, offset) gradient locations a queued entry ends up in (a sliced entry writes slabs first: "_target")."""
+        args, kw = e[0], e[1]
+        if "_target" in kw:
+            return list(kw["_target"])
+        out = [args[2]]
+        if kw.get("colsum") is not None:
+            out.append(kw["colsum"])
+        return out
 
     def _wgrad_sliced(self, part, red, tiles):
         """Few output tiles over a long reduction (the DMA neck's 768 x 384 projections over the 9408 image tokens: 72
@@ -1284,6 +1375,19 @@ class Engine:
         if self.side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
         self._frozen.clear()
+
+    def abort_pass(self):
+        """Forgets everything a forward / backward pass has queued but not launched: the weight-gradient queue, the batched
+        column sums, the deferred group, the frozen-buffer set, the pending gradient-range reports, the packing counters and
+        the tapes.  For a pass that died half way -- a hipGraph capture that raised: its queue entries point at capture-pool
+        buffers that were never written (a capture enqueues nothing), and the host-enqueued retry that follows must not
+        launch them."""
+        self._wq, self._csq, self._gq = [], [], []
+        self._gq_out, self._frozen = set(), set()
+        self._pending_reports, self._reporting = [], False
+        self._pack_seen = {}
+        self.tape = Tape()
+        self.last_tape = None
 
     def _writable(self, t):
         """Call before modifying gradient buffer ``t`` in place: a queued weight gradient that still reads it is launched

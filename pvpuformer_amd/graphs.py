@@ -105,6 +105,7 @@ class SegmentedBackward:
                 state["ctx"].__exit__(None, None, None)
             except Exception:
                 pass
+            eng.abort_pass()          # what the aborted pass queued points at capture-pool buffers nothing has written
             raise
         _lib.call, eng.grad_ready_hook = orig_call, orig_hook
         close_()

@@ -165,6 +165,7 @@ class VPUTrainStep:
                 import warnings
                 warnings.warn(f"VPUTrainStep: hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); this pass stays host-enqueued")
                 torch.cuda.synchronize()
+                eng.abort_pass()                 # (queue entries of the aborted capture must not reach the retry's launches)
                 self._passes[key] = False
                 return self._graph_pass(eng, st, ptype, it, after_forward, reducer)
         ent.fwd.replay()

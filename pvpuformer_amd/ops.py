@@ -160,6 +160,17 @@ def edt(mask_u8, zero_border=True):
     return dist
 
 
+def chamfer5(mask_u8, zero_border=True):
+    """cv2.distanceTransform(mask, DIST_L2, 5) -- the 5 x 5 chamfer approximation the training simulators use -- of uint8 masks
+    [B, H, W] on the GPU (vpu_chamfer5) -> float32 [B, H, W]."""
+    B, H, W = mask_u8.shape
+    mask_u8 = mask_u8.contiguous()
+    scratch = torch.empty(B, H + 2, W + 2, device=mask_u8.device, dtype=torch.int32)
+    dist = torch.empty(B, H, W, device=mask_u8.device, dtype=torch.float32)
+    _lib.call("vpu_chamfer5", ptr(mask_u8), ptr(scratch), ptr(dist), B, H, W, int(zero_border), _stream())
+    return dist
+
+
 def cc_roots(mask_u8):
     """8-connected components of uint8 masks [B, H, W] (vpu_cc_roots) -> int32 [B, H, W]: smallest linear index of the
     pixel's component, -1 on background."""
@@ -181,13 +192,16 @@ def cc_table(roots, kmax=4096):
 
 
 def colsum_batched(jobs):
-    """jobs: list of (in fp32 [rows, C], out fp32 [C] (tensor or (tensor, offset)), rows, C): out += column sums, 64 per
-    launch."""
+    """jobs: list of (in fp32 [rows, C], out fp32 [C] (tensor or (tensor, offset)), rows, C[, row_len, out_ld]): out += column
+    sums, 64 per launch.  row_len / out_ld: the output is a [C / row_len][row_len] block of a matrix with leading dimension
+    out_ld."""
     for i in range(0, len(jobs), 64):
         chunk = jobs[i:i + 64]
         arr = (_lib.ColsumJob * len(chunk))()
-        for j, (inp, out, rows, Cdim) in zip(arr, chunk):
+        for j, job in zip(arr, chunk):
+            inp, out, rows, Cdim = job[:4]
             j.inp, j.out, j.nrows, j.ncols = ptr(inp), ptr(out), rows, Cdim
+            j.row_len, j.out_ld = (job[4], job[5]) if len(job) > 4 and job[4] and job[5] != job[4] else (0, 0)
         _lib.call("vpu_colsum_batched", arr, len(chunk), _stream())
 
 

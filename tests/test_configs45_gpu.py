@@ -113,7 +113,8 @@ def test_bench_batch_bf16_step(golden_dir, fixture, B, logit_tol):
     descs = []
     def grouped(p):
         # problems are (args, kwargs) of ops.gemm: args = (A, B, C, M, N, K, ...); 256 x 128 tiles of the long reductions
-        descs.append(sum(-(-int(a[3]) // 256) * -(-int(a[4]) // 128) for a, _ in p if int(a[5]) >= 2048 and int(a[3]) >= 512))
+        # (round 4: the packed queue cuts problems at 256-row / 256-column blocks, so pieces of 256 rows count too)
+        descs.append(sum(-(-int(a[3]) // 256) * -(-int(a[4]) // 128) for a, _ in p if int(a[5]) >= 2048 and int(a[3]) >= 256 and int(a[4]) >= 256))
         orig["gemm_grouped"](p)
         gemms.append(ops.gemm_last_kernel())
     try:
@@ -128,18 +129,18 @@ def test_bench_batch_bf16_step(golden_dir, fixture, B, logit_tol):
             setattr(eng_ops, n, f)
     # ---- the instantiations this configuration is meant to select really ran
     used = set(gemms)
-    assert "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
+    assert "gemm_bf16_k4p_grouped_kernel<1, 1, true>" in used or "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
     assert any(k.startswith("gemm_bf16_k2_kernel<0, 0,") for k in used) and any(k.startswith("gemm_bf16_k2_kernel<0, 1,") for k in used)
-    # the long-reduction weight gradients (M = 6272 / 12288 token rows: 147+ K-tiles per output tile) leave in groups that
-    # fill their rounds of 256 CU-sized tiles (Engine._wgrad): a ViT-L block queues 128 / 128 / 32 / 96 tiles, which go
-    # as exact 256-tile groups (fc2 + fc1; proj + qkv + the next block's fc2; ...); a ViT-H block 200 / 200 / 50 / 150,
-    # which go as 450- and 750-tile groups (>= 88 % of their rounds).  (At D = 768 a block's 216 tiles under-fill a round
-    # and the queue is packed instead: tests/test_model_gpu.py::test_riding_weight_gradients_equal_separate_launches.)
+    # the long-reduction weight gradients (M = 6272 / 12288 token rows: 98+ K-steps per output tile) leave in PACKED launches
+    # (round 4, Engine._wgrad: every geometry packs under the K4 form): one round of 256 tiles of 256 x 256 = 512 of the
+    # 256 x 128 units counted here, big problems cut at 256-row / 256-column blocks so that the round is full, up to nine small
+    # ones riding (the counter above skips pieces narrower than 256, so a launch may show fewer than its 512).  Every ViT
+    # block's tiles must be in such launches, and most launches must be near-full rounds.
     per_block = {1024: 384, 1280: 600}[D]
     big = [t for t in descs if t >= 200]
     assert sum(big) >= per_block * (depth - 1), (sorted(set(descs)), per_block * depth)
-    assert max(big) >= {1024: 256, 1280: 450}[D]
-    assert sum(t >= 0.8 * 256 * -(-t // 256) for t in big) >= len(big) - 1, sorted(set(big))
+    assert max(big) >= 450
+    assert sum(t >= 400 for t in big) >= 0.75 * len(big), sorted(big)
     hd = D // cfg["num_heads"]
     if hd == 80:
         want = {"attn_fwd_lean_kernel<128, 2, 96>", "attn_bwd_dq_lean_kernel<128, 2, 96> attn_bwd_dkdv_lean_kernel<128, 1, 96>"}

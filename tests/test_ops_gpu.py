@@ -190,6 +190,16 @@ def test_colsum_batched(ops):
     ops.colsum_batched(jobs)
     torch.cuda.synchronize()
     assert torch.equal(flat.cpu(), ref)
+    # strided output blocks (row_len, out_ld): S slabs of a [24, 256] gradient summed into a column block of a [24, 1024]
+    # matrix (the head's fusion weight), few-row 16-byte form and (row_len 36: not 16-byte rows) the generic form
+    for S, N, K, ld, col in ((5, 24, 256, 1024, 512), (40, 24, 256, 1024, 256), (3, 10, 36, 100, 12)):
+        wide = torch.arange(0, N * ld, dtype=torch.float32).remainder(5).cuda()
+        slabs = torch.randint(-3, 4, (S, N, K), generator=g).float()
+        want = wide.clone().cpu().view(N, ld)
+        want[:, col:col + K] += slabs.sum(0)
+        ops.colsum_batched([(dev(slabs), (wide, col), S, N * K, K, ld)])
+        torch.cuda.synchronize()
+        assert torch.equal(wide.cpu().view(N, ld), want), (S, N, K)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -1393,6 +1403,64 @@ def test_gemm_k3_exact_and_epilogues(ops, tB, shape):
 
 
 @pytest.mark.parametrize("tB", [0, 1])
+@pytest.mark.parametrize("shape", [(3000, 1288, 256), (9408, 768, 768), (2500, 1544, 160)])
+def test_gemm_k3s_exact_and_epilogues(ops, tB, shape):
+    """The 128 x 128 ring kernel (vpu_gemm_set_option("k3", 4): 64 x 64 per wave, 32-deep K-steps through a three-stage ring,
+    three workgroups per CU) on the shapes the round-1 128 x 128 kernel serves: exact-integer operands give the fp32 matmul bit
+    for bit (ragged M and N, more tiles than workgroup slots, K of 5, 8 and 24 K-steps), every compile-time flag set."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(17)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[0, 1] = 3; A[1, 0] = -2; Bm[0, 1] = 1; Bm[1, 0] = -3
+    ref = A @ Bm.t()
+    Ad = dev(A).to(torch.bfloat16)
+    Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+    ldb = N if tB else K
+    bias = dev(torch.randint(-4, 5, (N,), generator=g).float())
+    R = dev(torch.randint(-4, 5, (M, N), generator=g).float()).to(torch.bfloat16)
+    aux = dev(torch.randint(-2, 3, (M, N), generator=g).float()).to(torch.bfloat16)
+
+    def run(k3, flags, A_=None, **kw):
+        Cd = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        pre = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_set_option("k3", k3)
+        ops.gemm_set_option("k2", 0)
+        try:
+            ops.gemm(Ad if A_ is None else A_, Bd, Cd, M, N, K, K, ldb, N, 0, transB=bool(tB), flags=flags, preact=pre, **kw)
+            name = ops.gemm_last_kernel()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_set_option("k3", -1)
+            ops.gemm_set_option("k2", -1)
+        assert ("k3s_kernel" in name) == bool(k3), name
+        return Cd.float().cpu(), pre.float().cpu()
+
+    bf = lambda t: t.to(torch.bfloat16).float()
+    if tB == 0:
+        out, _ = run(36, 0)
+        assert torch.equal(out, bf(ref))
+        out, _ = run(36, ops.EPI_BIAS, bias=bias)
+        assert torch.equal(out, bf(ref + bias.cpu()))
+        out, _ = run(36, ops.EPI_BIAS | ops.EPI_RELU, bias=bias)
+        assert torch.equal(out, bf(torch.relu(ref + bias.cpu())))
+        out, _ = run(36, ops.EPI_BIAS | ops.EPI_RESID, bias=bias, resid=R, ldr=N)
+        assert torch.equal(out, bf(ref + bias.cpu() + R.float().cpu()))
+        fl = ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU
+        As = (Ad.float() * 0.125).to(torch.bfloat16)      # GELU away from saturation
+        o_new, p_new = run(36, fl, A_=As, bias=bias * 0.25)
+        o_old, p_old = run(0, fl, A_=As, bias=bias * 0.25)
+        assert torch.equal(o_new, o_old) and torch.equal(p_new, p_old)
+    else:
+        out, _ = run(36, 0)
+        assert torch.equal(out, bf(ref))
+        out, _ = run(36, ops.EPI_MULAUX, aux=aux, ldaux=N)
+        assert torch.equal(out, bf(ref * aux.float().cpu()))
+        out, _ = run(36, ops.EPI_DRELU, aux=aux, ldaux=N)
+        assert torch.equal(out, bf(ref * (aux.float().cpu() > 0).float()))
+
+
+@pytest.mark.parametrize("tB", [0, 1])
 def test_gemm_grouped_skinny_form(ops, tB):
     """Groups whose problems are all skinny (<= 2560 rows, K <= 4096) run as 64 x 64 tiles with the four waves splitting K
     (gemm_bf16_skinny_grouped_kernel): bit-exact vs fp32 matmul on exact-integer operands -- fp32 accumulate output, bf16
@@ -1476,22 +1544,28 @@ def test_gemm_k2_grouped_wgrad(ops):
                          dict(transA=True, transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)))
         checks.append((Cd, cs, A.t() @ Bm + float(i + 1), A.sum(0) + 5.0))
     ops.gemm_set_option("k2", 1)
+    ops.gemm_set_option("k3", 0)
     try:
         ops.gemm_grouped(problems)
+        assert "k2_grouped" in ops.gemm_last_kernel()
         torch.cuda.synchronize()
     finally:
         ops.gemm_set_option("k2", -1)
+        ops.gemm_set_option("k3", -1)
     for Cd, cs, ref, csref in checks:
         assert torch.equal(Cd.cpu(), ref), (Cd.cpu() - ref).abs().max()
         if cs is not None:
             assert torch.equal(cs.cpu(), csref)
 
 
-def test_gemm_k3_grouped_wgrad(ops):
-    """The round-4 form of the same groups (vpu_gemm_set_option("k3", 1): 256 x 128 tiles in 256-thread workgroups, two per
-    CU, 32-deep K-steps through a three-stage ring, no K split): bit-exact accumulation into pre-filled fp32 outputs + the
-    fused bias-gradient column sums; ragged edges; more tiles than workgroup slots (a persistent workgroup walks several
-    tiles of different problems: 549 tiles on 512 slots); K of 64 and of 66 K-steps."""
+@pytest.mark.parametrize("opt", [1, 8, 24])
+def test_gemm_k3_grouped_wgrad(ops, opt):
+    """The round-4 forms of the same groups.  vpu_gemm_set_option("k3", 1): 256 x 128 tiles in 256-thread workgroups, two per
+    CU, 32-deep K-steps through a three-stage ring, no K split ("K3"); 8: 256 x 256 tiles, one 512-thread workgroup per CU,
+    five-stage ring ("K4"); 24: K4 with the software-pipelined K-step (fragments of the next half-step read and the DMA issued
+    between the MFMAs).  Bit-exact accumulation into pre-filled fp32 outputs + the fused bias-gradient column sums; ragged
+    edges; more tiles than workgroup slots (a persistent workgroup walks several tiles of different problems); K of 64 and 66
+    K-steps; and a problem given as BATCH ENTRIES -- the reduction slices of one gradient, each writing its own slab."""
     g = torch.Generator().manual_seed(29)
     shapes = [(3072, 768, 2048), (768, 3072, 2048), (2304, 776, 2048), (520, 760, 2048),         # (M, N, K): 72+72+63+18 tiles
               (3072, 768, 2112), (768, 3072, 2112), (2304, 768, 2112), (2056, 2056, 2112), (3072, 768, 2112),
@@ -1506,12 +1580,22 @@ def test_gemm_k3_grouped_wgrad(ops):
         problems.append(((Ad, Bd, Cd, M, N, K, M, N, N, 0),
                          dict(transA=True, transB=True, flags=ops.EPI_OUT_F32 | ops.EPI_ACCUM, colsum=cs)))
         checks.append((Cd, cs, A.t() @ Bm + float(i + 1), A.sum(0) + 5.0))
-    ops.gemm_set_option("k3", 1)
+    # one gradient [392, 264] over 3 x 2048 rows as three batch entries writing raw slabs (+ their column-sum slabs)
+    S, M, N, L = 3, 392, 264, 2048
+    A = torch.randint(-2, 3, (S * L, M), generator=g).float()
+    Bm = torch.randint(-2, 3, (S * L, N), generator=g).float()
+    Ad, Bd = dev(A).to(torch.bfloat16), dev(Bm).to(torch.bfloat16)
+    slab = torch.full((S, M, N), -7.0, device="cuda")
+    cslab = torch.zeros(S, M, device="cuda")
+    sliced = ((Ad, Bd, slab, M, N, L, M, N, N, 0),
+              dict(transA=True, transB=True, flags=ops.EPI_OUT_F32, colsum=cslab, batch=S, sA=(L * M, 0), sB=(L * N, 0), sC=(M * N, 0)))
+    ops.gemm_set_option("k3", opt)
     try:
-        ops.gemm_grouped(problems[:4])           # 225 tiles: one workgroup per CU would have nobody to overlap with -> K2
-        assert "k2_grouped" in ops.gemm_last_kernel()
-        ops.gemm_grouped(problems[4:])
-        assert "k3_grouped" in ops.gemm_last_kernel()
+        ops.gemm_grouped(problems[:4])           # 225 tiles of 256 x 128
+        if opt == 1:                             # (one workgroup per CU would have nobody to overlap with -> K2)
+            assert "k2_grouped" in ops.gemm_last_kernel()
+        ops.gemm_grouped(problems[4:] + [sliced])
+        assert {1: "k3_grouped", 8: "k4_grouped", 24: "k4p_grouped"}[opt] in ops.gemm_last_kernel()
         torch.cuda.synchronize()
     finally:
         ops.gemm_set_option("k3", -1)
@@ -1519,6 +1603,10 @@ def test_gemm_k3_grouped_wgrad(ops):
         assert torch.equal(Cd.cpu(), ref), (Cd.cpu() - ref).abs().max()
         if cs is not None:
             assert torch.equal(cs.cpu(), csref)
+    for z in range(S):
+        az, bz = A[z * L:(z + 1) * L], Bm[z * L:(z + 1) * L]
+        assert torch.equal(slab[z].cpu(), az.t() @ bz), z
+        assert torch.equal(cslab[z].cpu(), az.sum(0)), z
 
 
 def test_dropout_mask_and_fill(ops):

@@ -4,7 +4,7 @@ world-size-1 RCCL communicator (backend "nccl"), against the same step without a
 the engine-side cost of running under a reducer (queues flushed at every tape marker, no riding weight gradients,
 `reserve_cus` CUs kept out of the persistent GEMM grids, the all-reduce calls and stream waits) and, from a kernel trace of
 this script, whether RCCL's kernels run BESIDE the GEMMs or behind them.  What it cannot show: xGMI traffic -- no
-multi-GPU box is available to the build, the driver's scaling run is the first (DESIGN section 6).
+multi-GPU box is available to the build, the driver's scaling run is the first (DESIGN.md section 6).
 usage: python tools/dp_rehearsal.py [steps] [out.json]"""
 import json
 import os

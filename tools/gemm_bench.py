@@ -35,6 +35,15 @@ NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
     ("img kproj dgrad", 0, 1, M, 768, 384, 0),
     ("img kproj wgrad", 1, 1, 384, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
     ("img out 384", 0, 0, M, 768, 384, ops.EPI_BIAS | ops.EPI_RESID),
+    ("fpn lin 4.5", 0, 0, 150528, 128, 192, ops.EPI_BIAS),
+    ("fpn lin 8.2", 0, 0, 37632, 256, 384, ops.EPI_BIAS),
+    ("fpn lin 16", 0, 0, M, 512, 768, ops.EPI_BIAS),
+    ("head conv0", 0, 0, 150528, 256, 128, ops.EPI_BIAS | ops.EPI_RELU),
+    ("head conv1", 0, 0, 37632, 256, 256, ops.EPI_BIAS | ops.EPI_RELU),
+    ("head fuse0", 0, 0, 150528, 256, 256, ops.EPI_BIAS),
+    ("head fuse0 dgrad", 0, 1, 150528, 256, 256, ops.EPI_DRELU),
+    ("fpn lin 4.5 dgrad", 0, 1, 150528, 192, 128, 0),
+    ("fpn ct 4.3 dgrad", 0, 0, 37632, 384, 768, 0),
     ("fpn wgrad", 1, 1, 256, 1024, 150528, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
     ("head wgrad", 1, 1, 256, 128, 150528, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
 ]
@@ -46,6 +55,10 @@ def set_k2(opt):
     if opt == "k3":
         ops.gemm_set_option("k2", -1)
         ops.gemm_set_option("k3", 3)
+        return
+    if opt == "k3s":       # the 128 x 128 ring kernel where the round-1 128 x 128 kernel would run
+        ops.gemm_set_option("k2", -1)
+        ops.gemm_set_option("k3", 4)
         return
     ops.gemm_set_option("k3", 0 if opt != "-1" else -1)
     ops.gemm_set_option("k2", int(opt.split(":")[0]))

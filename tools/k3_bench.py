@@ -31,23 +31,26 @@ def main():
     cases = [("1 block (216 tiles)", blk), ("2 blocks (432 tiles)", blk + blk), ("4096x4096 (512 tiles)", [(4096, 4096)]),
              ("243-tile pack", [(3072, 768), (768, 3072), (2304, 768), (768, 768), (768, 384), (768, 384), (512, 384)]),
              ("486-tile pack", blk + blk + [(768, 384), (768, 384), (512, 384)] * 2)]
+    nsets = int(os.environ.get("K3_BENCH_SETS", "1"))      # > 1: cycle over that many operand sets (cold operands, as in the step)
     for name, shapes in cases:
-        probs, fl = problems(shapes)
+        sets = [problems(shapes) for _ in range(nsets)]
+        fl = sets[0][1]
         res = {}
         for rnd in range(5):
-            for k3 in (0, 1):
+            for k3 in (0, 1, 8, 24):
                 ops.gemm_set_option("k3", k3)
-                ops.gemm_grouped(probs)
+                ops.gemm_grouped(sets[0][0])
                 kern = ops.gemm_last_kernel()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(reps):
-                    ops.gemm_grouped(probs)
+                for r in range(reps):
+                    ops.gemm_grouped(sets[r % nsets][0])
                 e1.record()
                 torch.cuda.synchronize()
                 res.setdefault((k3, kern), []).append(e0.elapsed_time(e1) * 1e-3 / reps)
         ops.gemm_set_option("k3", -1)
-        txt = "   ".join(f"{'K3' if k[0] else 'K2'}: {sorted(v)[2] * 1e6:7.1f} us {fl / sorted(v)[2] / 1e12:6.0f} TF" for k, v in res.items())
+        nm = {0: "K2", 1: "K3", 8: "K4", 24: "K4P"}
+        txt = "   ".join(f"{nm[k[0]]}({k[1][10:13]}): {sorted(v)[2] * 1e6:7.1f} us {fl / sorted(v)[2] / 1e12:6.0f} TF" for k, v in res.items())
         print(f"{name:24s} {txt}", flush=True)
 
 
