@@ -196,12 +196,19 @@ def install_stubs():
 
 def install_simulator_standins():
     """Stand-ins for the two third-party calls inside the click / box simulators (isegm/engine/trainer.py:628,736,1176),
-    so that the reference's BOOKKEEPING around them can be run here: cv2.distanceTransform(DIST_L2, 5) -> exact
-    Euclidean transform, skimage.measure.label(connectivity=2) -> scipy 8-connected labelling.  Parity of the click
-    COORDINATES against real OpenCV therefore stays unpinned."""
+    so that the reference's BOOKKEEPING around them can be run here: cv2.distanceTransform(DIST_L2, 5) -> the oracle's
+    restatement of OpenCV's 5 x 5 chamfer transform (vpu_oracle.chamfer_l2_5x5; mask size 0 = precise -> the exact Euclidean
+    transform), skimage.measure.label(connectivity=2) -> scipy 8-connected labelling.  Parity of the click COORDINATES
+    against real OpenCV therefore stays unpinned."""
     from scipy import ndimage
+    import vpu_oracle as vo
     cv2 = sys.modules["cv2"]
-    cv2.distanceTransform = lambda m, dist_type, mask_size: ndimage.distance_transform_edt(m).astype(np.float32)
+
+    def distance_transform(m, dist_type, mask_size):
+        if dist_type == cv2.DIST_L2 and mask_size == 5:
+            return vo.chamfer_l2_5x5(m)
+        return ndimage.distance_transform_edt(m).astype(np.float32)
+    cv2.distanceTransform = distance_transform
     sk = _mod("skimage")
     skm = _mod("skimage.measure")
     sk.measure = skm

@@ -5,10 +5,11 @@ which error mask the P2CL label of that slot becomes, and the box prompt.  Mirro
 row; this one keeps the reference's CPU structure (numpy + scipy) so that the integer bookkeeping is identical.
 
 PARITY NOTE: the reference calls ``cv2.distanceTransform(mask, DIST_L2, 5)`` (5x5 chamfer approximation) and
-``skimage.measure.label(connectivity=2)``; neither library is in this image.  ``scipy.ndimage.distance_transform_edt``
-(exact Euclidean) and ``scipy.ndimage.label`` (8-connected) stand in, so click COORDINATES are parity-unpinned while slot
-/ order / label-mask / box bookkeeping is pinned by ``tests/golden/sim.npz`` (generated from the reference with the same
-two stand-ins).
+``skimage.measure.label(connectivity=2)``; neither library is in this image.  Round 4: the chamfer transform is RESTATED from
+OpenCV's published two-pass fixed-point algorithm (``chamfer_l2_5x5`` below, the same arithmetic as
+oracle/vpu_oracle.py::chamfer_l2_5x5 and the HIP kernel ``vpu_chamfer5``) and ``scipy.ndimage.label`` (8-connected) stands in
+for skimage, so slot / order / label-mask / box bookkeeping AND the click coordinates are pinned by ``tests/golden/sim.npz``
+(generated from the reference with the same two stand-ins) -- against real OpenCV the coordinates stay unpinned.
 """
 import random
 
@@ -25,22 +26,54 @@ GPU_CC = _os.environ.get("VPU_SIM_GPU_CC", "1") == "1"
 
 
 def distance_transform(mask_u8):
-    """Distance of every non-zero pixel to the nearest zero pixel (stand-in for cv2.distanceTransform DIST_L2)."""
+    """Distance of every non-zero pixel to the nearest zero pixel (cv2.distanceTransform DIST_L2, mask size 0 = precise)."""
     return ndimage.distance_transform_edt(mask_u8).astype(np.float32)
 
 
-def distance_transform_batch(masks, device=None):
-    """Exact Euclidean distance transforms of N masks [N,H,W] (bool / uint8), each treated as surrounded by zero pixels
-    (the reference pads by one pixel first, trainer.py:626-629) -> float32 [N,H,W].  On a CUDA ``device`` the HIP kernel
-    (ops.edt: bit-identical to the float64 transform cast to float32, tests/test_ops_gpu.py) does all N at once --
-    4.4 ms per 448x448 mask on the host was most of a NoBRS click --; without one, scipy on the host."""
+# OpenCV's 5x5 chamfer weights for DIST_L2 (1, 1.4, 2.1969 as float32) in its 16-bit fixed point (cvRound(x * 65536))
+_CH_A, _CH_B, _CH_C = 65536, 91750, 143976
+
+
+def chamfer_l2_5x5(mask):
+    """cv2.distanceTransform(mask, cv2.DIST_L2, 5) (trainer.py:628-629, 673-674, 736-737), restated from OpenCV's two-pass
+    algorithm (imgproc/distransform.cpp, distanceTransform_5x5, the C++ path): fixed-point distances, a forward raster pass
+    over the upper half of the 5x5 mask, a backward pass over the mirrored half, outside the image = infinity, result
+    float32(t) * 2^-16.  A row of a pass is the prefix minimum t[j] = a j + min_{k <= j} (cand[k] - a k)."""
+    m = np.asarray(mask) != 0
+    H, W = m.shape
+    INF = np.int64(1) << 40
+    a, b, c = np.int64(_CH_A), np.int64(_CH_B), np.int64(_CH_C)
+    T = np.full((H + 4, W + 4), INF, np.int64)
+    cols = np.arange(W, dtype=np.int64) * a
+    sh = lambda row, d: row[2 + d: 2 + d + W]
+    nb = lambda r1, r2: np.minimum.reduce([sh(r2, -1) + c, sh(r2, 1) + c, sh(r1, -2) + c, sh(r1, 2) + c,
+                                           sh(r1, -1) + b, sh(r1, 1) + b, sh(r1, 0) + a])
+    for i in range(H):
+        cand = np.where(m[i], nb(T[i + 1], T[i]), 0)
+        T[i + 2, 2:W + 2] = np.minimum.accumulate(cand - cols) + cols
+    for i in range(H - 1, -1, -1):
+        cand = np.minimum(T[i + 2, 2:W + 2], nb(T[i + 3], T[i + 4]))
+        T[i + 2, 2:W + 2] = np.minimum.accumulate((cand + cols)[::-1])[::-1] - cols
+    t = np.minimum(T[2:H + 2, 2:W + 2], np.int64(0xFFFFFFFF) - c)
+    return t.astype(np.float32) * np.float32(1.0 / 65536.0)
+
+
+def distance_transform_batch(masks, device=None, chamfer=False):
+    """Distance transforms of N masks [N,H,W] (bool / uint8), each treated as surrounded by zero pixels (the reference pads
+    by one pixel first, trainer.py:626-629) -> float32 [N,H,W].  ``chamfer``: the 5x5 chamfer approximation of the TRAINING
+    simulators (cv2 DIST_L2, 5) instead of the exact Euclidean transform (the Clicker's DIST_L2, 0).  On a CUDA ``device`` the
+    HIP kernels (ops.edt / ops.chamfer5, bit-identical to the host forms: tests/test_ops_gpu.py) do all N at once."""
     masks = np.ascontiguousarray(masks).astype(np.uint8)
     if device is not None and torch.device(device).type == "cuda":
         from pvpuformer_amd import ops
-        return ops.edt(torch.from_numpy(masks).to(device), zero_border=True).cpu().numpy()
+        f = ops.chamfer5 if chamfer else ops.edt
+        return f(torch.from_numpy(masks).to(device), zero_border=True).cpu().numpy()
     out = np.empty(masks.shape, np.float32)
     for i, m in enumerate(masks):
-        out[i] = ndimage.distance_transform_edt(np.pad(m, 1, "constant")).astype(np.float32)[1:-1, 1:-1]
+        if chamfer:
+            out[i] = chamfer_l2_5x5(np.pad(m, 1, "constant"))[1:-1, 1:-1]
+        else:
+            out[i] = ndimage.distance_transform_edt(np.pad(m, 1, "constant")).astype(np.float32)[1:-1, 1:-1]
     return out
 
 
@@ -202,7 +235,7 @@ def next_click(pred, gt, points, pred_thresh=0.49, np_rng=np.random, device=None
     [B,2n,3] (modified copy is returned).  Also returns the false-negative / false-positive masks."""
     fn = np.logical_and(gt, pred < pred_thresh)
     fp = np.logical_and(np.logical_not(gt), pred > pred_thresh)
-    dts = distance_transform_batch(np.concatenate([fn, fp], 0), device)   # zero border = the reference's np.pad(.., 1)
+    dts = distance_transform_batch(np.concatenate([fn, fp], 0), device, chamfer=True)   # zero border = the reference's np.pad(.., 1)
     n = points.shape[1] // 2
     points = points.copy()
     picks = []
@@ -351,7 +384,7 @@ def _get_next_promts_gpu(pred, gt, points, state, pred_thresh, as_allmask, jitte
         if xc >= 1 and yc >= 1 and bw >= 1 and bh >= 1:
             boxes[b] = (xc, yc, bw, bh, loc)
     # ---- next_click (trainer.py:615-654, 733-764)
-    dts = ops.edt(torch.cat([fn, fp], 0).to(torch.uint8), zero_border=True)                # [2B, H, W]
+    dts = ops.chamfer5(torch.cat([fn, fp], 0).to(torch.uint8), zero_border=True)           # [2B, H, W] (cv2 DIST_L2, 5)
     mx = dts.flatten(1).amax(1).cpu().numpy()                                              # fn maxima, then fp maxima
     is_pos = mx[:B] > mx[B:]
     pick_t = torch.from_numpy(np.where(is_pos, np.arange(B), np.arange(B) + B)).to(pred.device)

@@ -175,6 +175,29 @@ def test_cc_table_and_kept_region_boxes(ops):
     assert ps._kept_region_boxes(md, 8) == host                          # overflow: the host labelling takes over
 
 
+def test_chamfer5_bit_exact(ops):
+    """vpu_chamfer5 (cv2.distanceTransform(DIST_L2, 5) of the training simulators, restated from OpenCV's two-pass fixed-point
+    algorithm) == oracle/vpu_oracle.py::chamfer_l2_5x5 bit for bit: blobs, speckle, an empty and a full mask, 448 x 448 and a
+    ragged 96 x 131, with the implicit zero border the reference's np.pad gives and without."""
+    import vpu_oracle as vo
+    g = np.random.RandomState(3)
+    for H, W in ((448, 448), (96, 131)):
+        yy, xx = np.mgrid[0:H, 0:W]
+        masks = [((yy - H * 0.4) ** 2 / (H * 0.3) ** 2 + (xx - W * 0.5) ** 2 / (W * 0.35) ** 2 <= 1.0),
+                 g.rand(H, W) > 0.03, g.rand(H, W) > 0.6, np.zeros((H, W), bool), np.ones((H, W), bool)]
+        masks[0][H // 3: H // 3 + 7, W // 4: W // 2] = False
+        m = np.stack(masks).astype(np.uint8)
+        for border in (True, False):
+            got = ops.chamfer5(dev(torch.from_numpy(m)), zero_border=border).cpu().numpy()
+            for i in range(len(masks)):
+                want = vo.chamfer_l2_5x5(np.pad(m[i], 1))[1:-1, 1:-1] if border else vo.chamfer_l2_5x5(m[i])
+                assert np.array_equal(got[i], want), (H, W, border, i, np.abs(got[i] - want).max())
+    # against the exact transform: the chamfer metric (a = 1, b = 1.4 < sqrt 2, c = 2.1969 < sqrt 5) is within ~2-3 % of it
+    e = ops.edt(dev(torch.from_numpy(m[:1])), zero_border=True).cpu().numpy()[0]
+    c = ops.chamfer5(dev(torch.from_numpy(m[:1])), zero_border=True).cpu().numpy()[0]
+    assert np.all(c >= e * 0.97 - 1e-3) and np.all(c <= e * 1.03 + 1e-3)
+
+
 def test_colsum_batched(ops):
     """70 independent column sums (more than one launch's 64) of different shapes accumulate into slices of one flat
     buffer exactly like per-job fp32 sums (integer data: exact)."""

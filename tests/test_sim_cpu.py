@@ -34,6 +34,36 @@ def test_get_next_promts_bookkeeping_bit_exact(golden_dir):
         np.testing.assert_array_equal(sums, fx[f"r{r}_changed_sums"])
 
 
+def test_chamfer_restatements_agree():
+    """The 5 x 5 chamfer transform (cv2.distanceTransform(DIST_L2, 5), trainer.py:628-629): the oracle's restatement, the
+    mirror's host form and a literal two-pass loop over OpenCV's published update order give identical float32 maps."""
+    a, b, c = 65536, 91750, 143976
+
+    def loops(m):
+        H, W = m.shape
+        INF = 1 << 40
+        T = np.full((H + 4, W + 4), INF, np.int64)
+        for i in range(H):
+            for j in range(W):
+                I, J = i + 2, j + 2
+                T[I, J] = 0 if not m[i, j] else min(T[I - 2, J - 1] + c, T[I - 2, J + 1] + c, T[I - 1, J - 2] + c, T[I - 1, J - 1] + b,
+                                                    T[I - 1, J] + a, T[I - 1, J + 1] + b, T[I - 1, J + 2] + c, T[I, J - 1] + a)
+        for i in range(H - 1, -1, -1):
+            for j in range(W - 1, -1, -1):
+                I, J = i + 2, j + 2
+                if T[I, J] > a:
+                    T[I, J] = min(T[I, J], T[I + 2, J + 1] + c, T[I + 2, J - 1] + c, T[I + 1, J + 2] + c, T[I + 1, J + 1] + b,
+                                  T[I + 1, J] + a, T[I + 1, J - 1] + b, T[I + 1, J - 2] + c, T[I, J + 1] + a)
+        return T[2:H + 2, 2:W + 2].astype(np.float32) * np.float32(1 / 65536)
+    rs = np.random.RandomState(4)
+    for k in range(4):
+        m = np.pad(rs.rand(33, 45) > (0.1 + 0.2 * k), 1)
+        want = loops(m)
+        assert np.array_equal(vo.chamfer_l2_5x5(m), want) and np.array_equal(ps.chamfer_l2_5x5(m), want)
+    batch = ps.distance_transform_batch(np.stack([m[1:-1, 1:-1]]), None, chamfer=True)
+    assert np.array_equal(batch[0], want[1:-1, 1:-1])
+
+
 def test_points_nd_packing_bit_exact(golden_dir):
     fx = np.load(os.path.join(golden_dir, "sim.npz"))
     bp = BasePredictor.__new__(BasePredictor)

@@ -31,6 +31,8 @@ def main():
     cases = [("1 block (216 tiles)", blk), ("2 blocks (432 tiles)", blk + blk), ("4096x4096 (512 tiles)", [(4096, 4096)]),
              ("243-tile pack", [(3072, 768), (768, 3072), (2304, 768), (768, 768), (768, 384), (768, 384), (512, 384)]),
              ("486-tile pack", blk + blk + [(768, 384), (768, 384), (512, 384)] * 2)]
+    if os.environ.get("K3_BENCH_CASES") == "pack":      # (counter passes: one case, every kernel family)
+        cases = [c for c in cases if c[0].startswith("486")]
     nsets = int(os.environ.get("K3_BENCH_SETS", "1"))      # > 1: cycle over that many operand sets (cold operands, as in the step)
     for name, shapes in cases:
         sets = [problems(shapes) for _ in range(nsets)]
