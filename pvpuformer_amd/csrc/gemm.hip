@@ -961,7 +961,7 @@ __device__ __forceinline__ void k2_issue(const __amdgpu_buffer_rsrc_t rA, const 
 
 // One K-tile: DMA of a later K-tile into stage `wr`, fragments + MFMAs of the current one from stage `rd` (the stages are
 // __restrict__ parameters of an inlined function for the reason given at ring_step).
-template <int TA, int TB, int WN, bool CS, int WAITN, int RB>
+template <int TA, int TB, int WN, bool CS, int WAITN, int RB, bool SW = false>
 __device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
                                         const int (&voff)[K2Cfg<WN>::PW], const int soffA, const int soffB, const bool live,
                                         char* __restrict__ wr, const char* __restrict__ rd, const int wave, const int lane,
@@ -993,8 +993,11 @@ __device__ __forceinline__ void k2_step(const __amdgpu_buffer_rsrc_t rA, const _
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                // SW: operands swapped -- the accumulator tile is C^T, i.e. acc[i][j][r] = C[16 i + fr][16 j + 4 fq + r]
+                if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         if constexpr (CS && RB == 8) if (do_cs) {   // the two N-halves of the wave grid share the A fragments: each sums four of the eight row blocks
             if (wn == 0) {
 #pragma unroll
@@ -1167,6 +1170,94 @@ __device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)
     }
 }
 
+// Direct form (SW kernels, round 4): the MFMAs ran with swapped operands, so a lane holds FOUR CONSECUTIVE COLUMNS of one
+// row per accumulator tile: a[i][j][r] = C[16 i + fr][16 j + 4 fq + r].  One v_permlane16_swap per register pairs the
+// column blocks 2t / 2t+1 (odd 16-lane rows of the first operand <-> even rows of the second), after which every lane owns
+// 8 consecutive columns of its row -- 16-byte stores straight from the registers: no LDS transposition, no lgkmcnt waits,
+// and the ring stages are free for the next tile's DMA while the stores go out.  Same store count as k2_epi_fast.
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+template <int FL> struct K2PreD {
+    u32x4v x[4][2];    // residual or aux: [row block][column-block pair]
+};
+// The bias of a tile's 64 columns per wave travels as ONE 4-byte-per-lane LDS-DMA into a private 256-byte slot of the wave
+// (two slots, alternating per tile), requested immediately BEFORE the tile's first stage: any wait that covers that stage
+// covers it, so no counted s_waitcnt changes; the epilogue reads it back with two 16-byte LDS reads per 8 columns.  (As
+// global loads the 16 values per lane were requested right before the K-half exchange and cost registers there.)
+constexpr int K2_BIAS_LDS = 2 * 8 * 256;
+__device__ __forceinline__ void k2_bias_issue(const vpu_gemm_desc& p, const int ncol0, const int lane, char* slot) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(p.bias)), 0, p.N * 4, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)slot, 4, (ncol0 + lane) * 4, 0, 0, 0);   // columns >= N: zeros
+}
+__device__ __forceinline__ int k2_direct_col(const int lane) { const int fq = lane >> 4; return (fq & 1) * 16 + (fq >> 1) * 8; }
+template <int FL>
+__device__ __forceinline__ void k2_prefetch_direct(const vpu_gemm_desc& p, const int mrow0, const int ncol0, const int lane,
+                                                   K2PreD<FL>& q, const int npass) {
+    constexpr bool IS_RES = (FL & VPU_EPI_RESID) != 0;
+    const int fr = lane & 15, cl = k2_direct_col(lane);
+    if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DRELU)) != 0) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IS_RES ? p.resid : p.aux), 0, 0x7FFFFFFF, 0x00020000);
+        const int ld = IS_RES ? p.ldr : p.ldaux;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = mrow0 + pass * 16 + fr, n = ncol0 + 32 * t + cl;
+                const int row = (IS_RES && p.resid_period > 0) ? m % p.resid_period : m;
+                const int off = (pass < npass && m < p.M && n < p.N) ? (row * ld + n) * 2 : OOB_OFFSET;
+                q.x[pass][t] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+            }
+    }
+}
+template <int FL>
+__device__ __forceinline__ void k2_epi_direct(const vpu_gemm_desc& p, f32x4_t (&a)[4][4], const int mrow0, const int ncol0,
+                                              const int lane, const K2PreD<FL>& q, const int npass, const float* bl) {
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, 0x7FFFFFFF, 0x00020000);
+    const int fr = lane & 15, cl = k2_direct_col(lane);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (temporaries: __builtin_bit_cast applied to a vector-element lvalue read element 0 for every r)
+                const float x0 = a[pass][2 * t][r], x1 = a[pass][2 * t + 1][r];
+                const u32x2v sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+                v[r] = __uint_as_float(sw.x);
+                v[4 + r] = __uint_as_float(sw.y);
+            }
+            const int m = mrow0 + pass * 16 + fr, n = ncol0 + 32 * t + cl;
+            if constexpr ((FL & VPU_EPI_BIAS) != 0) {
+                float b[8];
+                load8(bl + 32 * t + cl, b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += b[j];
+            }
+            const int off = (pass < npass && m < p.M && n < p.N) ? (m * p.ldc + n) * 2 : OOB_OFFSET;
+            if constexpr ((FL & VPU_EPI_GELU) != 0) {
+                float d[8];
+                gelu_dgelu8(v, d);
+                if constexpr ((FL & VPU_EPI_SAVE_DGELU) != 0) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rP, off, 0, 0);
+            }
+            if constexpr ((FL & VPU_EPI_RELU) != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DRELU)) != 0) {
+                const bf16x8_t e = __builtin_bit_cast(bf16x8_t, q.x[pass][t]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = (float)e[j];
+                    if (FL & VPU_EPI_MULAUX) v[j] *= x;
+                    else if (FL & VPU_EPI_DRELU) v[j] *= (x > 0.f ? 1.f : 0.f);
+                    else v[j] += x;
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rC, off, 0, 0);
+        }
+}
+
 struct K2Tile {   // wave-uniform description of one output tile
     int m0, n0, tile_n, grp, M, N, K, lda, ldb;
     int z;            // batch entry (K3 grouped form: the reduction slices of one weight gradient), else 0
@@ -1240,16 +1331,22 @@ __device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const i
 
 // RB = 16-row blocks per wave: 8 (256-row tiles) or 7 (224-row tiles: M = 9408 = 42 x 224 fills 252 of 256 CUs per round
 // where 36.75 x 256 fills 222; the LDS layout keeps its 128-row sub-tiles, rows 112-127 of each are dead).
-template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB>
+template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB, bool SWP = false>
 __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
                                         const int tiles_m_arg, const int tiles_n_arg, const int vec) {
     using Cf = K2Cfg<WN>;
+    // SW: swapped MFMA operands + direct epilogue (k2_epi_direct); compile-time flag sets of the plain kernel only
+    constexpr bool SW = SWP && FL >= 0 && !GRP && !CS;
     static_assert(!CS || (WN == 2 && TA == 1 && RB == 8), "fused column sums: weight-gradient form, 256 x 128 tile");
     constexpr bool PP = WN == 2;       // ping-pong schedule of the two K-half groups + next tile's first stages requested early
     constexpr bool GEN = FL < 0;
     // vector-memory stores one wave issues in the exact-count epilogue of its 64 x 64 quarter
     constexpr int NST = GEN ? 0 : 8 * ((FL & VPU_EPI_SAVE_DGELU) ? 2 : 1);
     constexpr int W1 = GEN ? Cf::PW : Cf::PW + NST;   // first waits of a tile whose stages 0 / 1 were requested before those stores
+    constexpr int NSTW = 2 * NST;                     // WN = 4, SW: both 64-row halves' stores follow the next tile's first DMA
+    int par = 0;                                      // WN = 4: ring stage that receives this tile's K-tile 0
+    constexpr bool BL = SW && (FL & VPU_EPI_BIAS) != 0;  // bias through the wave's LDS slot (k2_bias_issue)
+    int bs = 0;                                       // bias slot of the current tile
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1287,10 +1384,15 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(((lane & 15) == 0) ? 1.0f : 0.0f);
 
-        char* s0 = lds;
+        char* s0 = PP ? lds : lds + par * Cf::STAGE;
         char* s1 = lds + Cf::STAGE;
-        char* s2 = lds + (Cf::S - 1) * Cf::STAGE;
+        char* s2 = PP ? lds + (Cf::S - 1) * Cf::STAGE : lds + (1 - par) * Cf::STAGE;
+        if constexpr (!PP) par ^= nk & 1;
+        char* const bslot = lds + Cf::LDS + (bs * 8 + wave) * 256;
+        char* const nbslot = lds + Cf::LDS + ((bs ^ 1) * 8 + wave) * 256;
+        bs ^= 1;
         if (!primed) {
+            if constexpr (BL) k2_bias_issue(p, n0 + wn * 64, lane, bslot);
             k2_issue<TA, TB, WN>(rA, rB, voff, 0, 0, true, s0, wave);
             if (Cf::S == 3) k2_issue<TA, TB, WN>(rA, rB, voff, stepA, stepB, 1 < nk, s1, wave);
         }
@@ -1301,25 +1403,31 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::PW) : "memory");
             __builtin_amdgcn_s_barrier();
             if (g == 1) __builtin_amdgcn_s_barrier();
-            if (primed) k2_step<TA, TB, WN, CS, W1, RB>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
-            else k2_step<TA, TB, WN, CS, Cf::PW, RB>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+            if (primed) k2_step<TA, TB, WN, CS, W1, RB, SW>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+            else k2_step<TA, TB, WN, CS, Cf::PW, RB, SW>(rA, rB, voff, 2 * stepA, 2 * stepB, 2 < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
             { char* t = s0; s0 = s1; s1 = s2; s2 = t; }
             for (int kt = 1; kt < nk; ++kt) {
                 const int kn = kt + 2;
-                k2_step<TA, TB, WN, CS, Cf::PW, RB>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+                k2_step<TA, TB, WN, CS, Cf::PW, RB, SW>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
                 char* t = s0; s0 = s1; s1 = s2; s2 = t;
             }
             if (g == 0) __builtin_amdgcn_s_barrier();   // the two groups meet again
         } else {
             for (int kt = 0; kt < nk; ++kt) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (a primed tile: K-tile 0 was requested before the previous tile's NSTW direct stores, which may still be in flight)
+                if (SW && primed && kt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();   // K-tile kt has landed for every wave; every wave is done reading K-tile kt-1
                 const int kn = kt + 1;
-                k2_step<TA, TB, WN, CS, -1, RB>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
+                k2_step<TA, TB, WN, CS, -1, RB, SW>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, s2, s0, wave, lane, wm, wn, g, do_cs, ones, acc, acc_cs);
                 char* t = s0; s0 = s2; s2 = t;
             }
+            // (measured and not kept: requesting the residual / aux operand of the direct 256-column form one K-step before the
+            // loop ends -- 32 or 64 more live registers in that step spill, and a scratch reload drains the vmcnt queue)
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the out-of-range tail pieces still write zeros into LDS)
+        // (the out-of-range tail pieces still write zeros into LDS; the direct 256-column form does not touch LDS in its
+        // epilogue and the same wave overwrites the same words with the next tile's pieces, in order: nothing to wait for)
+        if constexpr (!(SW && !PP)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int nxt = work + gridDim.x;
         const bool has_next = nxt < total_work;
         K2Tile nt = cur;
@@ -1339,9 +1447,21 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             // this wave's quarter: 64 x 64 (group 0: row blocks 0-3 of the wave tile; group 1: blocks 4 .. RB-1, 48 rows when RB = 7)
             const int mq = m0 + wm * (16 * RB) + g * 64, nq = n0 + wn * 64;
             const int npass = g == 0 ? 4 : RB - 4;
-            K2Pre<GEN ? 0 : FL> q;
-            if constexpr (!GEN) k2_prefetch<FL>(p, mq, nq, lane, q, npass);   // lands while the halves are exchanged
-            __syncthreads();
+            K2Pre<(GEN || SW) ? 0 : FL> q;
+            K2PreD<SW ? FL : 0> qd;
+            if constexpr (SW) k2_prefetch_direct<FL>(p, mq, nq, lane, qd, npass);
+            else if constexpr (!GEN) k2_prefetch<FL>(p, mq, nq, lane, q, npass);   // lands while the halves are exchanged
+            // the next tile's coordinates and DMA offsets now (integer divisions, ~100 instructions): they overlap the waits of
+            // the exchange instead of standing between its last barrier and the DMA that primes the next tile
+            if (has_next) {
+                k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
+                k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
+            }
+            // (raw barriers + explicit LDS waits in this exchange: __syncthreads() carries a fence, i.e. s_waitcnt vmcnt(0),
+            // which exposed the whole latency of the bias / residual / aux loads just requested -- once per tile)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();   // every wave is done with the ring (fragment reads consumed, own DMA pieces landed)
+            __builtin_amdgcn_sched_barrier(0);
             // the two K-half groups exchange half of their 128 x 64 partial tile: group 0 finishes rows 0-63, group 1 rows
             // 64-127 of it.  Fragment layouts are identical in both waves, so the registers travel as they are (16-byte LDS
             // accesses, lane-linear).  Wave w sends through [w * 16 KiB, + 16 KiB).
@@ -1359,7 +1479,10 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[g * 256 + wm * 128 + (wn * 4 + i) * 16 + fq * 4 + r] = acc_cs[i][r];
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             if (CS && do_cs && tid < K2_BM && m0 + tid < cur.M) p.colsum[m0 + tid] += red[tid] + red[256 + tid];
             f32x4_t fin[4][4];
 #pragma unroll
@@ -1367,19 +1490,53 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fin[i][j] = (g == 0 ? acc[i][j] : acc[4 + i < RB ? 4 + i : 0][j]) + theirs[(i * 4 + j) * 64];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __syncthreads();   // every wave has taken its partner's half: stages 0 and 1 can receive the next tile
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();   // every wave has taken its partner's half: stages 0 and 1 can receive the next tile
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
+                const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
+                const int nsA = TA ? nt.lda * (BK * 2) : BK * 2, nsB = TB ? nt.ldb * (BK * 2) : BK * 2;
+                if constexpr (BL) k2_bias_issue(p, nt.n0 + wn * 64, lane, nbslot);
+                k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds, wave);
+                k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
+            }
+            float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
+            if constexpr (SW) k2_epi_direct<FL>(p, fin, mq, nq, lane, qd, npass, reinterpret_cast<const float*>(bslot));
+            else if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
+            else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q, npass);
+        } else if constexpr (SW) {
+            // WN = 4, direct: nothing of the epilogue touches LDS, so the next tile's K-tile 0 is requested first -- into the
+            // stage the last K-step did not read (this wave's own dead tail pieces into it were requested earlier and land
+            // first: the vector-memory queue is in order) -- and the stores of this tile go out behind it
+            const int mw = m0 + wm * (16 * RB), nw = n0 + wn * 64;
+            K2PreD<FL> q0, q1;
+            k2_prefetch_direct<FL>(p, mw, nw, lane, q0, 4);
+            k2_prefetch_direct<FL>(p, mw + 64, nw, lane, q1, RB - 4);
             if (has_next) {
                 k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
                 k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
-                const int nsA = TA ? nt.lda * (BK * 2) : BK * 2, nsB = TB ? nt.ldb * (BK * 2) : BK * 2;
-                k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds, wave);
-                k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
+                if constexpr (BL) k2_bias_issue(p, nt.n0 + wn * 64, lane, nbslot);
+                k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds + par * Cf::STAGE, wave);
             }
-            float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
-            if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
-            else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q, npass);
+            {
+                f32x4_t fin[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fin[i][j] = acc[i][j];
+                k2_epi_direct<FL>(p, fin, mw, nw, lane, q0, 4, reinterpret_cast<const float*>(bslot));
+            }
+            {
+                f32x4_t fin[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fin[i][j] = acc[4 + i < RB ? 4 + i : 0][j];
+                k2_epi_direct<FL>(p, fin, mw + 64, nw, lane, q1, RB - 4, reinterpret_cast<const float*>(bslot));
+            }
         } else {
             __syncthreads();
             float* wl = reinterpret_cast<float*>(lds) + wave * 2048;
@@ -1396,7 +1553,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         // every wave is done with its epilogue LDS before the next tile's DMA / fragment reads touch it (raw barrier: the
         // global stores stay in flight)
         __builtin_amdgcn_s_barrier();
-        primed = PP && has_next && vec != 9;
+        primed = (PP || SW) && has_next && vec != 9;
         if (has_next && !primed) {
             k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
             k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
@@ -1408,10 +1565,10 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
     }
 }
 
-template <int TA, int TB, int WN, int FL, int RB>
+template <int TA, int TB, int WN, int FL, int RB, bool SWP = false>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
                                                            const int vec) {
-    k2_body<TA, TB, WN, false, FL, false, RB>(p, nullptr, tiles_m, tiles_n, vec);
+    k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec);
 }
 template <int TA, int TB, bool CS>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
@@ -2365,7 +2522,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 // measured (tools/gemm_bench.py, GEMM_BENCH_K2=0,1,3, M = 9408): the 256 x 128 form wins for K >= 2304
                 // (fc2 45.1 vs 47.6 us, fc1 dgrad 42.1 vs 46.7, qkv dgrad 33.9 vs 36.7) and for many-tile short-K problems
                 // (qkv 42.3 vs 49.0); one round of 222 tiles over K = 768 stays with the 128 x 128 kernel (proj 21.9 vs 19.8)
-                const bool narrow_ok = k2 == 1 || k2 == 3 || d->K >= 1024 || (int64_t)tm2 * tn2 >= 400;
+                // (round 4, direct epilogue: the one-round K = 768 problems now win too -- proj 18.1 vs 19.6 us, its dgrad 15.4 vs 16.6)
+                static const bool direct_env = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
+                const bool narrow_ok = k2 == 1 || k2 == 3 || d->K >= 1024 || (int64_t)tm2 * tn2 >= 400 ||
+                                       (direct_env && d->K >= 512 && (int64_t)tm2 * tn2 >= 200);
                 const int vec2 = noepi2 ? 9 : 1;
                 const int ncu = cu_count();
                 bool done = true;
@@ -2379,20 +2539,23 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 };
                 const int bn_sel = wide ? 256 : 128;
                 const bool short_tile = rb_env != 8 && (rb_env == 7 || cost(224, bn_sel) < cost(256, bn_sel));
-#define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_)                                                                     \
+                // direct epilogue (swapped MFMA operands, stores from the registers): VPU_GEMM_K2_DIRECT=0 keeps the LDS transposition
+                static const bool direct2 = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
+#define VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, SW_)                                                               \
     do {                                                                                                             \
         static bool attr_ = false;                                                                                   \
-        auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_, RB_>;                                                    \
+        auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_, RB_, SW_>;                                               \
         if (!attr_) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<WN_>::LDS); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<WN_>::LDS + K2_BIAS_LDS); \
             attr_ = true;                                                                                            \
         }                                                                                                            \
         const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
         const int tot_ = tm_ * tn_;                                                                                  \
-        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d>", TA_, TB_, WN_, FL_, RB_);                               \
-        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS, s>>>(*d, tm_, tn_, vec2);      \
+        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d, %s>", TA_, TB_, WN_, FL_, RB_, SW_ ? "true" : "false");   \
+        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2); \
     } while (0)
+#define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_) do { if (direct2) VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, true); else VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, false); } while (0)
 #define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_) do { if (short_tile) VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 7); else VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 8); } while (0)
 #define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2(TA_, TB_, 2, FL_); else done = false; } while (0)
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
@@ -2404,6 +2567,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
 #undef VPU_K2_BOTH
 #undef VPU_LAUNCH_K2
 #undef VPU_LAUNCH_K2_RB
+#undef VPU_LAUNCH_K2_SW
                 if (done) return vpu_check_launch("vpu_gemm");
             }
         }
