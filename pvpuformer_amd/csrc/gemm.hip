@@ -1214,6 +1214,16 @@ __device__ __forceinline__ void k2_epi_direct(const vpu_gemm_desc& p, f32x4_t (&
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, 0x7FFFFFFF, 0x00020000);
     const int fr = lane & 15, cl = k2_direct_col(lane);
+    // the wave's bias values out of its LDS slot, through inline asm: in front of a C++ LDS read of a slot that an LDS-DMA
+    // wrote, hipcc puts s_waitcnt vmcnt(0) -- which drained the next tile's primed stages (in flight here by design) before
+    // this tile's first store; the DMA that filled the slot is older than this tile's K-tile 0, which has been waited for
+    f32x4_t bq[2][2];
+    if constexpr ((FL & VPU_EPI_BIAS) != 0) {
+        const unsigned ba = (unsigned)reinterpret_cast<uintptr_t>(bl + cl);
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:144\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(bq[0][0]), "=&v"(bq[0][1]), "=&v"(bq[1][0]), "=&v"(bq[1][1]) : "v"(ba) : "memory");
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass)
 #pragma unroll
@@ -1229,10 +1239,8 @@ __device__ __forceinline__ void k2_epi_direct(const vpu_gemm_desc& p, f32x4_t (&
             }
             const int m = mrow0 + pass * 16 + fr, n = ncol0 + 32 * t + cl;
             if constexpr ((FL & VPU_EPI_BIAS) != 0) {
-                float b[8];
-                load8(bl + 32 * t + cl, b);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += b[j];
+                for (int j = 0; j < 4; ++j) { v[j] += bq[t][0][j]; v[4 + j] += bq[t][1][j]; }
             }
             const int off = (pass < npass && m < p.M && n < p.N) ? (m * p.ldc + n) * 2 : OOB_OFFSET;
             if constexpr ((FL & VPU_EPI_GELU) != 0) {
@@ -1331,12 +1339,12 @@ __device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const i
 
 // RB = 16-row blocks per wave: 8 (256-row tiles) or 7 (224-row tiles: M = 9408 = 42 x 224 fills 252 of 256 CUs per round
 // where 36.75 x 256 fills 222; the LDS layout keeps its 128-row sub-tiles, rows 112-127 of each are dead).
-template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB, bool SWP = false>
+template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB, int SWP = 0>
 __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
                                         const int tiles_m_arg, const int tiles_n_arg, const int vec) {
     using Cf = K2Cfg<WN>;
     // SW: swapped MFMA operands + direct epilogue (k2_epi_direct); compile-time flag sets of the plain kernel only
-    constexpr bool SW = SWP && FL >= 0 && !GRP && !CS;
+    constexpr bool SW = SWP >= 1 && FL >= 0 && !GRP && !CS;
     static_assert(!CS || (WN == 2 && TA == 1 && RB == 8), "fused column sums: weight-gradient form, 256 x 128 tile");
     constexpr bool PP = WN == 2;       // ping-pong schedule of the two K-half groups + next tile's first stages requested early
     constexpr bool GEN = FL < 0;
@@ -1346,6 +1354,10 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
     constexpr int NSTW = 2 * NST;                     // WN = 4, SW: both 64-row halves' stores follow the next tile's first DMA
     int par = 0;                                      // WN = 4: ring stage that receives this tile's K-tile 0
     constexpr bool BL = SW && (FL & VPU_EPI_BIAS) != 0;  // bias through the wave's LDS slot (k2_bias_issue)
+    // (measured and not kept, round 4: a cross-tile ring for the 256 x 128 form -- the last K-step's DMA slot requesting the
+    // next tile's K-tile 0 and bias, the K-half exchange in two 8-KiB rounds through the two free stages, the ring position
+    // carried from tile to tile: bit-exact, and no faster -- qkv 44.1 vs 44.6 us, fc2 49.8 vs 50.8, step 12.70 vs 12.69 ms --
+    // the stage-0 latency is not what a tile boundary costs)
     int bs = 0;                                       // bias slot of the current tile
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1388,6 +1400,12 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         char* s1 = lds + Cf::STAGE;
         char* s2 = PP ? lds + (Cf::S - 1) * Cf::STAGE : lds + (1 - par) * Cf::STAGE;
         if constexpr (!PP) par ^= nk & 1;
+        const int nxt = work + gridDim.x;
+        const bool has_next = nxt < total_work;
+        K2Tile nt = cur;
+        int nvoff[Cf::PW];
+#pragma unroll
+        for (int i = 0; i < Cf::PW; ++i) nvoff[i] = voff[i];
         char* const bslot = lds + Cf::LDS + (bs * 8 + wave) * 256;
         char* const nbslot = lds + Cf::LDS + ((bs ^ 1) * 8 + wave) * 256;
         bs ^= 1;
@@ -1428,12 +1446,6 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         // (the out-of-range tail pieces still write zeros into LDS; the direct 256-column form does not touch LDS in its
         // epilogue and the same wave overwrites the same words with the next tile's pieces, in order: nothing to wait for)
         if constexpr (!(SW && !PP)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nxt = work + gridDim.x;
-        const bool has_next = nxt < total_work;
-        K2Tile nt = cur;
-        int nvoff[Cf::PW];
-#pragma unroll
-        for (int i = 0; i < Cf::PW; ++i) nvoff[i] = voff[i];
 
         if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
             __syncthreads();
@@ -1449,13 +1461,19 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             const int npass = g == 0 ? 4 : RB - 4;
             K2Pre<(GEN || SW) ? 0 : FL> q;
             K2PreD<SW ? FL : 0> qd;
-            if constexpr (SW) k2_prefetch_direct<FL>(p, mq, nq, lane, qd, npass);
+            // (an opaque copy of the lane index for everything between the main loops of the direct form: what is derived
+            // from the lane is then recomputed per tile instead of being hoisted out of the tile loop, kept across the main
+            // loop and spilled -- a scratch reload sits in the vector-memory queue and its wait drains the operand loads and
+            // the primed stages)
+            int el = lane;
+            if constexpr (SW) asm volatile("" : "+v"(el));
+            if constexpr (SW) k2_prefetch_direct<FL>(p, mq, nq, el, qd, npass);
             else if constexpr (!GEN) k2_prefetch<FL>(p, mq, nq, lane, q, npass);   // lands while the halves are exchanged
             // the next tile's coordinates and DMA offsets now (integer divisions, ~100 instructions): they overlap the waits of
             // the exchange instead of standing between its last barrier and the DMA that primes the next tile
             if (has_next) {
                 k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
-                k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
+                k2_voff<TA, TB, WN, RB>(nt, wave, el, nvoff);
             }
             // (raw barriers + explicit LDS waits in this exchange: __syncthreads() carries a fence, i.e. s_waitcnt vmcnt(0),
             // which exposed the whole latency of the bias / residual / aux loads just requested -- once per tile)
@@ -1466,8 +1484,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             // 64-127 of it.  Fragment layouts are identical in both waves, so the registers travel as they are (16-byte LDS
             // accesses, lane-linear).  Wave w sends through [w * 16 KiB, + 16 KiB).
             const int fr = lane & 15, fq = lane >> 4;
-            f32x4_t* mine = reinterpret_cast<f32x4_t*>(lds + wave * 16384) + lane;
-            const f32x4_t* theirs = reinterpret_cast<const f32x4_t*>(lds + (wave ^ 4) * 16384) + lane;
+            f32x4_t* mine = reinterpret_cast<f32x4_t*>(lds + wave * 16384) + el;
+            const f32x4_t* theirs = reinterpret_cast<const f32x4_t*>(lds + (wave ^ 4) * 16384) + el;
             float* red = reinterpret_cast<float*>(lds + 8 * 16384);   // [2][256] fused column sums
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1497,12 +1515,12 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
                 const int nsA = TA ? nt.lda * (BK * 2) : BK * 2, nsB = TB ? nt.ldb * (BK * 2) : BK * 2;
-                if constexpr (BL) k2_bias_issue(p, nt.n0 + wn * 64, lane, nbslot);
+                if constexpr (BL) k2_bias_issue(p, nt.n0 + wn * 64, el, nbslot);
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds, wave);
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
             }
             float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
-            if constexpr (SW) k2_epi_direct<FL>(p, fin, mq, nq, lane, qd, npass, reinterpret_cast<const float*>(bslot));
+            if constexpr (SW) k2_epi_direct<FL>(p, fin, mq, nq, el, qd, npass, reinterpret_cast<const float*>(bslot));
             else if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
             else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q, npass);
         } else if constexpr (SW) {
@@ -1565,7 +1583,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
     }
 }
 
-template <int TA, int TB, int WN, int FL, int RB, bool SWP = false>
+template <int TA, int TB, int WN, int FL, int RB, int SWP = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
                                                            const int vec) {
     k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec);
@@ -2539,8 +2557,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 };
                 const int bn_sel = wide ? 256 : 128;
                 const bool short_tile = rb_env != 8 && (rb_env == 7 || cost(224, bn_sel) < cost(256, bn_sel));
-                // direct epilogue (swapped MFMA operands, stores from the registers): VPU_GEMM_K2_DIRECT=0 keeps the LDS transposition
-                static const bool direct2 = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
+                // VPU_GEMM_K2_DIRECT: 0 = LDS-transposed epilogue, 1 (default) = direct epilogue (swapped MFMA operands, stores
+                // from the registers)
+                static const int direct2 = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return e ? atoi(e) : 1; }();
 #define VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, SW_)                                                               \
     do {                                                                                                             \
         static bool attr_ = false;                                                                                   \
@@ -2552,10 +2571,14 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
         const int tot_ = tm_ * tn_;                                                                                  \
-        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d, %s>", TA_, TB_, WN_, FL_, RB_, SW_ ? "true" : "false");   \
+        NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d, %d>", TA_, TB_, WN_, FL_, RB_, SW_);                      \
         kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2); \
     } while (0)
-#define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_) do { if (direct2) VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, true); else VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, false); } while (0)
+#define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_)                                                                     \
+    do {                                                                                                             \
+        if (direct2 >= 1) VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, 1);                                               \
+        else VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, 0);                                                            \
+    } while (0)
 #define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_) do { if (short_tile) VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 7); else VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 8); } while (0)
 #define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2(TA_, TB_, 2, FL_); else done = false; } while (0)
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
