@@ -396,7 +396,7 @@ def main():
 
     def step_body():
         if not mode["overlap"]:
-            eng.zero_grad()
+            eng.zero_grad(lazy=True)        # (one backward follows: single-writer gradients are written, not accumulated)
         mask = ops.dropout_mask(B, model.head.channels, keep, dev)
         inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
         losses, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
@@ -416,7 +416,7 @@ def main():
     held = {}
 
     def head_body():
-        eng.zero_grad()
+        eng.zero_grad(lazy=True)
         mask = ops.dropout_mask(B, model.head.channels, keep, dev)
         inst, _ = eng.forward(image4, points, None, 0, mask, training=True, materialize_aux=False)
         losses, held["d_inst"], held["d_sim"] = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)

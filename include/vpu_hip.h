@@ -194,6 +194,10 @@ int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, in
  * mask.  Same (seed, call number) -> same mask. */
 int vpu_dropout_mask(float* out, int32_t n, float keep, uint64_t seed, uint64_t* state, void* stream);
 int vpu_fill_f32(float* p, float v, int64_t n, void* stream);
+/* base[off[r] .. off[r] + len[r]) <- v for n <= 160 ranges (host arrays; multiples of 4 floats from a 16-byte aligned base)
+ * in one launch: the flat gradient buffer of engine.py minus the weights whose gradient the producing GEMM writes without
+ * accumulating (Engine.zero_grad(lazy=True); reference semantics: optimizer.zero_grad() + backward, trainer.py:197-202). */
+int vpu_fill_ranges_f32(float* base, const int64_t* off, const int64_t* len, int32_t n, float v, void* stream);
 /* Diagnostic only (tools/reserve_cus_experiment.py): `wgs` workgroups of 512 threads, ~96 registers per thread, 16 KiB of
  * LDS, spinning for ~`cycles` shader cycles -- the footprint of a collective's channel workgroups. */
 int vpu_debug_spin(float* sink, int32_t wgs, int64_t cycles, void* stream);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "vpu_cast2d": [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P],
     "vpu_dropout_mask": [_P, _I, _F, C.c_uint64, _P, _P],
     "vpu_fill_f32": [_P, _F, _L, _P],
+    "vpu_fill_ranges_f32": [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _F, _P],
     "vpu_debug_spin": [_P, _I, _L, _P],
     "vpu_sigmoid_to_channel": [_P, _P, _I, _L, _I, _I, _P],
     "vpu_act_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],

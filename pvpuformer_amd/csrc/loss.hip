@@ -383,8 +383,11 @@ extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_
 }
 
 static inline int p2cl_band(int w) {
+    // VPU_P2CL_BAND: anchor rows per workgroup (A/B runs; default below)
+    static const int env = [] { const char* e = getenv("VPU_P2CL_BAND"); return e ? atoi(e) : 0; }();
     int b = 1024 / (w > 0 ? w : 1) - 1;
-    return b > P2_BAND_MAX ? P2_BAND_MAX : b;
+    const int cap = env > 0 && env <= P2_BAND_MAX ? env : P2_BAND_MAX;
+    return b > cap ? cap : b;
 }
 extern "C" int vpu_p2cl_up_nband(int32_t h, int32_t w) {
     const int band = p2cl_band(w);
@@ -415,7 +418,9 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
                                   160 * 1024 - 4096);   // (static: reduction scratch + the anchor tables)
         attr_set = true;
     }
-    p2cl_up_kernel<<<(unsigned)(B * S * nband), 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
+    // (as many threads as the pixel / cell passes use: (band + 1) * W / 4, a multiple of 64)
+    const int nthr = (int)((((int64_t)(band + 1) * (W / 4 > w ? W / 4 : w)) + 63) / 64 * 64);
+    p2cl_up_kernel<<<(unsigned)(B * S * nband), nthr < 1024 ? nthr : 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
                                                                   dsim_low, grad_scale, S, h, w, H, W, nband, max_rows, band);
     return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
 }

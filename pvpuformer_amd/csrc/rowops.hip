@@ -626,6 +626,30 @@ __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int64_t n)
     if (tail + tid < n) p[tail + tid] = v;
 }
 
+// p[off[r] .. off[r] + len[r]) <- v for up to FILL_MAX_RANGES ranges in ONE launch (round 4: the gradient buffer minus the
+// weights whose gradient is written, not accumulated, by the one GEMM that produces it).  A range is cut into chunks of
+// FILL_CHUNK floats, a workgroup takes one chunk; offsets and lengths are multiples of 4 floats from a 16-byte aligned base.
+constexpr int FILL_MAX_RANGES = 160;
+constexpr int FILL_CHUNK = 16384;
+struct FillRanges {
+    int n;
+    int first_chunk[FILL_MAX_RANGES + 1];
+    long long off[FILL_MAX_RANGES], len[FILL_MAX_RANGES];
+};
+__global__ __launch_bounds__(256) void fill_ranges_kernel(float* __restrict__ base, const FillRanges r, const float v) {
+    const int c = blockIdx.x;
+    int lo = 0, hi = r.n;          // the range whose chunk interval holds c
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (r.first_chunk[mid] <= c) lo = mid; else hi = mid;
+    }
+    const long long start = (long long)(c - r.first_chunk[lo]) * FILL_CHUNK;
+    const long long end = start + FILL_CHUNK < r.len[lo] ? start + FILL_CHUNK : r.len[lo];
+    float4* q = reinterpret_cast<float4*>(base + r.off[lo]);
+    const float4 v4 = make_float4(v, v, v, v);
+    for (long long i = (start >> 2) + threadIdx.x; i < (end >> 2); i += 256) q[i] = v4;
+}
+
 }  // namespace
 
 #define ST reinterpret_cast<hipStream_t>(stream)
@@ -859,6 +883,29 @@ extern "C" int vpu_dropout_mask(float* out, int32_t n, float keep, uint64_t seed
     }
     dropout_mask_kernel<<<1, 256, 0, ST>>>(out, n, keep, 1.0f / keep, (unsigned long long)seed, reinterpret_cast<unsigned long long*>(state));
     return vpu_check_launch("vpu_dropout_mask");
+}
+extern "C" int vpu_fill_ranges_f32(float* base, const int64_t* off, const int64_t* len, int32_t n, float v, void* stream) {
+    vpu_clear_stale_error();
+    if (!base || !off || !len || n < 1 || n > FILL_MAX_RANGES || (reinterpret_cast<uintptr_t>(base) & 15)) {
+        vpu_set_error("fill_ranges: 1 <= n <= 160 ranges, 16-byte aligned base");
+        return VPU_ERR_ARG;
+    }
+    FillRanges r;
+    r.n = n;
+    int chunks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (off[i] < 0 || len[i] <= 0 || (off[i] & 3) || (len[i] & 3)) {
+            vpu_set_error("fill_ranges: offsets and lengths must be positive multiples of 4 floats");
+            return VPU_ERR_ARG;
+        }
+        r.first_chunk[i] = chunks;
+        r.off[i] = off[i];
+        r.len[i] = len[i];
+        chunks += (int)((len[i] + FILL_CHUNK - 1) / FILL_CHUNK);
+    }
+    r.first_chunk[n] = chunks;
+    fill_ranges_kernel<<<(unsigned)chunks, 256, 0, ST>>>(base, r, v);
+    return vpu_check_launch("vpu_fill_ranges_f32");
 }
 extern "C" int vpu_fill_f32(float* p, float v, int64_t n, void* stream) {
     vpu_clear_stale_error();

@@ -152,6 +152,7 @@ class Engine:
         # sum adds the slabs to the gradients.  Before: a split-K launch + a reduce launch per problem, most of them at the
         # end of backward with the chip a quarter full (0.47 ms per step).
         self.unify_wgrad = os.environ.get("VPU_WGRAD_UNIFY", "1") != "0"
+        self.lazy_zero = os.environ.get("VPU_LAZY_ZERO", "1") != "0"   # zero_grad(lazy=True) honoured (A/B switch)
         self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
         self._pending_reports, self._reporting = [], False    # gradient ranges whose marker has been passed but not reported yet
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
@@ -185,6 +186,8 @@ class Engine:
             p.grad = self.gflat[o:o + numel].view(shape)
             self.params.append((p, o, shape, numel))
         self.shadow = torch.zeros(off, device=self.dev, dtype=torch.bfloat16) if self.dt == BF16 else None
+        self._lazy = set()
+        self._lazy_names, self._lazy_ranges = self._lazy_plan()
         D, P = self.D, self.P
         self.k3p = _rup(3 * P * P, 8)   # each half of the fused patch-embed K is padded to 16 bytes (P = 14: 588 -> 592)
         self.w_patch = torch.zeros(D, 2 * self.k3p, device=self.dev, dtype=self.td)
@@ -268,8 +271,42 @@ class Engine:
             self._kpe_cache[g] = k
         return k
 
-    def zero_grad(self):
-        ops.zero_(self.gflat)
+    def zero_grad(self, lazy=False):
+        """The flat gradient buffer <- 0.  ``lazy``: the caller promises that ONE backward of a training-mode forward comes
+        next and that nothing reads the gradients before it (the captured / timed training step: zero, forward, backward,
+        optimizer).  The weights whose gradient a single GEMM produces -- the ViT blocks' four linears, 69 % of ViT-B's
+        parameters -- are then left as they are: that GEMM WRITES their gradient instead of accumulating into it (0 + x = x:
+        the same bits), so neither the 4 bytes per parameter of this fill nor the read of C in the GEMM's epilogue happen.
+        What such a pass did not write by its end is zeroed then (``backward``, ``abort_pass``)."""
+        self._lazy = set()
+        if (lazy and self.lazy_zero and self.group_wgrad and self.dt == BF16 and not self.use_side and self.pack_wgrad
+                and self._lazy_ranges is not None):
+            ops.zero_ranges_(self.gflat, self._lazy_ranges)
+            self._lazy = set(self._lazy_names)
+        else:
+            ops.zero_(self.gflat)
+
+    def _lazy_plan(self):
+        """(names, complement ranges) of zero_grad(lazy=True); None when a range is not a multiple of 4 floats."""
+        names = [n for n in self.names if n.startswith("backbone.blocks.") and
+                 n.endswith((".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"))]
+        ranges, pos = [], 0
+        for n in names:                       # (self.names is in buffer order)
+            o, _, numel = self.names[n]
+            if o % 4 or numel % 4:
+                return [], None
+            if o > pos:
+                ranges.append((pos, o - pos))
+            pos = o + numel
+        if self.total > pos:
+            ranges.append((pos, self.total - pos))
+        return names, (ranges if names else None)
+
+    def _lazy_finish(self):
+        """Zeroes what a lazily zeroed pass has not written (a weight that got no gradient in this pass)."""
+        if self._lazy:
+            ops.zero_ranges_(self.gflat, [(self.names[n][0], self.names[n][2]) for n in sorted(self._lazy, key=lambda k: self.names[k][0])])
+            self._lazy = set()
 
     def attach_grads(self):
         """``param.grad`` must be the views of the flat gradient buffer the kernels accumulate into.  A caller that ran
@@ -342,7 +379,11 @@ class Engine:
         if self.group_wgrad and self.dt == BF16 and not self.use_side:
             ldc_ = K if ldc is None else ldc
             args = (dy, x, gout, N, K, M, ld_dy, ld_x, ldc_, self.dt)
-            kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
+            acc = EPI_ACCUM
+            if isinstance(gname, str) and gname in self._lazy:    # zero_grad(lazy=True): this GEMM writes the gradient
+                self._lazy.discard(gname)
+                acc = 0
+            kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | acc, colsum=self.G(bias) if fuse else None)
             L = self._token_rows
             if (self.unify_wgrad and self.pack_wgrad and (self.k3_wgrad or self.k4_wgrad) and L > 2048 and M > L and M % L == 0
                     and L % 64 == 0 and N % 8 == 0 and K % 8 == 0 and ld_dy % 8 == 0 and ld_x % 8 == 0 and ldc_ % 4 == 0):
@@ -1383,6 +1424,7 @@ class Engine:
         buffers that were never written (a capture enqueues nothing), and the host-enqueued retry that follows must not
         launch them."""
         self._wq, self._csq, self._gq = [], [], []
+        self._lazy_finish()       # (what zero_grad(lazy=True) left for a backward that will not happen)
         self._gq_out, self._frozen = set(), set()
         self._pending_reports, self._reporting = [], False
         self._pack_seen = {}
@@ -1422,6 +1464,7 @@ class Engine:
         self.tape = Tape()
         self.join_side()          # every queued weight gradient is launched ...
         self.flush_colsums()      # ... before the batched column sums (norm-layer partials, slabs of the sliced reductions)
+        self._lazy_finish()
         self._report_ready(final=True)
         if self.grad_ready_hook is not None:  # patch embeddings, cls/pos tokens: everything before block 0
             self.grad_ready_hook(0, self.names["backbone.blocks.0.norm1.weight"][0])

@@ -137,7 +137,8 @@ class VPUTrainStep:
         hook = reducer.ready if reducer is not None else None
         key = (ptype, it, tuple(st.net_input.shape), tuple(st.points.shape), None if st.curve is None else tuple(st.curve.shape),
                bool(self.model.training), bool(eng.shadow_valid), id(eng),   # (a stale bf16 shadow is re-cast inside forward)
-               reducer is not None, int(getattr(self.red, "reserve_cus", 0) or 0) if self._reserving else 0)
+               reducer is not None, int(getattr(self.red, "reserve_cus", 0) or 0) if self._reserving else 0,
+               bool(eng._lazy))   # (the first backward after zero_grad(lazy=True) WRITES the single-writer gradients: baked in)
         ent = self._passes.get(key)
         if ent is None or ent is False:
             if ent is None:
@@ -171,6 +172,7 @@ class VPUTrainStep:
         ent.fwd.replay()
         after_forward()
         ent.bwd.replay(hook)
+        eng._lazy = set()                        # (what a lazily zeroed step left unwritten, this replay has written)
         res = ent.res.clone()                    # (the caller may read the losses after later replays)
         return ent.inst, {"total": res[0], "nfl": res[1], "dice": res[2], "p2cl": res[3]}
 
@@ -226,7 +228,7 @@ class VPUTrainStep:
             # (the fused optimizer writes the shadow itself and refreshes the rest)
             eng.shadow_valid = False
         if zero_grad:
-            eng.zero_grad()
+            eng.zero_grad(lazy=True)      # (this call's one backward follows; nothing reads the gradients in between)
         self._reserving = self.red is not None and step          # (begin() keeps the reducer's CUs out of the GEMM grids)
         if self.red is not None and step:
             self.red.begin()

@@ -319,6 +319,17 @@ def zero_(t):
     return t
 
 
+def zero_ranges_(t, ranges):
+    """t[off : off + n] <- 0 for every (off, n) of ``ranges`` (fp32 tensor, multiples of 4 floats), 160 ranges per launch."""
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    for i in range(0, len(ranges), 160):
+        chunk = ranges[i:i + 160]
+        offs = (C.c_int64 * len(chunk))(*[int(o) for o, _ in chunk])
+        lens = (C.c_int64 * len(chunk))(*[int(n) for _, n in chunk])
+        _lib.call("vpu_fill_ranges_f32", ptr(t), offs, lens, len(chunk), 0.0, _stream())
+    return t
+
+
 def fill_f32(t, v, n=None):
     _lib.call("vpu_fill_f32", ptr(t), v, t.numel() if n is None else n, _stream())
 

@@ -509,6 +509,47 @@ def test_ismodel_public_coord_feature_methods(golden_dir):
     assert torch.equal(model.get_coord_features(image, None, pts), model.get_coord_features_with_prompt(image, None, pts))
 
 
+@pytest.mark.parametrize("fixture", ["tiny.npz", "vitb.npz"])
+def test_lazy_zero_grad_gives_the_same_gradients(golden_dir, fixture):
+    """zero_grad(lazy=True) (round 4): the ViT blocks' weight gradients are WRITTEN by the one GEMM that produces them and
+    not zeroed first.  With NaN in every gradient word beforehand, the lazily zeroed step must give the eagerly zeroed
+    step's buffer bit for bit (0 + x = x), a second backward without zero_grad must accumulate onto it, and a pass that is
+    aborted after the lazy zero must leave zeros where the GEMMs would have written."""
+    from pvpuformer_amd import ops
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, fixture, "bf16")
+    model.train()
+    model.head.dropout_ratio = 0.0
+    eng = model._ensure_engine()
+    gt, pts, img4 = batch["instances"].cuda(), batch["points"].cuda(), img4.cuda()
+
+    def step(lazy, zero=True):
+        if zero:
+            eng.gflat.fill_(float("nan"))
+            eng.zero_grad(lazy=lazy)
+        inst, _ = eng.forward(img4, pts, None, 0, None, training=True, materialize_aux=False)
+        _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
+        torch.cuda.synchronize()
+        return eng.gflat.clone()
+
+    step(False)                     # (the packing policy of the weight-gradient launches settles over the first passes)
+    ref = step(False)
+    assert torch.isfinite(ref).all()
+    got = step(True)
+    if eng.pack_wgrad and eng.lazy_zero:
+        assert eng._lazy_names and not eng._lazy      # the plan exists and every lazily skipped weight was written
+    assert torch.equal(got, ref)
+    twice = step(True, zero=False)  # accumulation onto a lazily zeroed pass
+    assert torch.allclose(twice, 2 * ref, rtol=1e-5, atol=1e-6)
+    # a pass that dies after the lazy zero: abort_pass() zeroes what the GEMMs would have written
+    eng.gflat.fill_(float("nan"))
+    eng.zero_grad(lazy=True)
+    eng.abort_pass()
+    torch.cuda.synchronize()
+    assert not torch.isnan(eng.gflat).any() and float(eng.gflat.abs().max()) == 0.0
+
+
 def test_failed_capture_leaves_no_queued_work_behind(golden_dir):
     """A hipGraph capture of the backward that raises half way: the engine's queues then hold entries pointing at
     capture-pool buffers nothing has written.  ``SegmentedBackward.capture`` calls ``Engine.abort_pass()`` before re-raising, so

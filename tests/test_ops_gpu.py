@@ -1662,3 +1662,23 @@ def test_dropout_mask_and_fill(ops):
         assert float(buf[off:off + n].abs().sum()) == 0.0 and float(buf[:off].sum()) == 5.0 * off and float(buf[off + n:].sum()) == 5.0 * (8 - off)
     h = torch.full((1001,), 3.0, device="cuda", dtype=torch.bfloat16)[:1000]
     assert float(O.zero_(h).float().abs().sum()) == 0.0
+
+
+def test_fill_ranges(ops):
+    """vpu_fill_ranges_f32: every listed range is zeroed, nothing else is touched (ragged chunk tails, 150 ranges)."""
+    g = torch.Generator().manual_seed(5)
+    n = 3_000_000
+    t = torch.full((n,), 7.0, device="cuda")
+    ranges, pos = [], 0
+    for i in range(150):
+        gap = 4 * int(torch.randint(1, 300, (1,), generator=g))
+        ln = 4 * int(torch.randint(1, 9000, (1,), generator=g))
+        ranges.append((pos + gap, ln))
+        pos += gap + ln
+    assert pos < n
+    ops.zero_ranges_(t, ranges)
+    torch.cuda.synchronize()
+    exp = torch.full((n,), 7.0)
+    for o, ln in ranges:
+        exp[o:o + ln] = 0.0
+    assert torch.equal(t.cpu(), exp)
