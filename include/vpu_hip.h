@@ -189,9 +189,10 @@ int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, in
                int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
 /* Dropout2d channel mask of the segmentation head (reference: transformer_helper/decode_head.py:82-86,210-215,
  * nn.Dropout2d(0.1) in train mode): out[i] = Bernoulli(keep) / keep for n = B * channels entries, from a counter-based
- * generator keyed by (seed, call number, i); the call number lives in state[0] (one uint64 in device memory, zeroed by the
- * caller once) and is advanced by the launch itself, so the call is capturable in a hipGraph and every replay draws a new
- * mask.  Same (seed, call number) -> same mask. */
+ * generator keyed by (seed ^ state[1], call number, i); `state` is TWO uint64 in device memory: [0] the call number (zeroed by
+ * the caller once, advanced by the launch itself, so the call is capturable in a hipGraph and every replay draws a new mask),
+ * [1] a seed word the caller may change between replays (a captured launch follows it; 0 = the `seed` argument alone).
+ * Same (seed ^ state[1], call number) -> same mask. */
 int vpu_dropout_mask(float* out, int32_t n, float keep, uint64_t seed, uint64_t* state, void* stream);
 int vpu_fill_f32(float* p, float v, int64_t n, void* stream);
 /* base[off[r] .. off[r] + len[r]) <- v for n <= 160 ranges (host arrays; multiples of 4 floats from a 16-byte aligned base)

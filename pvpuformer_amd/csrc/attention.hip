@@ -1297,10 +1297,9 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
-        static bool attr = false;
-        if (!attr) {
+        static VpuDevOnce attr;
+        if (attr.pending()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
-            attr = true;
         }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_win_kernel");
         attn_bwd_win_kernel<<<dim3(nb * H), 512, WIN_LDS, s>>>(a);

@@ -1733,7 +1733,7 @@ __device__ __forceinline__ void k3_step(const __amdgpu_buffer_rsrc_t rA, const _
 //   half 1: aH x B                               |  reads aL and B of K-step kt+1 (landed: the barrier at the top of kt)
 // Two register sets of half the A fragments (2 x 16 registers) and two of the B fragments (2 x 16) instead of one whole set
 // (48): the whole-step double buffer (96) does not fit beside the 128 accumulators.
-template <int TA, int TB, bool CS, int NWN>
+template <int TA, int TB, bool CS, int NWN, bool SWF = false>
 __device__ __forceinline__ void k3_half0(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB,
                                          const int (&voff)[K3Cfg<NWN>::PW], const int soffA, const int soffB, const bool live,
                                          char* __restrict__ wr, const char* __restrict__ rd, const int wave, const int lane,
@@ -1748,7 +1748,8 @@ __device__ __forceinline__ void k3_half0(const __amdgpu_buffer_rsrc_t rA, const 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aL[i], bc[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = SWF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[j], aL[i], acc[i][j], 0, 0, 0)    // (C^T tile: k3_epi_direct_f32)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(aL[i], bc[j], acc[i][j], 0, 0, 0);
     constexpr int NDS = (TA ? 2 : 1) * 4;      // LDS read instructions of this half
 #pragma unroll
     for (int gI = 0; gI < 4; ++gI) {           // masks: MFMA 0x8, DS read 0x100, VMEM read 0x20
@@ -1766,7 +1767,7 @@ __device__ __forceinline__ void k3_half0(const __amdgpu_buffer_rsrc_t rA, const 
             }
     }
 }
-template <int TA, int TB, bool CS, int NWN>
+template <int TA, int TB, bool CS, int NWN, bool SWF = false>
 __device__ __forceinline__ void k3_half1(const char* __restrict__ rd, const int lane, const int wm, const int wn,
                                          const bool do_cs, const bf16x8_t ones, const bf16x8_t (&aH)[4], const bf16x8_t (&bc)[4],
                                          bf16x8_t (&aL)[4], bf16x8_t (&bn)[4], f32x4_t (&acc)[8][4],
@@ -1781,7 +1782,8 @@ __device__ __forceinline__ void k3_half1(const char* __restrict__ rd, const int 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aH[i], bc[j], acc[4 + i][j], 0, 0, 0);
+            acc[4 + i][j] = SWF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[j], aH[i], acc[4 + i][j], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(aH[i], bc[j], acc[4 + i][j], 0, 0, 0);
     constexpr int NDS = (TA ? 2 : 1) * 4 + (TB ? 2 : 1) * 4;
 #pragma unroll
     for (int gI = 0; gI < 4; ++gI) {
@@ -1822,7 +1824,50 @@ __device__ __forceinline__ void k3_epi_fast_half(const vpu_gemm_desc& p, f32x4_t
     k2_epi_fast<FL>(p, fin, mw + H * 64, nq, wl, lane, q, H == 0 ? 4 : RB - 4);
 }
 
-template <int TA, int TB, bool CS, int FL, bool GRP, int RB, int NWN = 2, bool PIPE = false, int TM = 256>
+// Direct epilogue of the weight-gradient form (fp32 output, flags OUT_F32 [| ACCUM], alpha = 1: the host routes nothing else
+// here).  The MFMAs ran with swapped operands, so a lane holds FOUR CONSECUTIVE fp32 COLUMNS of one row per accumulator
+// tile -- acc[i][j][r] = C[mw + 16 i + fr][nq + 16 j + 4 fq + r] -- i.e. one 16-byte access, straight from the registers:
+// no LDS transposition, no waits on it.  ACCUM: C is requested two row blocks ahead of the adds.
+template <int RB>
+__device__ __forceinline__ void k3_epi_direct_f32(const vpu_gemm_desc& p, const int FLG, f32x4_t (&acc)[RB][4], const int mw,
+                                                  const int nq, const int lane, const int64_t coff, const int M) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.C) + coff, 0, 0x7FFFFFFF, 0x00020000);
+    int off[RB][4];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mw + 16 * i + fr, n = nq + 16 * j + 4 * fq;
+            off[i][j] = (m < M && n + 4 <= p.N) ? (m * p.ldc + n) * 4 : OOB_OFFSET;
+        }
+    if (FLG & VPU_EPI_ACCUM) {
+        u32x4v c[3][4];
+#pragma unroll
+        for (int i = 0; i < 2 && i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rC, off[i][j], 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            if (i + 2 < RB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[(i + 2) % 3][j] = __builtin_amdgcn_raw_buffer_load_b128(rC, off[i + 2][j], 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t v = acc[i][j] + __builtin_bit_cast(f32x4_t, c[i % 3][j]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rC, off[i][j], 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[i][j]), rC, off[i][j], 0, 0);
+    }
+}
+
+template <int TA, int TB, bool CS, int FL, bool GRP, int RB, int NWN = 2, bool PIPE = false, int TM = 256, bool SWF = false>
 __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
                                         const int tiles_m_arg, const int tiles_n_arg, const int vec_in) {
     using Cf = K3Cfg<NWN, TM>;
@@ -1899,14 +1944,14 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
                     const int st_n = st_c + 1 == Cf::S ? 0 : st_c + 1;
                     const int kn = kt + u + Cf::S - 1;
                     __builtin_amdgcn_s_setprio(1);
-                    if (u == 0) k3_half0<TA, TB, CS, NWN>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
-                                                          wave, lane, wm, wn, do_cs, ones, aL, b0, aH, acc, acc_cs);
-                    else k3_half0<TA, TB, CS, NWN>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
-                                                   wave, lane, wm, wn, do_cs, ones, aL, b1, aH, acc, acc_cs);
+                    if (u == 0) k3_half0<TA, TB, CS, NWN, SWF>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
+                                                               wave, lane, wm, wn, do_cs, ones, aL, b0, aH, acc, acc_cs);
+                    else k3_half0<TA, TB, CS, NWN, SWF>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
+                                                        wave, lane, wm, wn, do_cs, ones, aL, b1, aH, acc, acc_cs);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // aH is in registers
                     __builtin_amdgcn_sched_barrier(0);
-                    if (u == 0) k3_half1<TA, TB, CS, NWN>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b0, aL, b1, acc, acc_cs);
-                    else k3_half1<TA, TB, CS, NWN>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b1, aL, b0, acc, acc_cs);
+                    if (u == 0) k3_half1<TA, TB, CS, NWN, SWF>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b0, aL, b1, acc, acc_cs);
+                    else k3_half1<TA, TB, CS, NWN, SWF>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b1, aL, b0, acc, acc_cs);
                     __builtin_amdgcn_s_setprio(0);
                     st_w = st_c;
                     st_c = st_n;
@@ -1954,8 +1999,13 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
             }
             // (the two 64-row halves of the wave tile, written out twice: a loop over them that the compiler does not unroll
             // indexes the accumulators at run time and sends all 128 of them to scratch)
-            k3_epi_half<FL, RB, 0>(p, FLG, vec, acc, mw, nq, wl, lane, cur.coff);
-            if constexpr (RB > 4) k3_epi_half<FL, RB, 1>(p, FLG, vec, acc, mw, nq, wl, lane, cur.coff);
+            if constexpr (SWF) {
+                static_assert(!SWF || (PIPE && GRP), "direct fp32 epilogue: the pipelined grouped weight-gradient form");
+                k3_epi_direct_f32<RB>(p, FLG, acc, mw, nq, lane, cur.coff, cur.M);
+            } else {
+                k3_epi_half<FL, RB, 0>(p, FLG, vec, acc, mw, nq, wl, lane, cur.coff);
+                if constexpr (RB > 4) k3_epi_half<FL, RB, 1>(p, FLG, vec, acc, mw, nq, wl, lane, cur.coff);
+            }
         } else {
             // everything the epilogue reads from global memory is requested before its first store
             K2Pre<GEN ? 0 : FL> q0, q1;
@@ -1990,10 +2040,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k4_grouped_kernel(const vpu_gem
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
     k3_body<TA, TB, CS, -1, true, 8, 4>(ga->d[0], ga, 0, 0, vec);
 }
-template <int TA, int TB, bool CS>
+template <int TA, int TB, bool CS, bool SWF = false>
 __global__ __launch_bounds__(512) void gemm_bf16_k4p_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
-    k3_body<TA, TB, CS, -1, true, 8, 4, true>(ga->d[0], ga, 0, 0, vec);
+    k3_body<TA, TB, CS, -1, true, 8, 4, true, 256, SWF>(ga->d[0], ga, 0, 0, vec);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2503,11 +2553,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             const int vec3 = (noepi3 ? 9 : 1) | (stag3 << 8);
 #define VPU_LAUNCH_K3_RB(TA_, TB_, FL_, RB_)                                                                         \
     do {                                                                                                             \
-        static bool attr_ = false;                                                                                   \
+        static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k3_kernel<TA_, TB_, FL_, RB_>;                                                         \
-        if (!attr_) {                                                                                                \
+        if (attr_.pending()) {                                                                                                \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS); \
-            attr_ = true;                                                                                            \
         }                                                                                                            \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
         const int tot_ = tm_ * tn3;                                                                                  \
@@ -2562,11 +2611,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 static const int direct2 = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return e ? atoi(e) : 1; }();
 #define VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, SW_)                                                               \
     do {                                                                                                             \
-        static bool attr_ = false;                                                                                   \
+        static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_, RB_, SW_>;                                               \
-        if (!attr_) {                                                                                                \
+        if (attr_.pending()) {                                                                                                \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<WN_>::LDS + K2_BIAS_LDS); \
-            attr_ = true;                                                                                            \
         }                                                                                                            \
         const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
@@ -2605,11 +2653,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             d->K >= 64 && d->K <= skinny_k && (int64_t)tiles_m * tiles_n < 192) {
             const int tn64 = (d->N + SK_T - 1) / SK_T, tm64 = (d->M + SK_T - 1) / SK_T;
             const int kw = (int)(((d->K + 3) / 4 + 63) / 64 * 64);
-            static bool attr_sk = false;
-            if (!attr_sk) {
+            static VpuDevOnce attr_sk;
+            if (attr_sk.pending()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
-                attr_sk = true;
             }
             dim3 sgrid((unsigned)(tm64 * tn64)), sblock(256);
             NOTE_KERNEL("gemm_bf16_skinny_kernel<%d>", d->transB ? 1 : 0);
@@ -2652,11 +2699,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         unsigned* cnt_arg = nullptr;
 #define VPU_LAUNCH_RING(TA_, TB_, CS_, FL_)                                                                            \
     do {                                                                                                             \
-        static bool attr_ = false;                                                                                   \
+        static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_kernel<TA_, TB_, true, CS_, FL_, 3>;                                                   \
-        if (!attr_) {                                                                                                \
+        if (attr_.pending()) {                                                                                                \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
-            attr_ = true;                                                                                            \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_kernel<%d, %d, true, %s, %d, 3>", TA_, TB_, CS_ ? "true" : "false", FL_);              \
         kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
@@ -2685,11 +2731,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             launched = true;
 #define VPU_LAUNCH_K3S(TA_, TB_, FL_)                                                                                \
     do {                                                                                                             \
-        static bool attr_ = false;                                                                                   \
+        static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k3s_kernel<TA_, TB_, FL_>;                                                             \
-        if (!attr_) {                                                                                                \
+        if (attr_.pending()) {                                                                                                \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<2, 128>::LDS); \
-            attr_ = true;                                                                                            \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_k3s_kernel<%d, %d, %d>", TA_, TB_, FL_);                                                \
         kern_<<<dim3((unsigned)(tot3s < cap3s ? tot3s : cap3s)), dim3(256), K3Cfg<2, 128>::LDS, s>>>(*d, tiles_m, tiles_n, 1); \
@@ -2742,14 +2787,13 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         if (launched) {
         } else
         if (big) {
-            static bool attr_done = false;
-            if (!attr_done) {
+            static VpuDevOnce attr_done;
+            if (attr_done.pending()) {
                 const int sz = 3 * STAGE2;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
-                attr_done = true;
             }
             dim3 block2(512);
             NOTE_KERNEL("gemm_bf16_big_kernel<%d, %d>", key >> 1, key & 1);
@@ -2912,12 +2956,11 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         }
         for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g3.start[i] = total64;
         if (ok && total64 <= 2048) {
-            static bool attr_skg = false;
-            if (!attr_skg) {
+            static VpuDevOnce attr_skg;
+            if (attr_skg.pending()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
-                attr_skg = true;
             }
             NOTE_KERNEL("gemm_bf16_skinny_grouped_kernel<%d, %d>", key >> 1, key & 1);
             if (key == 3) gemm_bf16_skinny_grouped_kernel<1, 1><<<dim3((unsigned)total64), dim3(256), 8 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
@@ -2943,15 +2986,15 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g2.start[i] = total2;
         if (ok && total2 >= 192) {
             const int ncu = cu_count();
-            static bool attr0 = false, attr1 = false;
+            static VpuDevOnce attr0, attr1;
             if (key == 0) {
                 auto kern_ = gemm_bf16_k2_grouped_kernel<0, 0, false>;
-                if (!attr0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); attr0 = true; }
+                if (attr0.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 0, false>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
             } else {
                 auto kern_ = gemm_bf16_k2_grouped_kernel<0, 1, false>;
-                if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); attr1 = true; }
+                if (attr1.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 1, false>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
             }
@@ -2986,17 +3029,28 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                 total4 += ((descs[i].M + 255) / 256) * ((descs[i].N + 255) / 256) * descs[i].batch;
             }
             for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g4.start[i] = total4;
-            static bool attr4_ = false;
+            static VpuDevOnce attr4_;
             const bool pipe = (k3_opt() & 16) != 0;
-            if (!attr4_) {
+            // direct fp32 epilogue (swapped MFMA operands): plain weight-gradient descriptors only -- fp32 output with or
+            // without accumulation, alpha 1, 16-byte aligned rows; VPU_GEMM_K4_DIRECT=0 keeps the LDS-transposed epilogue
+            static const bool direct4_env = [] { const char* e = getenv("VPU_GEMM_K4_DIRECT"); return !e || e[0] != '0'; }();
+            bool direct4 = pipe && direct4_env;
+            for (int i = 0; i < n && direct4; ++i) {
+                const vpu_gemm_desc& q = descs[i];
+                direct4 = (q.flags & ~(VPU_EPI_OUT_F32 | VPU_EPI_ACCUM)) == 0 && (q.flags & VPU_EPI_OUT_F32) && q.alpha == 1.0f &&
+                          q.ldc % 4 == 0 && q.N % 4 == 0 && q.sCo % 4 == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 &&
+                          (int64_t)q.M * q.ldc * 4 < 0x7FFFFFF0LL;
+            }
+            if (attr4_.pending()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4p_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
-                attr4_ = true;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4p_grouped_kernel<1, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
             }
             const int ncu = cu_count();
             static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
-            NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true>", pipe ? "p" : "");
-            if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+            NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true%s>", pipe ? "p" : "", direct4 ? ", true" : "");
+            if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+            else if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
             else gemm_bf16_k4_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
         }
@@ -3005,10 +3059,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             return VPU_ERR_ARG;
         }
         if (ok && (any_batch || ((k3_opt() & 1) && total2 > cu_count()))) {
-            static bool attr3_ = false;
-            if (!attr3_) {
+            static VpuDevOnce attr3_;
+            if (attr3_.pending()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k3_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
-                attr3_ = true;
             }
             const int cap = 2 * cu_count();
             static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
@@ -3017,11 +3070,10 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             return vpu_check_launch("vpu_gemm_grouped");
         }
         if (ok && (total2 >= 192 || (very_long && total2 >= 96))) {
-            static bool attr_ = false;
+            static VpuDevOnce attr_;
             auto kern_ = gemm_bf16_k2_grouped_kernel<1, 1, true>;
-            if (!attr_) {
+            if (attr_.pending()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS);
-                attr_ = true;
             }
             const int ncu = cu_count();
             static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();

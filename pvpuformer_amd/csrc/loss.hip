@@ -163,37 +163,70 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         const float4 t0 = *reinterpret_cast<const float4*>(hr + (yq - r0 + 1) * W + X4);
         const float4 t1 = *reinterpret_cast<const float4*>(hr + (yq1 - r0 + 1) * W + X4);
         const float top[4] = {t0.x, t0.y, t0.z, t0.w}, bot[4] = {t1.x, t1.y, t1.z, t1.w};
+        // one test per THREAD for what almost never occurs -- a soft label (neither 0 nor 1) or the ignore label among its
+        // <= 20 values -- instead of three compares per pixel: the common loop below knows every label is 0 or 1
+        bool plain = true;
 #pragma unroll
         for (int k = 0; k < P2_SPAN; ++k) {
-            const int Y = Ya + k;
-            if (Y < Yb) {
-                const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
-                const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
-                float gout[4];
+            const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float pr = hy * top[q4] + ly * bot[q4];
-                    float y = ls[q4];
-                    const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
-                    if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
-                    const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-                    // hard labels (every mask this loss sees): one raw v_log_f32 (log2; the arguments are >= 1e-12, far from
-                    // the denormals that logf's ~14-instruction wrapper guards) and one reciprocal, no branch
-                    const bool yb = y != 0.f;
-                    const float q = yb ? a : c;
-                    float l = -0.69314718056f * __builtin_amdgcn_logf(q);
-                    const float rq = __builtin_amdgcn_rcpf(q);
-                    float g = yb ? -rq : rq;
-                    if (__builtin_expect(valid && yb && y != 1.f, 0)) {   // soft label: the general form
-                        l = -0.69314718056f * (__builtin_amdgcn_logf(a) * y + __builtin_amdgcn_logf(c) * (1.f - y));
-                        g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+            for (int q4 = 0; q4 < 4; ++q4) plain = plain && (ls[q4] == 0.f || ls[q4] == 1.f || Ya + k >= Yb);
+        }
+        if (plain) {
+#pragma unroll
+            for (int k = 0; k < P2_SPAN; ++k) {
+                const int Y = Ya + k;
+                if (Y < Yb) {
+                    const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
+                    const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
+                    float gout[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float pr = hy * top[q4] + ly * bot[q4];
+                        const bool yb = (ls[q4] != 0.f) != invert;     // the label after logical_not (trainer.py:330)
+                        const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                        // one raw v_log_f32 (log2; the arguments are >= 1e-12, far from the denormals that logf's
+                        // ~14-instruction wrapper guards) and one reciprocal, no branch
+                        const float q = yb ? a : c;
+                        part += -0.69314718056f * __builtin_amdgcn_logf(q);
+                        const float rq = __builtin_amdgcn_rcpf(q) * grad_scale;
+                        gout[q4] = yb ? -rq : rq;
                     }
-                    part += (valid && own) ? l : 0.f;
-                    gout[q4] = valid ? g * grad_scale : 0.f;
+                    *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
                 }
-                *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < P2_SPAN; ++k) {
+                const int Y = Ya + k;
+                if (Y < Yb) {
+                    const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
+                    const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
+                    float gout[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float pr = hy * top[q4] + ly * bot[q4];
+                        float y = ls[q4];
+                        const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
+                        if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
+                        const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                        const bool yb = y != 0.f;
+                        const float q = yb ? a : c;
+                        float l = -0.69314718056f * __builtin_amdgcn_logf(q);
+                        const float rq = __builtin_amdgcn_rcpf(q);
+                        float g = yb ? -rq : rq;
+                        if (valid && yb && y != 1.f) {   // soft label: the general form
+                            l = -0.69314718056f * (__builtin_amdgcn_logf(a) * y + __builtin_amdgcn_logf(c) * (1.f - y));
+                            g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+                        }
+                        part += valid ? l : 0.f;
+                        gout[q4] = valid ? g * grad_scale : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+                }
             }
         }
+        if (!own) part = 0.f;      // (the halo row's pixels belong to the band above)
     }
     const double t = block_sum_d((double)part, red);   // (its barriers also publish gp)
     if (threadIdx.x == 0) loss_part[(int64_t)plane * nband + band] = (float)t;
@@ -205,22 +238,33 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
     if (live) {
-        // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone)
+        // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone): <= P2_SPAN
+        // columns x <= P2_SPAN rows.  Column weights once per cell; a tap outside the range reads the cell's first pixel
+        // with weight zero (every gradient in gp is finite: |g| <= 1e12 * grad_scale), so the 25 taps are one LDS read with
+        // an immediate offset and two FMAs each, no compare
         const int Ya = tYa[ly_], Yb = tYa[ly_ + 1], Xa = tXa[x0], Xb = tXa[x0 + 1];
+        float wl0[P2_SPAN], wl1[P2_SPAN];
+        int xo[P2_SPAN];
+#pragma unroll
+        for (int ix = 0; ix < P2_SPAN; ++ix) {
+            const int X = Xa + ix;
+            const bool in = X < Xb;
+            const float lx = sw * (float)X - (float)x0;
+            wl0[ix] = in ? 1.f - lx : 0.f;
+            wl1[ix] = in ? lx : 0.f;
+            xo[ix] = in ? ix : 0;
+        }
 #pragma unroll
         for (int iy = 0; iy < P2_SPAN; ++iy) {
             const int Y = Ya + iy;
             if (Y < Yb) {
                 const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+                const float* grow = gp + (Y - Y0) * W + Xa;
                 float rx0 = 0.f, rx1 = 0.f;   // this row's gradient split over the left / right corner columns
 #pragma unroll
                 for (int ix = 0; ix < P2_SPAN; ++ix) {
-                    const int X = Xa + ix;
-                    if (X < Xb) {
-                        const float lx = sw * (float)X - (float)x0;
-                        const float g = gp[(Y - Y0) * W + X];
-                        rx0 += g * (1.f - lx); rx1 += g * lx;
-                    }
+                    const float g = grow[xo[ix]];
+                    rx0 += g * wl0[ix]; rx1 += g * wl1[ix];
                 }
                 g00 += hy * rx0; g01 += hy * rx1; g10 += ly * rx0; g11 += ly * rx1;
             }
@@ -412,11 +456,10 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
         vpu_set_error("p2cl_up: band does not fit LDS / one block ((band + 1) * W/4 <= 1024)");
         return VPU_ERR_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static VpuDevOnce attr_set;
+    if (attr_set.pending()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 4096);   // (static: reduction scratch + the anchor tables)
-        attr_set = true;
     }
     // (as many threads as the pixel / cell passes use: (band + 1) * W / 4, a multiple of 64)
     const int nthr = (int)((((int64_t)(band + 1) * (W / 4 > w ? W / 4 : w)) + 63) / 64 * 64);

@@ -600,7 +600,10 @@ __global__ __launch_bounds__(256) void sigmoid_to_channel_kernel(const float* __
 // One workgroup: every thread reads the call number before the barrier, thread 0 advances it after.
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, int n, float keep, float inv_keep,
                                                            unsigned long long seed, unsigned long long* __restrict__ state) {
+    // state[0]: call number; state[1]: seed word kept in device memory (XORed into the `seed` argument: a launch captured
+    // in a hipGraph follows a later re-seeding, and (seed, call number) can be saved and restored with a checkpoint)
     const unsigned long long call = state[0];
+    seed ^= state[1];
     __syncthreads();
     if (threadIdx.x == 0) state[0] = call + 1;
     for (int i = threadIdx.x; i < n; i += 256) {

@@ -1,7 +1,24 @@
 // Shared device helpers for the VPUFormer gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
+
+
+// "done once per DEVICE" flag of a call site (hipFuncSetAttribute is a per-device setting; a process that moves from one
+// device to another must repeat it there): one bit per device id.
+struct VpuDevOnce {
+    std::atomic<unsigned long long> done{0};
+    bool pending() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_relaxed) & bit) return false;
+        done.fetch_or(bit, std::memory_order_relaxed);
+        return true;
+    }
+};
+
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

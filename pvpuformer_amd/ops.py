@@ -287,28 +287,40 @@ def _drop_key(device):
     return key
 
 
+def _drop_entry(key, seed=None):
+    """state tensor of ``key``'s mask stream: int64 [call number, seed] in device memory (vpu_dropout_mask reads both)."""
+    if key not in _drop_state:
+        sd = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
+        _drop_state[key] = torch.tensor([0, sd], dtype=torch.int64, device=key)
+    return _drop_state[key]
+
+
 def dropout_mask(B, channels, keep, device, seed=None):
     """Dropout2d mask [B, channels] fp32 (values 0 or 1 / keep) from vpu_dropout_mask: one launch, capturable; the stream of
-    masks is a function of ``seed`` (default: torch.initial_seed() at the first call on that device) and the call count."""
+    masks is a function of the seed (default: torch.initial_seed() at the first call on that device; ``dropout_seed`` /
+    ``set_dropout_state`` change it, also for launches already captured in a hipGraph) and the call count."""
     key = _drop_key(device)
-    if key not in _drop_state:
-        _drop_state[key] = (torch.zeros(1, dtype=torch.int64, device=key), int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1))
-    state, sd = _drop_state[key]
+    state = _drop_entry(key, seed)
     out = torch.empty(B, channels, device=key, dtype=torch.float32)
-    _lib.call("vpu_dropout_mask", ptr(out), B * channels, float(keep), sd, ptr(state), _stream())
+    _lib.call("vpu_dropout_mask", ptr(out), B * channels, float(keep), 0, ptr(state), _stream())
     return out
 
 
 def dropout_seed(device, seed):
-    """Restarts the mask stream of ``device``: call count 0 (in place: captured launches keep pointing at the counter)
-    and a new seed (a kernel argument: launches captured before keep the seed they were captured with)."""
-    key = _drop_key(device)
-    sd = int(seed) & (2 ** 63 - 1)
-    if key in _drop_state:
-        _drop_state[key][0].zero_()
-        _drop_state[key] = (_drop_state[key][0], sd)
-    else:
-        _drop_state[key] = (torch.zeros(1, dtype=torch.int64, device=key), sd)
+    """Restarts the mask stream of ``device``: call count 0 and a new seed, both in place in device memory -- launches
+    captured before follow."""
+    set_dropout_state(device, {"seed": int(seed) & (2 ** 63 - 1), "calls": 0})
+
+
+def dropout_state(device):
+    """{"seed", "calls"} of ``device``'s mask stream (a device read: synchronises); part of FusedAdam.state_dict()."""
+    st = _drop_entry(_drop_key(device)).cpu()
+    return {"seed": int(st[1]), "calls": int(st[0])}
+
+
+def set_dropout_state(device, d):
+    st = _drop_entry(_drop_key(device))
+    st.copy_(torch.tensor([int(d["calls"]), int(d["seed"]) & (2 ** 63 - 1)], dtype=torch.int64))
 
 
 def zero_(t):

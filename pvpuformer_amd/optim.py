@@ -110,10 +110,19 @@ class FusedAdam:
         self.model._ensure_engine().zero_grad()
 
     def state_dict(self):
-        return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.lr}
+        """Adam state plus the Dropout2d mask stream of the model's device ({"seed", "calls"}: the reference's dropout follows
+        torch's RNG state, which a checkpoint of a run can carry; here the stream is (seed, call number) in device memory)."""
+        from . import ops
+        sd = {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.lr}
+        if self.m.is_cuda:
+            sd["dropout"] = ops.dropout_state(self.m.device)
+        return sd
 
     def load_state_dict(self, sd):
         self.step_count, self.m, self.v, self.lr = sd["step"], sd["m"], sd["v"], sd["lr"]
+        if sd.get("dropout") is not None and self.m.is_cuda:
+            from . import ops
+            ops.set_dropout_state(self.m.device, sd["dropout"])
 
 
 class OverlappedAdam:

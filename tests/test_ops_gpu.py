@@ -1655,6 +1655,18 @@ def test_dropout_mask_and_fill(ops):
     O._drop_state.clear()
     b = [O.dropout_mask(12, 256, 0.9, "cuda", seed=77) for _ in range(3)]
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # (seed, call number) live in device memory: a launch captured in a graph follows a re-seeding, and the pair can be
+    # saved and restored (FusedAdam.state_dict carries it)
+    O.dropout_seed("cuda", 77)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(captured, a[0])
+    assert O.dropout_state("cuda") == {"seed": 77, "calls": 1}
+    saved = O.dropout_state("cuda")
+    nxt = O.dropout_mask(12, 256, 0.9, "cuda")
+    assert torch.equal(nxt, a[1])
+    O.dropout_seed("cuda", 5)
+    O.set_dropout_state("cuda", saved)
+    assert torch.equal(O.dropout_mask(12, 256, 0.9, "cuda"), a[1])
     O._drop_state.clear()
     for n, off in ((1 << 20, 0), (1000003, 1), (7, 3), (3, 0)):
         buf = torch.full((n + 8,), 5.0, device="cuda")
