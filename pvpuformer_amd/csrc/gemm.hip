@@ -2536,7 +2536,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         }
         // K3 (bit 1 of the k3 option): the same problems as K2 below, 256 x 128 tiles in 256-thread workgroups, two per CU
-        if ((k3_opt() & 2) && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % K3_BK == 0 && d->K >= 256 &&
+        // (VPU_GEMM_K3_FORMS: a bit mask of single forms -- 1 bias, 2 bias+residual, 4 bias+GELU, 8 plain dgrad, 16 x aux -- for A/B runs)
+        static const int forms3 = [] { const char* e = getenv("VPU_GEMM_K3_FORMS"); return e ? atoi(e) : 0; }();
+        if (((k3_opt() & 2) || forms3) && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % K3_BK == 0 && d->K >= 256 &&
             !d->transA && d->alpha == 1.0f && (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL &&
             (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
             static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
@@ -2564,12 +2566,13 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         kern_<<<dim3((unsigned)(tot_ < cap3 ? tot_ : cap3)), dim3(256), K3_LDS, s>>>(*d, tm_, tn3, vec3);              \
     } while (0)
 #define VPU_LAUNCH_K3(TA_, TB_, FL_) do { if (short3) VPU_LAUNCH_K3_RB(TA_, TB_, FL_, 7); else VPU_LAUNCH_K3_RB(TA_, TB_, FL_, 8); } while (0)
+            const bool all3 = (k3_opt() & 2) != 0;
             if (!done3) {}
-            else if (key == 0 && f == F_B) VPU_LAUNCH_K3(0, 0, F_B);
-            else if (key == 0 && f == F_BR) VPU_LAUNCH_K3(0, 0, F_BR);
-            else if (key == 0 && f == F_G) VPU_LAUNCH_K3(0, 0, F_G);
-            else if (key == 1 && f == 0) VPU_LAUNCH_K3(0, 1, 0);
-            else if (key == 1 && f == F_M) VPU_LAUNCH_K3(0, 1, F_M);
+            else if (key == 0 && f == F_B && (all3 || (forms3 & 1))) VPU_LAUNCH_K3(0, 0, F_B);
+            else if (key == 0 && f == F_BR && (all3 || (forms3 & 2))) VPU_LAUNCH_K3(0, 0, F_BR);
+            else if (key == 0 && f == F_G && (all3 || (forms3 & 4))) VPU_LAUNCH_K3(0, 0, F_G);
+            else if (key == 1 && f == 0 && (all3 || (forms3 & 8))) VPU_LAUNCH_K3(0, 1, 0);
+            else if (key == 1 && f == F_M && (all3 || (forms3 & 16))) VPU_LAUNCH_K3(0, 1, F_M);
             else done3 = false;
 #undef VPU_LAUNCH_K3
 #undef VPU_LAUNCH_K3_RB
