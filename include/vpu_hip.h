@@ -60,6 +60,12 @@ typedef struct vpu_gemm_desc {
     int64_t workspace_bytes; /* split-K needs batch * slices * M * (N + 1) * 4 bytes + 256 KiB */
     float* colsum;           /* optional (bf16, transA=1, batch=1): colsum[m] += sum_k op(A)[m][k] -- the bias gradient
                                 fused into the weight-gradient GEMM whose A operand is dY */
+    int32_t cs_tn, cs_t0;    /* vpu_gemm_grouped, 256 x 256-tile weight-gradient kernels only.  cs_tn > 1: the column sums are
+                                DISTRIBUTED over the cs_tn column tiles (256 columns each) of the whole problem -- column tile
+                                t sums over K-steps [t nk / cs_tn, (t + 1) nk / cs_tn) and WRITES colsum[(z cs_tn + t) cs_ld + m]
+                                (a slab the caller adds up); cs_t0 = the global index of this descriptor's first column
+                                tile (a problem cut along its columns).  0 / 1: the classic form above */
+    int64_t cs_ld;           /* row stride of that slab (the row count of the whole problem) */
 } vpu_gemm_desc;
 
 /* Up to VPU_GEMM_GROUP_MAX independent bf16 problems run by ONE launch of vpu_gemm_grouped: start[i] = first tile of
@@ -202,6 +208,10 @@ int vpu_fill_ranges_f32(float* base, const int64_t* off, const int64_t* len, int
 /* Diagnostic only (tools/reserve_cus_experiment.py): `wgs` workgroups of 512 threads, ~96 registers per thread, 16 KiB of
  * LDS, spinning for ~`cycles` shader cycles -- the footprint of a collective's channel workgroups. */
 int vpu_debug_spin(float* sink, int32_t wgs, int64_t cycles, void* stream);
+/* Diagnostic only (tools/k4_drift.py): a device buffer of 8 x uint64 per workgroup (or NULL to stop) into which the packed
+ * weight-gradient kernel of vpu_gemm_grouped stamps the shader cycle counter at the start, the quarters and the end of each
+ * tile's main loop -- how far the tiles of one XCD drift apart. */
+int vpu_debug_gemm_times(void* dev_buf);
 /* out[b][channel][:] = sigmoid(logits[b][:]) for an fp32 [B][channels][HW] tensor: the previous-mask channel of the next
  * click iteration's input (isegm/engine/trainer.py:428, :384) */
 int vpu_sigmoid_to_channel(const float* logits, float* out, int32_t B, int64_t HW, int32_t channels, int32_t channel,

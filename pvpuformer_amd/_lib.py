@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("resid_period", C.c_int32),
         ("alpha", C.c_float), ("post_mul", C.c_float), ("post_add", C.c_float),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("colsum", C.c_void_p),
+        ("cs_tn", C.c_int32), ("cs_t0", C.c_int32), ("cs_ld", C.c_int64),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "vpu_fill_f32": [_P, _F, _L, _P],
     "vpu_fill_ranges_f32": [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _F, _P],
     "vpu_debug_spin": [_P, _I, _L, _P],
+    "vpu_debug_gemm_times": [_P],
     "vpu_sigmoid_to_channel": [_P, _P, _I, _L, _I, _I, _P],
     "vpu_act_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
     "vpu_pue_encode": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

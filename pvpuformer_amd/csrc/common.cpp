@@ -21,4 +21,4 @@ int vpu_check_launch(const char* what) {
 }
 
 extern "C" const char* vpu_last_error(void) { return g_err; }
-extern "C" int vpu_abi_version(void) { return 1; }
+extern "C" int vpu_abi_version(void) { return 2; }   // 2: vpu_gemm_desc.cs_tn / cs_t0 / cs_ld

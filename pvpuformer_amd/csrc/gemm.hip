@@ -1869,7 +1869,8 @@ __device__ __forceinline__ void k3_epi_direct_f32(const vpu_gemm_desc& p, const 
 
 template <int TA, int TB, bool CS, int FL, bool GRP, int RB, int NWN = 2, bool PIPE = false, int TM = 256, bool SWF = false>
 __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
-                                        const int tiles_m_arg, const int tiles_n_arg, const int vec_in) {
+                                        const int tiles_m_arg, const int tiles_n_arg, const int vec_in,
+                                        unsigned long long* __restrict__ dbg = nullptr) {   // (vpu_debug_gemm_times: 8 stamps per workgroup)
     using Cf = K3Cfg<NWN, TM>;
     static_assert(!CS || (TA == 1 && RB == 8), "fused column sums: weight-gradient form");
     static_assert(TM == 256 || (RB == 4 && NWN == 2 && !GRP && !PIPE && !CS), "128-row tiles: single problems, 64 x 64 per wave");
@@ -1903,7 +1904,16 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
         for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const bool do_cs = CS && p.colsum != nullptr && cur.tile_n == 0;   // block-uniform
+        // fused bias column sums.  Classic form: the tiles of the first column block sum over the whole reduction -- a third
+        // of a ViT block's tiles then run 17 % longer than the rest, and a packed launch is ONE round: it lasts as long as
+        // its slowest tile (tools/k4_drift.py: 58 of 256 workgroups at 262-277 us, the others at 225-230).  Distributed form
+        // (cs_tn > 1, round 4): EVERY column tile of the row block sums over its own 1 / cs_tn of the K-steps and WRITES its
+        // partial into row (z * cs_tn + global column tile) of a slab the host adds up afterwards (colsum_batched): equal
+        // work per tile, one writer per word, no zeroing.
+        const int cs_tn = (CS && p.colsum != nullptr && p.cs_tn > 1) ? p.cs_tn : 0;
+        const int cs_gt = cs_tn ? p.cs_t0 + cur.tile_n : 0;
+        const int cs_kb = cs_tn ? (int)((int64_t)cs_gt * nk / cs_tn) : 0, cs_ke = cs_tn ? (int)((int64_t)(cs_gt + 1) * nk / cs_tn) : nk;
+        const bool do_cs = CS && p.colsum != nullptr && (cs_tn > 0 || cur.tile_n == 0);   // block-uniform
         f32x4_t acc_cs[Cf::NCS];
 #pragma unroll
         for (int i = 0; i < Cf::NCS; ++i) acc_cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -1931,7 +1941,10 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 for (int i = 0; i < 4; ++i) aL[i] = k3_frag<TA>(la, i * 16, lane);
             }
             int st_c = 0, st_w = Cf::S - 1;      // stage of K-step kt / stage the next DMA goes to
+            if (dbg && tid == 0) dbg[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+            const int q1 = (nk >> 2) & ~1, q2 = (nk >> 1) & ~1, q3 = (3 * nk >> 2) & ~1;
             for (int kt = 0; kt < nk; kt += 2) {
+                if (dbg && tid == 0 && (kt == q1 || kt == q2 || kt == q3)) dbg[blockIdx.x * 8 + (kt == q1 ? 1 : kt == q2 ? 2 : 3)] = __builtin_amdgcn_s_memrealtime();
                 // (two K-steps per iteration: the B register sets swap roles, every index is a compile-time constant)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -1944,14 +1957,15 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
                     const int st_n = st_c + 1 == Cf::S ? 0 : st_c + 1;
                     const int kn = kt + u + Cf::S - 1;
                     __builtin_amdgcn_s_setprio(1);
+                    const bool cs_now = do_cs && kt + u >= cs_kb && kt + u < cs_ke;
                     if (u == 0) k3_half0<TA, TB, CS, NWN, SWF>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
-                                                               wave, lane, wm, wn, do_cs, ones, aL, b0, aH, acc, acc_cs);
+                                                               wave, lane, wm, wn, cs_now, ones, aL, b0, aH, acc, acc_cs);
                     else k3_half0<TA, TB, CS, NWN, SWF>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + st_w * Cf::STAGE, lds + st_c * Cf::STAGE,
-                                                        wave, lane, wm, wn, do_cs, ones, aL, b1, aH, acc, acc_cs);
+                                                        wave, lane, wm, wn, cs_now, ones, aL, b1, aH, acc, acc_cs);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // aH is in registers
                     __builtin_amdgcn_sched_barrier(0);
-                    if (u == 0) k3_half1<TA, TB, CS, NWN, SWF>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b0, aL, b1, acc, acc_cs);
-                    else k3_half1<TA, TB, CS, NWN, SWF>(lds + st_n * Cf::STAGE, lane, wm, wn, do_cs, ones, aH, b1, aL, b0, acc, acc_cs);
+                    if (u == 0) k3_half1<TA, TB, CS, NWN, SWF>(lds + st_n * Cf::STAGE, lane, wm, wn, cs_now, ones, aH, b0, aL, b1, acc, acc_cs);
+                    else k3_half1<TA, TB, CS, NWN, SWF>(lds + st_n * Cf::STAGE, lane, wm, wn, cs_now, ones, aH, b1, aL, b0, acc, acc_cs);
                     __builtin_amdgcn_s_setprio(0);
                     st_w = st_c;
                     st_c = st_n;
@@ -1970,13 +1984,14 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
             __builtin_amdgcn_s_barrier();
             const int kn = kt + Cf::S - 1;
             k3_step<TA, TB, CS, RB, NWN, TM>(rA, rB, voff, kn * stepA, kn * stepB, kn < nk, lds + wr_i * Cf::STAGE, lds + rd_i * Cf::STAGE,
-                                             wave, lane, wm, wn, do_cs, ones, acc, acc_cs);
+                                             wave, lane, wm, wn, do_cs && kt >= cs_kb && kt < cs_ke, ones, acc, acc_cs);
             rd_i = rd_i + 1 == Cf::S ? 0 : rd_i + 1;
             wr_i = wr_i + 1 == Cf::S ? 0 : wr_i + 1;
         }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the out-of-range tail pieces still write zeros into LDS)
         __syncthreads();
+        if (dbg && tid == 0) dbg[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
         float* wl = reinterpret_cast<float*>(lds + wave * 4096);   // 16 rows x 64 fp32 per wave
         const int mw = m0 + wm * (16 * RB), nq = n0 + wn * 64;
         if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only
@@ -1994,7 +2009,10 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = m0 + wm * 128 + (wn * Cf::NCS + i) * 16 + fq * 4 + r;
-                        if (row < cur.M) p.colsum[(int64_t)cur.z * cur.M + row] += acc_cs[i][r];   // (a batch entry's sums: colsum + z M)
+                        if (row < cur.M) {
+                            if (cs_tn) p.colsum[((int64_t)cur.z * cs_tn + cs_gt) * p.cs_ld + row] = acc_cs[i][r];   // (this tile's slab row)
+                            else p.colsum[(int64_t)cur.z * cur.M + row] += acc_cs[i][r];   // (a batch entry's sums: colsum + z M)
+                        }
                     }
             }
             // (the two 64-row halves of the wave tile, written out twice: a loop over them that the compiler does not unroll
@@ -2041,9 +2059,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k4_grouped_kernel(const vpu_gem
     k3_body<TA, TB, CS, -1, true, 8, 4>(ga->d[0], ga, 0, 0, vec);
 }
 template <int TA, int TB, bool CS, bool SWF = false>
-__global__ __launch_bounds__(512) void gemm_bf16_k4p_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
+__global__ __launch_bounds__(512) void gemm_bf16_k4p_grouped_kernel(const vpu_gemm_group ga_unused, const int vec,
+                                                                    unsigned long long* dbg) {
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
-    k3_body<TA, TB, CS, -1, true, 8, 4, true, 256, SWF>(ga->d[0], ga, 0, 0, vec);
+    k3_body<TA, TB, CS, -1, true, 8, 4, true, 256, SWF>(ga->d[0], ga, 0, 0, vec, dbg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2438,6 +2457,8 @@ inline int k2_opt() { const int v = g_opt_k2.load(std::memory_order_relaxed); re
 // CUs the persistent launches leave unclaimed (vpu_gemm_set_option("reserve_cus")): room for the channel kernels of a
 // collective that runs beside backward (pvpuformer_amd/parallel.py)
 std::atomic<int> g_opt_reserve{0};
+// diagnostic (vpu_debug_gemm_times): device buffer of 8 cycle-counter stamps per workgroup of the K4P kernel, or null
+std::atomic<unsigned long long*> g_dbg_times{nullptr};
 inline int cu_count() {
     static const int v = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int r = g_opt_reserve.load(std::memory_order_relaxed);
@@ -2461,6 +2482,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) { vpu_set_error("vpu_gemm: null operand"); return VPU_ERR_ARG; }
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->inner <= 0 || d->batch % d->inner) {
         vpu_set_error("vpu_gemm: bad sizes (M,N,K,batch > 0; batch % inner == 0)");
+        return VPU_ERR_ARG;
+    }
+    if (d->colsum && d->cs_tn > 1) {
+        vpu_set_error("vpu_gemm: cs_tn > 1 (distributed column sums) is a vpu_gemm_grouped form");
         return VPU_ERR_ARG;
     }
     const int f = d->flags;
@@ -3023,6 +3048,13 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         for (int i = 0; i < n; ++i) very_long = very_long && descs[i].K >= 8192;
         // (K3: two free-running workgroups per CU -- measured against K2 on grouped weight gradients over 9408 rows: 512 tiles
         // 246 vs 284 us, 432 tiles 280 vs 299, but 216 tiles -- one workgroup per CU, nobody to overlap with -- 201 vs 149)
+        bool any_dcs = false;      // distributed column sums: only the 256 x 256-tile kernels below implement them
+        for (int i = 0; i < n; ++i) any_dcs = any_dcs || (descs[i].colsum && descs[i].cs_tn > 1);
+        if (any_dcs && !(ok && (k3_opt() & 8))) {
+            vpu_set_error("vpu_gemm_grouped: cs_tn > 1 (distributed column sums) needs the K4 weight-gradient path (k3 option bit 8, "
+                          "K % 64 == 0, K >= 2048, aligned operands)");
+            return VPU_ERR_ARG;
+        }
         if (ok && (k3_opt() & 8)) {
             // K4: 256 x 256 tiles, one 512-thread workgroup per CU, five-stage ring
             vpu_gemm_group g4 = ga;
@@ -3052,8 +3084,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             const int ncu = cu_count();
             static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true%s>", pipe ? "p" : "", direct4 ? ", true" : "");
-            if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
-            else if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+            unsigned long long* dbg4 = g_dbg_times.load(std::memory_order_relaxed);
+            if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1, dbg4);
+            else if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1, dbg4);
             else gemm_bf16_k4_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
         }
@@ -3098,4 +3131,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         default: gemm_bf16_grouped_kernel<1, 1, true><<<grid, block, 4 * TILE_BYTES, s>>>(ga, vec_arg); break;
     }
     return vpu_check_launch("vpu_gemm_grouped");
+}
+
+extern "C" int vpu_debug_gemm_times(void* dev_buf) {
+    g_dbg_times.store(reinterpret_cast<unsigned long long*>(dev_buf), std::memory_order_relaxed);
+    return VPU_OK;
 }

@@ -153,6 +153,10 @@ class Engine:
         # end of backward with the chip a quarter full (0.47 ms per step).
         self.unify_wgrad = os.environ.get("VPU_WGRAD_UNIFY", "1") != "0"
         self.lazy_zero = os.environ.get("VPU_LAZY_ZERO", "1") != "0"   # zero_grad(lazy=True) honoured (A/B switch)
+        # fused bias column sums of the packed K4 launches DISTRIBUTED over a problem's column tiles (vpu_hip.h: cs_tn): with
+        # the classic form the tiles of the first column block -- a third of a ViT block's -- run 17 % longer than the
+        # others, and a packed launch is one round of tiles (tools/k4_drift.py).  VPU_WGRAD_DCS=0: classic form (A/B runs)
+        self.dist_colsum = os.environ.get("VPU_WGRAD_DCS", "1") != "0"
         self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
         self._pending_reports, self._reporting = [], False    # gradient ranges whose marker has been passed but not reported yet
         self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
@@ -385,6 +389,9 @@ class Engine:
                 acc = 0
             kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | acc, colsum=self.G(bias) if fuse else None)
             L = self._token_rows
+            ctn = (K + 255) // 256      # column tiles of the K4 launches
+            dcs = (fuse and self.dist_colsum and self.k4_wgrad and self.pack_wgrad and ctn > 1 and M % 64 == 0 and M > 2048
+                   and N % 8 == 0 and K % 8 == 0)      # (long reductions only: what vpu_gemm_grouped gives to the K4 kernels)
             if (self.unify_wgrad and self.pack_wgrad and (self.k3_wgrad or self.k4_wgrad) and L > 2048 and M > L and M % L == 0
                     and L % 64 == 0 and N % 8 == 0 and K % 8 == 0 and ld_dy % 8 == 0 and ld_x % 8 == 0 and ldc_ % 4 == 0):
                 # S = M / L reduction slices as the batch entries of one problem: entry z reads rows [z L, (z + 1) L) of dy and
@@ -394,13 +401,24 @@ class Engine:
                 slab = self._new(S * N * K, dtype=torch.float32)
                 post = [((slab, 0), gout, S, N * K, K, ldc_)]
                 cs = None
-                if fuse:
+                if fuse and dcs:
+                    cs = (self._new(S * ctn * N, dtype=torch.float32), 0)            # (every word is written by exactly one tile)
+                    post.append((cs, self.G(bias), S * ctn, N))
+                elif fuse:
                     cs = (ops.zero_(self._new(S * N, dtype=torch.float32)), 0)       # (the kernel accumulates into it)
                     post.append((cs, self.G(bias), S, N))
                 args = (dy, x, (slab, 0), N, K, L, ld_dy, ld_x, K, self.dt)
                 kw = dict(transA=True, transB=True, flags=EPI_OUT_F32, colsum=cs, batch=S, sA=(L * ld_dy, 0), sB=(L * ld_x, 0),
                           sC=(N * K, 0), _post=post, _target=[gout] + ([self.G(bias)] if fuse else []))
+                if fuse and dcs:
+                    kw.update(cs_tn=ctn, cs_t0=0, cs_ld=N)
                 M = L
+            elif dcs and self.unify_wgrad:
+                # un-sliced (a ViT block's linears): the column tiles' partial sums go to a [ctn, N] slab, one batched column
+                # sum adds it to the bias gradient after the launch that holds the LAST part of this problem
+                cs = (self._new(ctn * N, dtype=torch.float32), 0)
+                kw.update(colsum=cs, cs_tn=ctn, cs_t0=0, cs_ld=N, _post=[(cs, self.G(bias), ctn, N)],
+                          _target=[gout, self.G(bias)])
             self._wq.append((args, kw, ((N + 127) // 128) * ((K + 127) // 128) * kw.get("batch", 1), M))   # (the queue keeps dy and x alive)
             for t in (dy, x):
                 tt = t[0] if isinstance(t, tuple) else t
@@ -1238,15 +1256,19 @@ class Engine:
         adv = lambda t, n: (t[0], t[1] + n) if isinstance(t, tuple) else (t, n)
         t128 = lambda n_, k_: ((n_ + 127) // 128) * ((k_ + 127) // 128)
         cs = kw.get("colsum")
+        hkw = {k: v for k, v in kw.items() if k != "_post"}     # (the slab is added up after the LAST part's launch: the tail keeps "_post")
         if rows * Cn >= cols * R:
             r = rows * 256
-            head = ((dy, x, g, r, K, M, ld_dy, ld_x, ldc, dt), kw, t128(r, K), red)
+            head = ((dy, x, g, r, K, M, ld_dy, ld_x, ldc, dt), hkw, t128(r, K), red)
             tail = ((adv(dy, r), x, adv(g, r * ldc), N - r, K, M, ld_dy, ld_x, ldc, dt),
                     dict(kw, colsum=None if cs is None else adv(cs, r)), t128(N - r, K), red)
         else:
             c = cols * tn
-            head = ((dy, x, g, N, c, M, ld_dy, ld_x, ldc, dt), kw, t128(N, c), red)
-            tail = ((dy, adv(x, c), adv(g, c), N, K - c, M, ld_dy, ld_x, ldc, dt), dict(kw, colsum=None), t128(N, K - c), red)
+            head = ((dy, x, g, N, c, M, ld_dy, ld_x, ldc, dt), hkw, t128(N, c), red)
+            # (distributed column sums: every column tile owns a slice of the reduction -- the tail keeps the slab and
+            # starts at global column tile cs_t0 + c / 256; classic form: the sums belong to the first column block)
+            tkw = dict(kw, cs_t0=kw["cs_t0"] + c // 256) if kw.get("cs_tn", 0) > 1 else dict(kw, colsum=None)
+            tail = ((dy, adv(x, c), adv(g, c), N, K - c, M, ld_dy, ld_x, ldc, dt), tkw, t128(N, K - c), red)
         return head, tail
 
     def flush_wgrads(self, only_kind=None, ride=False, keep_riders=False, touching=None, budget=None, entries=None):
@@ -1323,7 +1345,7 @@ class Engine:
             tiles = sum(e[2] for e in part)
             # (reductions beyond ~16k rows -- the head / FPN maps -- keep the per-problem split-K launch with up to 128
             # slices: measured 18.5 vs 17.9 ms per step when they were cut into 8 slices here)
-            elig = [e for e in part if e[0][8] == e[0][4] and e[1].get("batch", 1) == 1]     # slabs are summed into contiguous gradients only
+            elig = [e for e in part if e[0][8] == e[0][4] and e[1].get("batch", 1) == 1 and not e[1].get("cs_tn")]     # slabs are summed into contiguous gradients only
             etiles = sum(e[2] for e in elig)
             if self.split_wgrad and 2048 < red <= 16384 and len(elig) >= 2 and etiles < 200:
                 self._wgrad_sliced(elig, red, etiles)
@@ -1335,14 +1357,14 @@ class Engine:
             elif len(part) >= 2 and (red == 0 or tiles >= 200 or nk * 0.6 < len(part) * 35.0):
                 for i in range(0, len(part), 16):        # (one launch holds 16 descriptors)
                     chunk = part[i:i + 16]
-                    if len(chunk) == 1 and chunk[0][1].get("batch", 1) == 1:
+                    if len(chunk) == 1 and chunk[0][1].get("batch", 1) == 1 and not chunk[0][1].get("cs_tn"):
                         ops.gemm(*chunk[0][0], **self._pub(chunk[0][1]))
                     else:
                         ops.gemm_grouped([(e[0], self._pub(e[1])) for e in chunk])
             else:
                 for args, kw, _, _ in part:
-                    if kw.get("batch", 1) > 1:
-                        ops.gemm_grouped([(args, self._pub(kw))])     # (reduction slices: the grouped K3 / K4 form walks them)
+                    if kw.get("batch", 1) > 1 or kw.get("cs_tn"):
+                        ops.gemm_grouped([(args, self._pub(kw))])     # (reduction slices / distributed column sums: the grouped K4 form)
                     else:
                         ops.gemm(*args, **self._pub(kw))
             for e in part:                               # the slabs of a sliced problem are added to its gradient by the

@@ -64,7 +64,8 @@ def split_k_workspace(device, nbytes=128 << 20):
 
 def _fill_desc(d, A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, transB=False, flags=0, bias=None, resid=None,
                ldr=0, aux=None, ldaux=0, preact=None, alpha=1.0, post_mul=1.0, post_add=0.0, batch=1, inner=1,
-               sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto", colsum=None):
+               sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), resid_period=0, workspace="auto", colsum=None,
+               cs_tn=0, cs_t0=0, cs_ld=0):
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
     d.bias, d.resid, d.aux, d.preact = ptr(bias), ptr(resid), ptr(aux), ptr(preact)
     d.M, d.N, d.K = M, N, K
@@ -79,6 +80,7 @@ def _fill_desc(d, A, B, Cout, M, N, K, lda, ldb, ldc, dtype, transA=False, trans
     d.resid_period = resid_period
     d.alpha, d.post_mul, d.post_add = alpha, post_mul, post_add
     d.colsum = ptr(colsum)
+    d.cs_tn, d.cs_t0, d.cs_ld = int(cs_tn), int(cs_t0), int(cs_ld)      # (distributed column sums: include/vpu_hip.h)
     if workspace == "auto":
         c0 = Cout[0] if isinstance(Cout, tuple) else Cout
         workspace = split_k_workspace(c0.device)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vpu_hip.h but not exported"
     # and the ctypes table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.load().vpu_abi_version() == 1
+    assert _lib.load().vpu_abi_version() == 2
 
 
 def test_gemm_desc_layout_matches_header():

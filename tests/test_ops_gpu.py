@@ -1694,3 +1694,50 @@ def test_fill_ranges(ops):
     for o, ln in ranges:
         exp[o:o + ln] = 0.0
     assert torch.equal(t.cpu(), exp)
+
+
+def test_gemm_k4_distributed_column_sums(ops):
+    """cs_tn > 1 (round 4): every column tile of a packed weight-gradient problem sums the bias gradient over its own slice
+    of the reduction and WRITES its partial into its row of a [cs_tn, M] slab -- also for a problem cut along its columns
+    into two descriptors (cs_t0) and for reduction slices (batch entries: rows z * cs_tn + t).  Exact-integer operands: the
+    slab rows must add up to the column sums of dY bit for bit, C must be the plain product, untouched slab words stay."""
+    R, M, N = 4224, 512, 768               # reduction rows (132 K-steps of 32: 44 per column tile; slices of 2112), G is [M, N]
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-2, 3, (R, M), generator=g).float()
+    B = torch.randint(-2, 3, (R, N), generator=g).float()
+    Ad, Bd = A.cuda().to(torch.bfloat16), B.cuda().to(torch.bfloat16)
+    ref, cref = A.t() @ B, A.sum(0)
+    tn = N // 256
+    ops.gemm_set_option("k3", 24)
+    try:
+        # one descriptor
+        C = torch.full((M, N), 9.0, device="cuda")
+        slab = torch.full((tn, M), 5.0, device="cuda")
+        ops.gemm_grouped([((Ad, Bd, C, M, N, R, M, N, N, 0), dict(transA=True, transB=True, flags=ops.EPI_OUT_F32, colsum=slab, cs_tn=tn, cs_t0=0, cs_ld=M))])
+        torch.cuda.synchronize()
+        assert "k4p" in ops.gemm_last_kernel()
+        assert torch.equal(C.cpu(), ref) and torch.equal(slab.sum(0).cpu(), cref)
+        assert (slab.abs().sum(1) > 0).all()          # every column tile contributed a slice
+        # the same problem cut along its columns: 256 + 512 columns
+        C2 = torch.full((M, N), 9.0, device="cuda")
+        slab2 = torch.full((tn, M), 5.0, device="cuda")
+        kw = dict(transA=True, transB=True, flags=ops.EPI_OUT_F32, colsum=slab2, cs_tn=tn, cs_ld=M)
+        ops.gemm_grouped([((Ad, Bd, C2, M, 256, R, M, N, N, 0), dict(kw, cs_t0=0)),
+                          ((Ad, (Bd, 256), (C2, 256), M, N - 256, R, M, N, N, 0), dict(kw, cs_t0=1))])
+        torch.cuda.synchronize()
+        assert torch.equal(C2.cpu(), ref) and torch.equal(slab2.cpu(), slab.cpu())
+        # two reduction slices as batch entries: slabs of C and rows z * tn + t of the column-sum slab
+        L = R // 2
+        if L % 64 == 0:
+            C3 = torch.zeros(2, M, N, device="cuda")
+            slab3 = torch.full((2 * tn, M), 5.0, device="cuda")
+            ops.gemm_grouped([((Ad, Bd, C3, M, N, L, M, N, N, 0), dict(kw, colsum=slab3, cs_t0=0, batch=2, sA=(L * M, 0), sB=(L * N, 0), sC=(M * N, 0)))])
+            torch.cuda.synchronize()
+            assert torch.equal(C3.sum(0).cpu(), ref) and torch.equal(slab3.sum(0).cpu(), cref)
+            assert torch.equal(slab3[:tn].sum(0).cpu(), A[:L].sum(0))
+        # the classic kernels refuse the form
+        ops.gemm_set_option("k3", 0)
+        with pytest.raises(Exception, match="cs_tn"):
+            ops.gemm_grouped([((Ad, Bd, C, M, N, R, M, N, N, 0), dict(transA=True, transB=True, flags=ops.EPI_OUT_F32, colsum=slab, cs_tn=tn, cs_t0=0, cs_ld=M))])
+    finally:
+        ops.gemm_set_option("k3", -1)
