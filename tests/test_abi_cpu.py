@@ -28,5 +28,6 @@ def test_library_exports_every_declared_symbol():
 
 def test_gemm_desc_layout_matches_header():
     from pvpuformer_amd._lib import GemmDesc
-    # 7 pointers, 10 int32, 8 int64, 5 int32, 3 floats, pointer + int64 -- must equal the C struct size
-    assert ctypes.sizeof(GemmDesc) == 7 * 8 + 10 * 4 + 8 * 8 + 5 * 4 + 3 * 4 + 24
+    # 7 pointers, 10 int32, 8 int64, 5 int32, 3 floats, pointer + int64 + pointer, then (ABI 2) cs_tn / cs_t0 (2 int32) and
+    # cs_ld (int64) -- must equal the C struct size
+    assert ctypes.sizeof(GemmDesc) == 7 * 8 + 10 * 4 + 8 * 8 + 5 * 4 + 3 * 4 + 24 + 2 * 4 + 8
