@@ -13,6 +13,11 @@ from tools.k3_bench import problems  # noqa: E402
 
 shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768)] * 2 + [(768, 3072), (256, 1024)]
 probs, fl = problems(shapes)
+if os.environ.get("K4_DRIFT_DCS", "1") == "1":      # distributed bias column sums (the engine's default), else the classic form
+    for (args, kw), (m, n) in zip(probs, shapes):
+        tn = (n + 255) // 256
+        if tn > 1:
+            kw.update(colsum=torch.zeros(tn, m, device="cuda"), cs_tn=tn, cs_t0=0, cs_ld=m)
 ops.gemm_set_option("k3", 24)
 for _ in range(3):
     ops.gemm_grouped(probs)
