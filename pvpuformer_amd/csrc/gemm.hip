@@ -1197,12 +1197,22 @@ __device__ __forceinline__ void k2_prefetch_direct(const vpu_gemm_desc& p, const
     if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX | VPU_EPI_DRELU)) != 0) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IS_RES ? p.resid : p.aux), 0, 0x7FFFFFFF, 0x00020000);
         const int ld = IS_RES ? p.ldr : p.ldaux;
+        bool per = false;
+        if constexpr (IS_RES) {
+            int pv = __builtin_amdgcn_readfirstlane(p.resid_period > 0 ? 1 : 0);
+            asm volatile("" : "+s"(pv));          // (opaque scalar: the modulo below stays behind a branch)
+            per = pv != 0;
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int m = mrow0 + pass * 16 + fr, n = ncol0 + 32 * t + cl;
-                const int row = (IS_RES && p.resid_period > 0) ? m % p.resid_period : m;
+                // (the periodic residual -- a broadcast pos_embed -- behind a UNIFORM branch: as a select the compiler computed
+                // the integer modulo for every load of every tile, ~300 instructions per wave: 1.2 us of the 4.5-us handover of
+                // the ViT blocks' residual forms, which never use it; tools/k2_stamps.py)
+                int row = m;
+                if (IS_RES && per) row = m % p.resid_period;
                 const int off = (pass < npass && m < p.M && n < p.N) ? (row * ld + n) * 2 : OOB_OFFSET;
                 q.x[pass][t] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
             }
@@ -1341,7 +1351,8 @@ __device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const i
 // where 36.75 x 256 fills 222; the LDS layout keeps its 128-row sub-tiles, rows 112-127 of each are dead).
 template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB, int SWP = 0>
 __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
-                                        const int tiles_m_arg, const int tiles_n_arg, const int vec) {
+                                        const int tiles_m_arg, const int tiles_n_arg, const int vec,
+                                        unsigned long long* __restrict__ dbg = nullptr) {   // (vpu_debug_gemm_times: 16 stamps per workgroup)
     using Cf = K2Cfg<WN>;
     // SW: swapped MFMA operands + direct epilogue (k2_epi_direct); compile-time flag sets of the plain kernel only
     constexpr bool SW = SWP >= 1 && FL >= 0 && !GRP && !CS;
@@ -1374,7 +1385,9 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         k2_tile_setup<WN, GRP, RB>(work, total_work, p_arg, ga, tiles_n_arg, cur);
         k2_voff<TA, TB, WN, RB>(cur, wave, lane, voff);
     }
+    int dbg_t = 0;       // tile number of this workgroup (diagnostic stamps: tile start / main loop end / epilogue end)
     while (work < total_work) {
+        if (dbg && tid == 0 && dbg_t < 5) dbg[blockIdx.x * 16 + 3 * dbg_t] = __builtin_amdgcn_s_memrealtime();
         const vpu_gemm_desc& p = GRP ? ga->d[cur.grp] : p_arg;
         const int FLG = GEN ? p.flags : FL;
         const int m0 = cur.m0, n0 = cur.n0;
@@ -1446,6 +1459,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         // (the out-of-range tail pieces still write zeros into LDS; the direct 256-column form does not touch LDS in its
         // epilogue and the same wave overwrites the same words with the next tile's pieces, in order: nothing to wait for)
         if constexpr (!(SW && !PP)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg && tid == 0 && dbg_t < 5) dbg[blockIdx.x * 16 + 3 * dbg_t + 1] = __builtin_amdgcn_s_memrealtime();
 
         if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
             __syncthreads();
@@ -1480,6 +1494,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();   // every wave is done with the ring (fragment reads consumed, own DMA pieces landed)
             __builtin_amdgcn_sched_barrier(0);
+            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
             // the two K-half groups exchange half of their 128 x 64 partial tile: group 0 finishes rows 0-63, group 1 rows
             // 64-127 of it.  Fragment layouts are identical in both waves, so the registers travel as they are (16-byte LDS
             // accesses, lane-linear).  Wave w sends through [w * 16 KiB, + 16 KiB).
@@ -1511,6 +1526,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();   // every wave has taken its partner's half: stages 0 and 1 can receive the next tile
             __builtin_amdgcn_sched_barrier(0);
+            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
             if (has_next) {
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
@@ -1520,7 +1536,10 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
             }
             float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
+            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime();
             if constexpr (SW) k2_epi_direct<FL>(p, fin, mq, nq, el, qd, npass, reinterpret_cast<const float*>(bslot));
+            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+            if constexpr (SW) {}
             else if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
             else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q, npass);
         } else if constexpr (SW) {
@@ -1531,6 +1550,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             K2PreD<FL> q0, q1;
             k2_prefetch_direct<FL>(p, mw, nw, lane, q0, 4);
             k2_prefetch_direct<FL>(p, mw + 64, nw, lane, q1, RB - 4);
+            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
             if (has_next) {
                 k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
                 k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
@@ -1545,7 +1565,9 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fin[i][j] = acc[i][j];
+                if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
                 k2_epi_direct<FL>(p, fin, mw, nw, lane, q0, 4, reinterpret_cast<const float*>(bslot));
+                if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime();
             }
             {
                 f32x4_t fin[4][4];
@@ -1554,6 +1576,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fin[i][j] = acc[4 + i < RB ? 4 + i : 0][j];
                 k2_epi_direct<FL>(p, fin, mw + 64, nw, lane, q1, RB - 4, reinterpret_cast<const float*>(bslot));
+                if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
             }
         } else {
             __syncthreads();
@@ -1571,6 +1594,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         // every wave is done with its epilogue LDS before the next tile's DMA / fragment reads touch it (raw barrier: the
         // global stores stay in flight)
         __builtin_amdgcn_s_barrier();
+        if (dbg && tid == 0 && dbg_t < 5) dbg[blockIdx.x * 16 + 3 * dbg_t + 2] = __builtin_amdgcn_s_memrealtime();
+        ++dbg_t;
         primed = (PP || SW) && has_next && vec != 9;
         if (has_next && !primed) {
             k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
@@ -1585,8 +1610,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 
 template <int TA, int TB, int WN, int FL, int RB, int SWP = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
-                                                           const int vec) {
-    k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec);
+                                                           const int vec, unsigned long long* dbg) {
+    k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec, dbg);
 }
 template <int TA, int TB, bool CS>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
@@ -2648,7 +2673,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
         const int tot_ = tm_ * tn_;                                                                                  \
         NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d, %d>", TA_, TB_, WN_, FL_, RB_, SW_);                      \
-        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2); \
+        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2, g_dbg_times.load(std::memory_order_relaxed)); \
     } while (0)
 #define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_)                                                                     \
     do {                                                                                                             \
