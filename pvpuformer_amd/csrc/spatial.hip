@@ -1297,8 +1297,11 @@ extern "C" int vpu_convseg_fwd(const void* x, const float* w, const float* bias,
 }
 extern "C" int vpu_convseg_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
+    // (workgroups of the conv_seg / fused head backward = rows of their partial-sum output; VPU_CONVSEG_NBLK sets the cap for
+    // A/B runs -- measured in the step, round 4: 512 / 1024 / 2048 / 4096 workgroups 12.66-12.68 / 12.61 / 12.68-12.71 / 12.69 ms)
+    static const int cap = [] { const char* e = getenv("VPU_CONVSEG_NBLK"); const int v = e ? atoi(e) : 512; return v < 1 ? 1 : v; }();
     int64_t n = rows / 64;
-    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
+    return (int)(n < 1 ? 1 : (n > cap ? cap : n));
 }
 extern "C" int vpu_convseg_bwd(const float* dout, const void* x, const float* w, const float* mask, void* dx,
                                int32_t accum, float* part, float* part_b, int64_t rows, int64_t HW, int32_t C,
