@@ -300,6 +300,13 @@ int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, int32_t wg,
  * also the im2col of Conv2d(2, stride 2) (is_vpu_model.py:80). */
 int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, int32_t B, int32_t h, int32_t w, int32_t C,
                        int32_t dir, int32_t dtype, void* stream);
+/* The backward of the depth-to-space of a ConvTranspose2d(2, stride 2) on channels-last maps (vpu_pixel_shuffle2 with
+ * dir = 1) PLUS the bias gradient's partial sums in the same pass: part[block][c] = sum of in[..][c] over the fine pixels the
+ * workgroup moved, vpu_pixel_unshuffle2_nblk(C) rows (a multiple of C / 8, <= 1024); the caller adds the rows up
+ * (vpu_colsum_batched).  Reference: the ConvTranspose2d bias gradient of transformer_helper's FPN necks (sum over B, H, W). */
+int vpu_pixel_unshuffle2_nblk(int32_t C);
+int vpu_pixel_unshuffle2_sums(const void* in, void* out, float* part, int32_t B, int32_t h, int32_t w, int32_t C,
+                              int32_t dtype, void* stream);
 /* GroupNorm(1, C) [+ GELU] on channels-last maps (is_vpu_model.py:57-85). stats = workspace fp64 [B][nchunk][2],
  * mean/rstd fp32 [B]. */
 int vpu_groupnorm_nchunk(void);

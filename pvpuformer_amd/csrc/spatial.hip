@@ -144,6 +144,52 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* __restrict
     }
 }
 
+// dir 1 with the bias gradient of the transposed convolution in the same pass (round 4): part[block][c] = this workgroup's sum
+// over its fine pixels of x[..][c] -- the stand-alone column sum read the 2h x 2w map a second time (12 us per layer at
+// ViT-B bs 12, three layers).  The grid is a multiple of C / 8, so a thread keeps its channel group over its whole loop;
+// the workgroup's 256 threads are reduced through LDS in thread order, the rows of `part` by the caller's batched column
+// sum: a fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_unshuffle2_sums_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                                    float* __restrict__ part, int B, int h, int w, int C) {
+    __shared__ float red[256][8];
+    const int chunks = C / 8;
+    const int W2 = 2 * w;
+    const int64_t total = (int64_t)B * h * w * chunks;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ck = (int)(i0 % chunks);
+    for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / chunks;
+        const int x = (int)(m % w), y = (int)((m / w) % h);
+        const int64_t b = m / ((int64_t)w * h);
+        const int64_t coarse = m * (C * 4) + (int64_t)ck * 32;
+        const int64_t fine0 = (((b * 2 * h) + 2 * y) * W2 + 2 * x) * C + ck * 8;
+        float v[4][8];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            float o[8];
+            load8(src + fine0 + ((int64_t)(dd >> 1) * W2 + (dd & 1)) * C, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[(j * 4 + dd) >> 3][(j * 4 + dd) & 7] = o[j]; s[j] += o[j]; }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store8(dst + coarse + g * 8, v[g]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = s[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        // the threads of this workgroup whose channel group is c / 8: t = first, first + chunks, ...
+        const int g = c >> 3, base = (int)(((int64_t)blockIdx.x * 256) % chunks);
+        int first = g - base;
+        if (first < 0) first += chunks;
+        float acc = 0.f;
+        for (int t = first; t < 256; t += chunks) acc += red[t][c & 7];
+        part[(int64_t)blockIdx.x * C + c] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------ GroupNorm(1, C)
 constexpr int GN_CHUNKS = 64;
 
@@ -1164,6 +1210,22 @@ extern "C" int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, 
     DISPATCH_T(dtype, pixel_shuffle2_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)in, (T*)out,
                                                                                                bias, B, h, w, C, dir);)
     return vpu_check_launch("vpu_pixel_shuffle2");
+}
+extern "C" int vpu_pixel_unshuffle2_nblk(int32_t C) {
+    vpu_clear_stale_error();
+    const int chunks = C / 8;
+    return chunks < 1 || chunks > 1024 ? 0 : (1024 / chunks) * chunks;
+}
+extern "C" int vpu_pixel_unshuffle2_sums(const void* in, void* out, float* part, int32_t B, int32_t h, int32_t w, int32_t C,
+                                         int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    const int nblk = C % 8 ? 0 : vpu_pixel_unshuffle2_nblk(C);
+    if (!in || !out || !part || nblk < 1 || C > 2048 || B < 1 || h < 1 || w < 1) {
+        vpu_set_error("pixel_unshuffle2_sums: C % 8 == 0, C <= 2048, non-null pointers");
+        return VPU_ERR_ARG;
+    }
+    DISPATCH_T(dtype, pixel_unshuffle2_sums_kernel<T><<<nblk, 256, 0, ST>>>((const T*)in, (T*)out, part, B, h, w, C);)
+    return vpu_check_launch("vpu_pixel_unshuffle2_sums");
 }
 extern "C" int vpu_groupnorm_nchunk(void) {
     vpu_clear_stale_error(); return GN_CHUNKS; }

@@ -756,8 +756,14 @@ class Engine:
                 if y.g is None:
                     return
                 dt = self._new(M, 4 * Cout)
-                ops.pixel_shuffle2(y.g, dt, None, B, h, w, Cout, inverse=True)
-                self._colsum_to(y.g, Cout, prefix + ".bias", B * 4 * h * w, Cout)
+                if Cout % 8 == 0 and Cout <= 2048:
+                    # (round 4: the bias gradient's partial sums come out of the same pass; one more job of the batched
+                    # column sums instead of a second read of the map and two launches)
+                    part, nb = ops.pixel_unshuffle2_sums(y.g, dt, B, h, w, Cout)
+                    self._csq.append((part, self.G(prefix + ".bias"), nb, Cout))
+                else:
+                    ops.pixel_shuffle2(y.g, dt, None, B, h, w, Cout, inverse=True)
+                    self._colsum_to(y.g, Cout, prefix + ".bias", B * 4 * h * w, Cout)
                 # dW[Cin, 4Cout] += x^T dt   (launched directly: as a 36-tile rider of the grouped launches it displaced
                 # the neck's small problems and cost more than it saved, 858 vs 864 images/s)
                 if self.unify_wgrad and self.pack_wgrad and self.dt == BF16 and self.group_wgrad and not self.use_side:

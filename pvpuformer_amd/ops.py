@@ -405,6 +405,15 @@ def pixel_shuffle2(src, dst, bias, B, h, w, Cdim, inverse=False):
               _stream())
 
 
+def pixel_unshuffle2_sums(src, dst, B, h, w, Cdim):
+    """dst = depth-to-space^-1(src) as pixel_shuffle2(inverse=True), plus the per-channel partial sums of src (the transposed
+    convolution's bias gradient): returns (part fp32 [nblk, Cdim], nblk) for a batched column sum."""
+    nblk = _lib.load().vpu_pixel_unshuffle2_nblk(Cdim)
+    part = torch.empty(nblk, Cdim, device=dst.device, dtype=torch.float32)
+    _lib.call("vpu_pixel_unshuffle2_sums", ptr(src), ptr(dst), ptr(part), B, h, w, Cdim, code_of(src), _stream())
+    return part, nblk
+
+
 def groupnorm_nchunk():
     return _lib.load().vpu_groupnorm_nchunk()
 

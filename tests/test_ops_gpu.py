@@ -1741,3 +1741,22 @@ def test_gemm_k4_distributed_column_sums(ops):
             ops.gemm_grouped([((Ad, Bd, C, M, N, R, M, N, N, 0), dict(transA=True, transB=True, flags=ops.EPI_OUT_F32, colsum=slab, cs_tn=tn, cs_t0=0, cs_ld=M))])
     finally:
         ops.gemm_set_option("k3", -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("C", [64, 192, 200])
+def test_pixel_unshuffle2_sums(ops, dtype, C):
+    """vpu_pixel_unshuffle2_sums: the same bytes as pixel_shuffle2(inverse=True), and partial rows whose sum is the per-channel
+    sum of the fine map (the ConvTranspose2d bias gradient) -- exact with small-integer data, for channel counts whose C / 8 does
+    and does not divide 256."""
+    B, h, w = 3, 5, 7
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(-3, 4, (B * 2 * h * 2 * w, C), generator=g).float().cuda().to(dtype)
+    ref = torch.empty(B * h * w, 4 * C, device="cuda", dtype=dtype)
+    ops.pixel_shuffle2(x, ref, None, B, h, w, C, inverse=True)
+    out = torch.full_like(ref, 9.0)
+    part, nb = ops.pixel_unshuffle2_sums(x, out, B, h, w, C)
+    torch.cuda.synchronize()
+    assert tuple(part.shape) == (nb, C) and nb % (C // 8) == 0
+    assert torch.equal(out, ref)
+    assert torch.equal(part.sum(0).cpu(), x.float().sum(0).cpu())
