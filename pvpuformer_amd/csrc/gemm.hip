@@ -2782,6 +2782,17 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             const int cap3s = 3 * cu_count();
             const int tot3s = tiles_m * tiles_n;
             launched = true;
+            // a bf16 output accumulated in place (a second gradient into the same activation gradient: the neck's 384 -> 768
+            // projections, 9408 x 768 x 384, seven per step on the two-stage kernel's run-time epilogue, 20.6 us) IS the
+            // residual form with the residual = C: same arithmetic (fp32 sum of the old bf16 value and the accumulator, one
+            // rounding), every element read and written by the same lane, the reads requested before the first store
+            vpu_gemm_desc dacc = *d;
+            const bool acc_as_res = key == 1 && f == VPU_EPI_ACCUM && d->dtype == VPU_BF16 && !d->resid;
+            if (acc_as_res) {
+                dacc.flags = VPU_EPI_RESID; dacc.resid = d->C; dacc.ldr = d->ldc; dacc.resid_period = 0;
+                dacc.sRo = d->sCo; dacc.sRi = d->sCi;
+            }
+            const vpu_gemm_desc* dk = acc_as_res ? &dacc : d;
 #define VPU_LAUNCH_K3S(TA_, TB_, FL_)                                                                                \
     do {                                                                                                             \
         static VpuDevOnce attr_;                                                                                   \
@@ -2790,7 +2801,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<2, 128>::LDS); \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_k3s_kernel<%d, %d, %d>", TA_, TB_, FL_);                                                \
-        kern_<<<dim3((unsigned)(tot3s < cap3s ? tot3s : cap3s)), dim3(256), K3Cfg<2, 128>::LDS, s>>>(*d, tiles_m, tiles_n, 1); \
+        kern_<<<dim3((unsigned)(tot3s < cap3s ? tot3s : cap3s)), dim3(256), K3Cfg<2, 128>::LDS, s>>>(*dk, tiles_m, tiles_n, 1); \
     } while (0)
             if (key == 0 && f == F_B) VPU_LAUNCH_K3S(0, 0, F_B);
             else if (key == 0 && f == F_BR) VPU_LAUNCH_K3S(0, 0, F_BR);
@@ -2800,6 +2811,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             else if (key == 1 && f == F_D) VPU_LAUNCH_K3S(0, 1, F_D);
             else if (key == 1 && f == 0) VPU_LAUNCH_K3S(0, 1, 0);
             else if (key == 1 && f == F_M) VPU_LAUNCH_K3S(0, 1, F_M);
+            else if (acc_as_res) VPU_LAUNCH_K3S(0, 1, VPU_EPI_RESID);
             else launched = false;
 #undef VPU_LAUNCH_K3S
         }

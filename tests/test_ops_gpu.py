@@ -1760,3 +1760,21 @@ def test_pixel_unshuffle2_sums(ops, dtype, C):
     assert tuple(part.shape) == (nb, C) and nb % (C // 8) == 0
     assert torch.equal(out, ref)
     assert torch.equal(part.sum(0).cpu(), x.float().sum(0).cpu())
+
+
+def test_gemm_bf16_accumulate_in_place_on_k3s(ops):
+    """A bf16 output accumulated in place (flags = ACCUM, transB, K <= 384: the neck's second gradient into an activation
+    gradient) runs as the residual form of the 128 x 128 ring kernel with the residual = C: exact-integer operands give
+    C_old + A B bit for bit, also with a ragged last tile."""
+    for M, N, K in ((9408, 768, 384), (4200, 264, 256), (1000, 264, 256)):
+        g = torch.Generator().manual_seed(7)
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        B = torch.randint(-2, 3, (K, N), generator=g).float()
+        C0 = torch.randint(-8, 9, (M, N), generator=g).float()
+        Ad, Bd = A.cuda().to(torch.bfloat16), B.cuda().to(torch.bfloat16)
+        C = C0.cuda().to(torch.bfloat16)
+        ops.gemm(Ad, Bd, C, M, N, K, K, N, N, 0, transB=True, flags=ops.EPI_ACCUM)
+        torch.cuda.synchronize()
+        if M >= 4096:        # (the small problem goes to the skinny kernel: same contract)
+            assert "k3s_kernel<0, 1, 64>" in ops.gemm_last_kernel(), ops.gemm_last_kernel()
+        assert torch.equal(C.float().cpu(), (C0 + A @ B).to(torch.bfloat16).float())
