@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                                         unsigned long long* __restrict__ dbg = nullptr) {   // (vpu_debug_gemm_times: 16 stamps per workgroup)
     using Cf = K2Cfg<WN>;
     // SW: swapped MFMA operands + direct epilogue (k2_epi_direct); compile-time flag sets of the plain kernel only
-    constexpr bool SW = SWP >= 1 && FL >= 0 && !GRP && !CS;
+    constexpr bool SW = SWP >= 1 && FL >= 0 && !CS;      // (also the grouped form with ONE compile-time flag set for all its problems)
     static_assert(!CS || (WN == 2 && TA == 1 && RB == 8), "fused column sums: weight-gradient form, 256 x 128 tile");
     constexpr bool PP = WN == 2;       // ping-pong schedule of the two K-half groups + next tile's first stages requested early
     constexpr bool GEN = FL < 0;
@@ -1531,7 +1531,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
                 const int nsA = TA ? nt.lda * (BK * 2) : BK * 2, nsB = TB ? nt.ldb * (BK * 2) : BK * 2;
-                if constexpr (BL) k2_bias_issue(p, nt.n0 + wn * 64, el, nbslot);
+                if constexpr (BL) k2_bias_issue(GRP ? ga->d[nt.grp] : p, nt.n0 + wn * 64, el, nbslot);
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds, wave);
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
             }
@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
-                if constexpr (BL) k2_bias_issue(p, nt.n0 + wn * 64, lane, nbslot);
+                if constexpr (BL) k2_bias_issue(GRP ? ga->d[nt.grp] : p, nt.n0 + wn * 64, lane, nbslot);
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, 0, 0, true, lds + par * Cf::STAGE, wave);
             }
             {
@@ -1612,6 +1612,13 @@ template <int TA, int TB, int WN, int FL, int RB, int SWP = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
                                                            const int vec, unsigned long long* dbg) {
     k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec, dbg);
+}
+// forward / dgrad groups whose problems share ONE compile-time flag set (round 4: the DMA neck's image-side K / V projections,
+// bias only): the direct epilogue of the plain kernel instead of the run-time one
+template <int TA, int TB, int FL>
+__global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_fl_kernel(const vpu_gemm_group ga_unused, const int vec) {
+    const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
+    k2_body<TA, TB, 2, false, FL, true, 8, 1>(ga->d[0], ga, 0, 0, vec);
 }
 template <int TA, int TB, bool CS>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_grouped_kernel(const vpu_gemm_group ga_unused, const int vec) {
@@ -3049,6 +3056,28 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128);
         }
         for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g2.start[i] = total2;
+        // all problems bias-only (forward) / plain (dgrad), bf16 output: the compile-time form with the direct epilogue
+        bool same_fl = ok;
+        for (int i = 0; i < n && same_fl; ++i)
+            same_fl = descs[i].flags == (key == 0 ? VPU_EPI_BIAS : 0) && (key != 0 || descs[i].bias) && descs[i].dtype == VPU_BF16 &&
+                      (int64_t)descs[i].M * descs[i].ldc * 2 < 0x7FFFFFF0LL;
+        static const bool k2g_fl = [] { const char* e = getenv("VPU_GEMM_K2G_FL"); return !e || e[0] != '0'; }();
+        if (ok && total2 >= 192 && same_fl && k2g_fl) {
+            const int ncu = cu_count();
+            static VpuDevOnce attrf0, attrf1;
+            if (key == 0) {
+                auto kern_ = gemm_bf16_k2_grouped_fl_kernel<0, 0, VPU_EPI_BIAS>;
+                if (attrf0.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS + K2_BIAS_LDS); }
+                NOTE_KERNEL("gemm_bf16_k2_grouped_fl_kernel<0, 0, 1>");
+                kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS + K2_BIAS_LDS, s>>>(g2, 1);
+            } else {
+                auto kern_ = gemm_bf16_k2_grouped_fl_kernel<0, 1, 0>;
+                if (attrf1.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS + K2_BIAS_LDS); }
+                NOTE_KERNEL("gemm_bf16_k2_grouped_fl_kernel<0, 1, 0>");
+                kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS + K2_BIAS_LDS, s>>>(g2, 1);
+            }
+            return vpu_check_launch("vpu_gemm_grouped");
+        }
         if (ok && total2 >= 192) {
             const int ncu = cu_count();
             static VpuDevOnce attr0, attr1;

@@ -1778,3 +1778,38 @@ def test_gemm_bf16_accumulate_in_place_on_k3s(ops):
         if M >= 4096:        # (the small problem goes to the skinny kernel: same contract)
             assert "k3s_kernel<0, 1, 64>" in ops.gemm_last_kernel(), ops.gemm_last_kernel()
         assert torch.equal(C.float().cpu(), (C0 + A @ B).to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("tB", [0, 1])
+def test_gemm_k2_grouped_forward_forms(ops, tB):
+    """Forward / dgrad GROUPS on the 256 x 128 kernel (the DMA neck's image-side K / V projections: two 9408 x 384 x 768
+    problems in one launch).  Problems that share one flag set -- bias only (forward) / none (dgrad) -- take the compile-time
+    form with the direct epilogue (round 4), any other mix the run-time epilogue: both must give the fp32 product of
+    exact-integer operands bit for bit, with a different bias per problem and a ragged last row tile."""
+    g = torch.Generator().manual_seed(9)
+    probs, refs = [], []
+    for (M, N, K) in ((9408, 384, 768), (9408, 384, 768), (2000, 256, 512)):
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        W = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-4, 5, (N,), generator=g).float()
+        Ad = A.cuda().to(torch.bfloat16)
+        Wd = (W.t().contiguous() if tB else W).cuda().to(torch.bfloat16)
+        C = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        kw = dict(transB=bool(tB), flags=0 if tB else ops.EPI_BIAS, bias=None if tB else b.cuda())
+        probs.append(((Ad, Wd, C, M, N, K, K, N if tB else K, N, 0), kw))
+        refs.append((A @ W.t() + (0 if tB else b)).to(torch.bfloat16).float())
+    ops.gemm_grouped(probs)
+    torch.cuda.synchronize()
+    assert f"k2_grouped_fl_kernel<0, {tB}, {0 if tB else 1}>" in ops.gemm_last_kernel(), ops.gemm_last_kernel()
+    for (args, _), ref in zip(probs, refs):
+        assert torch.equal(args[2].float().cpu(), ref)
+    if not tB:      # a mixed group (one problem with a ReLU): the run-time epilogue
+        for (args, kw) in probs:
+            args[2].fill_(7.0)
+        probs[2][1]["flags"] = ops.EPI_BIAS | ops.EPI_RELU
+        ops.gemm_grouped(probs)
+        torch.cuda.synchronize()
+        assert "k2_grouped_kernel<0, 0, false>" in ops.gemm_last_kernel(), ops.gemm_last_kernel()
+        refs[2] = refs[2].clamp_min(0)
+        for (args, _), ref in zip(probs, refs):
+            assert torch.equal(args[2].float().cpu(), ref)
