@@ -2639,9 +2639,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         {
             static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             const int k2 = k2_opt();
+            // (VPU_GEMM_K2_MIN_TILES / VPU_GEMM_K2G_MIN_TILES: the smallest tile counts the plain / grouped-compile-time K2
+            // forms take -- A/B knobs)
+            static const int k2_min_tiles = [] { const char* e = getenv("VPU_GEMM_K2_MIN_TILES"); return e ? atoi(e) : 160; }();
             const int tm2 = (d->M + K2_BM - 1) / K2_BM, tn2 = (d->N + 127) / 128;
             if (k2 > 0 && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % BK == 0 && d->K >= 256 &&
-                (int64_t)tm2 * tn2 >= 160 && !d->transA && d->alpha == 1.0f &&
+                (int64_t)tm2 * tn2 >= k2_min_tiles && !d->transA && d->alpha == 1.0f &&
                 (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL && (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
                 constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
                               F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
@@ -3062,7 +3065,8 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             same_fl = descs[i].flags == (key == 0 ? VPU_EPI_BIAS : 0) && (key != 0 || descs[i].bias) && descs[i].dtype == VPU_BF16 &&
                       (int64_t)descs[i].M * descs[i].ldc * 2 < 0x7FFFFFF0LL;
         static const bool k2g_fl = [] { const char* e = getenv("VPU_GEMM_K2G_FL"); return !e || e[0] != '0'; }();
-        if (ok && total2 >= 192 && same_fl && k2g_fl) {
+        static const int k2g_min_tiles = [] { const char* e = getenv("VPU_GEMM_K2G_MIN_TILES"); return e ? atoi(e) : 100; }();   // (192 -> 100: 12.57 -> 12.53 ms, within noise; the run-time form keeps 192)
+        if (ok && total2 >= k2g_min_tiles && same_fl && k2g_fl) {
             const int ncu = cu_count();
             static VpuDevOnce attrf0, attrf1;
             if (key == 0) {
