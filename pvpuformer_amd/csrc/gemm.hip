@@ -2695,6 +2695,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
                 else if (key == 0 && f == F_BR) VPU_K2_BOTH(0, 0, F_BR);
                 else if (key == 0 && f == F_G) VPU_K2_BOTH(0, 0, F_G);
+                else if (key == 0 && f == 0) VPU_K2_BOTH(0, 0, 0);      // (round 4: the head's bias-free fusion / FPN convolutions)
                 else if (key == 1 && f == 0) VPU_K2_BOTH(0, 1, 0);
                 else if (key == 1 && f == F_M) VPU_K2_BOTH(0, 1, F_M);
                 else done = false;

@@ -1353,6 +1353,8 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
         return Cd.float().cpu(), pre.float().cpu()
 
     if tB == 0:
+        out, _ = run(k2, 0)                      # (round 4: the bias-free form of the head's fusion / FPN convolutions)
+        assert torch.equal(out, ref.to(torch.bfloat16).float())
         out, _ = run(k2, ops.EPI_BIAS, bias=bias)
         assert torch.equal(out, (ref + bias.cpu()).to(torch.bfloat16).float())
         out, _ = run(k2, ops.EPI_BIAS | ops.EPI_RESID, bias=bias, resid=R, ldr=N)
