@@ -3102,12 +3102,14 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     }
     // K2 form: weight-gradient groups over a long reduction whose 256 x 128 tiles fill most of the chip
     if (key == 3 && k2_opt() > 0 && vec) {
+        // (VPU_GEMM_K4_MIN_K: the shortest reduction the 256 x 256-tile weight-gradient kernels take -- A/B knob)
+        static const int k4_min_k = [] { const char* e = getenv("VPU_GEMM_K4_MIN_K"); return e ? atoi(e) : 2048; }();
         bool ok = true;
         int total2 = 0;
         vpu_gemm_group g2 = ga;
         for (int i = 0; i < n; ++i) {
             const vpu_gemm_desc* d = descs + i;
-            ok = ok && d->K % BK == 0 && d->K >= 2048 && d->N % 8 == 0 && d->M % 8 == 0;
+            ok = ok && d->K % BK == 0 && d->K >= k4_min_k && d->N % 8 == 0 && d->M % 8 == 0;
             g2.start[i] = total2;
             total2 += ((d->M + K2_BM - 1) / K2_BM) * ((d->N + 127) / 128) * d->batch;
         }
