@@ -3167,7 +3167,13 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             vpu_set_error("vpu_gemm_grouped: batch > 1 needs K % 64 == 0, K >= 2048, M % 8 == 0, N % 8 == 0 and aligned operands");
             return VPU_ERR_ARG;
         }
-        if (ok && (any_batch || ((k3_opt() & 1) && total2 > cu_count()))) {
+        // (VPU_GEMM_K3G_MIN_K > 0: short-reduction weight-gradient groups -- the neck's token-side gradients, 576 rows -- with a
+        // reduction of at least that many rows on the K3 form: A/B knob)
+        static const int k3g_min_k = [] { const char* e = getenv("VPU_GEMM_K3G_MIN_K"); return e ? atoi(e) : 0; }();
+        bool ok_short = k3g_min_k > 0 && !any_batch && !any_dcs && total2 >= 96;
+        for (int i = 0; i < n && ok_short; ++i)
+            ok_short = descs[i].K % BK == 0 && descs[i].K >= k3g_min_k && descs[i].K < 2048 && descs[i].N % 8 == 0 && descs[i].M % 8 == 0;
+        if ((ok && (any_batch || ((k3_opt() & 1) && total2 > cu_count()))) || ok_short) {
             static VpuDevOnce attr3_;
             if (attr3_.pending()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k3_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
