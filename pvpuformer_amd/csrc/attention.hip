@@ -551,7 +551,14 @@ __device__ __forceinline__ void wg_problem(int gx, int nbh, int& bh, int& xb) {
 constexpr float RESCALE_TH = 8.0f;   // log2 units: probabilities relative to the reference maximum stay below 2^8
 
 template <int HD, int QT, int HC>
-__global__ __launch_bounds__(256) void attn_fwd_lean_kernel(const AttnArgs a) {
+// (HD = 64, two tiles per wave: five workgroups per CU -- the window forward is 1152 workgroups, 1.125 rounds of the 1024 slots
+// that 126 registers give, i.e. two rounds; VPU_ATTN_FWD_OCC picks the variant for A/B runs)
+// Measured, round 4: occupancy 5 = 96 registers + 120 bytes of scratch in the loop: 51.5 us (window) / 106 us (global) against
+// 22.9 / 37 -- the default stays 1 (no bound).
+#ifndef VPU_ATTN_FWD_OCC
+#define VPU_ATTN_FWD_OCC 1
+#endif
+__global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) void attn_fwd_lean_kernel(const AttnArgs a) {
     constexpr int KS = HC / 32, DT = HC / 16;   // computed width HC <= image width HD (head dim 80 / 96: 96 of the 128 columns)
     using S = Stg<HD>;
     __shared__ __attribute__((aligned(16))) char ldsK[2][CH * HD * 2];
