@@ -304,6 +304,14 @@ int vpu_pixel_shuffle2(const void* in, void* out, const float* bias, int32_t B, 
  * dir = 1) PLUS the bias gradient's partial sums in the same pass: part[block][c] = sum of in[..][c] over the fine pixels the
  * workgroup moved, vpu_pixel_unshuffle2_nblk(C) rows (a multiple of C / 8, <= 1024); the caller adds the rows up
  * (vpu_colsum_batched).  Reference: the ConvTranspose2d bias gradient of transformer_helper's FPN necks (sum over B, H, W). */
+/* vpu_pixel_shuffle2 (dir 0: depth-to-space + bias) with the GroupNorm(1, C) statistics of its output in the same pass: stats =
+ * the [B][vpu_groupnorm_nchunk()][2] double partials vpu_groupnorm_fwd computes in its first kernel; vpu_groupnorm_apply is
+ * that function's second kernel alone (normalise [+ GELU] with given partials).  Reference: ConvTranspose2d -> GroupNorm /
+ * LayerNorm2d pairs of the FPN necks (models_vit / transformer_helper SimpleFPN). */
+int vpu_pixel_shuffle2_gn_stats(const void* in, void* out, const float* bias, double* stats, int32_t B, int32_t h, int32_t w,
+                                int32_t C, int32_t dtype, void* stream);
+int vpu_groupnorm_apply(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, const double* stats,
+                        int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu, int32_t dtype, void* stream);
 int vpu_pixel_unshuffle2_nblk(int32_t C);
 int vpu_pixel_unshuffle2_sums(const void* in, void* out, float* part, int32_t B, int32_t h, int32_t w, int32_t C,
                               int32_t dtype, void* stream);

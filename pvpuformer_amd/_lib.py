@@ -83,6 +83,8 @@ SIGNATURES = {
     "vpu_patch_im2col": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_window_permute": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_pixel_shuffle2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_pixel_shuffle2_gn_stats": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpu_groupnorm_apply": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _I, _I, _P],
     "vpu_pixel_unshuffle2_nblk": [_I],
     "vpu_pixel_unshuffle2_sums": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpu_groupnorm_nchunk": [],

@@ -216,6 +216,53 @@ struct GnMap {
     }
 };
 
+// dir 0 of pixel_shuffle2 (depth-to-space + bias) with the GroupNorm(1, C) statistics of its OUTPUT in the same pass (round 4):
+// block (b, chunk) moves the coarse cells [chunk * cells / GN_CHUNKS, ...) of image b and leaves the sum and the sum of
+// squares of the ROUNDED values it wrote in stats[b][chunk] -- what gn_stats_kernel would read back from the 2h x 2w map.
+// (gn_finalize adds the GN_CHUNKS partials of an image whatever part of the image each one covers.)
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_shuffle2_gn_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                                const float* __restrict__ bias, double* __restrict__ stats,
+                                                                int h, int w, int C) {
+    __shared__ double red[8];
+    const int chunks = C / 8, W2 = 2 * w;
+    const int b = blockIdx.x;
+    const int64_t cells = (int64_t)h * w;
+    const int64_t per = (cells + GN_CHUNKS - 1) / GN_CHUNKS;
+    const int64_t c0 = (int64_t)blockIdx.y * per, c1 = c0 + per < cells ? c0 + per : cells;
+    double ds = 0.0, dq = 0.0;
+    for (int64_t i = c0 * chunks + threadIdx.x; i < c1 * chunks; i += 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t m = i / chunks;                     // coarse cell (y, x) of image b
+        const int x = (int)(m % w), y = (int)(m / w);
+        const int64_t coarse = ((int64_t)b * cells + m) * (C * 4) + (int64_t)ck * 32;
+        const int64_t fine0 = ((((int64_t)b * 2 * h) + 2 * y) * W2 + 2 * x) * C + ck * 8;
+        float v[4][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load8(src + coarse + g * 8, v[g]);
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) load8(bias + ck * 8, bb);
+        float sq = 0.f, qq = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = to_f32(from_f32<T>(v[(j * 4 + dd) >> 3][(j * 4 + dd) & 7] + bb[j]));
+                sq += o[j]; qq += o[j] * o[j];
+            }
+            store8(dst + fine0 + ((int64_t)(dd >> 1) * W2 + (dd & 1)) * C, o);
+        }
+        ds += sq; dq += qq;
+    }
+    const double S = block_sum_d(ds, red);
+    const double Q = block_sum_d(dq, red);
+    if (threadIdx.x == 0) {
+        stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 0] = S;
+        stats[((int64_t)b * GN_CHUNKS + blockIdx.y) * 2 + 1] = Q;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int64_t HW,
                                                        int C) {
@@ -1238,6 +1285,23 @@ extern "C" int vpu_groupnorm_fwd(const void* x, const float* w, const float* b, 
     DISPATCH_T(dtype, gn_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, stats, HW, C);
                gn_apply_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, stats, HW, C, eps, gelu);)
     return vpu_check_launch("vpu_groupnorm_fwd");
+}
+extern "C" int vpu_pixel_shuffle2_gn_stats(const void* in, void* out, const float* bias, double* stats, int32_t B, int32_t h,
+                                           int32_t w, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (C % 8 || !in || !out || !stats || B < 1 || h < 1 || w < 1) { vpu_set_error("pixel_shuffle2_gn_stats: C % 8, non-null pointers"); return VPU_ERR_ARG; }
+    dim3 grid(B, GN_CHUNKS);
+    DISPATCH_T(dtype, pixel_shuffle2_gn_kernel<T><<<grid, 256, 0, ST>>>((const T*)in, (T*)out, bias, stats, h, w, C);)
+    return vpu_check_launch("vpu_pixel_shuffle2_gn_stats");
+}
+extern "C" int vpu_groupnorm_apply(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                   const double* stats, int32_t B, int64_t HW, int32_t C, float eps, int32_t gelu,
+                                   int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (C % 8 || C > 4096 || (C > 2048 && C % 16)) { vpu_set_error("groupnorm: C % 8 (16 above 2048), C <= 4096"); return VPU_ERR_ARG; }
+    dim3 grid(B, GN_CHUNKS);
+    DISPATCH_T(dtype, gn_apply_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, stats, HW, C, eps, gelu);)
+    return vpu_check_launch("vpu_groupnorm_apply");
 }
 extern "C" int vpu_groupnorm_bwd(const void* dy, const void* x, const float* w, const float* b, const float* mean,
                                  const float* rstd, void* dx, float* part, double* stats, int32_t B, int64_t HW,

@@ -46,11 +46,12 @@ class Tape:
 
 class Var:
     """An activation and (lazily) its gradient."""
-    __slots__ = ("t", "g")
+    __slots__ = ("t", "g", "gn_stats")
 
     def __init__(self, t):
         self.t = t
         self.g = None
+        self.gn_stats = None      # GroupNorm(1, C) statistics partials left by the producer (conv_t2), or None
 
 
 def _rup(x, m):
@@ -726,10 +727,15 @@ class Engine:
     def groupnorm(self, x, prefix, B, HW, Cdim, gelu):
         y = Var(torch.empty_like(x.t))
         nch = ops.groupnorm_nchunk()
-        stats = self._new(B, nch, 2, dtype=torch.float64)
         mean, rstd = self._new(B, dtype=torch.float32), self._new(B, dtype=torch.float32)
-        ops.groupnorm_fwd(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, stats, B, HW,
-                          Cdim, 1e-5, gelu)
+        stats = getattr(x, "gn_stats", None)
+        if stats is not None:        # (round 4: conv_t2 left the statistics partials of its output: no statistics pass)
+            ops.groupnorm_apply(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, stats, B, HW,
+                                Cdim, 1e-5, gelu)
+        else:
+            stats = self._new(B, nch, 2, dtype=torch.float64)
+            ops.groupnorm_fwd(x.t, self.Pm(prefix + ".weight"), self.Pm(prefix + ".bias"), y.t, mean, rstd, stats, B, HW,
+                              Cdim, 1e-5, gelu)
         if self.training:
             def bwd():
                 if y.g is None:
@@ -743,13 +749,18 @@ class Engine:
             self.tape.append(bwd)
         return y
 
-    def conv_t2(self, x, prefix, B, h, w, Cin, Cout):
-        """ConvTranspose2d(Cin, Cout, 2, stride=2) on channels-last tokens = GEMM + depth-to-space."""
+    def conv_t2(self, x, prefix, B, h, w, Cin, Cout, gn_next=False):
+        """ConvTranspose2d(Cin, Cout, 2, stride=2) on channels-last tokens = GEMM + depth-to-space.  ``gn_next``: a
+        GroupNorm(1, C) follows -- its statistics partials come out of the depth-to-space pass (y.gn_stats)."""
         M = B * h * w
         t = self._new(M, 4 * Cout)
         ops.gemm(x.t, self.W(prefix + ".weight"), t, M, 4 * Cout, Cin, Cin, 4 * Cout, 4 * Cout, self.dt, transB=True)
         y = Var(self._new(B * 4 * h * w, Cout))
-        ops.pixel_shuffle2(t, y.t, self.Pm(prefix + ".bias"), B, h, w, Cout)
+        if gn_next and Cout % 8 == 0:
+            y.gn_stats = self._new(B, ops.groupnorm_nchunk(), 2, dtype=torch.float64)
+            ops.pixel_shuffle2_gn_stats(t, y.t, self.Pm(prefix + ".bias"), y.gn_stats, B, h, w, Cout)
+        else:
+            ops.pixel_shuffle2(t, y.t, self.Pm(prefix + ".bias"), B, h, w, Cout)
         del t
         if self.training:
             def bwd():
@@ -998,14 +1009,14 @@ class Engine:
         # FPN branches (is_vpu_model.py:55-86), channels-last
         o = self.out_dims
         c4 = max(o[0] * 2, D // 2)
-        a = self.conv_t2(maps[0], "neck.down_4.0", B, g, g, D, c4)
+        a = self.conv_t2(maps[0], "neck.down_4.0", B, g, g, D, c4, gn_next=True)
         a = self.groupnorm(a, "neck.down_4.1", B, 4 * NT, c4, True)
-        a = self.conv_t2(a, "neck.down_4.3", B, 2 * g, 2 * g, c4, c4 // 2)
+        a = self.conv_t2(a, "neck.down_4.3", B, 2 * g, 2 * g, c4, c4 // 2, gn_next=True)
         a = self.groupnorm(a, "neck.down_4.4", B, 16 * NT, c4 // 2, False)
         a = self.linear(a, "neck.down_4.5.weight", "neck.down_4.5.bias", B * 16 * NT, o[0], c4 // 2)
         d4 = self.groupnorm(a, "neck.down_4.6", B, 16 * NT, o[0], True)
         c8 = max(o[1], D // 2)
-        a = self.conv_t2(maps[1], "neck.down_8.0", B, g, g, D, c8)
+        a = self.conv_t2(maps[1], "neck.down_8.0", B, g, g, D, c8, gn_next=True)
         a = self.groupnorm(a, "neck.down_8.1", B, 4 * NT, c8, False)
         a = self.linear(a, "neck.down_8.2.weight", "neck.down_8.2.bias", B * 4 * NT, o[1], c8)
         d8 = self.groupnorm(a, "neck.down_8.3", B, 4 * NT, o[1], True)

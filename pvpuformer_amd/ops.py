@@ -405,6 +405,17 @@ def pixel_shuffle2(src, dst, bias, B, h, w, Cdim, inverse=False):
               _stream())
 
 
+def pixel_shuffle2_gn_stats(src, dst, bias, stats, B, h, w, Cdim):
+    """pixel_shuffle2 (depth-to-space + bias) that also leaves GroupNorm(1, C)'s statistics partials of its output in
+    ``stats`` (float64 [B, groupnorm_nchunk(), 2]): groupnorm_apply then normalises without a statistics pass."""
+    _lib.call("vpu_pixel_shuffle2_gn_stats", ptr(src), ptr(dst), ptr(bias), ptr(stats), B, h, w, Cdim, code_of(src), _stream())
+
+
+def groupnorm_apply(x, w, b, y, mean, rstd, stats, B, HW, Cdim, eps, gelu):
+    _lib.call("vpu_groupnorm_apply", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), ptr(stats), B, HW, Cdim, eps,
+              int(gelu), code_of(x), _stream())
+
+
 def pixel_unshuffle2_sums(src, dst, B, h, w, Cdim):
     """dst = depth-to-space^-1(src) as pixel_shuffle2(inverse=True), plus the per-channel partial sums of src (the transposed
     convolution's bias gradient): returns (part fp32 [nblk, Cdim], nblk) for a batched column sum."""

@@ -1815,3 +1815,31 @@ def test_gemm_k2_grouped_forward_forms(ops, tB):
         refs[2] = refs[2].clamp_min(0)
         for (args, _), ref in zip(probs, refs):
             assert torch.equal(args[2].float().cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pixel_shuffle2_gn_stats(ops, dtype):
+    """vpu_pixel_shuffle2_gn_stats + vpu_groupnorm_apply == vpu_pixel_shuffle2 + vpu_groupnorm_fwd: the same map bit for bit,
+    the same mean / rstd / normalised output up to the summation order of the statistics (float64 partials)."""
+    B, h, w, C = 3, 9, 11, 48
+    g = torch.Generator().manual_seed(4)
+    t = (torch.randn(B * h * w, 4 * C, generator=g)).cuda().to(dtype)
+    bias = torch.randn(C, generator=g).cuda()
+    gw, gb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    HW = 4 * h * w
+    nch = ops.groupnorm_nchunk()
+    y0 = torch.empty(B * HW, C, device="cuda", dtype=dtype)
+    ops.pixel_shuffle2(t, y0, bias, B, h, w, C)
+    o0, m0, r0 = torch.empty_like(y0), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    st0 = torch.empty(B, nch, 2, device="cuda", dtype=torch.float64)
+    ops.groupnorm_fwd(y0, gw, gb, o0, m0, r0, st0, B, HW, C, 1e-5, True)
+    y1 = torch.full_like(y0, 3.0)
+    st1 = torch.empty(B, nch, 2, device="cuda", dtype=torch.float64)
+    ops.pixel_shuffle2_gn_stats(t, y1, bias, st1, B, h, w, C)
+    o1, m1, r1 = torch.empty_like(y0), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    ops.groupnorm_apply(y1, gw, gb, o1, m1, r1, st1, B, HW, C, 1e-5, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0)
+    assert torch.allclose(st1.sum(1), st0.sum(1), rtol=1e-6, atol=1e-4)      # (fp32 partials of 32 values against 8, then float64)
+    assert torch.allclose(m1, m0, rtol=1e-6, atol=1e-7) and torch.allclose(r1, r0, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(o1.float(), o0.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
