@@ -233,9 +233,11 @@ int vpu_pue_encode(const float* points, const int32_t* boxes, const float* lut, 
  * one-hot 0 (is_vpu_model.py:294-352); a sample without a valid positive click keeps its rows.  The profiles come from the
  * host (GaussianVector_scribble, ops.py:244-296, draws from Python's `random` while deleting points: sequential by
  * construction).  out / out64 / ld as in vpu_pue_encode.
- * vpu_draw_polyline: ISModel.draw_scribble (is_model.py:123-146): the open poly-line through curve[b][0..P) (int32 x, y)
- * with thickness 3 is OR-ed into the positive channel of disks [B][2][H][W]; a pixel is set iff its squared distance to a
- * segment is <= 1 (cv2.polylines itself is not available to pin against). */
+ * vpu_draw_polyline: ISModel.draw_scribble (is_model.py:123-146): cv2.polylines(image, [curve], False, 255, 3) -- the open
+ * poly-line through curve[b][0..P) (int32 x, y), thickness 3, LINE_8 -- OR-ed into the positive channel of disks
+ * [B][2][H][W].  OpenCV's algorithm restated (modules/imgproc/src/drawing.cpp: PolyLine -> ThickLine -> FillConvexPoly +
+ * Line2 + Circle; oracle/vpu_oracle.py holds the same restatement in numpy, equal bit for bit); real cv2 is not available
+ * to pin it against. */
 int vpu_pue_scribble_rows(const float* points, const double* vec, void* out, double* out64, int32_t B, int32_t n,
                           int32_t num_max, int32_t img, int32_t ld, int32_t dtype, void* stream);
 int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, int32_t P, int32_t H, int32_t W, void* stream);
@@ -279,8 +281,9 @@ int vpu_cc_roots(const uint8_t* mask, int32_t* roots, int32_t B, int32_t H, int3
 int vpu_cc_table(const int32_t* roots, int32_t* slots, int32_t* table, int32_t kmax, int32_t B, int32_t H, int32_t W,
                  void* stream);
 
-/* DistMaps disks (ops.py:347-379, use_disks, spatial_scale 1) + optional draw_box outline (is_model.py:97-121).
- * out fp32 [B][2][H][W] in {0,1}. */
+/* DistMaps disks (ops.py:347-379, use_disks, spatial_scale 1) + optional draw_box outline (is_model.py:97-121:
+ * cv2.rectangle((x0, y0), (x1, y1), 255, 3) = the closed 4-segment poly-line through the same restated ThickLine as
+ * vpu_draw_polyline, into channel 0 (slot < n) or 1).  out fp32 [B][2][H][W] in {0,1}. */
 int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t B, int32_t n, int32_t H, int32_t W,
                   float radius, void* stream);
 
@@ -289,6 +292,10 @@ int vpu_disk_maps(const float* points, const int32_t* boxes, float* out, int32_t
  * (models_vit.py:225-239 folded into addressing).  image4 fp32 [B][4][H][W]; disks fp32 [B][2][H][W]. */
 int vpu_patch_im2col(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W, int32_t P,
                      int32_t win_tokens, int32_t dtype, void* stream);
+/* The same with the rgb planes of image4 normalised ALREADY: the public backbone_forward(image, coord_features, ...) of the
+ * reference (is_vpu_model.py:383-419) receives what ISModel.prepare_input returned. */
+int vpu_patch_im2col_prenorm(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W, int32_t P,
+                             int32_t win_tokens, int32_t dtype, void* stream);
 /* token re-ordering between window order and raster order; dir=0: raster->window, 1: window->raster.
  * x,y [B][g*g][C] */
 int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, int32_t wg, int32_t C, int32_t dir, int32_t dtype,

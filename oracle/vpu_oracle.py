@@ -377,49 +377,247 @@ def disk_maps(points, H, W, radius=5):
     return out
 
 
+# ---- OpenCV's thick-line drawing, restated (a3) ------------------------------------------------------------------------------
+# ISModel.draw_box / draw_scribble (is_model.py:97-146) call cv2.rectangle(..., 3) and cv2.polylines(..., False, ..., 3) on a
+# uint8 single-channel canvas with the default LINE_8 / shift 0.  OpenCV 4.7.0 (requirements.txt:88) is not installable here,
+# so the functions below RESTATE its algorithm from modules/imgproc/src/drawing.cpp, function for function: rectangle ->
+# PolyLine(closed) ; polylines -> PolyLine ; PolyLine -> ThickLine per segment (end-cap flags 3 for the first segment of an
+# open poly-line, 2 for every other one) ; ThickLine (thickness > 1) = FillConvexPoly of the quadrilateral p +- dp, dp = the
+# perpendicular of length (thickness * 2^15 + odd * 2^15) / |p1 - p0| in 16.16 fixed point (cvRound of doubles), plus a filled
+# Circle of radius (thickness * 2^15 + 2^15) >> 16 at the flagged ends ; FillConvexPoly = the outline through Line2 (16.16
+# DDA, end point first) plus the two-edge scan conversion with its +2^15 rounding ; clipLine as Line2 uses it.
+# PARITY UNPINNED against real cv2 (no fixture of the reference's holds a drawn outline): restated from the algorithm as
+# published, integer for integer; what IS pinned is HIP == these functions bit for bit, and every downstream tensor of the
+# box / scribble modes through them (tests/golden/tiny*.npz, vitl.npz).
+_XY_SHIFT = 16
+_XY_ONE = 1 << _XY_SHIFT
+
+
+def _cdiv(a, b):
+    """C++ int64 division (truncation toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def _cv_round(x):
+    """cvRound(double): round half to even (lrint under the default rounding mode)."""
+    return int(np.rint(np.float64(x)))
+
+
+def _cv_clip_line(width, height, p1, p2):
+    """clipLine(Size2l, Point2l&, Point2l&) (drawing.cpp): Cohen-Sutherland with the intersections through doubles truncated
+    to int64.  Returns (visible, p1, p2)."""
+    x1, y1 = p1
+    x2, y2 = p2
+    right, bottom = width - 1, height - 1
+    if width <= 0 or height <= 0:
+        return False, p1, p2
+    c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8
+    c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8
+    if (c1 & c2) == 0 and (c1 | c2) != 0:
+        if c1 & 12:
+            a = 0 if c1 < 8 else bottom
+            x1 += int(np.float64(a - y1) * np.float64(x2 - x1) / np.float64(y2 - y1))
+            y1 = a
+            c1 = (x1 < 0) + (x1 > right) * 2
+        if c2 & 12:
+            a = 0 if c2 < 8 else bottom
+            x2 += int(np.float64(a - y2) * np.float64(x2 - x1) / np.float64(y2 - y1))
+            y2 = a
+            c2 = (x2 < 0) + (x2 > right) * 2
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1:
+                a = 0 if c1 == 1 else right
+                y1 += int(np.float64(a - x1) * np.float64(y2 - y1) / np.float64(x2 - x1))
+                x1 = a
+                c1 = 0
+            if c2:
+                a = 0 if c2 == 1 else right
+                y2 += int(np.float64(a - x2) * np.float64(y2 - y1) / np.float64(x2 - x1))
+                x2 = a
+                c2 = 0
+    return (c1 | c2) == 0, (x1, y1), (x2, y2)
+
+
+def _cv_line2(img, p1, p2):
+    """Line2 (drawing.cpp): a line between two 16.16 points as a fixed-point DDA along the major axis, the rounded END point
+    first.  img: bool [H, W]."""
+    H, W = img.shape
+    ok, (x1, y1), (x2, y2) = _cv_clip_line(W << _XY_SHIFT, H << _XY_SHIFT, p1, p2)
+    if not ok:
+        return
+
+    def put(x, y):
+        if 0 <= x < W and 0 <= y < H:
+            img[y, x] = True
+    dx, dy = x2 - x1, y2 - y1
+    ax, ay = abs(dx), abs(dy)
+    if ax > ay:
+        if dx < 0:
+            x1, x2, y1, y2, dy = x2, x1, y2, y1, -dy
+        y_step = _cdiv(dy << _XY_SHIFT, ax | 1)
+        ecount = (x2 - x1) >> _XY_SHIFT
+    else:
+        if dy < 0:
+            x1, x2, y1, y2, dx = x2, x1, y2, y1, -dx
+        x_step = _cdiv(dx << _XY_SHIFT, ay | 1)
+        ecount = (y2 - y1) >> _XY_SHIFT
+    x1 += _XY_ONE >> 1
+    y1 += _XY_ONE >> 1
+    put((x2 + (_XY_ONE >> 1)) >> _XY_SHIFT, (y2 + (_XY_ONE >> 1)) >> _XY_SHIFT)
+    if ax > ay:
+        x = x1 >> _XY_SHIFT
+        for k in range(ecount + 1):
+            put(x + k, (y1 + k * y_step) >> _XY_SHIFT)
+    else:
+        y = y1 >> _XY_SHIFT
+        for k in range(ecount + 1):
+            put((x1 + k * x_step) >> _XY_SHIFT, y + k)
+
+
+def _cv_fill_convex_poly(img, v):
+    """FillConvexPoly(img, v, npts, color, LINE_8, shift = XY_SHIFT) (drawing.cpp): the outline edge by edge through Line2, then
+    the scan conversion between a left-going and a right-going edge walker started at the top-most vertex.  v: 16.16 points."""
+    H, W = img.shape
+    npts, shift = len(v), _XY_SHIFT
+    delta = (1 << shift) >> 1
+    delta1 = delta2 = _XY_ONE >> 1
+    xmin = xmax = v[0][0]
+    ymin = ymax = v[0][1]
+    imin = 0
+    p0 = v[-1]
+    for i, p in enumerate(v):
+        if p[1] < ymin:
+            ymin, imin = p[1], i
+        ymax, xmax, xmin = max(ymax, p[1]), max(xmax, p[0]), min(xmin, p[0])
+        _cv_line2(img, p0, p)
+        p0 = p
+    xmin, xmax = (xmin + delta) >> shift, (xmax + delta) >> shift
+    ymin, ymax = (ymin + delta) >> shift, (ymax + delta) >> shift
+    if npts < 3 or xmax < 0 or ymax < 0 or xmin >= W or ymin >= H:
+        return
+    ymax = min(ymax, H - 1)
+    e_idx, e_di = [imin, imin], [1, npts - 1]
+    e_ye, e_x, e_dx = [ymin, ymin], [-_XY_ONE, -_XY_ONE], [0, 0]
+    edges, y = npts, ymin
+    while True:
+        for i in range(2):
+            if y >= e_ye[i]:
+                idx0, di = e_idx[i], e_di[i]
+                idx = idx0 + di
+                if idx >= npts:
+                    idx -= npts
+                while True:
+                    edges -= 1
+                    if not edges + 1 > 0:         # for (; edges-- > 0; )
+                        break
+                    ty = (v[idx][1] + delta) >> shift
+                    if ty > y:
+                        xs, xe = v[idx0][0], v[idx][0]
+                        e_ye[i] = ty
+                        e_dx[i] = _cdiv((xe - xs) * 2 + (ty - y), 2 * (ty - y))
+                        e_x[i] = xs
+                        e_idx[i] = idx
+                        break
+                    idx0 = idx
+                    idx += di
+                    if idx >= npts:
+                        idx -= npts
+        if edges < 0:
+            break
+        if y >= 0:
+            left, right = (1, 0) if e_x[0] > e_x[1] else (0, 1)
+            xx1 = (e_x[left] + delta1) >> _XY_SHIFT
+            xx2 = (e_x[right] + delta2) >> _XY_SHIFT
+            if xx2 >= 0 and xx1 < W:
+                img[y, max(xx1, 0):min(xx2, W - 1) + 1] = True
+        e_x[0] += e_dx[0]
+        e_x[1] += e_dx[1]
+        y += 1
+        if not y <= ymax:
+            break
+
+
+def _cv_circle_fill(img, cx, cy, radius):
+    """Circle(img, center, radius, color, fill = 1) (drawing.cpp): the midpoint circle's horizontal spans, clipped."""
+    H, W = img.shape
+    err, dx, dy, plus, minus = 0, radius, 0, 1, (radius << 1) - 1
+
+    def hline(y, xa, xb):
+        if 0 <= y < H and xb >= 0 and xa < W:
+            img[y, max(xa, 0):min(xb, W - 1) + 1] = True
+    while dx >= dy:
+        hline(cy - dy, cx - dx, cx + dx)
+        hline(cy + dy, cx - dx, cx + dx)
+        hline(cy - dx, cx - dy, cx + dy)
+        hline(cy + dx, cx - dy, cx + dy)
+        dy += 1
+        err += plus
+        plus += 2
+        if err > 0:             # mask = (err <= 0) - 1
+            err -= minus
+            dx -= 1
+            minus -= 2
+
+
+def _cv_thick_line(img, p0, p1, thickness, flags):
+    """ThickLine(img, p0, p1, color, thickness > 1, LINE_8, flags, shift = 0) (drawing.cpp).  flags bit 0 / 1: end cap at p0 / p1."""
+    assert thickness > 1
+    p0 = (int(p0[0]) << _XY_SHIFT, int(p0[1]) << _XY_SHIFT)
+    p1 = (int(p1[0]) << _XY_SHIFT, int(p1[1]) << _XY_SHIFT)
+    inv = np.float64(1.0 / _XY_ONE)
+    dx, dy = np.float64(p0[0] - p1[0]) * inv, np.float64(p1[1] - p0[1]) * inv
+    r = dx * dx + dy * dy
+    odd = thickness & 1
+    th = thickness << (_XY_SHIFT - 1)
+    if abs(r) > np.finfo(np.float64).eps:
+        r = np.float64(th + odd * _XY_ONE * 0.5) / np.sqrt(r)
+        dpx, dpy = _cv_round(dy * r), _cv_round(dx * r)
+        _cv_fill_convex_poly(img, [(p0[0] + dpx, p0[1] + dpy), (p0[0] - dpx, p0[1] - dpy),
+                                   (p1[0] - dpx, p1[1] - dpy), (p1[0] + dpx, p1[1] + dpy)])
+    for i, p in enumerate((p0, p1)):
+        if flags & (i + 1):
+            _cv_circle_fill(img, (p[0] + (_XY_ONE >> 1)) >> _XY_SHIFT, (p[1] + (_XY_ONE >> 1)) >> _XY_SHIFT,
+                            (th + (_XY_ONE >> 1)) >> _XY_SHIFT)
+
+
+def cv_polyline_mask(H, W, pts, closed, thickness=3):
+    """PolyLine(img, v, count, is_closed, color, thickness, LINE_8, 0) (drawing.cpp) on an empty [H, W] canvas -> bool mask of
+    the pixels it sets.  pts: integer (x, y) pairs."""
+    img = np.zeros((H, W), bool)
+    pts = [(int(x), int(y)) for x, y in pts]
+    if not pts:
+        return img
+    i = len(pts) - 1 if closed else 0
+    flags = 2 + (0 if closed else 1)
+    p0 = pts[i]
+    for p in pts[(0 if closed else 1):]:
+        _cv_thick_line(img, p0, p, thickness, flags)
+        p0, flags = p, 2
+    return img
+
+
 def box_outline(canvas, box, n_points, thickness=3):
-    """ISModel.draw_box (is_model.py:97-121): 3-px rectangle outline OR-ed into channel
-    0 (slot < n) or 1.  PARITY UNPINNED: the reference calls cv2.rectangle, absent here; this
-    rasteriser marks every pixel within (thickness-1)/2 (Chebyshev) of the outline."""
+    """ISModel.draw_box (is_model.py:97-121): cv2.rectangle((x0, y0), (x1, y1), 255, 3) = the closed 4-segment poly-line
+    (x0,y0) (x1,y0) (x1,y1) (x0,y1) OR-ed into channel 0 (slot < n) or 1, through the restated ThickLine above."""
     xc, yc, w, h, slot = [int(v) for v in box]
     ch = 0 if slot < n_points else 1
     x0, x1, y0, y1 = xc - w // 2, xc + w // 2, yc - h // 2, yc + h // 2
-    t = (thickness - 1) // 2
     H, W = canvas.shape[-2:]
-    ys = np.arange(H)[:, None]
-    xs = np.arange(W)[None, :]
-    inside_outer = (xs >= x0 - t) & (xs <= x1 + t) & (ys >= y0 - t) & (ys <= y1 + t)
-    inside_inner = (xs > x0 + t) & (xs < x1 - t) & (ys > y0 + t) & (ys < y1 - t)
-    band = inside_outer & ~inside_inner
+    band = cv_polyline_mask(H, W, [(x0, y0), (x1, y0), (x1, y1), (x0, y1)], True, thickness)
     # the reference round-trips the channel through uint8 (x.astype(int)*255 // 255): identity on {0,1}
     canvas[ch] = np.where(band, np.float32(1.0), canvas[ch])
     return canvas
 
 
 def polyline_raster(canvas, curve, thickness=3):
-    """ISModel.draw_scribble (is_model.py:123-146): an open poly-line of thickness 3 through the int32-truncated scribble
-    points, OR-ed into channel 0 (always the positive channel).  PARITY UNPINNED like the box outline: the reference calls
-    cv2.polylines, absent here.  Rule of this rasteriser (exact integer arithmetic, shared with the HIP kernel): a pixel is
-    set iff its squared Euclidean distance to one of the segments is <= ((thickness - 1) / 2)^2 = 1: for a pixel whose
-    projection falls inside the segment cross^2 <= len^2, otherwise the nearer end point within distance 1."""
+    """ISModel.draw_scribble (is_model.py:123-146): cv2.polylines(image, [curve], False, 255, 3) -- the open poly-line
+    through the int32-truncated scribble points, OR-ed into channel 0 (always the positive channel) -- through the restated
+    ThickLine above (a one-point curve draws nothing: PolyLine's loop starts at the second point)."""
     pts = np.asarray(curve)
     pts = np.column_stack((pts[:, 0].astype(np.int32), pts[:, 1].astype(np.int32))).astype(np.int64)
-    r2 = ((thickness - 1) // 2) ** 2
     H, W = canvas.shape[-2:]
-    ys, xs = np.mgrid[0:H, 0:W].astype(np.int64)
-    hit = np.zeros((H, W), bool)
-    for (x0, y0), (x1, y1) in zip(pts[:-1], pts[1:]):
-        dx, dy = x1 - x0, y1 - y0
-        px, py = xs - x0, ys - y0
-        L2 = dx * dx + dy * dy
-        dot = px * dx + py * dy
-        cross = px * dy - py * dx
-        inside = (L2 > 0) & (dot >= 0) & (dot <= L2) & (cross * cross <= r2 * L2)   # (a repeated point is its end disks only)
-        e0 = px * px + py * py <= r2
-        e1 = (xs - x1) ** 2 + (ys - y1) ** 2 <= r2
-        hit |= inside | e0 | e1
-    if len(pts) == 1:
-        hit |= (xs - pts[0, 0]) ** 2 + (ys - pts[0, 1]) ** 2 <= r2
+    hit = cv_polyline_mask(H, W, pts, False, thickness)
     canvas[0] = np.where(hit, np.float32(1.0), canvas[0])
     return canvas
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vpu_error_masks": [_P, _P, _P, _P, _I, _I, _P],
     "vpu_disk_maps": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpu_patch_im2col": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_patch_im2col_prenorm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_window_permute": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_pixel_shuffle2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpu_pixel_shuffle2_gn_stats": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

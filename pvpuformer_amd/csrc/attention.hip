@@ -1182,6 +1182,302 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass backward, several per CU
+// Round 5.  The kernel above holds a whole (window, head) problem in 132 KB of LDS and 210 registers: ONE workgroup per CU,
+// two waves per SIMD, and 576 problems on 256 CUs are 2.25 rounds -- the third one a quarter full; inside a round nothing
+// overlaps a workgroup's 6.4-us prologue or the latencies of its loop (LDS read -> MFMA -> exp -> LDS write -> barrier ->
+// LDS read -> MFMA).  This form trades LDS traffic for occupancy: a 256-thread workgroup that needs 37 KB of LDS and < 128
+// registers, FOUR per CU, so that all 576 problems of a ViT-B window block are resident at once (1024 slots) and a SIMD
+// always has another problem's wave to issue from:
+//   * the keys are walked in PASSES of 4 NU tiles of 16 (NU per wave: K / V fragments and the dK / dV accumulators of one
+//     tile are 48 registers); a pass streams every 32-query block of Q and dO through a three-stage ring of 8-KB stages
+//     filled by LDS-DMA (no staging registers; rows >= n arrive as zeros), two steps ahead, and the ring runs on across the
+//     pass boundaries -- the price: Q / dO are read from LDS once per pass instead of once;
+//   * per step exactly as above: S and dP once, P / dS in the accumulator layout are the operands of dV / dK, dS goes
+//     through a [key][32 queries] image for dQ (new swizzle: conflict-free for the 16-lane write groups and the 32-lane
+//     transposing-read halves; the old image cost 2.45 M bank-conflict cycles per launch); ONE barrier per step, none
+//     between passes (a wave's K / V fragments and its K^T operand of the dQ product come straight from global memory);
+//   * dQ, dK and dV are computed TRANSPOSED (swapped MFMA operands: the same registers), so a lane owns four consecutive
+//     columns of one row: 8-byte stores; the dQ of a later pass adds to what the earlier ones stored (same thread, same
+//     address: read back as the MFMA's C operand -- one more bf16 rounding of the partial sum per pass);
+//   * delta = rowsum(dO * O) and -lse come in through registers in the prologue (every load in flight at once).
+constexpr int WP_NST = 5;                                   // Q / dO ring stages: a block is requested WP_NST - 2 steps before its first read
+constexpr int WP_BLK = CH * 64 * 2;                         // one [32][64] bf16 block image: 4 KB
+constexpr int WP_STAGE = 2 * WP_BLK;                        // Q block | dO block
+template <int NU> struct WpCfg {
+    static constexpr int SROWS = 64 * NU + 16;              // dS image rows: the pass's keys + 16 spare rows (unowned slots write there)
+    static constexpr int SBUF = SROWS * 64;
+    static constexpr int LDS = WP_NST * WP_STAGE + 2 * SBUF + 2 * WIN_ROWS * 4;      // NU = 1: 40960 + 10240 + 2048 = 53248: three per CU
+};
+
+// dS image [key][32 queries]: 64-byte rows of eight 8-byte units.  unit ^= {bit 2: row bit 2, bit 1: row bit 3, bit 0: row bit
+// 1}: the 16 consecutive rows of a ds_write_b64 lane group fill 16 distinct 8-byte slots of the 128-byte bank row, the 8
+// consecutive rows x 4 units of a ds_read_b64_tr_b16 half fill the 256-byte bank row exactly once.
+__device__ __forceinline__ int ds_swz(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
+// [query][32 keys] fragment (k order permuted as frag_tr_perm's) out of the image: queries 16 t .. 16 t + 15
+__device__ __forceinline__ bf16x8_t frag_ds(const char* lds, int t, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int r0 = 4 * g + q, u = ((t * 4 + p) ^ ds_swz(r0)) << 3;     // (rows r0 and 16 + r0 share the swizzle)
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + r0 * 64 + u));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + (16 + r0) * 64 + u));
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// frag_rc_tr as an ext-vector load (through HIP's uint4 struct the load carries TBAA info, and hipcc then puts s_waitcnt
+// vmcnt(0) in front of it while an LDS-DMA is pending)
+__device__ __forceinline__ bf16x8_t frag_rc_trv(const char* lds, int row16, int ks, int lane) {
+    const u32x4v v = *reinterpret_cast<const u32x4v*>(lds + tr_off<64>(row16 + (lane & 15), 2 * (ks * 4 + (lane >> 4))));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+typedef __attribute__((address_space(3))) void* lds_vptr3;
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+// rows [r0 + 8 piece, + 8) x 64 columns of a [*, ld] matrix -> 1 KB of a transposing-read image by ONE LDS-DMA instruction of
+// this wave (lane -> row r0 + 8 piece + lane / 8, LDS chunk lane % 8 <- the source chunk the image's swizzle puts there)
+__device__ __forceinline__ void wp_dma_rows(__amdgpu_buffer_rsrc_t rs, int ld, int r0, int n, char* img, int piece, int lane) {
+    const int rl = piece * 8 + (lane >> 3), row = r0 + rl;
+    const int chunk = (lane & 7) ^ (((rl >> 1) & 3) << 1);
+    const int voff = row < n ? (row * ld + chunk * 8) * 2 : (int)0x80000000;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr3)(img + piece * 1024), 16, voff, 0, 0, 0);
+}
+
+template <int NU> struct WpAcc { f32x4_t dk[NU][4], dv[NU][4]; };
+
+// One step = one 32-query block of one pass.  `wr` (the stage the DMA of step + WP_NST - 1 goes to), `rd` (this step's stage)
+// and `sS` (this step's dS image) are __restrict__ parameters of an inlined function on purpose: the scoped no-alias
+// information is what keeps hipcc from putting s_waitcnt vmcnt(0) in front of every LDS read that follows the DMA in program
+// order.  `dqr`: this block's dQ^T tile of the wave (bf16, in registers across the passes).
+template <int NU>
+__device__ __forceinline__ void wp_step(const AttnArgs& a, __amdgpu_buffer_rsrc_t rsQ, __amdgpu_buffer_rsrc_t rsG, char* __restrict__ wr,
+                                        const char* __restrict__ rd, char* __restrict__ sS, const float* __restrict__ ldsL,
+                                        const float* __restrict__ ldsD, int qc, int qcn, int nn, bool first_pass, int nkb,
+                                        const bf16x8_t (&kf)[NU][2], const bf16x8_t (&vf)[NU][2], const bf16x8_t (&ktf)[2 * NU],
+                                        const int (&srow)[NU], const int (&sswz)[NU], WpAcc<NU>& acc, bf16x4v (&dqr)[2],
+                                        int wave, int lane, float sc2) {
+    constexpr int HD = 64, KS = 2, DT = 4;
+    const int g = lane >> 4;
+    const char* sQ = rd;
+    const char* sO = rd + WP_BLK;
+    bf16x8_t pf[NU], dsf[NU];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x4_t nl2 = *reinterpret_cast<const f32x4_t*>(ldsL + qc + 16 * t + 4 * g);
+        const f32x4_t nds = *reinterpret_cast<const f32x4_t*>(ldsD + qc + 16 * t + 4 * g);
+        f32x4_t s[NU], dp[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t qfr = frag_rc_trv(sQ, 16 * t, ks, lane), ofr = frag_rc_trv(sO, 16 * t, ks, lane);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], s[u], 0, 0, 0);
+                dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[u][ks], dp[u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            bf16x4v w4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // element [query = qc + 16 t + 4 g + r][key = the slot's tile, column lane & 15]
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sc2, nl2[r]));
+                const float ds = p * __builtin_fmaf(dp[u][r], a.scale, nds[r]);
+                pf[u][4 * t + r] = (bf16_t)p;
+                w4[r] = (bf16_t)ds;
+                dsf[u][4 * t + r] = w4[r];
+            }
+            *reinterpret_cast<bf16x4v*>(sS + srow[u] + (((4 * t + g) ^ sswz[u]) << 3)) = w4;
+        }
+    }
+    // my pieces of step + 1 have landed (requested WP_NST - 2 steps ago; the WP_NST - 3 younger requests -- two DMA instructions per
+    // step, real or out of range -- stay in flight), my dS units are written; then everybody's
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (WP_NST - 3)) : "memory");
+    // step + WP_NST - 1 -> the stage step - 1 used (everybody is past its last read: they all passed phase A of this step); past the
+    // end of the problem the request is out of range: zeros, no memory traffic, the same count
+    wp_dma_rows(rsQ, a.ldq, qcn, nn, wr, wave, lane);
+    wp_dma_rows(rsG, a.ldo, qcn, nn, wr + WP_BLK, wave, lane);
+    // dV^T += dO^T P, dK^T += Q^T dS (transposed products: swapped operands): [d = 16 dt + 4 g + r][key = lane & 15]
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8_t otf = frag_tr_perm<HD>(sO, dt, lane), qtf = frag_tr_perm<HD>(sQ, dt, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            acc.dv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[u], acc.dv[u][dt], 0, 0, 0);
+            acc.dk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[u], acc.dk[u][dt], 0, 0, 0);
+        }
+    }
+    // dQ^T tile [d = 16 wave + 4 g + r][query = qc + 16 t + (lane & 15)] over the pass's keys, on top of the earlier passes'
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x4_t dq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq[r] = first_pass ? 0.f : (float)dqr[t][r];
+#pragma unroll
+        for (int kb = 0; kb < 2 * NU; ++kb)
+            if (kb < nkb) dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kb], frag_ds(sS + kb * 32 * 64, t, lane), dq, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dqr[t][r] = (bf16_t)dq[r];
+    }
+}
+
+// K / V fragments of a wave's tile(s) of a pass, and the K^T operand of its dQ columns over the pass's keys: straight from global
+// memory (no LDS image, no barrier); rows >= n are zeros
+template <int NU>
+__device__ __forceinline__ void wp_pass_kv(const bf16_t* k, const bf16_t* v, int ldk, int tbase, int ntile, int n, int wave, int lane,
+                                           bf16x8_t (&kf)[NU][2], bf16x8_t (&vf)[NU][2]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int slot = NU * wave + u;
+        const int key0 = slot < ntile ? (tbase + slot) * 16 : n;          // (an unowned slot reads nothing)
+        load_rows_as_bn<2>(k, ldk, key0, n, lane, kf[u], 64);
+        load_rows_as_bn<2>(v, ldk, key0, n, lane, vf[u], 64);
+    }
+}
+template <int NU>
+__device__ __forceinline__ void wp_pass_kt(__amdgpu_buffer_rsrc_t rsK, int ldk, int tbase, int n, int wave, int lane, bf16x8_t (&ktf)[2 * NU]) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int kb = 0; kb < 2 * NU; ++kb) {
+        // lane (g, c): K[key = 16 tbase + 32 kb + {4 g + j, 16 + 4 g + j}][column 16 wave + c], j = 0..3
+        s16x8_t kk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = tbase * 16 + 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+            kk[j] = __builtin_amdgcn_raw_buffer_load_b16(rsK, key < n ? (key * ldk + 16 * wave + c) * 2 : (int)0x80000000, 0, 0);
+        }
+        ktf[kb] = __builtin_bit_cast(bf16x8_t, kk);
+    }
+}
+
+template <int NU>
+__global__ __launch_bounds__(256, NU == 1 ? 3 : 2) void attn_bwd_winp_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KS = 2, DT = 4, TP = 4 * NU;     // tiles per pass
+    typedef WpCfg<NU> Cf;
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    char* const ring = wlds;
+    char* const ldsS = wlds + WP_NST * WP_STAGE;
+    float* const ldsD = reinterpret_cast<float*>(ldsS + 2 * Cf::SBUF);   // -delta * scale per query
+    float* const ldsL = ldsD + WIN_ROWS;                                 // -lse * log2 e per query
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.x, bw = bh / a.H, h = bh % a.H, n = a.nq;
+    const int64_t rb = (int64_t)bw * n;
+    const bf16_t* q = a.q + rb * a.ldq + h * HD;
+    const bf16_t* k = a.k + rb * a.ldk + h * HD;
+    const bf16_t* v = a.v + rb * a.ldk + h * HD;
+    const bf16_t* o = a.o + rb * a.ldo + h * HD;
+    const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
+    const float sc2 = a.scale * LOG2E;
+    const int NT = (n + 15) >> 4, nch = (n + CH - 1) / CH, NPS = (NT + TP - 1) / TP, total = NPS * nch;
+    const __amdgpu_buffer_rsrc_t rsQ = rows_rsrc(q, n, a.ldq, HD, 2), rsK = rows_rsrc(k, n, a.ldk, HD, 2);
+    const __amdgpu_buffer_rsrc_t rsG = rows_rsrc(d_o, n, a.ldo, HD, 2), rsO = rows_rsrc(o, n, a.ldo, HD, 2);
+    // ---- prologue: step 0 by DMA; -lse and delta = rowsum(dO * O) through registers; the first pass's operands; steps 1 .. WP_NST - 2
+    // by DMA; the dS images zeroed (a pass with an odd tile count reads the 16 rows behind its last tile: they must hold finite
+    // numbers -- their K rows are zeros)
+    wp_dma_rows(rsQ, a.ldq, 0, n, ring, wave, lane);
+    wp_dma_rows(rsG, a.ldo, 0, n, ring + WP_BLK, wave, lane);
+    bf16x8_t kf[NU][KS], vf[NU][KS], ktf[2 * NU];
+    {
+        const __amdgpu_buffer_rsrc_t rsL = rows_rsrc(reinterpret_cast<const char*>(a.lse + (int64_t)bh * n), 1, 0, n, 4);
+        const float pl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, tid * 4, 0, 0));   // (rows >= n: out of range = 0)
+        u32x4v pg[WIN_MAX_KB], po[WIN_MAX_KB];
+        const int ch = tid & 7, row0 = tid >> 3;      // piece i: row row0 + 32 i, 16-byte chunk ch
+#pragma unroll
+        for (int i = 0; i < WIN_MAX_KB; ++i) {
+            const int row = row0 + 32 * i;
+            const int off = (i < nch && row < n) ? (row * a.ldo + ch * 8) * 2 : (int)0x80000000;
+            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsG, off, 0, 0);
+            po[i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, off, 0, 0);
+        }
+        wp_pass_kv<NU>(k, v, a.ldk, 0, min(TP, NT), n, wave, lane, kf, vf);
+        wp_pass_kt<NU>(rsK, a.ldk, 0, n, wave, lane, ktf);
+#pragma unroll
+        for (int j = 1; j < WP_NST - 1; ++j) {       // step j = block j % nch of pass j / nch (out of range past the end)
+            const int bj = j % nch;
+            const int nn = j < total ? n : 0;
+            wp_dma_rows(rsQ, a.ldq, bj * CH, nn, ring + j * WP_STAGE, wave, lane);
+            wp_dma_rows(rsG, a.ldo, bj * CH, nn, ring + j * WP_STAGE + WP_BLK, wave, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < (2 * Cf::SBUF / 16 + 255) / 256; ++i)
+            if (tid + i * 256 < 2 * Cf::SBUF / 16) *reinterpret_cast<u32x4v*>(ldsS + (tid + i * 256) * 16) = (u32x4v){0u, 0u, 0u, 0u};
+        ldsL[tid] = -pl * LOG2E;
+#pragma unroll
+        for (int i = 0; i < WIN_MAX_KB; ++i) {
+            const bf16x8_t x = __builtin_bit_cast(bf16x8_t, pg[i]), y = __builtin_bit_cast(bf16x8_t, po[i]);
+            float dl = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)x[j] * (float)y[j];
+            dl += __shfl_xor(dl, 1, 64);
+            dl += __shfl_xor(dl, 2, 64);
+            dl += __shfl_xor(dl, 4, 64);
+            if (ch == 0) ldsD[row0 + 32 * i] = -dl * a.scale;
+        }
+    }
+    // (step 0 and everything requested before the last 2 (WP_NST - 2) DMA instructions have landed)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (WP_NST - 2)) : "memory");
+    bf16x4v dqr[WIN_MAX_KB][2];        // this wave's dQ^T tiles of every block: bf16 across the passes, stored once at the end
+    int st = 0, step = 0;
+    for (int ps = 0; ps < NPS; ++ps) {
+        const int tbase = TP * ps, ntile = min(TP, NT - tbase), nkb = (ntile + 1) >> 1;
+        int srow[NU], sswz[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int slot = NU * wave + u;
+            const int krow = (slot < ntile ? slot * 16 : 64 * NU) + c;        // its dS rows in the pass's image; unowned: the spare rows
+            srow[u] = krow * 64;
+            sswz[u] = ds_swz(krow);
+        }
+        WpAcc<NU> acc;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { acc.dk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc.dv[u][dt] = acc.dk[u][dt]; }
+#pragma unroll
+        for (int i = 0; i < WIN_MAX_KB; ++i) {
+            if (i < nch) {
+                const int wst = st == 0 ? WP_NST - 1 : st - 1;        // the stage of step - 1 = of step + WP_NST - 1
+                const int sn = step + WP_NST - 1;                     // the step requested now: block sn % nch (the ring runs on into the next pass)
+                wp_step<NU>(a, rsQ, rsG, ring + wst * WP_STAGE, ring + st * WP_STAGE, ldsS + (step & 1) * Cf::SBUF, ldsL, ldsD, i * CH,
+                            (sn % nch) * CH, sn < total ? n : 0, ps == 0, nkb, kf, vf, ktf, srow, sswz, acc, dqr[i], wave, lane, sc2);
+                st = st == WP_NST - 1 ? 0 : st + 1;
+                ++step;
+            }
+        }
+        // ---- dK / dV of my tile(s): lane (g, c) holds [d = 16 dt + 4 g + r][key = tile * 16 + c]; then the next pass's operands
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int slot = NU * wave + u, kk = (tbase + slot) * 16 + c;
+            if (slot < ntile && kk < n) {
+                bf16_t* kr = a.dk + (rb + kk) * a.ldgk + h * HD + 4 * g;
+                bf16_t* vr = a.dv + (rb + kk) * a.ldgk + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4v k4, v4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { k4[r] = (bf16_t)acc.dk[u][dt][r]; v4[r] = (bf16_t)acc.dv[u][dt][r]; }
+                    *reinterpret_cast<bf16x4v*>(kr + 16 * dt) = k4;
+                    *reinterpret_cast<bf16x4v*>(vr + 16 * dt) = v4;
+                }
+            }
+        }
+        if (ps + 1 < NPS) {
+            wp_pass_kv<NU>(k, v, a.ldk, tbase + TP, min(TP, NT - tbase - TP), n, wave, lane, kf, vf);
+            wp_pass_kt<NU>(rsK, a.ldk, tbase + TP, n, wave, lane, ktf);
+        }
+    }
+    // ---- dQ: lane (g, c) holds [d = 16 wave + 4 g + r][query = 32 i + 16 t + c]
+    bf16_t* const dqp = a.dq + rb * a.ldgq + h * HD + 16 * wave + 4 * g;
+#pragma unroll
+    for (int i = 0; i < WIN_MAX_KB; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qq = i * CH + 16 * t + c;
+            if (i < nch && qq < n) *reinterpret_cast<bf16x4v*>(dqp + (int64_t)qq * a.ldgq) = dqr[i][t];
+        }
+}
+
 // "lean" = 1 (default): the kernels above; 0: the round-1 step kernels (kept for A/B runs and as a second implementation in
 // the tests).  VPU_ATTN_LEAN sets the process default.
 std::atomic<int> g_opt_lean{-1}, g_opt_onepass{-1};
@@ -1189,10 +1485,10 @@ inline bool xcd_map_enabled() {   // VPU_ATTN_XCDMAP=0: the plain 2-D grid (A/B 
     static const int e0 = [] { const char* e = getenv("VPU_ATTN_XCDMAP"); return e ? atoi(e) : 1; }();
     return e0 != 0;
 }
-inline bool onepass_enabled() {   // "onepass": the one-workgroup-per-(window, head) backward for n <= 256, head dim 64
+inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backward for n <= 256, head dim 64: 2 = key passes, four workgroups per CU (round 5), 1 = one per CU, 0 = two kernels
     static const int e0 = [] { const char* e = getenv("VPU_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
     const int v = g_opt_onepass.load(std::memory_order_relaxed);
-    return (v >= 0 ? v : e0) != 0;
+    return v >= 0 ? v : e0;
 }
 inline bool wide_two() {   // two query tiles per wave also in the 128-column instantiation (head dims 80 / 96: ViT-H, the neck)
     static const int e0 = [] { const char* e = getenv("VPU_ATTN_WIDE2"); return e ? atoi(e) : 1; }();
@@ -1223,12 +1519,12 @@ extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
         g_opt_lean.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
-    if (name && !strcmp(name, "onepass") && value >= -1 && value <= 1) {
+    if (name && !strcmp(name, "onepass") && value >= -1 && value <= 2) {
         g_opt_onepass.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
     vpu_set_error("vpu_attn_set_option: known options: lean (-1 environment default VPU_ATTN_LEAN, 0 round-1 step kernels, 1 lean kernels), "
-                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems)");
+                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems with one workgroup per CU, 2 in key passes with four)");
     return VPU_ERR_ARG;
 }
 
@@ -1303,6 +1599,18 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (lean_enabled() && onepass_enabled() == 2 && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB && ldgq % 4 == 0 && ldgk % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 && (reinterpret_cast<uintptr_t>(dv) & 7) == 0) {
+        // three workgroups per CU (round 5); "onepass" = 1 selects the one-workgroup-per-CU form below
+        static VpuDevOnce attrp;
+        if (attrp.pending() && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_winp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WpCfg<1>::LDS) != hipSuccess) {
+            vpu_set_error("xattn_bwd: hipFuncSetAttribute(attn_bwd_winp_kernel<1>, dynamic LDS) failed");
+            return VPU_ERR_LAUNCH;
+        }
+        snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_winp_kernel<1>");
+        attn_bwd_winp_kernel<1><<<dim3(nb * H), 256, WpCfg<1>::LDS, s>>>(a);
+        return vpu_check_launch("vpu_xattn_bwd");
+    }
     if (lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
         static VpuDevOnce attr;
         if (attr.pending()) {

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
 #pragma unroll
         for (int iy = 0; iy < P2_SPAN; ++iy) {
             const int Y = Ya + iy;
-            if (Y < Yb) {
+            if (Y < Yb && Xa < Xb) {     // (a cell that owns no column reads nothing: grow[0] would be the NEXT row's first pixel)
                 const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
                 const float* grow = gp + (Y - Y0) * W + Xa;
                 float rx0 = 0.f, rx1 = 0.f;   // this row's gradient split over the left / right corner columns

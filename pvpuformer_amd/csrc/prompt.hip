@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void pue_encode_kernel(const float* __restrict
 
 // One thread per pixel, both polarity channels.  fp32 with separately rounded sub / mul / add (no FMA
 // contraction) so that the <= r^2 comparison is bit-exact with torch (ops.py:359-375).
-__global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict__ points, const int* __restrict__ boxes,
-                                                        float* __restrict__ out, int n, int H, int W, float r2) {
+__global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict__ points, float* __restrict__ out, int n, int H,
+                                                        int W, float r2) {
     extern __shared__ float sp[];  // [2n][2] + 2 counts
     const int b = blockIdx.y;
     int* cnt = reinterpret_cast<int*>(sp + 4 * n);
@@ -115,14 +115,6 @@ __global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict_
     if (pix >= H * W) return;
     const int r = pix / W, c = pix % W;
     const float fr = (float)r, fc = (float)c;
-    int bch = -1, x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-    if (boxes) {
-        const int* bx = boxes + b * 5;
-        bch = bx[4] < n ? 0 : 1;
-        // python floor division for the half sizes (is_model.py:107)
-        const int hw = fdiv(bx[2], 2), hh = fdiv(bx[3], 2);
-        x0 = bx[0] - hw; x1 = bx[0] + hw; y0 = bx[1] - hh; y1 = bx[1] + hh;
-    }
     for (int g = 0; g < 2; ++g) {
         float best = 1e6f;
         const int ng = cnt[g];
@@ -133,13 +125,7 @@ __global__ __launch_bounds__(256) void disk_maps_kernel(const float* __restrict_
             const float d = __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(dc, dc));
             best = fminf(best, d);
         }
-        float v = best <= r2 ? 1.f : 0.f;
-        if (g == bch) {
-            const bool outer = c >= x0 - 1 && c <= x1 + 1 && r >= y0 - 1 && r <= y1 + 1;
-            const bool inner = c > x0 + 1 && c < x1 - 1 && r > y0 + 1 && r < y1 - 1;
-            if (outer && !inner) v = 1.f;
-        }
-        out[(((int64_t)b * 2 + g) * H + r) * W + c] = v;
+        out[(((int64_t)b * 2 + g) * H + r) * W + c] = best <= r2 ? 1.f : 0.f;
     }
 }
 
@@ -181,28 +167,242 @@ __global__ __launch_bounds__(256) void pue_scribble_rows_kernel(const float* __r
     }
 }
 
-// one block per (segment, sample): the threads walk the segment's bounding box grown by one pixel
-__global__ __launch_bounds__(256) void draw_polyline_kernel(const int* __restrict__ curve, float* __restrict__ disks, int P,
-                                                            int H, int W) {
-    const int seg = blockIdx.x, b = blockIdx.y;
-    const int* c = curve + ((int64_t)b * P + seg) * 2;
-    const long long x0 = c[0], y0 = c[1];
-    const bool last = seg + 1 >= P;
-    const long long x1 = last ? x0 : c[2], y1 = last ? y0 : c[3];
-    const long long dx = x1 - x0, dy = y1 - y0, L2 = dx * dx + dy * dy;
-    const int bx0 = (int)max(min(x0, x1) - 1, 0LL), bx1 = (int)min(max(x0, x1) + 1, (long long)W - 1);
-    const int by0 = (int)max(min(y0, y1) - 1, 0LL), by1 = (int)min(max(y0, y1) + 1, (long long)H - 1);
+// ---- OpenCV's ThickLine (thickness 3, LINE_8, shift 0), one block per (segment, sample) ------------------------------------
+// cv2.rectangle / cv2.polylines with thickness 3 (is_model.py:109,129) = PolyLine -> ThickLine per segment (modules/imgproc/
+// src/drawing.cpp; restated function for function in oracle/vpu_oracle.py, which this code equals bit for bit): the filled
+// quadrilateral p +- dp (dp: the perpendicular of length 2^17 / |p1 - p0| in 16.16 fixed point, cvRound of doubles) through
+// FillConvexPoly -- its outline by Line2, its inside by the two-edge scan conversion -- plus a filled Circle of radius 2 at the
+// flagged ends.  The drawing routines are sequential; here every thread decides ONE pixel of the segment's bounding box (grown
+// by 3) with their closed forms: a DDA position is start + k * step, a scan row's edge positions are x0 + (y - y0) * dx inside
+// a PHASE (the rows between two edge set-ups; thread 0 runs the set-up state machine over the <= 5 phases of a quadrilateral).
+constexpr int TL_SHIFT = 16;
+constexpr long long TL_ONE = 1LL << TL_SHIFT;
+
+__device__ __forceinline__ long long tl_cdiv(long long a, long long b) { return a / b; }   // C++ division truncates: as OpenCV's
+
+struct TlEdge {          // Line2 after clipping and ordering
+    int ok, xmajor, ecount, ex, ey;    // ex, ey: the rounded end point (drawn first)
+    long long s0, t0, step;            // x-major: pixel (s0 + k, (t0 + k step) >> 16); y-major: ((t0 + k step) >> 16, s0 + k)
+};
+struct TlPhase { int y0, y1; long long x0, dx0, x1, dx1; };
+struct TlSeg {
+    int quad, nphase, flags, cx[2], cy[2];
+    TlEdge e[4];
+    TlPhase ph[6];
+};
+
+__device__ void tl_clip(long long width, long long height, long long& x1, long long& y1, long long& x2, long long& y2, int& vis) {
+    const long long right = width - 1, bottom = height - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    vis = (c1 | c2) == 0;
+}
+
+__device__ void tl_edge_setup(TlEdge& e, long long x1, long long y1, long long x2, long long y2, int H, int W) {
+    int vis;
+    tl_clip((long long)W << TL_SHIFT, (long long)H << TL_SHIFT, x1, y1, x2, y2, vis);
+    e.ok = vis;
+    if (!vis) return;
+    long long dx = x2 - x1, dy = y2 - y1;
+    const long long ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+    e.xmajor = ax > ay;
+    if (ax > ay) {
+        if (dx < 0) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dy = -dy; }
+        e.step = tl_cdiv(dy * TL_ONE, ax | 1);
+        e.ecount = (int)((x2 - x1) >> TL_SHIFT);
+    } else {
+        if (dy < 0) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dx = -dx; }
+        e.step = tl_cdiv(dx * TL_ONE, ay | 1);
+        e.ecount = (int)((y2 - y1) >> TL_SHIFT);
+    }
+    x1 += TL_ONE >> 1;
+    y1 += TL_ONE >> 1;
+    e.ex = (int)((x2 + (TL_ONE >> 1)) >> TL_SHIFT);
+    e.ey = (int)((y2 + (TL_ONE >> 1)) >> TL_SHIFT);
+    if (e.xmajor) { e.s0 = x1 >> TL_SHIFT; e.t0 = y1; }
+    else { e.s0 = y1 >> TL_SHIFT; e.t0 = x1; }
+}
+
+// thread 0: everything of ThickLine(p0, p1, thickness 3) that does not depend on the pixel
+__device__ void tl_seg_setup(TlSeg& sg, int px0, int py0, int px1, int py1, int flags, int H, int W) {
+    const long long p0x = (long long)px0 << TL_SHIFT, p0y = (long long)py0 << TL_SHIFT;
+    const long long p1x = (long long)px1 << TL_SHIFT, p1y = (long long)py1 << TL_SHIFT;
+    sg.flags = flags;
+    sg.cx[0] = px0; sg.cy[0] = py0; sg.cx[1] = px1; sg.cy[1] = py1;      // (p + 2^15) >> 16 of an integer point
+    const double inv = 1.0 / (double)TL_ONE;
+    const double dx = (double)(p0x - p1x) * inv, dy = (double)(p1y - p0y) * inv;
+    double r = dx * dx + dy * dy;
+    sg.quad = 0; sg.nphase = 0;
+    for (int i = 0; i < 4; ++i) sg.e[i].ok = 0;
+    if (!(fabs(r) > 2.220446049250313e-16)) return;      // DBL_EPSILON: a repeated point draws its end caps only
+    const long long th = 3LL << (TL_SHIFT - 1);
+    r = ((double)th + (double)TL_ONE * 0.5) / sqrt(r);   // (thickness 3 is odd)
+    const long long dpx = (long long)rint(dy * r), dpy = (long long)rint(dx * r);     // cvRound: half to even
+    long long vx[4] = {p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx};
+    long long vy[4] = {p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy};
+    sg.quad = 1;
+    // FillConvexPoly (npts 4, shift 16): outline edges v3->v0, v0->v1, v1->v2, v2->v3
+    const long long delta = TL_ONE >> 1;
+    long long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+    int imin = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        ymax = vy[i] > ymax ? vy[i] : ymax;
+        xmax = vx[i] > xmax ? vx[i] : xmax;
+        xmin = vx[i] < xmin ? vx[i] : xmin;
+        const int j = (i + 3) & 3;
+        tl_edge_setup(sg.e[i], vx[j], vy[j], vx[i], vy[i], H, W);
+    }
+    xmin = (xmin + delta) >> TL_SHIFT; xmax = (xmax + delta) >> TL_SHIFT;
+    ymin = (ymin + delta) >> TL_SHIFT; ymax = (ymax + delta) >> TL_SHIFT;
+    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    if (ymax > H - 1) ymax = H - 1;
+    int e_idx[2] = {imin, imin}, e_di[2] = {1, 3}, e_ye[2] = {(int)ymin, (int)ymin};
+    long long e_x[2] = {-TL_ONE, -TL_ONE}, e_dx[2] = {0, 0};
+    int edges = 4, y = (int)ymin;
+    while (true) {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= e_ye[i]) {
+                int idx0 = e_idx[i];
+                const int di = e_di[i];
+                int idx = idx0 + di;
+                if (idx >= 4) idx -= 4;
+                for (; edges-- > 0;) {
+                    const int ty = (int)((vy[idx] + delta) >> TL_SHIFT);
+                    if (ty > y) {
+                        const long long xs = vx[idx0], xe = vx[idx];
+                        e_ye[i] = ty;
+                        e_dx[i] = tl_cdiv((xe - xs) * 2 + (ty - y), 2LL * (ty - y));
+                        e_x[i] = xs;
+                        e_idx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di;
+                    if (idx >= 4) idx -= 4;
+                }
+            }
+        }
+        if (edges < 0) break;
+        // rows [y, yn) share this set-up: the next one happens at the smaller ye (both > y now, or the edge walker is spent)
+        int yn = e_ye[0] < e_ye[1] ? e_ye[0] : e_ye[1];
+        if (yn <= y) yn = y + 1;
+        if (yn > (int)ymax + 1) yn = (int)ymax + 1;
+        TlPhase& p = sg.ph[sg.nphase++];
+        p.y0 = y; p.y1 = yn; p.x0 = e_x[0]; p.dx0 = e_dx[0]; p.x1 = e_x[1]; p.dx1 = e_dx[1];
+        e_x[0] += e_dx[0] * (yn - y);
+        e_x[1] += e_dx[1] * (yn - y);
+        y = yn;
+        if (y > (int)ymax || sg.nphase >= 6) break;
+    }
+}
+
+__device__ __forceinline__ bool tl_hit(const TlSeg& sg, int x, int y, int W) {
+    // end caps: Circle(center, 2, fill): rows cy +- dy hold |x - cx| <= dx, rows cy +- dx hold |x - cx| <= dy, over the midpoint
+    // iterations (dx, dy) = (2, 0), (1, 1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (sg.flags & (i + 1)) {
+            const int ax = abs(x - sg.cx[i]), ay = abs(y - sg.cy[i]);
+            int err = 0, dx = 2, dy = 0, plus = 1, minus = 3;
+            while (dx >= dy) {
+                if ((ay == dy && ax <= dx) || (ay == dx && ax <= dy)) return true;
+                ++dy; err += plus; plus += 2;
+                if (err > 0) { err -= minus; --dx; minus -= 2; }
+            }
+        }
+    if (!sg.quad) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const TlEdge& e = sg.e[i];
+        if (!e.ok) continue;
+        if (x == e.ex && y == e.ey) return true;
+        const long long k = (e.xmajor ? x : y) - e.s0;
+        if (k >= 0 && k <= e.ecount && ((e.t0 + k * e.step) >> TL_SHIFT) == (e.xmajor ? y : x)) return true;
+    }
+    for (int i = 0; i < sg.nphase; ++i) {
+        const TlPhase& p = sg.ph[i];
+        if (y >= p.y0 && y < p.y1) {
+            if (y < 0) return false;
+            const long long a = p.x0 + p.dx0 * (y - p.y0), b = p.x1 + p.dx1 * (y - p.y0);
+            const long long l = a > b ? b : a, r = a > b ? a : b;
+            int xx1 = (int)((l + (TL_ONE >> 1)) >> TL_SHIFT), xx2 = (int)((r + (TL_ONE >> 1)) >> TL_SHIFT);
+            if (!(xx2 >= 0 && xx1 < W)) return false;
+            return x >= xx1 && x <= xx2;
+        }
+    }
+    return false;
+}
+
+// the threads of a block walk the segment's bounding box grown by 3 pixels (half width 2 + the roundings)
+__device__ void tl_draw_segment(TlSeg& sg, int x0, int y0, int x1, int y1, int flags, float* __restrict__ plane, int H, int W) {
+    if (threadIdx.x == 0) tl_seg_setup(sg, x0, y0, x1, y1, flags, H, W);
+    __syncthreads();
+    const long long lx = (long long)min(x0, x1) - 3, hx = (long long)max(x0, x1) + 3;
+    const long long ly = (long long)min(y0, y1) - 3, hy = (long long)max(y0, y1) + 3;
+    const int bx0 = (int)max(lx, 0LL), bx1 = (int)min(hx, (long long)W - 1);
+    const int by0 = (int)max(ly, 0LL), by1 = (int)min(hy, (long long)H - 1);
     if (bx1 < bx0 || by1 < by0) return;
     const int bw = bx1 - bx0 + 1, npx = bw * (by1 - by0 + 1);
-    float* ch0 = disks + (int64_t)b * 2 * H * W;          // channel 0: always the positive channel (is_model.py:124,145)
-    for (int i = threadIdx.x; i < npx; i += 256) {
+    for (int i = threadIdx.x; i < npx; i += blockDim.x) {
         const int x = bx0 + i % bw, y = by0 + i / bw;
-        const long long px = x - x0, py = y - y0;
-        const long long dot = px * dx + py * dy, cross = px * dy - py * dx;
-        const bool inside = L2 > 0 && dot >= 0 && dot <= L2 && cross * cross <= L2;
-        const long long qx = x - x1, qy = y - y1;
-        if (inside || px * px + py * py <= 1 || qx * qx + qy * qy <= 1) ch0[(int64_t)y * W + x] = 1.0f;
+        if (tl_hit(sg, x, y, W)) plane[(int64_t)y * W + x] = 1.0f;
     }
+}
+
+// cv2.polylines(image, [curve], False, 255, 3): segment seg = points seg, seg + 1; end caps at both ends of the first
+// segment, at the end of every other one (PolyLine's flags).  A one-point curve draws nothing.
+__global__ __launch_bounds__(256) void draw_polyline_kernel(const int* __restrict__ curve, float* __restrict__ disks, int P,
+                                                            int H, int W) {
+    __shared__ TlSeg sg;
+    const int seg = blockIdx.x, b = blockIdx.y;
+    if (seg + 1 >= P) return;
+    const int* c = curve + ((int64_t)b * P + seg) * 2;
+    // channel 0: always the positive channel (is_model.py:124,145)
+    tl_draw_segment(sg, c[0], c[1], c[2], c[3], seg == 0 ? 3 : 2, disks + (int64_t)b * 2 * H * W, H, W);
+}
+
+// cv2.rectangle((x0, y0), (x1, y1), 255, 3) = the closed poly-line (x0,y0) (x1,y0) (x1,y1) (x0,y1): segment s runs from corner
+// s - 1 to corner s with an end cap at corner s (is_model.py:97-121; python floor division for the half sizes)
+__global__ __launch_bounds__(256) void draw_box_kernel(const int* __restrict__ boxes, float* __restrict__ disks, int n, int H, int W) {
+    __shared__ TlSeg sg;
+    const int seg = blockIdx.x, b = blockIdx.y;
+    const int* bx = boxes + b * 5;
+    const int ch = bx[4] < n ? 0 : 1;
+    const int hw = fdiv(bx[2], 2), hh = fdiv(bx[3], 2);
+    const int x0 = bx[0] - hw, x1 = bx[0] + hw, y0 = bx[1] - hh, y1 = bx[1] + hh;
+    const int cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
+    const int j = (seg + 3) & 3;
+    tl_draw_segment(sg, cx[j], cy[j], cx[seg], cy[seg], 2, disks + ((int64_t)b * 2 + ch) * H * W, H, W);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,7 +684,8 @@ extern "C" int vpu_pue_scribble_rows(const float* points, const double* vec, voi
 extern "C" int vpu_draw_polyline(const int32_t* curve, float* disks, int32_t B, int32_t P, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
     if (!curve || !disks || B <= 0 || P <= 0 || P > 65535 || H <= 0 || W <= 0) { vpu_set_error("draw_polyline: sizes"); return VPU_ERR_ARG; }
-    draw_polyline_kernel<<<dim3((unsigned)P, (unsigned)B), 256, 0, ST>>>(curve, disks, P, H, W);
+    if (P < 2) return VPU_OK;        // (PolyLine draws segments: a single point draws nothing)
+    draw_polyline_kernel<<<dim3((unsigned)(P - 1), (unsigned)B), 256, 0, ST>>>(curve, disks, P, H, W);
     return vpu_check_launch("vpu_draw_polyline");
 }
 
@@ -525,7 +726,8 @@ extern "C" int vpu_disk_maps(const float* points, const int32_t* boxes, float* o
     vpu_clear_stale_error();
     if (B <= 0 || n <= 0 || n > 1024) { vpu_set_error("disk_maps: sizes"); return VPU_ERR_ARG; }
     dim3 grid((H * W + 255) / 256, B);
-    disk_maps_kernel<<<grid, 256, 2 * n * 2 * sizeof(float) + 2 * sizeof(int), ST>>>(points, boxes, out, n, H, W, radius * radius);
+    disk_maps_kernel<<<grid, 256, 2 * n * 2 * sizeof(float) + 2 * sizeof(int), ST>>>(points, out, n, H, W, radius * radius);
+    if (boxes) draw_box_kernel<<<dim3(4, (unsigned)B), 256, 0, ST>>>(boxes, out, n, H, W);    // cv2.rectangle(..., 3) on top
     return vpu_check_launch("vpu_disk_maps");
 }
 

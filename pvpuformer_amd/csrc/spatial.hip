@@ -18,7 +18,9 @@ __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 
 // ------------------------------------------------------------------------------ patch im2col
 // cols[(b*T + t_win)][ch*P*P + py*P + px], ch: 0-2 normalised rgb (ops.py:403-407), 3 prev mask, 4-5 disks
-template <typename T>
+// NORM = false: the rgb planes of img4 are normalised already (ISModel.prepare_input ran on the caller's side: the public
+// backbone_forward, is_vpu_model.py:383-419)
+template <typename T, bool NORM = true>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img4,
                                                            const float* __restrict__ disks, T* __restrict__ cols,
                                                            int B, int H, int W, int P, int wg) {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
             const float* src = ch < 4 ? img4 + (((int64_t)b * 4 + ch) * H + y) * W + x
                                       : disks + (((int64_t)b * 2 + (ch - 4)) * H + y) * W + x;
             load8(src, o);
-            if (ch < 3) {
+            if (NORM && ch < 3) {
                 const float mu = c_mean[ch], isd = c_std[ch];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (o[j] - mu) / isd;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
                 const int y = ty * P + rem / P, x = tx * P + rem % P;
                 if (ch < 4) {
                     v = img4[(((int64_t)b * 4 + ch) * H + y) * W + x];
-                    if (ch < 3) v = (v - c_mean[ch]) / c_std[ch];
+                    if (NORM && ch < 3) v = (v - c_mean[ch]) / c_std[ch];
                 } else {
                     v = disks[(((int64_t)b * 2 + (ch - 4)) * H + y) * W + x];
                 }
@@ -1239,6 +1241,18 @@ extern "C" int vpu_patch_im2col(const float* image4, const float* disks, void* c
     DISPATCH_T(dtype, patch_im2col_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
         image4, disks, (T*)cols, B, H, W, P, win_tokens);)
     return vpu_check_launch("vpu_patch_im2col");
+}
+extern "C" int vpu_patch_im2col_prenorm(const float* image4, const float* disks, void* cols, int32_t B, int32_t H, int32_t W,
+                                        int32_t P, int32_t win_tokens, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (H % P || W % P || (W / P) % win_tokens || (H / P) % win_tokens) {
+        vpu_set_error("patch_im2col_prenorm: H,W % P, grid % window");
+        return VPU_ERR_ARG;
+    }
+    const int64_t total = (int64_t)B * (H / P) * (W / P) * (2 * ((3 * P * P + 7) / 8));
+    DISPATCH_T(dtype, (patch_im2col_kernel<T, false><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+        image4, disks, (T*)cols, B, H, W, P, win_tokens));)
+    return vpu_check_launch("vpu_patch_im2col_prenorm");
 }
 extern "C" int vpu_window_permute(const void* x, void* y, int32_t B, int32_t g, int32_t wg, int32_t C, int32_t dir,
                                   int32_t dtype, void* stream) {

@@ -391,8 +391,10 @@ class Engine:
             kw = dict(transA=True, transB=True, flags=EPI_OUT_F32 | acc, colsum=self.G(bias) if fuse else None)
             L = self._token_rows
             ctn = (K + 255) // 256      # column tiles of the K4 launches
+            al16 = lambda t: (ops.ptr(t) & 15) == 0
             dcs = (fuse and self.dist_colsum and self.k4_wgrad and self.pack_wgrad and ctn > 1 and M % 64 == 0 and M > 2048
-                   and N % 8 == 0 and K % 8 == 0)      # (long reductions only: what vpu_gemm_grouped gives to the K4 kernels)
+                   and N % 8 == 0 and K % 8 == 0 and ld_dy % 8 == 0 and ld_x % 8 == 0 and al16(dy) and al16(x))
+            # (long reductions with 16-byte-aligned operands only: what vpu_gemm_grouped gives to the K4 kernels)
             if (self.unify_wgrad and self.pack_wgrad and (self.k3_wgrad or self.k4_wgrad) and L > 2048 and M > L and M % L == 0
                     and L % 64 == 0 and N % 8 == 0 and K % 8 == 0 and ld_dy % 8 == 0 and ld_x % 8 == 0 and ldc_ % 4 == 0):
                 # S = M / L reduction slices as the batch entries of one problem: entry z reads rows [z L, (z + 1) L) of dy and
@@ -818,12 +820,15 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ model
     def forward(self, image4, points, boxes=None, prompt_type=0, drop_mask=None, training=False, taps=None,
-                materialize_aux=True, scribble=None):
+                materialize_aux=True, scribble=None, coord_override=None, prenorm=False):
         """image4 fp32 [B,4,H,W]; points fp32 [B,2n,3]; boxes int32 [B,5] (prompt_type 1); scribble (prompt_type 2) =
         (curve int32 [B,P,2] poly-line vertices, profiles float64 [B, 2*img] from isegm/model/scribble.py).
         Returns instances fp32 [B,1,H,W] (logits) and instances_aux fp32 [B,S,H,W].  ``materialize_aux=False`` skips the
         38.5 MB/img upsample of the P2CL similarities: aux is None, the low-resolution planes stay in ``self.sim_low``
-        [B,S,h,w] for the fused loss (ops.p2cl_up_fwd_bwd) and backward() takes their gradient as ``d_sim_low``."""
+        [B,S,h,w] for the fused loss (ops.p2cl_up_fwd_bwd) and backward() takes their gradient as ``d_sim_low``.
+        ``coord_override`` fp32 [B,2,H,W]: the two click-map channels of the coordinate features as the CALLER made them
+        (no disk maps / outlines are drawn); ``prenorm``: the rgb planes of image4 are normalised already -- both for the
+        public ``backbone_forward`` (is_vpu_model.py:383-419)."""
         assert image4.is_cuda and image4.dtype == torch.float32 and image4.is_contiguous()
         if not self.shadow_valid:
             self.refresh_weights()
@@ -853,15 +858,19 @@ class Engine:
             prof = self._upload(scribble[1], torch.float64)
             assert curve.shape[0] == B and tuple(prof.shape) == (B, 2 * self.img)
         # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
-        disks = self._new(B, 2, H, W_, dtype=torch.float32)
-        ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, self.norm_radius)
-        if use_scr:     # ISModel.draw_scribble (is_model.py:123-146): poly-line into the positive channel
-            ops.draw_polyline(curve, disks, B, curve.shape[1], H, W_)
+        if coord_override is not None:
+            disks = coord_override.to(device=self.dev, dtype=torch.float32).contiguous()
+            assert tuple(disks.shape) == (B, 2, H, W_)
+        else:
+            disks = self._new(B, 2, H, W_, dtype=torch.float32)
+            ops.disk_maps(points, boxes if use_box else None, disks, B, n, H, W_, self.norm_radius)
+            if use_scr:     # ISModel.draw_scribble (is_model.py:123-146): poly-line into the positive channel
+                ops.draw_polyline(curve, disks, B, curve.shape[1], H, W_)
         if taps is not None:
             taps["disks"] = disks
         KP = 2 * self.k3p
         cols = self._new(M, KP)
-        ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg)
+        ops.patch_im2col(image4, disks, cols, B, H, W_, P, self.wg, prenorm=prenorm)
         x = Var(self._new(M, D))
         ops.gemm(cols, self.w_patch, x.t, M, D, KP, KP, KP, D, self.dt,
                  flags=EPI_BIAS | EPI_RESID, bias=self.b_patch, resid=pos_win, ldr=D, resid_period=NT)
@@ -1362,7 +1371,11 @@ class Engine:
             tiles = sum(e[2] for e in part)
             # (reductions beyond ~16k rows -- the head / FPN maps -- keep the per-problem split-K launch with up to 128
             # slices: measured 18.5 vs 17.9 ms per step when they were cut into 8 slices here)
-            elig = [e for e in part if e[0][8] == e[0][4] and e[1].get("batch", 1) == 1 and not e[1].get("cs_tn")]     # slabs are summed into contiguous gradients only
+            # slabs are summed into contiguous gradients only -- and ADDED to them (colsum_batched: out +=), so an entry
+            # that must WRITE its gradient (zero_grad(lazy=True): no EPI_ACCUM, the target still holds the previous step's
+            # values) is never sliced: it stays with the GEMM launches below, which honour the flag
+            elig = [e for e in part if e[0][8] == e[0][4] and e[1].get("batch", 1) == 1 and not e[1].get("cs_tn")
+                    and (e[1].get("flags", 0) & EPI_ACCUM)]
             etiles = sum(e[2] for e in elig)
             if self.split_wgrad and 2048 < red <= 16384 and len(elig) >= 2 and etiles < 200:
                 self._wgrad_sliced(elig, red, etiles)

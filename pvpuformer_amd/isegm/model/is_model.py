@@ -23,11 +23,16 @@ class ISModel(nn.Module):
         self.maps_transform = nn.Identity()
 
     def prepare_input(self, image):
-        """Kept for API parity (is_model.py:59-66); on the product path normalisation is fused into the patch im2col."""
+        """is_model.py:59-66: (normalised rgb, previous mask) -- ``(x - mean) / std`` as BatchImageNormalize does it
+        (ops.py:398-407: a clone, sub_, div_).  The model's own ``forward`` does not come through here (the normalisation is
+        fused into the patch im2col); this serves callers of the public pieces: ``backbone_forward`` takes what it returns."""
         prev_mask = None
         if self.with_prev_mask:
             prev_mask = image[:, 3:, :, :]
             image = image[:, :3, :, :]
+        mean = torch.as_tensor([.485, .456, .406], dtype=torch.float, device=image.device)[None, :, None, None]
+        std = torch.as_tensor([.229, .224, .225], dtype=torch.float, device=image.device)[None, :, None, None]
+        image = image.clone().sub_(mean).div_(std)
         return image, prev_mask
 
     # ---- the coordinate-feature builders of is_model.py:71-146 as public methods (the model's own forward builds the same maps

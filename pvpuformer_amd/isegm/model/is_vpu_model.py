@@ -170,20 +170,7 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         (x, y), bounding rectangles [B,1,4] of (x_center, y_center, width, height)] as ``cal_scribble`` returns them
         (numpy, not tensors: trainer.py:1192-1243) (is_vpu_model.py:383-438)."""
         eng = self._ensure_engine()
-        if not edloss:
-            raise NotImplementedError("edloss=False (plain head.forward) is not used by the VPU trainer / predictor")
-        boxes, scribble = None, None
-        if as_prompt_type == 1:
-            points, boxes, _ = prompts
-        elif as_prompt_type == 2:
-            from .scribble import scribble_curves, scribble_profiles
-            points, _, (scr_pts, scr_rects) = prompts
-            if torch.is_tensor(scr_pts):
-                scr_pts, scr_rects = scr_pts.detach().cpu().numpy(), scr_rects.detach().cpu().numpy()
-            scribble = (torch.from_numpy(scribble_curves(scr_pts)),
-                        torch.from_numpy(scribble_profiles(scr_pts, scr_rects, self.image_size[0])))   # draws from `random`
-        elif as_prompt_type != 0:
-            raise ValueError(f"as_prompt_type must be 0 (clicks), 1 (box) or 2 (scribble), got {as_prompt_type}")
+        points, boxes, scribble = self._unpack_prompts(points, prompts, as_prompt_type, edloss)
         image = image.contiguous().float()
         if not self.weights_frozen or not eng.shadow_valid:
             eng.refresh_weights()
@@ -226,5 +213,44 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         g.replay()
         return inst, aux
 
-    def backbone_forward(self, *a, **k):
-        raise NotImplementedError("use forward(); the stages are fused inside the engine")
+    def _unpack_prompts(self, points, prompts, as_prompt_type, edloss):
+        """(points, boxes, scribble operands of the engine) from the reference's ``prompts`` tuple (is_vpu_model.py:401-408)."""
+        if not edloss:
+            raise NotImplementedError("edloss=False (plain head.forward) is not used by the VPU trainer / predictor")
+        boxes, scribble = None, None
+        if as_prompt_type == 1:
+            points, boxes, _ = prompts
+        elif as_prompt_type == 2:
+            from .scribble import scribble_curves, scribble_profiles
+            points, _, (scr_pts, scr_rects) = prompts
+            if torch.is_tensor(scr_pts):
+                scr_pts, scr_rects = scr_pts.detach().cpu().numpy(), scr_rects.detach().cpu().numpy()
+            scribble = (torch.from_numpy(scribble_curves(scr_pts)),
+                        torch.from_numpy(scribble_profiles(scr_pts, scr_rects, self.image_size[0])))   # draws from `random`
+        elif as_prompt_type != 0:
+            raise ValueError(f"as_prompt_type must be 0 (clicks), 1 (box) or 2 (scribble), got {as_prompt_type}")
+        return points, boxes, scribble
+
+    def backbone_forward(self, image, coord_features=None, points=None, prompts=None, as_prompt_type=0, edloss=True, pclout=False):
+        """is_vpu_model.py:383-419: everything between ``get_coord_features_with_prompt`` and the final x4 upsample, as a public
+        method: ``image`` [B,3,H,W] normalised (``prepare_input``'s), ``coord_features`` [B,3,H,W] (previous mask + the two
+        click maps, exactly as given: nothing is drawn here) -> {'instances': [B,1,H/4,W/4] logits, 'instances_aux':
+        [B,2n,H/4,W/4] similarities}.  The stages stay fused inside the engine: the caller's planes go into the patch
+        embedding's operand through ``vpu_patch_im2col_prenorm``, the low-resolution maps come out through the engine's taps.
+        Inference only (the outputs carry no autograd graph: training goes through ``forward``)."""
+        eng = self._ensure_engine()
+        points, boxes, scribble = self._unpack_prompts(points, prompts, as_prompt_type, edloss)
+        if coord_features is None or coord_features.shape[1] != 3:
+            raise ValueError("backbone_forward: coord_features must be [B, 3, H, W] (previous mask + two click maps)")
+        coord = coord_features.to(device=image.device, dtype=torch.float32)
+        image4 = torch.cat([image.float(), coord[:, :1]], dim=1).contiguous()
+        if not self.weights_frozen or not eng.shadow_valid:
+            eng.refresh_weights()
+        drop_mask = None
+        if self.training and self.head.dropout_ratio > 0:
+            drop_mask = ops.dropout_mask(image.shape[0], self.head.channels, 1.0 - self.head.dropout_ratio, image.device)
+        taps = {}
+        with torch.no_grad():
+            eng.forward(image4, points, boxes, as_prompt_type, drop_mask, training=False, taps=taps, materialize_aux=False,
+                        scribble=scribble, coord_override=coord[:, 1:3], prenorm=True)
+        return {'instances': taps["seg_lowres"].float(), 'instances_aux': taps["sim_lowres"].float() if self.with_aux_output else None}

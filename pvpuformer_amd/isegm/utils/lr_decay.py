@@ -1,53 +1,58 @@
-"""Layer-wise learning-rate decay groups, API-compatible with isegm/utils/lr_decay.py:15-84 (BEiT scheme): returns the
-same torch-style list of param groups; ``per_param_table`` flattens it to {name: (lr_scale, weight_decay)} for the fused
-optimizer."""
+"""Layer-wise learning-rate decay (BEiT scheme) behind the reference's API, isegm/utils/lr_decay.py:15-84:
+``param_groups_lrd`` returns a torch-style list of param groups whose ORDER, lr / weight-decay values and backbone group
+keys ("layer_<id>_<decay|no_decay>") are the reference's -- they are behaviour: the optimizer state of a checkpoint is
+indexed by group position.  Built here as a two-step table: every backbone tensor is first mapped to a (depth, decays)
+bucket, the buckets are then emitted in first-seen order; neck and head tensors follow, one group per tensor.
+``per_param_table`` flattens the groups to {name: (lr_scale, weight_decay)} for the fused optimizer's segment table."""
+import re
+
+_BLOCK = re.compile(r"blocks\.(\d+)\.")
 
 
 def get_layer_id_for_vit(name, num_layers):
-    """lr_decay.py:72-84."""
-    if name in ['cls_token', 'pos_embed']:
-        return 0
-    if name.startswith('patch_embed'):
-        return 0
-    if name.startswith('blocks'):
-        return int(name.split('.')[1]) + 1
-    return num_layers
+    """Depth of a backbone tensor (lr_decay.py:72-84): the embedding stage (cls_token, pos_embed, patch_embed*) is depth 0,
+    transformer block i is depth i + 1, everything after the blocks (norms, classifier) is depth ``num_layers``."""
+    m = _BLOCK.match(name)
+    if m:
+        return 1 + int(m.group(1))
+    embedding_stage = name in ("cls_token", "pos_embed") or name.startswith("patch_embed")
+    return 0 if embedding_stage else num_layers
+
+
+def _bucket_of(name, tensor, skip_decay, depth_count):
+    """(depth, regularised?) of one backbone tensor: vectors (biases, norm scales) and the names the model exempts are not
+    weight-decayed (lr_decay.py:32-37)."""
+    regularised = tensor.ndim != 1 and name not in skip_decay
+    return get_layer_id_for_vit(name, depth_count), regularised
 
 
 def param_groups_lrd(model, lr, weight_decay=0.05, no_weight_decay_list=(), layer_decay=.75):
-    """lr_decay.py:15-69: backbone tensors grouped by (layer id, decay / no decay) with lr * layer_decay**(L - id);
-    1-D tensors and the no-decay list get weight_decay 0; neck / head tensors one group each, base lr, full decay."""
-    param_groups = {}
-    num_layers = len(model.backbone.blocks) + 1
-    layer_scales = [layer_decay ** (num_layers - i) for i in range(num_layers + 1)]
-    for n, p in model.backbone.named_parameters():
-        if not p.requires_grad:
+    """lr_decay.py:15-69.  Backbone: one group per (depth, regularised?) bucket at lr * layer_decay ** (L - depth), L =
+    number of blocks + 1, weight decay 0 for the unregularised buckets.  Neck and head: one group per tensor at the
+    optimizer's base lr with the full weight decay.  Each group also carries ``names`` (full parameter names: the fused
+    optimizer addresses the flat buffer by name)."""
+    depth_count = len(model.backbone.blocks) + 1
+    rate_at = {d: layer_decay ** (depth_count - d) for d in range(depth_count + 1)}
+    buckets = {}          # insertion-ordered: a bucket's position is where its first tensor appears
+    for name, tensor in model.backbone.named_parameters():
+        if not tensor.requires_grad:
             continue
-        if p.ndim == 1 or n in no_weight_decay_list:
-            g_decay, this_decay = "no_decay", 0.
-        else:
-            g_decay, this_decay = "decay", weight_decay
-        layer_id = get_layer_id_for_vit(n, num_layers)
-        group_name = "layer_%d_%s" % (layer_id, g_decay)
-        if group_name not in param_groups:
-            this_scale = layer_scales[layer_id]
-            param_groups[group_name] = {"lr_scale": this_scale, "lr": lr * this_scale, "weight_decay": this_decay,
-                                        "params": [], "names": []}
-        param_groups[group_name]["params"].append(p)
-        param_groups[group_name]["names"].append("backbone." + n)
-    params = list(param_groups.values())
-    for prefix, sub in (("neck.", model.neck), ("head.", model.head)):
-        for n, p in sub.named_parameters():
-            if p.requires_grad:
-                params.append({"params": p, "weight_decay": weight_decay, "names": [prefix + n]})
-    return params
+        depth, regularised = _bucket_of(name, tensor, no_weight_decay_list, depth_count)
+        key = f"layer_{depth}_{'decay' if regularised else 'no_decay'}"
+        entry = buckets.get(key)
+        if entry is None:
+            entry = buckets[key] = dict(lr_scale=rate_at[depth], lr=lr * rate_at[depth],
+                                        weight_decay=weight_decay if regularised else 0., params=[], names=[])
+        entry["params"].append(tensor)
+        entry["names"].append(f"backbone.{name}")
+    groups = list(buckets.values())
+    for owner in ("neck", "head"):
+        for name, tensor in getattr(model, owner).named_parameters():
+            if tensor.requires_grad:
+                groups.append(dict(params=tensor, weight_decay=weight_decay, names=[f"{owner}.{name}"]))
+    return groups
 
 
 def per_param_table(groups, base_lr):
     """{full parameter name: (lr / base_lr, weight_decay)} for every tensor that appears in ``groups``."""
-    table = {}
-    for g in groups:
-        scale = g.get("lr", base_lr) / base_lr
-        for n in g["names"]:
-            table[n] = (scale, g.get("weight_decay", 0.0))
-    return table
+    return {name: (g.get("lr", base_lr) / base_lr, g.get("weight_decay", 0.0)) for g in groups for name in g["names"]}

@@ -392,8 +392,10 @@ def disk_maps(points, boxes, out, B, n, H, W, radius):
     _lib.call("vpu_disk_maps", ptr(points), ptr(boxes), ptr(out), B, n, H, W, float(radius), _stream())
 
 
-def patch_im2col(image4, disks, cols, B, H, W, P, win_tokens):
-    _lib.call("vpu_patch_im2col", ptr(image4), ptr(disks), ptr(cols), B, H, W, P, win_tokens, code_of(cols), _stream())
+def patch_im2col(image4, disks, cols, B, H, W, P, win_tokens, prenorm=False):
+    """``prenorm``: the rgb planes are normalised already (vpu_patch_im2col_prenorm)."""
+    _lib.call("vpu_patch_im2col_prenorm" if prenorm else "vpu_patch_im2col", ptr(image4), ptr(disks), ptr(cols), B, H, W, P,
+              win_tokens, code_of(cols), _stream())
 
 
 def window_permute(x, y, B, g, wg, Cdim, to_raster):

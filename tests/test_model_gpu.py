@@ -509,6 +509,42 @@ def test_ismodel_public_coord_feature_methods(golden_dir):
     assert torch.equal(model.get_coord_features(image, None, pts), model.get_coord_features_with_prompt(image, None, pts))
 
 
+@pytest.mark.parametrize("ptype", [0, 1])
+def test_backbone_forward_public_method(golden_dir, ptype):
+    """VitMultiGaussianVector_ed_Model.backbone_forward (is_vpu_model.py:383-419) as a public method of the mirror: fed with
+    what ``prepare_input`` and ``get_coord_features_with_prompt`` return -- the reference's own ``forward`` body, is_vpu_model.py:
+    426-430 -- and followed by the x4 align-corners upsample (:431-436) it reproduces ``forward``: the mask logits to fp32
+    rounding (the rgb planes are normalised on the caller's side by torch instead of inside the im2col kernel), against the
+    reference's recorded low-resolution logits within the 1e-3 parity bound; a coordinate map the caller edits is honoured."""
+    import torch.nn.functional as F
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "tiny.npz", "f32")
+    img = img4.cuda()
+    pts, boxes = batch["points"].cuda(), batch["boxes"].cuda()
+    prompts = None if ptype == 0 else (pts, boxes, None)
+    with torch.no_grad():
+        full = model(img, pts, prompts, ptype)
+        image, prev = model.prepare_input(img)
+        coord = model.get_coord_features_with_prompt(image, prev, pts, prompts, ptype)
+        low = model.backbone_forward(image, coord, pts, prompts, ptype)
+    S = cfg["img"]
+    assert tuple(low["instances"].shape) == (img.shape[0], 1, S // 4, S // 4)
+    assert tuple(low["instances_aux"].shape) == (img.shape[0], 2 * cfg["num_max_points"], S // 4, S // 4)
+    up = F.interpolate(low["instances"], size=(S, S), mode="bilinear", align_corners=True)
+    up_aux = F.interpolate(low["instances_aux"], size=(S, S), mode="bilinear", align_corners=True)
+    assert _relerr(up.cpu().numpy(), full["instances"].cpu().numpy()) < 1e-5
+    assert _relerr(up_aux.cpu().numpy(), full["instances_aux"].cpu().numpy()) < 1e-5
+    mode = "click" if ptype == 0 else "box"
+    assert _relerr(up[..., ::7, ::7].cpu().numpy(), fx[f"{mode}_instances_sub"]) < 1e-3
+    # the caller's coordinate features are what reaches the patch embedding: blanking the click maps changes the output
+    blank = coord.clone()
+    blank[:, 1:] = 0
+    with torch.no_grad():
+        other = model.backbone_forward(image, blank, pts, prompts, ptype)
+    assert float((other["instances"] - low["instances"]).abs().max()) > 1e-4
+    with pytest.raises(ValueError):
+        model.backbone_forward(image, coord[:, :2], pts, prompts, ptype)
+
+
 @pytest.mark.parametrize("fixture", ["tiny.npz", "vitb.npz"])
 def test_lazy_zero_grad_gives_the_same_gradients(golden_dir, fixture):
     """zero_grad(lazy=True) (round 4): the ViT blocks' weight gradients are WRITTEN by the one GEMM that produces them and
@@ -548,6 +584,69 @@ def test_lazy_zero_grad_gives_the_same_gradients(golden_dir, fixture):
     eng.abort_pass()
     torch.cuda.synchronize()
     assert not torch.isnan(eng.gflat).any() and float(eng.gflat.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,variant", [(12, "default"), (12, "small_budget"), (12, "hook"), (6, "default"), (6, "nodcs"),
+                                       (3, "default"), (3, "hook")])
+def test_lazy_zero_grad_at_bench_shapes(golden_dir, B, variant):
+    """zero_grad(lazy=True) on the launch paths the timed step uses -- ViT-B at B = 12 (M = 9408: the packed
+    K4P launches with the non-accumulating epilogue, distributed column sums, reduction slices), with a small pack budget
+    (`_split_entry` cuts entries that carry distributed column sums), with a reducer hook attached (the `late` flushes) -- and
+    on the ones odd batches take: B = 6 / 3 (M = 4704 / 2352 rows: M % 64 != 0, no distributed column sums, the entries
+    eligible for `_wgrad_sliced`, whose slab add ACCUMULATES and once added the new gradient to the previous step's) and
+    VPU_WGRAD_DCS=0.  NaN in every gradient word beforehand; the lazily zeroed step must equal the eagerly zeroed one (bit
+    for bit where both take the same launches)."""
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    big = vo.synth_batch(B, cfg["img"], seed=100)
+    x = torch.cat([big["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1).cuda()
+    pts, gt = big["points"].cuda(), big["instances"].cuda()
+    model.train()
+    model.head.dropout_ratio = 0.0
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+    if variant == "nodcs":
+        eng.dist_colsum = False
+    orig_pack = type(eng).pack_tiles
+    if variant == "small_budget":
+        eng.pack_tiles = lambda total=None, cap=256: 100      # every block's gradients are cut several times
+    seen = []
+    if variant == "hook":
+        class Red:
+            reserve_cus = 16
+
+            def ready(self, lo, hi):
+                seen.append((lo, hi))
+        eng.grad_ready_hook = Red().ready
+
+    def step(lazy):
+        eng.gflat.fill_(float("nan"))
+        eng.zero_grad(lazy=lazy)
+        inst, _ = eng.forward(x, pts, None, 0, None, training=True, materialize_aux=False)
+        _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
+        torch.cuda.synchronize()
+        return eng.gflat.clone()
+    try:
+        step(False)
+        ref = step(False)
+        assert torch.isfinite(ref).all()
+        got = step(True)
+        assert eng._lazy_names and not eng._lazy
+        # B = 12: the same launches either way -> the same bits.  Odd batches: a written (non-accumulating) entry is kept out of
+        # `_wgrad_sliced`, so its reduction is summed in another order than the eagerly zeroed step's -- equal up to fp32
+        # rounding (measured 1.3e-8 absolute), where the defect this test guards doubled the gradient
+        same = (lambda a, b: torch.equal(a, b)) if B == 12 else (lambda a, b: torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max())))
+        assert same(got, ref), float((got - ref).abs().max())
+        again = step(True)          # a second lazily zeroed step onto the first one's values: still the same
+        assert torch.equal(again, got)
+        if variant == "hook":
+            assert seen and sum(hi - lo for lo, hi in seen) % eng.total == 0
+    finally:
+        eng.grad_ready_hook = None
+        if variant == "small_budget":
+            del eng.pack_tiles
+        assert type(eng).pack_tiles is orig_pack
 
 
 def test_failed_capture_leaves_no_queued_work_behind(golden_dir):
@@ -997,7 +1096,8 @@ def test_scribble_prompt_rows_and_polyline_bit_exact(golden_dir):
     ref[0, 0, 5, 5] = 1.0
     for b in range(3):
         ref[b] = vo.polyline_raster(ref[b], curves[b, 0])
-    assert np.array_equal(disks.cpu().numpy(), ref) and ref[2].sum() == 5 and ref[:, 1].sum() == 0
+    # (every vertex the same pixel: no quadrilateral, the radius-2 end caps of cv2's thick line only: 1 + 3 + 5 + 3 + 1 pixels)
+    assert np.array_equal(disks.cpu().numpy(), ref) and ref[2].sum() == 13 and ref[:, 1].sum() == 0
 
 
 def test_tiny_scribble_mode_matches_reference(golden_dir):

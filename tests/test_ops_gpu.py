@@ -574,6 +574,54 @@ def test_pue_and_disks_bit_exact(ops, golden_dir):
     assert np.array_equal(d.cpu().numpy(), exp)
 
 
+def test_thick_line_rasteriser_equals_opencv_restatement(ops):
+    """a3: vpu_draw_polyline / the box outline of vpu_disk_maps against the oracle's restatement of OpenCV's PolyLine ->
+    ThickLine -> FillConvexPoly / Line2 / Circle (oracle/vpu_oracle.py), bit for bit: random open poly-lines (short steps as
+    the stroke simulator makes them, long slanted ones, repeated points, points outside the canvas, one- and two-point
+    curves) and boxes (degenerate, clipped by the border, 1-pixel sides)."""
+    import vpu_oracle as vo
+    rs = np.random.RandomState(7)
+    H, W = 97, 131
+    curves = []
+    for k in range(24):
+        P = 12
+        if k < 8:       # a walk with small steps
+            pts = np.cumsum(rs.randint(-4, 5, size=(P, 2)), 0) + np.array([W // 2, H // 2])
+        elif k < 16:    # long slanted segments, some leaving the canvas
+            pts = np.column_stack((rs.randint(-20, W + 20, P), rs.randint(-20, H + 20, P)))
+        elif k < 20:    # repeated points and axis-aligned runs
+            pts = np.repeat(np.column_stack((rs.randint(0, W, P // 2), rs.randint(0, H, P // 2))), 2, 0)
+            pts[1::4, 0] = pts[0::4, 0]
+        else:           # everything on the border / in a corner
+            pts = np.column_stack((rs.choice([0, 1, W - 2, W - 1], P), rs.choice([0, 1, H - 2, H - 1], P)))
+        curves.append(pts.astype(np.int32))
+    curves = np.stack(curves)
+    d = torch.zeros(len(curves), 2, H, W, device="cuda")
+    ops.draw_polyline(torch.from_numpy(curves).cuda(), d, len(curves), curves.shape[1], H, W)
+    got = d.cpu().numpy()
+    for b in range(len(curves)):
+        exp = vo.polyline_raster(np.zeros((2, H, W), np.float32), curves[b])
+        assert np.array_equal(got[b], exp), (b, int((got[b] != exp).sum()))
+    for P in (1, 2):   # a single point draws nothing; two points draw one segment with both end caps
+        d = torch.zeros(1, 2, H, W, device="cuda")
+        ops.draw_polyline(torch.from_numpy(curves[:1, :P].copy()).cuda(), d, 1, P, H, W)
+        assert np.array_equal(d.cpu().numpy()[0], vo.polyline_raster(np.zeros((2, H, W), np.float32), curves[0, :P]))
+    # known answers of the restated algorithm: a horizontal thickness-3 line covers rows y-2 .. y+2 (half width 2^17 in 16.16,
+    # Line2 draws the outline rows) with radius-2 caps: 4 cap pixels beyond each end
+    m = vo.cv_polyline_mask(20, 30, [(5, 5), (20, 5)], False)
+    assert m[3:8, 5:21].all() and m.sum() == 5 * 16 + 8
+    boxes = np.array([[60, 40, 50, 30, 0], [60, 40, 51, 31, 30], [3, 3, 20, 20, 1], [128, 95, 30, 30, 40], [50, 50, 0, 0, 2],
+                      [50, 50, 1, 1, 2], [70, 20, 2, 40, 25], [65, 48, 200, 150, 3]], np.int32)
+    nb = len(boxes)
+    none = -torch.ones(nb, 48, 3, device="cuda")
+    d = torch.zeros(nb, 2, H, W, device="cuda")
+    ops.disk_maps(none, torch.from_numpy(boxes).cuda(), d, nb, 24, H, W, 5.0)
+    got = d.cpu().numpy()
+    for b in range(nb):
+        exp = vo.box_outline(np.zeros((2, H, W), np.float32), boxes[b], 24)
+        assert np.array_equal(got[b], exp), (b, boxes[b], int((got[b] != exp).sum()))
+
+
 # ------------------------------------------------------------------------------------------------ spatial
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_patch_im2col_and_permute(ops, dtype):
@@ -1144,10 +1192,12 @@ def test_flash_attention_fwd_bwd(ops, attn_form, hd, n, nb):
 
 @pytest.mark.parametrize("n,nb,H", [(196, 5, 3), (256, 2, 2), (208, 1, 1), (100, 3, 2), (64, 2, 4), (16, 3, 1), (4, 2, 1), (132, 2, 12), (50, 2, 2), (197, 1, 2)])
 def test_one_pass_window_backward(ops, n, nb, H):
-    """The one-workgroup-per-(window, head) backward (attn_bwd_win_kernel: head dim 64, n <= 256) against torch fp32 on the
-    bf16-rounded inputs AND against the two-kernel backward it replaces: key-tile counts 13 (2,2,2,2,2,1,1,1 tiles per
-    wave), 16, 13 exact, 7 (ragged last tile), 4, 1 and a quarter tile; every gradient within 2e-2 of its scale and within
-    bf16 rounding of the two-kernel result; the launch really was the one-pass kernel."""
+    """The one-pass (window, head) backward kernels (head dim 64, n <= 256) against torch fp32 on the bf16-rounded inputs AND
+    against the two-kernel backward they replace -- the round-5 form in key passes (attn_bwd_winp_kernel<1>: four 16-key tiles
+    per pass, one per wave, four workgroups per CU) and the round-3 form (attn_bwd_win_kernel: one workgroup per CU): key-tile
+    counts 13 (four passes of 4, 4, 4, 1 tiles), 16, 13 exact, 7 (ragged last tile), 4, 1 and a quarter tile; every gradient
+    within 2e-2 of its scale and within bf16 rounding of the two-kernel result (dQ of the pass form: one more bf16 rounding
+    of the partial sum per key pass, hence 1.5e-2); the launch really was the kernel asked for; bitwise reproducible."""
     hd = 64
     D = H * hd
     qkv = dev(rnd(nb * n, 3 * D, seed=160 + n, scale=1.5)).to(torch.bfloat16)
@@ -1159,34 +1209,35 @@ def test_one_pass_window_backward(ops, n, nb, H):
     ref = torch.softmax((x[0] @ x[1].transpose(-1, -2)) * scale, -1) @ x[2]
     dO = dev(rnd(nb * n, D, seed=161 + n)).to(torch.bfloat16)
     ref.backward(dO.float().view(nb, n, H, hd).transpose(1, 2))
+    names = {2: "attn_bwd_winp_kernel<1>", 1: "attn_bwd_win_kernel"}
     res = {}
     try:
-        for onepass in (1, 0):
+        for onepass in (2, 1, 0):
             ops.attn_set_option("onepass", onepass)
             dqkv = torch.full_like(qkv, float("nan"))
             delta = torch.zeros(nb * H, n, device="cuda")
             ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, delta, dqkv, (dqkv, D), (dqkv, 2 * D), nb, H, n, hd, 3 * D, D,
                          3 * D, scale)
-            assert (ops.attn_last_kernel() == "attn_bwd_win_kernel") == bool(onepass), ops.attn_last_kernel()
+            assert ops.attn_last_kernel() == names.get(onepass, ops.attn_last_kernel()) and \
+                (onepass > 0 or "attn_bwd_dq" in ops.attn_last_kernel()), ops.attn_last_kernel()
             res[onepass] = dqkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4)
+            # no atomics, no cross-wave reduction whose order could vary: the same launch gives the same bits every time
+            for _ in range(3 if onepass else 0):
+                again = torch.full_like(qkv, float("nan"))
+                ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, torch.zeros(nb * H, n, device="cuda"), again, (again, D),
+                             (again, 2 * D), nb, H, n, hd, 3 * D, D, 3 * D, scale)
+                assert torch.equal(again.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4), res[onepass])
     finally:
         ops.attn_set_option("onepass", -1)
-    # no atomics, no cross-wave reduction whose order could vary: the same launch gives the same bits every time
-    ops.attn_set_option("onepass", 1)
-    try:
-        for _ in range(4):
-            again = torch.full_like(qkv, float("nan"))
-            ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, torch.zeros(nb * H, n, device="cuda"), again, (again, D),
-                         (again, 2 * D), nb, H, n, hd, 3 * D, D, 3 * D, scale)
-            assert torch.equal(again.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4), res[1])
-    finally:
-        ops.attn_set_option("onepass", -1)
-    for i, name in enumerate("qkv"):
-        ref_g = x.grad[i]
-        sc = ref_g.abs().max().item()
-        assert torch.isfinite(res[1][i]).all(), name
-        assert (res[1][i] - ref_g).abs().max().item() < 2e-2 * sc, (name, (res[1][i] - ref_g).abs().max().item(), sc)
-        assert (res[1][i] - res[0][i]).abs().max().item() < 1e-2 * sc, (name, (res[1][i] - res[0][i]).abs().max().item(), sc)
+    for mode in (2, 1):
+        for i, name in enumerate("qkv"):
+            ref_g = x.grad[i]
+            sc = ref_g.abs().max().item()
+            assert torch.isfinite(res[mode][i]).all(), (mode, name)
+            err, dif = (res[mode][i] - ref_g).abs().max().item(), (res[mode][i] - res[0][i]).abs().max().item()
+            print(f"[one-pass {mode}] n={n} d{name}: vs torch {err / sc:.2e}, vs two kernels {dif / sc:.2e} of the scale")
+            assert err < 2e-2 * sc, (mode, name, err, sc)
+            assert dif < (1.5e-2 if mode == 2 and name == "q" else 1e-2) * sc, (mode, name, dif, sc)
 
 
 def test_attention_large_scores_raise_the_reference(ops, attn_form):
