@@ -363,6 +363,16 @@ int vpu_gate_apply(const void* x, const float* cg, const float* sg, void* out, i
 int vpu_gate_bwd(const void* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
                  const int32_t* argc, void* dx, int32_t accum, void* dQ, void* dK, float* part, int32_t B, int32_t nq,
                  int32_t N, int32_t C, int32_t dtype, void* stream);
+/* The three gates of SimpleFPN (is_vpu_model.py:106-121: the same x against the three (queries, keys) pairs of the DMA neck)
+ * in one launch per pass: vpu_gate_fwd_n = the statistics of all n <= 3 gates (ONE launch) + out[i] = x (1 + cg_i + sg_i) for
+ * every gate (ONE launch, x read once); cg / argq [n][B][C], sg / argc [n][B][N].  vpu_gate_bwd_n: dout[i] = the gradient of
+ * out[i]; dx (+)= sum_i dout_i (1 + cg_i + sg_i), summed in fp32 and rounded once; dQ[i] / dK[i] as in vpu_gate_bwd;
+ * part = workspace fp32 [n][B][64][C].  Q, K, out, dout, dQ, dK: HOST arrays of n device pointers. */
+int vpu_gate_fwd_n(const void* const* Q, const void* const* K, const void* x, void* const* out, float* cg, int32_t* argq,
+                   float* sg, int32_t* argc, int32_t n, int32_t B, int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream);
+int vpu_gate_bwd_n(const void* const* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
+                   const int32_t* argc, void* dx, int32_t accum, void* const* dQ, void* const* dK, float* part, int32_t n,
+                   int32_t B, int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream);
 /* conv_seg: Dropout2d + 1x1 conv to one channel (decode_head.py:210-215).  x [rows][C] channels-last,
  * rows = B*HW; mask fp32 [B][C] (keep/(1-p)) or NULL; out fp32 [rows]. */
 int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out, int64_t rows,

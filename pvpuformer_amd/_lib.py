@@ -98,6 +98,9 @@ SIGNATURES = {
     "vpu_gate_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpu_gate_apply": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpu_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpu_gate_fwd_n": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, C.POINTER(C.c_void_p), _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_gate_bwd_n": [C.POINTER(C.c_void_p), _P, _P, _P, _P, _P, _P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _I, _I, _I,
+                       _I, _I, _I, _P],
     "vpu_convseg_fwd": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P],
     "vpu_convseg_bwd_nblk": [_L],
     "vpu_convseg_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _I, _P],

@@ -995,6 +995,21 @@ constexpr int WIN_LDS_M = WIN_ROWS * 64 * 2;                    // one [256][64]
 constexpr int WIN_LDS_S = 2 * (WIN_ROWS + 16) * 32 * 2;         // two [256 keys + 16 spare rows][32 queries] dS images
 constexpr int WIN_LDS = 3 * WIN_LDS_M + WIN_LDS_S + 2 * WIN_ROWS * 4;
 
+// dS image [key][32 queries]: 64-byte rows of eight 8-byte units.  unit ^= {bit 2: row bit 2, bit 1: row bit 3, bit 0: row bit
+// 1}: the 16 consecutive rows of a ds_write_b64 lane group fill 16 distinct 8-byte slots of the 128-byte bank row, the 8
+// consecutive rows x 4 units of a ds_read_b64_tr_b16 half fill the 256-byte bank row exactly once.
+__device__ __forceinline__ int ds_swz(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
+// [query][32 keys] fragment (k order permuted as frag_tr_perm's) out of the image: queries 16 t .. 16 t + 15
+__device__ __forceinline__ bf16x8_t frag_ds(const char* lds, int t, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int r0 = 4 * g + q, u = ((t * 4 + p) ^ ds_swz(r0)) << 3;     // (rows r0 and 16 + r0 share the swizzle)
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + r0 * 64 + u));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + (16 + r0) * 64 + u));
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
 // A fragment (16 rows x 32 columns, ds_read_b128) out of an image in the transposing-read layout
 template <int HD> __device__ __forceinline__ bf16x8_t frag_rc_tr(const char* lds, int row16, int ks, int lane) {
     const uint4 v = *reinterpret_cast<const uint4*>(lds + tr_off<HD>(row16 + (lane & 15), 2 * (ks * 4 + (lane >> 4))));
@@ -1079,7 +1094,7 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
     for (int u = 0; u < 2; ++u) {
         const int krow = (u < nu ? (tile0 + u) * 16 : WIN_ROWS) + c;
         srow[u] = krow * 64;
-        smask[u] = (((krow >> 1) & 3) << 2) & 7;          // tr_off<32>(krow, unit) = krow * 64 + ((unit ^ mask) << 3)
+        smask[u] = ds_swz(krow);          // (round 5: the conflict-free image of the pass form below; was tr_off<32>'s swizzle: 2.45 M conflict cycles per launch)
     }
     f32x4_t adk[2][DT], adv[2][DT];
 #pragma unroll
@@ -1098,7 +1113,7 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
 #pragma unroll
         for (int kb = 0; kb < WIN_MAX_KB; ++kb)
             if (kb < NKB) {
-                const bf16x8_t af = frag_tr_perm<32>(sS + kb * 32 * 64, my_t, lane);
+                const bf16x8_t af = frag_ds(sS + kb * 32 * 64, my_t, lane);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ktf[kb], acc, 0, 0, 0);
             }
 #pragma unroll
@@ -1210,21 +1225,6 @@ template <int NU> struct WpCfg {
     static constexpr int LDS = WP_NST * WP_STAGE + 2 * SBUF + 2 * WIN_ROWS * 4;      // NU = 1: 40960 + 10240 + 2048 = 53248: three per CU
 };
 
-// dS image [key][32 queries]: 64-byte rows of eight 8-byte units.  unit ^= {bit 2: row bit 2, bit 1: row bit 3, bit 0: row bit
-// 1}: the 16 consecutive rows of a ds_write_b64 lane group fill 16 distinct 8-byte slots of the 128-byte bank row, the 8
-// consecutive rows x 4 units of a ds_read_b64_tr_b16 half fill the 256-byte bank row exactly once.
-__device__ __forceinline__ int ds_swz(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
-// [query][32 keys] fragment (k order permuted as frag_tr_perm's) out of the image: queries 16 t .. 16 t + 15
-__device__ __forceinline__ bf16x8_t frag_ds(const char* lds, int t, int lane) {
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int r0 = 4 * g + q, u = ((t * 4 + p) ^ ds_swz(r0)) << 3;     // (rows r0 and 16 + r0 share the swizzle)
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + r0 * 64 + u));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + (16 + r0) * 64 + u));
-    s16x8_t v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8_t, v);
-}
 // frag_rc_tr as an ext-vector load (through HIP's uint4 struct the load carries TBAA info, and hipcc then puts s_waitcnt
 // vmcnt(0) in front of it while an LDS-DMA is pending)
 __device__ __forceinline__ bf16x8_t frag_rc_trv(const char* lds, int row16, int ks, int lane) {
@@ -1614,7 +1614,7 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     if (lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
         static VpuDevOnce attr;
         if (attr.pending()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+            VPU_SET_LDS(WIN_LDS, attn_bwd_win_kernel);
         }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_win_kernel");
         attn_bwd_win_kernel<<<dim3(nb * H), 512, WIN_LDS, s>>>(a);

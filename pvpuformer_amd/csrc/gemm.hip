@@ -2615,7 +2615,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k3_kernel<TA_, TB_, FL_, RB_>;                                                         \
         if (attr_.pending()) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS); \
+            VPU_SET_LDS(K3_LDS, kern_); \
         }                                                                                                            \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
         const int tot_ = tm_ * tn3;                                                                                  \
@@ -2677,7 +2677,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_, RB_, SW_>;                                               \
         if (attr_.pending()) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<WN_>::LDS + K2_BIAS_LDS); \
+            VPU_SET_LDS(K2Cfg<WN_>::LDS + K2_BIAS_LDS, kern_); \
         }                                                                                                            \
         const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
@@ -2719,8 +2719,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             const int kw = (int)(((d->K + 3) / 4 + 63) / 64 * 64);
             static VpuDevOnce attr_sk;
             if (attr_sk.pending()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
+                VPU_SET_LDS(4 * TILE_BYTES, gemm_bf16_skinny_kernel<0>);
+                VPU_SET_LDS(8 * TILE_BYTES, gemm_bf16_skinny_kernel<1>);
             }
             dim3 sgrid((unsigned)(tm64 * tn64)), sblock(256);
             NOTE_KERNEL("gemm_bf16_skinny_kernel<%d>", d->transB ? 1 : 0);
@@ -2766,7 +2766,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_kernel<TA_, TB_, true, CS_, FL_, 3>;                                                   \
         if (attr_.pending()) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
+            VPU_SET_LDS(6 * TILE_BYTES, kern_); \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_kernel<%d, %d, true, %s, %d, 3>", TA_, TB_, CS_ ? "true" : "false", FL_);              \
         kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
@@ -2809,7 +2809,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k3s_kernel<TA_, TB_, FL_>;                                                             \
         if (attr_.pending()) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<2, 128>::LDS); \
+            VPU_SET_LDS((K3Cfg<2, 128>::LDS), kern_); \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_k3s_kernel<%d, %d, %d>", TA_, TB_, FL_);                                                \
         kern_<<<dim3((unsigned)(tot3s < cap3s ? tot3s : cap3s)), dim3(256), K3Cfg<2, 128>::LDS, s>>>(*dk, tiles_m, tiles_n, 1); \
@@ -2866,10 +2866,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             static VpuDevOnce attr_done;
             if (attr_done.pending()) {
                 const int sz = 3 * STAGE2;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sz);
+                VPU_SET_LDS(sz, gemm_bf16_big_kernel<0, 0>);
+                VPU_SET_LDS(sz, gemm_bf16_big_kernel<0, 1>);
+                VPU_SET_LDS(sz, gemm_bf16_big_kernel<1, 0>);
+                VPU_SET_LDS(sz, gemm_bf16_big_kernel<1, 1>);
             }
             dim3 block2(512);
             NOTE_KERNEL("gemm_bf16_big_kernel<%d, %d>", key >> 1, key & 1);
@@ -3034,9 +3034,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         if (ok && total64 <= 2048) {
             static VpuDevOnce attr_skg;
             if (attr_skg.pending()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny_grouped_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
+                VPU_SET_LDS(4 * TILE_BYTES, gemm_bf16_skinny_grouped_kernel<0, 0>);
+                VPU_SET_LDS(8 * TILE_BYTES, gemm_bf16_skinny_grouped_kernel<0, 1>);
+                VPU_SET_LDS(8 * TILE_BYTES, gemm_bf16_skinny_grouped_kernel<1, 1>);
             }
             NOTE_KERNEL("gemm_bf16_skinny_grouped_kernel<%d, %d>", key >> 1, key & 1);
             if (key == 3) gemm_bf16_skinny_grouped_kernel<1, 1><<<dim3((unsigned)total64), dim3(256), 8 * TILE_BYTES, s>>>(g3, vec ? 1 : 0);
@@ -3072,12 +3072,12 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             static VpuDevOnce attrf0, attrf1;
             if (key == 0) {
                 auto kern_ = gemm_bf16_k2_grouped_fl_kernel<0, 0, VPU_EPI_BIAS>;
-                if (attrf0.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS + K2_BIAS_LDS); }
+                if (attrf0.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS + K2_BIAS_LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_fl_kernel<0, 0, 1>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS + K2_BIAS_LDS, s>>>(g2, 1);
             } else {
                 auto kern_ = gemm_bf16_k2_grouped_fl_kernel<0, 1, 0>;
-                if (attrf1.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS + K2_BIAS_LDS); }
+                if (attrf1.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS + K2_BIAS_LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_fl_kernel<0, 1, 0>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS + K2_BIAS_LDS, s>>>(g2, 1);
             }
@@ -3088,12 +3088,12 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             static VpuDevOnce attr0, attr1;
             if (key == 0) {
                 auto kern_ = gemm_bf16_k2_grouped_kernel<0, 0, false>;
-                if (attr0.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); }
+                if (attr0.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 0, false>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
             } else {
                 auto kern_ = gemm_bf16_k2_grouped_kernel<0, 1, false>;
-                if (attr1.pending()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS); }
+                if (attr1.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 1, false>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
             }
@@ -3150,9 +3150,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                           (int64_t)q.M * q.ldc * 4 < 0x7FFFFFF0LL;
             }
             if (attr4_.pending()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4p_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k4p_grouped_kernel<1, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3Cfg<4>::LDS);
+                VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4_grouped_kernel<1, 1, true>);
+                VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4p_grouped_kernel<1, 1, true>);
+                VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4p_grouped_kernel<1, 1, true, true>);
             }
             const int ncu = cu_count();
             static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
@@ -3176,7 +3176,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         if ((ok && (any_batch || ((k3_opt() & 1) && total2 > cu_count()))) || ok_short) {
             static VpuDevOnce attr3_;
             if (attr3_.pending()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k3_grouped_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
+                VPU_SET_LDS(K3_LDS, gemm_bf16_k3_grouped_kernel<1, 1, true>);
             }
             const int cap = 2 * cu_count();
             static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
@@ -3188,7 +3188,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             static VpuDevOnce attr_;
             auto kern_ = gemm_bf16_k2_grouped_kernel<1, 1, true>;
             if (attr_.pending()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, K2Cfg<2>::LDS);
+                VPU_SET_LDS(K2Cfg<2>::LDS, kern_);
             }
             const int ncu = cu_count();
             static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();

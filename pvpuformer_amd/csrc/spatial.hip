@@ -908,6 +908,188 @@ __global__ __launch_bounds__(256) void gate_bwd_cols_kernel(const float* __restr
     dQ[k] = from_f32<T>(to_f32(dQ[k]) + t * g * (1.f - g));
 }
 
+// ---- the three gates of SimpleFPN in one launch each (round 5).  is_vpu_model.py:106-121 builds x_i = x + x cg_i + x sg_i for the
+// three (queries, keys) pairs the DMA neck returns: same x, three gate pairs.  Per gate the round-1 kernels above took two
+// statistics launches and one pass over x forward, two launches and a read-modify-write of dx backward: nine / six launches,
+// x read three times, dx rewritten three times.  Here: ONE statistics launch (column blocks, then row blocks, gate = grid y),
+// ONE apply launch (x read once, three maps written), one row pass backward (dx = sum_i dout_i (1 + cg_i + sg_i) in fp32,
+// rounded once) + one column launch.  Values per gate are the single-gate kernels' (same operations in the same order);
+// dx differs from three chained launches by the roundings it no longer makes.
+constexpr int GATE_MAXN = 3;
+struct GateSet {
+    const void* Q[GATE_MAXN];      // queries [B][nq][C]
+    const void* K[GATE_MAXN];      // keys [B][N][C]
+    void* out[GATE_MAXN];          // forward: gated maps; backward: the maps' gradients (read)
+    void* dQ[GATE_MAXN];
+    void* dK[GATE_MAXN];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gate_stats_n_kernel(const GateSet gs, float* __restrict__ cg, int* __restrict__ argq,
+                                                           float* __restrict__ sg, int* __restrict__ argc, int B, int nq, int N,
+                                                           int C, int col_blocks) {
+    const int gi = blockIdx.y;
+    if ((int)blockIdx.x < col_blocks) {         // column maxima over the queries: thread -> (sample, channel)
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= (int64_t)B * C) return;
+        const T* Q = (const T*)gs.Q[gi];
+        const int c = (int)(i % C), b = (int)(i / C);
+        float mx = -INFINITY;
+        int am = 0;
+#pragma unroll 8
+        for (int q = 0; q < nq; ++q) {
+            const float v = to_f32(Q[((int64_t)b * nq + q) * C + c]);
+            if (v > mx) { mx = v; am = q; }
+        }
+        cg[(int64_t)gi * B * C + i] = sigmoid_f(mx);
+        argq[(int64_t)gi * B * C + i] = am;
+        return;
+    }
+    // row maxima over the channels: one wave per row
+    const T* K = (const T*)gs.K[gi];
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)B * N, row = (int64_t)(blockIdx.x - col_blocks) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int ck = lane; ck < (C >> 3); ck += 64) {      // (C % 8 == 0: checked by the launcher)
+        float v[8];
+        load8(K + row * C + ck * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v[j] > mx) { mx = v[j]; am = ck * 8 + j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    if (lane == 0) { sg[(int64_t)gi * rows + row] = sigmoid_f(mx); argc[(int64_t)gi * rows + row] = am; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_apply_n_kernel(const T* __restrict__ x, const float* __restrict__ cg,
+                                                           const float* __restrict__ sg, const GateSet gs, int B, int N, int C) {
+    const int chunks = C / 8;
+    const int64_t rows = (int64_t)B * N, total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t row = i / chunks;
+        const int b = (int)(row / N);
+        float v[8];
+        load8(x + row * C + ck * 8, v);
+#pragma unroll
+        for (int gi = 0; gi < GATE_MAXN; ++gi)
+            if (gi < gs.n) {
+                float g[8], o[8];
+                load8(cg + ((int64_t)gi * B + b) * C + ck * 8, g);
+                const float s = sg[(int64_t)gi * rows + row];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = v[j] * (1.f + g[j] + s);
+                store8((T*)gs.out[gi] + row * C + ck * 8, o);
+            }
+    }
+}
+// one wave per row n: dx, the dsg of every gate (+ scatter into its dK), per-column partials of every dcg
+template <typename T, int NCHK>
+__global__ __launch_bounds__(256) void gate_bwd_rows_n_kernel(const GateSet gs, const T* __restrict__ x, const float* __restrict__ cg,
+                                                              const float* __restrict__ sg, const int* __restrict__ argc,
+                                                              T* __restrict__ dx, int accum, float* __restrict__ part, int B, int N,
+                                                              int C) {
+    __shared__ float red[4][8 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int per = (N + GATE_NBLK - 1) / GATE_NBLK;
+    const int n0 = blockIdx.y * per, n1 = n0 + per < N ? n0 + per : N;
+    const int64_t rows = (int64_t)B * N;
+    float dcg[GATE_MAXN][NCHK][8], g[GATE_MAXN][NCHK][8];
+#pragma unroll
+    for (int gi = 0; gi < GATE_MAXN; ++gi)
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {
+            const int c = (lane + i * 64) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dcg[gi][i][j] = 0.f; g[gi][i][j] = 0.f; }
+            if (gi < gs.n && c < C) load8(cg + ((int64_t)gi * B + b) * C + c, g[gi][i]);
+        }
+    for (int n = n0 + wave; n < n1; n += 4) {
+        const int64_t row = (int64_t)b * N + n;
+        float s[GATE_MAXN], dot[GATE_MAXN];
+#pragma unroll
+        for (int gi = 0; gi < GATE_MAXN; ++gi) { s[gi] = gi < gs.n ? sg[(int64_t)gi * rows + row] : 0.f; dot[gi] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                float xv[8], o[8];
+                load8(x + row * C + c, xv);
+                if (accum) load8(dx + row * C + c, o);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                }
+#pragma unroll
+                for (int gi = 0; gi < GATE_MAXN; ++gi)
+                    if (gi < gs.n) {
+                        float dv[8];
+                        load8((const T*)gs.out[gi] + row * C + c, dv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float t = dv[j] * xv[j];
+                            dot[gi] += t;
+                            dcg[gi][i][j] += t;
+                            o[j] += dv[j] * (1.f + g[gi][i][j] + s[gi]);
+                        }
+                    }
+                store8(dx + row * C + c, o);
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < GATE_MAXN; ++gi)
+            if (gi < gs.n) {
+                const float d = wave_sum(dot[gi]);
+                if (lane == 0) {
+                    T* dK = (T*)gs.dK[gi];
+                    const int64_t k = row * C + argc[(int64_t)gi * rows + row];
+                    dK[k] = from_f32<T>(to_f32(dK[k]) + d * s[gi] * (1.f - s[gi]));
+                }
+            }
+    }
+#pragma unroll
+    for (int gi = 0; gi < GATE_MAXN; ++gi)
+        if (gi < gs.n) {
+#pragma unroll
+            for (int i = 0; i < NCHK; ++i) {
+                const int c = (lane + i * 64) * 8;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[wave][j * 64 + lane] = dcg[gi][i][j];
+                __syncthreads();
+                if (wave == 0 && c < C) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
+                    store8(part + (((int64_t)gi * B + b) * GATE_NBLK + blockIdx.y) * C + c, o);
+                }
+            }
+        }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_cols_n_kernel(const float* __restrict__ part, const float* __restrict__ cg,
+                                                              const int* __restrict__ argq, const GateSet gs, int B, int nq, int C) {
+    const int gi = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int c = (int)(i % C), b = (int)(i / C);
+    float t = 0.f;
+    for (int k = 0; k < GATE_NBLK; ++k) t += part[(((int64_t)gi * B + b) * GATE_NBLK + k) * C + c];
+    const float g = cg[(int64_t)gi * B * C + i];
+    T* dQ = (T*)gs.dQ[gi];
+    const int64_t k = ((int64_t)b * nq + argq[(int64_t)gi * B * C + i]) * C + c;
+    dQ[k] = from_f32<T>(to_f32(dQ[k]) + t * g * (1.f - g));
+}
+
 // ------------------------------------------------------------------------------ conv_seg (C -> 1, Dropout2d mask)
 template <typename T>
 __global__ __launch_bounds__(256) void convseg_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -1420,6 +1602,51 @@ extern "C" int vpu_gate_bwd(const void* dout, const void* x, const float* cg, co
                gate_bwd_cols_kernel<T><<<vpu_grid_for((int64_t)B * C, 256), 256, 0, ST>>>(part, cg, argq, (T*)dQ, B, nq,
                                                                                          C);)
     return vpu_check_launch("vpu_gate_bwd");
+}
+extern "C" int vpu_gate_fwd_n(const void* const* Q, const void* const* K, const void* x, void* const* out, float* cg, int32_t* argq,
+                              float* sg, int32_t* argc, int32_t n, int32_t B, int32_t nq, int32_t N, int32_t C, int32_t dtype,
+                              void* stream) {
+    vpu_clear_stale_error();
+    if (n < 1 || n > GATE_MAXN || C % 8 || !Q || !K || !x || !out || !cg || !argq || !sg || !argc || B < 1 || nq < 1 || N < 1) {
+        vpu_set_error("gate_fwd_n: 1 <= n <= 3 gates, C % 8 == 0, non-null pointers");
+        return VPU_ERR_ARG;
+    }
+    GateSet gs{};
+    gs.n = n;
+    for (int i = 0; i < n; ++i) {
+        gs.Q[i] = Q[i]; gs.K[i] = K[i]; gs.out[i] = out[i];
+        if (!Q[i] || !K[i] || !out[i]) { vpu_set_error("gate_fwd_n: null operand"); return VPU_ERR_ARG; }
+    }
+    const int col_blocks = vpu_grid_for((int64_t)B * C, 256);
+    const unsigned row_blocks = (unsigned)(((int64_t)B * N + 3) / 4);
+    const int64_t total = (int64_t)B * N * (C / 8);
+    DISPATCH_T(dtype,
+               gate_stats_n_kernel<T><<<dim3(col_blocks + row_blocks, n), 256, 0, ST>>>(gs, cg, argq, sg, argc, B, nq, N, C, col_blocks);
+               gate_apply_n_kernel<T><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>((const T*)x, cg, sg, gs, B, N, C);)
+    return vpu_check_launch("vpu_gate_fwd_n");
+}
+extern "C" int vpu_gate_bwd_n(const void* const* dout, const void* x, const float* cg, const int32_t* argq, const float* sg,
+                              const int32_t* argc, void* dx, int32_t accum, void* const* dQ, void* const* dK, float* part, int32_t n,
+                              int32_t B, int32_t nq, int32_t N, int32_t C, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (n < 1 || n > GATE_MAXN || C % 8 || C > 2048 || !dout || !x || !dx || !dQ || !dK || !part) {
+        vpu_set_error("gate_bwd_n: 1 <= n <= 3 gates, C % 8 == 0, C <= 2048, non-null pointers");
+        return VPU_ERR_ARG;
+    }
+    GateSet gs{};
+    gs.n = n;
+    for (int i = 0; i < n; ++i) {
+        gs.out[i] = const_cast<void*>(dout[i]); gs.dQ[i] = dQ[i]; gs.dK[i] = dK[i];
+        if (!dout[i] || !dQ[i] || !dK[i]) { vpu_set_error("gate_bwd_n: null operand"); return VPU_ERR_ARG; }
+    }
+    dim3 grid(B, GATE_NBLK);
+    const int nchk = (C + 511) / 512;
+#define VPU_GATE_ROWS(NCHK_)                                                                                                   \
+    DISPATCH_T(dtype, (gate_bwd_rows_n_kernel<T, NCHK_><<<grid, 256, 0, ST>>>(gs, (const T*)x, cg, sg, argc, (T*)dx, accum, part, B, N, C));)
+    if (nchk <= 1) { VPU_GATE_ROWS(1) } else if (nchk == 2) { VPU_GATE_ROWS(2) } else if (nchk == 3) { VPU_GATE_ROWS(3) } else { VPU_GATE_ROWS(4) }
+#undef VPU_GATE_ROWS
+    DISPATCH_T(dtype, gate_bwd_cols_n_kernel<T><<<dim3(vpu_grid_for((int64_t)B * C, 256), n), 256, 0, ST>>>(part, cg, argq, gs, B, nq, C);)
+    return vpu_check_launch("vpu_gate_bwd_n");
 }
 extern "C" int vpu_convseg_fwd(const void* x, const float* w, const float* bias, const float* mask, float* out,
                                int64_t rows, int64_t HW, int32_t C, int32_t dtype, void* stream) {

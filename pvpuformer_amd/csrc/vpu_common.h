@@ -39,6 +39,17 @@ int vpu_check_launch(const char* what);
 // hipGetLastError() is per-thread and NOT cleared by successful calls: drop whatever an earlier runtime call of the
 // host program left behind so that vpu_check_launch() reports this launch only.
 static inline void vpu_clear_stale_error() { (void)hipGetLastError(); }
+// Raises a kernel's dynamic-LDS limit (done once per device by the callers, see VpuDevOnce); a refusal ends the C-ABI call that
+// asked for it with VPU_ERR_LAUNCH instead of surfacing later as a launch failure with no cause attached.
+#define VPU_SET_LDS(bytes, ...)                                                                                          \
+    do {                                                                                                                 \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (bytes)) != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                                                     \
+            vpu_set_error("hipFuncSetAttribute(" #__VA_ARGS__ ", hipFuncAttributeMaxDynamicSharedMemorySize) failed");   \
+            return VPU_ERR_LAUNCH;                                                                                       \
+        }                                                                                                                \
+    } while (0)
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

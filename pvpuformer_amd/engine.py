@@ -982,37 +982,44 @@ class Engine:
                 for v in (q0, hs[0][0], hs[1][0], hs[2][0]):
                     self.acc(v, q_out.g)
             self.tape.append(bwd_qout)
-        # gates (is_vpu_model.py:106-121)
+        # gates (is_vpu_model.py:106-121): x_i = x (1 + cg_i + sg_i) for the three (queries, keys) pairs -- round 5: the three
+        # gates in ONE statistics launch and ONE pass over x forward (vpu_gate_fwd_n), one row pass + one column launch backward
+        # (vpu_gate_bwd_n: dx summed in fp32 over the three gates, rounded once) instead of nine / six launches
         maps = [xr]
-        for qi, ki in hs:
-            cg, sg = self._new(B, D, dtype=torch.float32), self._new(B, NT, dtype=torch.float32)
-            aq = self._new(B, D, dtype=torch.int32)
-            ac = self._new(B, NT, dtype=torch.int32)
-            ops.gate_stats(qi.t, ki.t, cg, aq, sg, ac, B, nq, NT, D)
-            xg = Var(self._new(M, D))
-            ops.gate_apply(xr.t, cg, sg, xg.t, B, NT, D)
-            if training:
-                def bwd_gate(xg=xg, qi=qi, ki=ki, cg=cg, sg=sg, aq=aq, ac=ac):
-                    if xg.g is None:
-                        return
-                    if any(v.g is None for v in (qi, ki)):
-                        # the gate gradients are scattered at arg-max positions into zeroed buffers: ONE fill for the
-                        # buffers of all three gates (their backward closures run back to back), not one per tensor
-                        pend = [v for pair in hs for v in pair if v.g is None]
-                        pool = ops.zero_(torch.empty(sum(v.t.numel() for v in pend), device=self.dev, dtype=self.td))
-                        o_ = 0
-                        for v in pend:
-                            v.g = pool[o_:o_ + v.t.numel()].view_as(v.t)
-                            o_ += v.t.numel()
-                    accum = xr.g is not None
-                    if not accum:
-                        xr.g = torch.empty_like(xr.t)
-                    for t_ in (xr.g, qi.g, ki.g):
-                        self._writable(t_)
-                    part = self._new(B, 64, D, dtype=torch.float32)
-                    ops.gate_bwd(xg.g, xr.t, cg, aq, sg, ac, xr.g, accum, qi.g, ki.g, part, B, nq, NT, D)
-                self.tape.append(bwd_gate)
-            maps.append(xg)
+        ng = len(hs)
+        cg, sg = self._new(ng, B, D, dtype=torch.float32), self._new(ng, B, NT, dtype=torch.float32)
+        aq, ac = self._new(ng, B, D, dtype=torch.int32), self._new(ng, B, NT, dtype=torch.int32)
+        xgs = [Var(self._new(M, D)) for _ in range(ng)]
+        ops.gate_fwd_n([qi.t for qi, _ in hs], [ki.t for _, ki in hs], xr.t, [v.t for v in xgs], cg, aq, sg, ac, B, nq, NT, D)
+        if training:
+            def bwd_gates():
+                live = [i for i in range(ng) if xgs[i].g is not None]
+                if not live:
+                    return
+                if any(v.g is None for i in live for v in hs[i]):
+                    # the gate gradients are scattered at arg-max positions into zeroed buffers: ONE fill for all of them
+                    pend = [v for i in live for v in hs[i] if v.g is None]
+                    pool = ops.zero_(torch.empty(sum(v.t.numel() for v in pend), device=self.dev, dtype=self.td))
+                    o_ = 0
+                    for v in pend:
+                        v.g = pool[o_:o_ + v.t.numel()].view_as(v.t)
+                        o_ += v.t.numel()
+                accum = xr.g is not None
+                if not accum:
+                    xr.g = torch.empty_like(xr.t)
+                for t_ in [xr.g] + [v.g for i in live for v in hs[i]]:
+                    self._writable(t_)
+                part = self._new(ng, B, 64, D, dtype=torch.float32)
+                if len(live) == ng:
+                    ops.gate_bwd_n([v.g for v in xgs], xr.t, cg, aq, sg, ac, xr.g, accum, [hs[i][0].g for i in live],
+                                   [hs[i][1].g for i in live], part, B, nq, NT, D)
+                else:       # (a map without a gradient: the single-gate launches over the views of the batched statistics)
+                    for i in live:
+                        ops.gate_bwd(xgs[i].g, xr.t, cg[i], aq[i], sg[i], ac[i], xr.g, accum, hs[i][0].g, hs[i][1].g, part[i], B, nq,
+                                     NT, D)
+                        accum = True
+            self.tape.append(bwd_gates)
+        maps += xgs
         if taps is not None:
             taps["q_out"] = q_out.t
         # FPN branches (is_vpu_model.py:55-86), channels-last

@@ -472,6 +472,22 @@ def gate_bwd(dout, x, cg, argq, sg, argc, dx, accum, dQ, dK, part, B, nq, N, Cdi
               ptr(dK), ptr(part), B, nq, N, Cdim, code_of(x), _stream())
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
+
+
+def gate_fwd_n(Qs, Ks, x, outs, cg, argq, sg, argc, B, nq, N, Cdim):
+    """The n <= 3 gates of SimpleFPN against one x: statistics (one launch) + gated maps (one launch).  cg / argq [n, B, C],
+    sg / argc [n, B, N]."""
+    _lib.call("vpu_gate_fwd_n", _ptr_array(Qs), _ptr_array(Ks), ptr(x), _ptr_array(outs), ptr(cg), ptr(argq), ptr(sg), ptr(argc),
+              len(Qs), B, nq, N, Cdim, code_of(x), _stream())
+
+
+def gate_bwd_n(douts, x, cg, argq, sg, argc, dx, accum, dQs, dKs, part, B, nq, N, Cdim):
+    _lib.call("vpu_gate_bwd_n", _ptr_array(douts), ptr(x), ptr(cg), ptr(argq), ptr(sg), ptr(argc), ptr(dx), int(accum),
+              _ptr_array(dQs), _ptr_array(dKs), ptr(part), len(douts), B, nq, N, Cdim, code_of(x), _stream())
+
+
 def convseg_fwd(x, w, bias, mask, out, rows, HW, Cdim):
     _lib.call("vpu_convseg_fwd", ptr(x), ptr(w), ptr(bias), ptr(mask), ptr(out), rows, HW, Cdim, code_of(x), _stream())
 

@@ -792,6 +792,57 @@ def test_upsum_relu_equals_fusion_over_concat(ops, dtype, n):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C", [64, 768, 1280])
+def test_batched_gates_equal_single_gate_launches(ops, dtype, C):
+    """vpu_gate_fwd_n / vpu_gate_bwd_n (round 5: the three gates of SimpleFPN in one launch per pass) against the single-gate
+    kernels, gate for gate: statistics, arg-max indices and gated maps bit for bit; dQ / dK bit for bit (same operations in
+    the same order); dx = the fp32 sum over the three gates rounded once -- equal to the chained single-gate launches in
+    fp32, within their extra bf16 roundings otherwise -- and against torch autograd.  C = 768 / 1280: two / three 512-column
+    chunks per row (ViT-B / ViT-H)."""
+    td = TD[dtype]
+    B, nq, N, n = 2, 48, 196, 3
+    x = dev(rnd(B, N, C, seed=50)).to(td)
+    Qs = [dev(rnd(B, nq, C, seed=51 + i)).to(td) for i in range(n)]
+    Ks = [dev(rnd(B, N, C, seed=61 + i)).to(td) for i in range(n)]
+    cg, sg = torch.empty(n, B, C, device="cuda"), torch.empty(n, B, N, device="cuda")
+    aq = torch.empty(n, B, C, device="cuda", dtype=torch.int32)
+    ac = torch.empty(n, B, N, device="cuda", dtype=torch.int32)
+    outs = [torch.empty_like(x) for _ in range(n)]
+    ops.gate_fwd_n(Qs, Ks, x, outs, cg, aq, sg, ac, B, nq, N, C)
+    for i in range(n):
+        cg1, sg1 = torch.empty(B, C, device="cuda"), torch.empty(B, N, device="cuda")
+        aq1, ac1 = torch.empty(B, C, device="cuda", dtype=torch.int32), torch.empty(B, N, device="cuda", dtype=torch.int32)
+        ops.gate_stats(Qs[i], Ks[i], cg1, aq1, sg1, ac1, B, nq, N, C)
+        o1 = torch.empty_like(x)
+        ops.gate_apply(x, cg1, sg1, o1, B, N, C)
+        assert torch.equal(cg[i], cg1) and torch.equal(sg[i], sg1) and torch.equal(aq[i], aq1) and torch.equal(ac[i], ac1)
+        assert torch.equal(outs[i], o1)
+    douts = [dev(rnd(B, N, C, seed=71 + i)).to(td) for i in range(n)]
+    for accum in (False, True):
+        dx0 = dev(rnd(B, N, C, seed=80)).to(td)
+        dx = dx0.clone()
+        dQs = [dev(rnd(B, nq, C, seed=81 + i)).to(td) for i in range(n)]
+        dKs = [dev(rnd(B, N, C, seed=91 + i)).to(td) for i in range(n)]
+        dQ1, dK1 = [t.clone() for t in dQs], [t.clone() for t in dKs]
+        ops.gate_bwd_n(douts, x, cg, aq, sg, ac, dx, accum, dQs, dKs, torch.empty(n, B, 64, C, device="cuda"), B, nq, N, C)
+        dx1 = dx0.clone()
+        for i in range(n):
+            ops.gate_bwd(douts[i], x, cg[i], aq[i], sg[i], ac[i], dx1, accum or i > 0, dQ1[i], dK1[i],
+                         torch.empty(B, 64, C, device="cuda"), B, nq, N, C)
+            assert torch.equal(dQs[i], dQ1[i]) and torch.equal(dKs[i], dK1[i]), i
+        xf = x.float().clone().requires_grad_(True)       # (a fresh leaf per pass: x.float() IS x in fp32)
+        ref = sum((xf * (1 + cg[i].unsqueeze(1) + sg[i].unsqueeze(2)) * douts[i].float()).sum() for i in range(n))
+        ref.backward()
+        want = xf.grad + (dx0.float() if accum else 0)
+        if dtype == 1:
+            torch.testing.assert_close(dx, dx1, atol=1e-5, rtol=1e-5)
+            torch.testing.assert_close(dx, want, atol=1e-5, rtol=1e-5)
+        else:       # one rounding instead of three: closer to the fp32 sum than the chained launches are
+            e_n, e_1 = (dx.float() - want).abs().max().item(), (dx1.float() - want).abs().max().item()
+            assert e_n <= e_1 + 1e-6 and e_n < 4e-2 * want.abs().max().item(), (e_n, e_1)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 def test_gates_and_convseg(ops, dtype):
     td = TD[dtype]
     B, nq, N, C = 2, 48, 784, 64
