@@ -190,9 +190,23 @@ int vpu_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t pe
 /* out = a + b + c + d (q_out, is_vpu_model.py:104); any of b,c,d may be NULL */
 int vpu_add4(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n, int32_t dtype,
              void* stream);
+/* the adjoint of vpu_add4: dst[i] = src (accum[i] == 0) or dst[i] += src, i < ndst <= 4, ONE launch; dst / accum: host arrays */
+int vpu_fanout_add(const void* src, void* const* dst, const int32_t* accum, int32_t ndst, int64_t n, int32_t dtype, void* stream);
 /* dst[r][c] (dtype_dst, ld_dst) = src[r][c] (fp32/bf16, ld_src), zero-filling columns [cols, cols_pad) */
 int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst,
                int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
+/* Up to 8 strided 2-D casts of fp32 sources in ONE launch: dst[map(r)][c] = src[r][c] (+ src2[r][c] when src2 != NULL, same
+ * leading dimension), zeros in columns [cols, cols_pad); dst_dtype VPU_BF16 / VPU_F32; map = identity, or (perm_g > 0, rows ==
+ * perm_g^2) raster -> window order of a perm_g x perm_g token grid with perm_wg-wide windows (models_vit.py:225-239).  The
+ * per-step derived operands of the engine (fused patch-embed weight + bias, K-padded PuE weight, window-ordered pos_embed). */
+typedef struct vpu_cast_job {
+    const float* src;
+    const float* src2;
+    void* dst;
+    int64_t ld_src, ld_dst, rows;
+    int32_t cols, cols_pad, dst_dtype, perm_g, perm_wg;
+} vpu_cast_job;
+int vpu_cast2d_batched(const vpu_cast_job* jobs, int32_t n, void* stream);
 /* Dropout2d channel mask of the segmentation head (reference: transformer_helper/decode_head.py:82-86,210-215,
  * nn.Dropout2d(0.1) in train mode): out[i] = Bernoulli(keep) / keep for n = B * channels entries, from a counter-based
  * generator keyed by (seed ^ state[1], call number, i); `state` is TWO uint64 in device memory: [0] the call number (zeroed by

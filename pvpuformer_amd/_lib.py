@@ -41,6 +41,12 @@ class ColsumJob(C.Structure):
                 ("row_len", C.c_int32), ("out_ld", C.c_int32)]
 
 
+class CastJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src2", C.c_void_p), ("dst", C.c_void_p), ("ld_src", C.c_int64), ("ld_dst", C.c_int64),
+                ("rows", C.c_int64), ("cols", C.c_int32), ("cols_pad", C.c_int32), ("dst_dtype", C.c_int32),
+                ("perm_g", C.c_int32), ("perm_wg", C.c_int32)]
+
+
 SIGNATURES = {
     "vpu_gemm": [C.POINTER(GemmDesc), _P],
     "vpu_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
@@ -62,6 +68,8 @@ SIGNATURES = {
     "vpu_add_bcast": [_P, _P, _P, _L, _L, _I, _P],
     "vpu_add4": [_P, _P, _P, _P, _P, _L, _I, _P],
     "vpu_cast2d": [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P],
+    "vpu_cast2d_batched": [C.POINTER(CastJob), _I, _P],
+    "vpu_fanout_add": [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I, _L, _I, _P],
     "vpu_dropout_mask": [_P, _I, _F, C.c_uint64, _P, _P],
     "vpu_fill_f32": [_P, _F, _L, _P],
     "vpu_fill_ranges_f32": [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _F, _P],

@@ -555,6 +555,30 @@ __global__ __launch_bounds__(256) void add4_kernel(const T* __restrict__ a, cons
         store8(out + i * 8, x);
     }
 }
+// the adjoint of add4: every dst_i (+)= src, ONE launch (q_out = q + q_1 + q_2 + q_3 hands its gradient to four tensors)
+struct FanOut { void* dst[4]; int accum[4]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void fanout_add_kernel(const T* __restrict__ src, const FanOut f, int64_t nchunk) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * 256) {
+        float x[8];
+        load8(src + i * 8, x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < f.n) {
+                T* d = (T*)f.dst[k];
+                float y[8];
+                if (f.accum[k]) {
+                    load8(d + i * 8, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) y[j] += x[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) y[j] = x[j];
+                }
+                store8(d + i * 8, y);
+            }
+    }
+}
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast2d_kernel(const TS* __restrict__ src, int64_t ld_src, TD* __restrict__ dst,
                                                      int64_t ld_dst, int64_t rows, int cols, int cols_pad) {
@@ -563,6 +587,39 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const TS* __restrict__ src,
         const int64_t r = i / cols_pad;
         const int c = (int)(i - r * cols_pad);
         dst[r * ld_dst + c] = from_f32<TD>(c < cols ? to_f32(src[r * ld_src + c]) : 0.f);
+    }
+}
+// up to CAST_MAXJ strided 2-D casts of fp32 sources in ONE launch (grid y = job): dst[map(r)][c] = src[r][c] (+ src2[r][c]), zeros
+// in the pad columns; map = identity, or the window order of a g x g token grid (perm_g > 0: row r is a raster index, see
+// window_permute_kernel) -- the per-step derived operands of Engine.refresh_weights (fused patch-embed weight and bias, the
+// K-padded PuE weight, the window-ordered position embedding) were five launches
+constexpr int CAST_MAXJ = 8;
+struct CastJob {
+    const float* src;
+    const float* src2;
+    void* dst;
+    long long ld_src, ld_dst, rows;
+    int cols, cols_pad, dst_dtype, perm_g, perm_wg;
+};
+struct CastBatch { CastJob j[CAST_MAXJ]; };
+__global__ __launch_bounds__(256) void cast2d_batched_kernel(const CastBatch b) {
+    const CastJob& q = b.j[blockIdx.y];
+    const int64_t total = q.rows * q.cols_pad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / q.cols_pad;
+        const int c = (int)(i - r * q.cols_pad);
+        float v = 0.f;
+        if (c < q.cols) {
+            v = q.src[r * q.ld_src + c];
+            if (q.src2) v += q.src2[r * q.ld_src + c];
+        }
+        int64_t ro = r;
+        if (q.perm_g > 0) {
+            const int g = q.perm_g, wg = q.perm_wg, nw = g / wg, t = (int)r, ty = t / g, tx = t % g;
+            ro = ((ty / wg) * nw + tx / wg) * wg * wg + (ty % wg) * wg + tx % wg;
+        }
+        if (q.dst_dtype == VPU_BF16) reinterpret_cast<bf16_t*>(q.dst)[ro * q.ld_dst + c] = (bf16_t)v;
+        else reinterpret_cast<float*>(q.dst)[ro * q.ld_dst + c] = v;
     }
 }
 // dz = dy * act'(aux) on a strided 2-D view (rows x cols, cols % 8 == 0); kind 0: relu (aux = output or input),
@@ -667,7 +724,8 @@ extern "C" int vpu_layernorm_fwd_pe(const void* x, const float* w, const float* 
         return VPU_ERR_ARG;
     }
     // balanced persistent grid: at most 2048 workgroups (8 per CU), every wave the same number of rows (+-1)
-    const int64_t nb = (rows + 3) / 4, trips = (nb + 2047) / 2048;
+    static const int64_t capf = [] { const char* e = getenv("VPU_LN_FWD_CAP"); const int v = e ? atoi(e) : 2048; return (int64_t)(v < 256 ? 256 : v); }();
+    const int64_t nb = (rows + 3) / 4, trips = (nb + capf - 1) / capf;
     const unsigned grid = (unsigned)((nb + trips - 1) / trips);
 #define VPU_LN_FWD(NCH_)                                                                                              \
     if (pe) { DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_, true><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)pe, pe_rows, (T*)y2);) } \
@@ -819,6 +877,20 @@ extern "C" int vpu_add4(const void* a, const void* b, const void* c, const void*
     DISPATCH_T(dtype, add4_kernel<T><<<grid, 256, 0, ST>>>((const T*)a, (const T*)b, (const T*)c, (const T*)d, (T*)out, n / 8);)
     return vpu_check_launch("vpu_add4");
 }
+extern "C" int vpu_fanout_add(const void* src, void* const* dst, const int32_t* accum, int32_t ndst, int64_t n, int32_t dtype,
+                              void* stream) {
+    vpu_clear_stale_error();
+    if (!src || !dst || !accum || ndst < 1 || ndst > 4 || n % 8) { vpu_set_error("fanout_add: 1 <= ndst <= 4, n % 8 == 0"); return VPU_ERR_ARG; }
+    FanOut f{};
+    f.n = ndst;
+    for (int i = 0; i < ndst; ++i) {
+        if (!dst[i]) { vpu_set_error("fanout_add: null destination"); return VPU_ERR_ARG; }
+        f.dst[i] = dst[i]; f.accum[i] = accum[i];
+    }
+    const int grid = vpu_grid_for(n / 8, 256, 4096);
+    DISPATCH_T(dtype, fanout_add_kernel<T><<<grid, 256, 0, ST>>>((const T*)src, f, n / 8);)
+    return vpu_check_launch("vpu_fanout_add");
+}
 extern "C" int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
                           int64_t ld_dst, int64_t rows, int32_t cols, int32_t cols_pad, void* stream) {
     vpu_clear_stale_error();
@@ -833,6 +905,24 @@ extern "C" int vpu_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, vo
         cast2d_kernel<bf16_t, bf16_t><<<grid, 256, 0, ST>>>((const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, cols_pad);
     else { vpu_set_error("cast2d: dtype"); return VPU_ERR_ARG; }
     return vpu_check_launch("vpu_cast2d");
+}
+extern "C" int vpu_cast2d_batched(const vpu_cast_job* jobs, int32_t n, void* stream) {
+    vpu_clear_stale_error();
+    if (!jobs || n < 1 || n > CAST_MAXJ) { vpu_set_error("cast2d_batched: 1 <= n <= 8 jobs"); return VPU_ERR_ARG; }
+    CastBatch b{};
+    int64_t most = 1;
+    for (int i = 0; i < n; ++i) {
+        const vpu_cast_job& j = jobs[i];
+        if (!j.src || !j.dst || j.rows < 1 || j.cols < 1 || j.cols_pad < j.cols || (j.dst_dtype != VPU_BF16 && j.dst_dtype != VPU_F32) ||
+            (j.perm_g > 0 && (j.perm_wg < 1 || j.perm_g % j.perm_wg || j.rows != (int64_t)j.perm_g * j.perm_g))) {
+            vpu_set_error("cast2d_batched: null operand, empty job, dtype, or a row map that does not fit the rows");
+            return VPU_ERR_ARG;
+        }
+        b.j[i] = CastJob{j.src, j.src2, j.dst, j.ld_src, j.ld_dst, j.rows, j.cols, j.cols_pad, j.dst_dtype, j.perm_g, j.perm_wg};
+        most = most > j.rows * j.cols_pad ? most : j.rows * j.cols_pad;
+    }
+    cast2d_batched_kernel<<<dim3(vpu_grid_for(most, 256, 2048), n), 256, 0, ST>>>(b);
+    return vpu_check_launch("vpu_cast2d_batched");
 }
 extern "C" int vpu_act_bwd(const void* dy, int64_t ld_dy, const void* aux, int64_t ld_aux, void* dz, int64_t ld_dz,
                            int64_t rows, int32_t cols, int32_t kind, int32_t dtype, void* stream) {

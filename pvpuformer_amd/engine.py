@@ -224,15 +224,19 @@ class Engine:
         if self.dt == BF16 and not shadow_is_fresh:
             ops.cast2d(self.flat, self.total, self.shadow, self.total, 1, self.total)
         k3 = 3 * P * P
-        ops.cast2d(self.Pm("backbone.patch_embed.proj.weight"), k3, (self.w_patch, 0), 2 * self.k3p, D, k3)
-        ops.cast2d(self.Pm("patch_embed_coords.proj.weight"), k3, (self.w_patch, self.k3p), 2 * self.k3p, D, k3)
-        ops.add4(self.Pm("backbone.patch_embed.proj.bias"), self.Pm("patch_embed_coords.proj.bias"), None, None,
-                 self.b_patch, D)
-        ops.cast2d(self.Pm("neck.ffn_layer.lin1.weight"), self.E, self.w_lin1p, self.Epad, 2048, self.E, self.Epad)
-        tmp = torch.empty(self.NT, D, device=self.dev, dtype=self.td)
         po = self.names["backbone.pos_embed"][0]
-        ops.cast2d((self.flat, po + D), D, tmp, D, self.NT, D)
-        ops.window_permute(tmp, self.pos_win, 1, self.g, self.wg, D, to_raster=False)
+        # the derived operands in ONE launch (round 5: vpu_cast2d_batched; five launches before): the two patch embeddings side
+        # by side in the fused weight, the sum of their biases, the K-padded PuE weight, pos_embed[:, 1:] in window order
+        ops.cast2d_batched([
+            dict(src=self.Pm("backbone.patch_embed.proj.weight"), dst=(self.w_patch, 0), ld_src=k3, ld_dst=2 * self.k3p, rows=D, cols=k3),
+            dict(src=self.Pm("patch_embed_coords.proj.weight"), dst=(self.w_patch, self.k3p), ld_src=k3, ld_dst=2 * self.k3p, rows=D,
+                 cols=k3),
+            dict(src=self.Pm("backbone.patch_embed.proj.bias"), src2=self.Pm("patch_embed_coords.proj.bias"), dst=self.b_patch,
+                 ld_src=D, ld_dst=D, rows=1, cols=D),
+            dict(src=self.Pm("neck.ffn_layer.lin1.weight"), dst=self.w_lin1p, ld_src=self.E, ld_dst=self.Epad, rows=2048, cols=self.E,
+                 cols_pad=self.Epad),
+            dict(src=(self.flat, po + D), dst=self.pos_win, ld_src=D, ld_dst=D, rows=self.NT, cols=D, perm=(self.g, self.wg)),
+        ])
         self._pos_cache = {self.g: self.pos_win}      # other grids are re-derived from the new weights on demand
         self.shadow_valid = True
 
@@ -976,11 +980,17 @@ class Engine:
         q_out = Var(self._new(B * nq, D))
         ops.add4(q0.t, hs[0][0].t, hs[1][0].t, hs[2][0].t, q_out.t, nQ)
         if training:
-            def bwd_qout():
+            def bwd_qout():       # the gradient of the sum goes to its four terms: one launch (vpu_fanout_add)
                 if q_out.g is None:
                     return
-                for v in (q0, hs[0][0], hs[1][0], hs[2][0]):
-                    self.acc(v, q_out.g)
+                vs = (q0, hs[0][0], hs[1][0], hs[2][0])
+                had = [v.g is not None for v in vs]
+                for v, h_ in zip(vs, had):
+                    if h_:
+                        self._writable(v.g)
+                    else:
+                        v.g = torch.empty_like(q_out.g)
+                ops.fanout_add(q_out.g, [v.g for v in vs], had, q_out.g.numel())
             self.tape.append(bwd_qout)
         # gates (is_vpu_model.py:106-121): x_i = x (1 + cg_i + sg_i) for the three (queries, keys) pairs -- round 5: the three
         # gates in ONE statistics launch and ONE pass over x forward (vpu_gate_fwd_n), one row pass + one column launch backward
@@ -1157,8 +1167,9 @@ class Engine:
                         ops.head_grad_fused(fn.g, fn.t, inv_f, dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask,
                                             fused.g, part, part_b, B * HW4, HW4, Cc)
                         relu_done[0] = True
-                        ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
-                        ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
+                        # (conv_seg's weight / bias partial rows join the batched column sums of the norm layers: flush_colsums)
+                        self._csq.append((part, self.G("head.conv_seg.weight"), nb, Cc))
+                        self._csq.append((part_b, self.G("head.conv_seg.bias"), nb, 1))
                         return
                     accum = fused.g is not None
                     if not accum:
@@ -1169,8 +1180,8 @@ class Engine:
                     ops.convseg_bwd(dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask, fused.g, int(accum) | 2, part,
                                     part_b, B * HW4, HW4, Cc)
                     relu_done[0] = True
-                    ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
-                    ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
+                    self._csq.append((part, self.G("head.conv_seg.weight"), nb, Cc))
+                    self._csq.append((part_b, self.G("head.conv_seg.bias"), nb, 1))
             # must run BEFORE the closures of query / fused: insert at the position just after they were recorded
             self.tape.append(bwd_head)
         self.last_tape = tape if training else None

@@ -259,11 +259,31 @@ def add4(a, b, c, d, out, n):
     _lib.call("vpu_add4", ptr(a), ptr(b), ptr(c), ptr(d), ptr(out), n, code_of(a), _stream())
 
 
+def fanout_add(src, dsts, accum, n):
+    """dsts[i] (+)= src for up to four tensors in one launch (accum[i]: add / overwrite)."""
+    arr = (C.c_void_p * len(dsts))(*[ptr(t) for t in dsts])
+    acc = (C.c_int32 * len(dsts))(*[int(bool(a)) for a in accum])
+    _lib.call("vpu_fanout_add", ptr(src), arr, acc, len(dsts), n, code_of(src), _stream())
+
+
 def cast2d(src, ld_src, dst, ld_dst, rows, cols, cols_pad=None):
     s = src[0] if isinstance(src, tuple) else src
     d = dst[0] if isinstance(dst, tuple) else dst
     _lib.call("vpu_cast2d", ptr(src), code_of(s), ld_src, ptr(dst), code_of(d), ld_dst, rows, cols,
               cols if cols_pad is None else cols_pad, _stream())
+
+
+def cast2d_batched(jobs):
+    """jobs: up to 8 dicts(src fp32 (tensor or (tensor, offset)), dst, ld_src, ld_dst, rows, cols[, cols_pad, src2, perm]):
+    dst[map(r)][c] = src[r][c] (+ src2[r][c]) in dst's dtype, ONE launch; perm = (g, wg): raster -> window row order."""
+    arr = (_lib.CastJob * len(jobs))()
+    for j, q in zip(arr, jobs):
+        d = q["dst"][0] if isinstance(q["dst"], tuple) else q["dst"]
+        j.src, j.src2, j.dst = ptr(q["src"]), ptr(q.get("src2")), ptr(q["dst"])
+        j.ld_src, j.ld_dst, j.rows = q["ld_src"], q["ld_dst"], q["rows"]
+        j.cols, j.cols_pad, j.dst_dtype = q["cols"], q.get("cols_pad", q["cols"]), code_of(d)
+        j.perm_g, j.perm_wg = q.get("perm", (0, 0))
+    _lib.call("vpu_cast2d_batched", arr, len(jobs), _stream())
 
 
 def act_bwd(dy, ld_dy, aux, ld_aux, dz, ld_dz, rows, cols, kind, dtype):

@@ -792,6 +792,54 @@ def test_upsum_relu_equals_fusion_over_concat(ops, dtype, n):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+def test_batched_cast_and_fanout_add(ops, dtype):
+    """vpu_cast2d_batched (the engine's per-step derived operands in one launch: strided casts, a two-source sum, zero-filled pad
+    columns, the raster -> window row map) against vpu_cast2d / vpu_add4 / vpu_window_permute job by job, bit for bit; and
+    vpu_fanout_add (the adjoint of add4: up to four destinations overwritten or accumulated in one launch) against add4."""
+    td = TD[dtype]
+    D, k3, k3p, E, Ep, g, wg = 64, 147, 152, 203, 208, 8, 4
+    w1, w2 = dev(rnd(D, k3, seed=1)), dev(rnd(D, k3, seed=2))
+    b1, b2 = dev(rnd(D, seed=3)), dev(rnd(D, seed=4))
+    lin, pos = dev(rnd(32, E, seed=5)), dev(rnd(g * g + 1, D, seed=6))
+    fused, bsum = torch.zeros(D, 2 * k3p, device="cuda", dtype=td), torch.empty(D, device="cuda")
+    linp, posw = torch.full((32, Ep), 7.0, device="cuda", dtype=td), torch.empty(g * g, D, device="cuda", dtype=td)
+    ops.cast2d_batched([
+        dict(src=w1, dst=(fused, 0), ld_src=k3, ld_dst=2 * k3p, rows=D, cols=k3),
+        dict(src=w2, dst=(fused, k3p), ld_src=k3, ld_dst=2 * k3p, rows=D, cols=k3),
+        dict(src=b1, src2=b2, dst=bsum, ld_src=D, ld_dst=D, rows=1, cols=D),
+        dict(src=lin, dst=linp, ld_src=E, ld_dst=Ep, rows=32, cols=E, cols_pad=Ep),
+        dict(src=(pos, D), dst=posw, ld_src=D, ld_dst=D, rows=g * g, cols=D, perm=(g, wg)),
+    ])
+    ref_f = torch.zeros_like(fused)
+    ops.cast2d(w1, k3, (ref_f, 0), 2 * k3p, D, k3)
+    ops.cast2d(w2, k3, (ref_f, k3p), 2 * k3p, D, k3)
+    ref_b = torch.empty_like(bsum)
+    ops.add4(b1, b2, None, None, ref_b, D)
+    ref_l = torch.empty_like(linp)
+    ops.cast2d(lin, E, ref_l, Ep, 32, E, Ep)
+    tmp, ref_p = torch.empty(g * g, D, device="cuda", dtype=td), torch.empty_like(posw)
+    ops.cast2d((pos, D), D, tmp, D, g * g, D)
+    ops.window_permute(tmp, ref_p, 1, g, wg, D, to_raster=False)
+    assert torch.equal(fused, ref_f) and torch.equal(bsum, ref_b) and torch.equal(linp, ref_l) and torch.equal(posw, ref_p)
+    src = dev(rnd(48, 64, seed=7)).to(td)
+    dsts = [dev(rnd(48, 64, seed=8 + i)).to(td) for i in range(4)]
+    want = [d.clone() for d in dsts]
+    acc = [True, False, True, False]
+    for d, a in zip(want, acc):
+        if a:
+            ops.add4(d, src, None, None, d, d.numel())
+        else:
+            d.copy_(src)
+    ops.fanout_add(src, dsts, acc, src.numel())
+    assert all(torch.equal(d, w) for d, w in zip(dsts, want))
+    one = dev(rnd(48, 64, seed=20)).to(td)
+    w1_ = one.clone()
+    ops.add4(w1_, src, None, None, w1_, one.numel())
+    ops.fanout_add(src, [one], [True], src.numel())
+    assert torch.equal(one, w1_)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("C", [64, 768, 1280])
 def test_batched_gates_equal_single_gate_launches(ops, dtype, C):
     """vpu_gate_fwd_n / vpu_gate_bwd_n (round 5: the three gates of SimpleFPN in one launch per pass) against the single-gate
