@@ -1607,14 +1607,6 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
             vpu_set_error("xattn_bwd: hipFuncSetAttribute(attn_bwd_winp_kernel<1>, dynamic LDS) failed");
             return VPU_ERR_LAUNCH;
         }
-        static const int nu2 = [] { const char* e = getenv("VPU_ATTN_WINP_NU"); return e ? atoi(e) : 1; }();
-        if (nu2 == 2) {     // two tiles per wave: two passes over 13 tiles, two workgroups per CU (A/B runs)
-            static VpuDevOnce attrp2;
-            if (attrp2.pending()) VPU_SET_LDS(WpCfg<2>::LDS, attn_bwd_winp_kernel<2>);
-            snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_winp_kernel<2>");
-            attn_bwd_winp_kernel<2><<<dim3(nb * H), 256, WpCfg<2>::LDS, s>>>(a);
-            return vpu_check_launch("vpu_xattn_bwd");
-        }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_winp_kernel<1>");
         attn_bwd_winp_kernel<1><<<dim3(nb * H), 256, WpCfg<1>::LDS, s>>>(a);
         return vpu_check_launch("vpu_xattn_bwd");
