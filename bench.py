@@ -229,14 +229,15 @@ def pmc_traffic(kernel, args):
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))     # the newest round's
     if not found or args.model != "vitb" or args.batch != 12 or args.dtype != "bf16":
-        return None
+        return None, None
     path = found[-1]
     tab = json.load(open(path))
     v = tab.get(kernel)
     if not v:
-        return None
+        return None, None
     n, tot = v["launches"], v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"])
-    return round(tot / n)
+    # (a LOOKUP of the builder-recorded PMC passes, not a measurement of this run: the JSON line says so)
+    return round(tot / n), f"profiles/{os.path.basename(path)} (builder-recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
 
 
 class GemmProbe:
@@ -562,8 +563,9 @@ def main():
     if agg:
         name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        traffic, traffic_source = pmc_traffic(name, args)
         roof = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4), "traffic": pmc_traffic(name, args),
+                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "all_gemm_variants": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3),
                                            "launches": v[2]} for k, v in sorted(agg.items())}}

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvpu_hip.so")
+# VPU_LIB_DIAG=1: the diagnostic build (csrc/build.sh diag: -DVPU_DIAG, time stamps in the K2 / K4P kernels) for tools/k2_stamps.py and
+# tools/k4_drift.py; the product library carries no stamp code
+LIB_PATH = os.path.join(_HERE, "libvpu_hip_diag.so" if os.environ.get("VPU_LIB_DIAG", "0") == "1" else "libvpu_hip.so")
 
 BF16, F32 = 0, 1
 

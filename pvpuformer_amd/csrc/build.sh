@@ -4,21 +4,25 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value"
-mkdir -p build
+# `build.sh diag`: the diagnostic library libvpu_hip_diag.so (-DVPU_DIAG: time-stamp code in the K2 / K4P GEMM kernels, read by
+# tools/k2_stamps.py and tools/k4_drift.py through VPU_LIB_DIAG=1).  The product library has neither the stamp pointer nor the code.
+OUT=libvpu_hip.so; BUILD=build
+if [ "$1" = "diag" ]; then FLAGS="$FLAGS -DVPU_DIAG"; OUT=libvpu_hip_diag.so; BUILD=build_diag; fi
+mkdir -p $BUILD
 pids=()
 for f in gemm attention rowops spatial prompt loss optim; do
   # attention.hip: MFMA results straight into VGPRs (the softmax consumes every score tile with VALU instructions; with the
   # accumulator-register form hipcc copies each tile through v_accvgpr_read and the kernels drop to one wave per SIMD)
   EXTRA=""; [ $f = attention ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
-  $HIPCC $FLAGS $EXTRA -c $f.hip -o build/$f.o &
+  $HIPCC $FLAGS $EXTRA -c $f.hip -o $BUILD/$f.o &
   pids+=($!)
 done
-$HIPCC $FLAGS -c common.cpp -o build/common.o &
+$HIPCC $FLAGS -c common.cpp -o $BUILD/common.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 # link beside the target and rename: a rename is atomic, so a process that polls for the library (bench.py, ranks > 0) or
 # dlopens it while another one builds sees the old file or the complete new one, never a half-written ELF
-TMP=../libvpu_hip.so.tmp.$$
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $TMP build/*.o
-mv -f $TMP ../libvpu_hip.so
-echo "built $(cd .. && pwd)/libvpu_hip.so"
+TMP=../$OUT.tmp.$$
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $TMP $BUILD/*.o
+mv -f $TMP ../$OUT
+echo "built $(cd .. && pwd)/$OUT"

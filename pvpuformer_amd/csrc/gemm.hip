@@ -1351,8 +1351,8 @@ __device__ __forceinline__ void k2_voff(const K2Tile& t, const int wave, const i
 // where 36.75 x 256 fills 222; the LDS layout keeps its 128-row sub-tiles, rows 112-127 of each are dead).
 template <int TA, int TB, int WN, bool CS, int FL, bool GRP, int RB, int SWP = 0>
 __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
-                                        const int tiles_m_arg, const int tiles_n_arg, const int vec,
-                                        unsigned long long* __restrict__ dbg = nullptr) {   // (vpu_debug_gemm_times: 16 stamps per workgroup)
+                                        const int tiles_m_arg, const int tiles_n_arg, const int vec
+                                        VPU_DBG_PARAM_DEF) {   // (-DVPU_DIAG, vpu_debug_gemm_times: 16 stamps per workgroup)
     using Cf = K2Cfg<WN>;
     // SW: swapped MFMA operands + direct epilogue (k2_epi_direct); compile-time flag sets of the plain kernel only
     constexpr bool SW = SWP >= 1 && FL >= 0 && !CS;      // (also the grouped form with ONE compile-time flag set for all its problems)
@@ -1387,7 +1387,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
     }
     int dbg_t = 0;       // tile number of this workgroup (diagnostic stamps: tile start / main loop end / epilogue end)
     while (work < total_work) {
-        if (dbg && tid == 0 && dbg_t < 5) dbg[blockIdx.x * 16 + 3 * dbg_t] = __builtin_amdgcn_s_memrealtime();
+        VPU_STAMP(tid == 0 && dbg_t < 5, blockIdx.x * 16 + 3 * dbg_t);
         const vpu_gemm_desc& p = GRP ? ga->d[cur.grp] : p_arg;
         const int FLG = GEN ? p.flags : FL;
         const int m0 = cur.m0, n0 = cur.n0;
@@ -1459,7 +1459,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         // (the out-of-range tail pieces still write zeros into LDS; the direct 256-column form does not touch LDS in its
         // epilogue and the same wave overwrites the same words with the next tile's pieces, in order: nothing to wait for)
         if constexpr (!(SW && !PP)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (dbg && tid == 0 && dbg_t < 5) dbg[blockIdx.x * 16 + 3 * dbg_t + 1] = __builtin_amdgcn_s_memrealtime();
+        VPU_STAMP(tid == 0 && dbg_t < 5, blockIdx.x * 16 + 3 * dbg_t + 1);
 
         if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only; the impossible compare keeps the accumulators live
             __syncthreads();
@@ -1494,7 +1494,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();   // every wave is done with the ring (fragment reads consumed, own DMA pieces landed)
             __builtin_amdgcn_sched_barrier(0);
-            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+            VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 10);
             // the two K-half groups exchange half of their 128 x 64 partial tile: group 0 finishes rows 0-63, group 1 rows
             // 64-127 of it.  Fragment layouts are identical in both waves, so the registers travel as they are (16-byte LDS
             // accesses, lane-linear).  Wave w sends through [w * 16 KiB, + 16 KiB).
@@ -1526,7 +1526,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();   // every wave has taken its partner's half: stages 0 and 1 can receive the next tile
             __builtin_amdgcn_sched_barrier(0);
-            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+            VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 11);
             if (has_next) {
                 const __amdgpu_buffer_rsrc_t nA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.A), 0, 0x7FFFFFFF, 0x00020000);
                 const __amdgpu_buffer_rsrc_t nB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nt.B), 0, 0x7FFFFFFF, 0x00020000);
@@ -1536,9 +1536,9 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 k2_issue<TA, TB, WN>(nA, nB, nvoff, nsA, nsB, BK < nt.K, lds + Cf::STAGE, wave);
             }
             float* wl = reinterpret_cast<float*>(lds + 2 * Cf::STAGE + wave * 4096);   // 16 rows x 64 fp32, in stage 2
-            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+            VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 12);
             if constexpr (SW) k2_epi_direct<FL>(p, fin, mq, nq, el, qd, npass, reinterpret_cast<const float*>(bslot));
-            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+            VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 13);
             if constexpr (SW) {}
             else if constexpr (GEN) k2_epi64<true, 16>(p, FLG, vec, fin, mq, nq, wl, lane, mq + 16 * npass);
             else k2_epi_fast<FL>(p, fin, mq, nq, wl, lane, q, npass);
@@ -1550,7 +1550,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
             K2PreD<FL> q0, q1;
             k2_prefetch_direct<FL>(p, mw, nw, lane, q0, 4);
             k2_prefetch_direct<FL>(p, mw + 64, nw, lane, q1, RB - 4);
-            if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+            VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 10);
             if (has_next) {
                 k2_tile_setup<WN, GRP, RB>(nxt, total_work, p_arg, ga, tiles_n_arg, nt);
                 k2_voff<TA, TB, WN, RB>(nt, wave, lane, nvoff);
@@ -1565,9 +1565,9 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fin[i][j] = acc[i][j];
-                if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+                VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 11);
                 k2_epi_direct<FL>(p, fin, mw, nw, lane, q0, 4, reinterpret_cast<const float*>(bslot));
-                if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+                VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 12);
             }
             {
                 f32x4_t fin[4][4];
@@ -1576,7 +1576,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fin[i][j] = acc[4 + i < RB ? 4 + i : 0][j];
                 k2_epi_direct<FL>(p, fin, mw + 64, nw, lane, q1, RB - 4, reinterpret_cast<const float*>(bslot));
-                if (dbg && tid == 0 && dbg_t == 0) dbg[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+                VPU_STAMP(tid == 0 && dbg_t == 0, blockIdx.x * 16 + 13);
             }
         } else {
             __syncthreads();
@@ -1594,7 +1594,7 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
         // every wave is done with its epilogue LDS before the next tile's DMA / fragment reads touch it (raw barrier: the
         // global stores stay in flight)
         __builtin_amdgcn_s_barrier();
-        if (dbg && tid == 0 && dbg_t < 5) dbg[blockIdx.x * 16 + 3 * dbg_t + 2] = __builtin_amdgcn_s_memrealtime();
+        VPU_STAMP(tid == 0 && dbg_t < 5, blockIdx.x * 16 + 3 * dbg_t + 2);
         ++dbg_t;
         primed = (PP || SW) && has_next && vec != 9;
         if (has_next && !primed) {
@@ -1610,8 +1610,8 @@ __device__ __forceinline__ void k2_body(const vpu_gemm_desc& p_arg, const vpu_ge
 
 template <int TA, int TB, int WN, int FL, int RB, int SWP = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_k2_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n,
-                                                           const int vec, unsigned long long* dbg) {
-    k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec, dbg);
+                                                           const int vec VPU_DBG_PARAM) {
+    k2_body<TA, TB, WN, false, FL, false, RB, SWP>(p, nullptr, tiles_m, tiles_n, vec VPU_DBG_PASS);
 }
 // forward / dgrad groups whose problems share ONE compile-time flag set (round 4: the DMA neck's image-side K / V projections,
 // bias only): the direct epilogue of the plain kernel instead of the run-time one
@@ -1901,8 +1901,8 @@ __device__ __forceinline__ void k3_epi_direct_f32(const vpu_gemm_desc& p, const 
 
 template <int TA, int TB, bool CS, int FL, bool GRP, int RB, int NWN = 2, bool PIPE = false, int TM = 256, bool SWF = false>
 __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_gemm_group* __restrict__ ga,
-                                        const int tiles_m_arg, const int tiles_n_arg, const int vec_in,
-                                        unsigned long long* __restrict__ dbg = nullptr) {   // (vpu_debug_gemm_times: 8 stamps per workgroup)
+                                        const int tiles_m_arg, const int tiles_n_arg, const int vec_in
+                                        VPU_DBG_PARAM_DEF) {   // (-DVPU_DIAG, vpu_debug_gemm_times: 8 stamps per workgroup)
     using Cf = K3Cfg<NWN, TM>;
     static_assert(!CS || (TA == 1 && RB == 8), "fused column sums: weight-gradient form");
     static_assert(TM == 256 || (RB == 4 && NWN == 2 && !GRP && !PIPE && !CS), "128-row tiles: single problems, 64 x 64 per wave");
@@ -1973,10 +1973,10 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
                 for (int i = 0; i < 4; ++i) aL[i] = k3_frag<TA>(la, i * 16, lane);
             }
             int st_c = 0, st_w = Cf::S - 1;      // stage of K-step kt / stage the next DMA goes to
-            if (dbg && tid == 0) dbg[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+            VPU_STAMP(tid == 0, blockIdx.x * 8 + 0);
             const int q1 = (nk >> 2) & ~1, q2 = (nk >> 1) & ~1, q3 = (3 * nk >> 2) & ~1;
             for (int kt = 0; kt < nk; kt += 2) {
-                if (dbg && tid == 0 && (kt == q1 || kt == q2 || kt == q3)) dbg[blockIdx.x * 8 + (kt == q1 ? 1 : kt == q2 ? 2 : 3)] = __builtin_amdgcn_s_memrealtime();
+                VPU_STAMP(tid == 0 && (kt == q1 || kt == q2 || kt == q3), blockIdx.x * 8 + (kt == q1 ? 1 : kt == q2 ? 2 : 3));
                 // (two K-steps per iteration: the B register sets swap roles, every index is a compile-time constant)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -2023,7 +2023,7 @@ __device__ __forceinline__ void k3_body(const vpu_gemm_desc& p_arg, const vpu_ge
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the out-of-range tail pieces still write zeros into LDS)
         __syncthreads();
-        if (dbg && tid == 0) dbg[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+        VPU_STAMP(tid == 0, blockIdx.x * 8 + 4);
         float* wl = reinterpret_cast<float*>(lds + wave * 4096);   // 16 rows x 64 fp32 per wave
         const int mw = m0 + wm * (16 * RB), nq = n0 + wn * 64;
         if (vec == 9) {  // diagnostic (VPU_GEMM_NOEPI=1): main loop only
@@ -2091,10 +2091,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_k4_grouped_kernel(const vpu_gem
     k3_body<TA, TB, CS, -1, true, 8, 4>(ga->d[0], ga, 0, 0, vec);
 }
 template <int TA, int TB, bool CS, bool SWF = false>
-__global__ __launch_bounds__(512) void gemm_bf16_k4p_grouped_kernel(const vpu_gemm_group ga_unused, const int vec,
-                                                                    unsigned long long* dbg) {
+__global__ __launch_bounds__(512) void gemm_bf16_k4p_grouped_kernel(const vpu_gemm_group ga_unused, const int vec VPU_DBG_PARAM) {
     const vpu_gemm_group* ga = (const vpu_gemm_group*)__builtin_amdgcn_kernarg_segment_ptr();
-    k3_body<TA, TB, CS, -1, true, 8, 4, true, 256, SWF>(ga->d[0], ga, 0, 0, vec, dbg);
+    k3_body<TA, TB, CS, -1, true, 8, 4, true, 256, SWF>(ga->d[0], ga, 0, 0, vec VPU_DBG_PASS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2490,7 +2489,9 @@ inline int k2_opt() { const int v = g_opt_k2.load(std::memory_order_relaxed); re
 // collective that runs beside backward (pvpuformer_amd/parallel.py)
 std::atomic<int> g_opt_reserve{0};
 // diagnostic (vpu_debug_gemm_times): device buffer of 8 cycle-counter stamps per workgroup of the K4P kernel, or null
+#ifdef VPU_DIAG
 std::atomic<unsigned long long*> g_dbg_times{nullptr};
+#endif
 inline int cu_count() {
     static const int v = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int r = g_opt_reserve.load(std::memory_order_relaxed);
@@ -2683,7 +2684,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
         const int tot_ = tm_ * tn_;                                                                                  \
         NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d, %d>", TA_, TB_, WN_, FL_, RB_, SW_);                      \
-        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2, g_dbg_times.load(std::memory_order_relaxed)); \
+        kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2 VPU_DBG_LOAD); \
     } while (0)
 #define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_)                                                                     \
     do {                                                                                                             \
@@ -3157,9 +3158,8 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             const int ncu = cu_count();
             static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true%s>", pipe ? "p" : "", direct4 ? ", true" : "");
-            unsigned long long* dbg4 = g_dbg_times.load(std::memory_order_relaxed);
-            if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1, dbg4);
-            else if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1, dbg4);
+            if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1 VPU_DBG_LOAD);
+            else if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1 VPU_DBG_LOAD);
             else gemm_bf16_k4_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
         }
@@ -3213,6 +3213,13 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
 }
 
 extern "C" int vpu_debug_gemm_times(void* dev_buf) {
+#ifdef VPU_DIAG
     g_dbg_times.store(reinterpret_cast<unsigned long long*>(dev_buf), std::memory_order_relaxed);
     return VPU_OK;
+#else
+    (void)dev_buf;
+    vpu_set_error("vpu_debug_gemm_times: this library was built without -DVPU_DIAG (csrc/build.sh diag builds libvpu_hip_diag.so: the "
+                  "product kernels carry no time-stamp code)");
+    return VPU_ERR_ARG;
+#endif
 }

@@ -21,85 +21,117 @@ constexpr int LN_BWD_WAVES = 8;   // part rows: rows / 16, at most 512
 // PE: a second output y2 = y + pe[row % pe_rows] (the position-embedding add every normalised token / image map of the DMA
 // neck goes through before its q / k projections, transformer.py:439-457): the sum is taken from the ROUNDED y, as the
 // separate add launch takes it.
-template <typename T, int NCH, bool PE>
+template <typename T, int NCH, bool PE, int RW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             int64_t rows, int C, float eps, const T* __restrict__ pe,
                                                             int64_t pe_rows, T* __restrict__ y2) {
+    // RW rows per wave and trip (round 5, RW = 2: the two rows' loads are in flight together and their reduction chains
+    // interleave); a trip's rows are `half` apart (the number of waves in the grid)
     const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t half = (int64_t)gridDim.x * 4, stride = half * RW;
+    int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row0 >= rows) return;
     float ww[NCH][8], bb[NCH][8];
-    Raw8<T> cur[NCH], nxt[NCH];
+    Raw8<T> cur[RW][NCH], nxt[RW][NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + i * 64) * 8;
-        if (c < C) { load8(w + c, ww[i]); load8(b + c, bb[i]); cur[i].load(x + row * C + c); }
+        if (c < C) {
+            load8(w + c, ww[i]); load8(b + c, bb[i]);
+#pragma unroll
+            for (int k = 0; k < RW; ++k)
+                if (row0 + k * half < rows) cur[k][i].load(x + (row0 + k * half) * C + c);
+        }
     }
-    const float invC = 1.0f / (float)C;
-    for (; row < rows; row += stride) {
-        const int64_t nr = row + stride;
-        if (nr < rows) {
+    for (; row0 < rows; row0 += stride) {
+        const int64_t nr = row0 + stride;
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = (lane + i * 64) * 8;
-                if (c < C) nxt[i].load(x + nr * C + c);
+        for (int k = 0; k < RW; ++k)
+            if (nr + k * half < rows) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) nxt[k][i].load(x + (nr + k * half) * C + c);
+                }
             }
-        }
-        float v[NCH][8];
-        float s = 0.f;
+        float v[RW][NCH][8];
+        float s[RW], q[RW], mu[RW], rs[RW];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + i * 64) * 8;
-            if (c < C) {
-                cur[i].get(v[i]);
+        for (int k = 0; k < RW; ++k) {
+            s[k] = 0.f;
+            if (row0 + k * half < rows) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[i][j];
-            }
-        }
-        const float mu = wave_sum(s) / C;
-        float q = 0.f;
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) {
+                        cur[k][i].get(v[k][i]);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + i * 64) * 8;
-            if (c < C) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
-            }
-        }
-        const float rs = rsqrtf(wave_sum(q) / C + eps);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-        T* yr = y + row * C;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + i * 64) * 8;
-            if (c < C) {
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * ww[i][j] + bb[i][j];
-                store8(yr + c, o);
-                if (PE) {
-                    float pv[8];
-                    load8(pe + (row % pe_rows) * C + c, pv);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = to_f32(from_f32<T>(o[j])) + pv[j];
-                    store8(y2 + row * C + c, o);
+                        for (int j = 0; j < 8; ++j) s[k] += v[k][i][j];
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) cur[i] = nxt[i];
+        for (int k = 0; k < RW; ++k) mu[k] = wave_sum(s[k]) / C;
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            q[k] = 0.f;
+            if (row0 + k * half < rows) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float d = v[k][i][j] - mu[k]; q[k] += d * d; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RW; ++k) rs[k] = rsqrtf(wave_sum(q[k]) / C + eps);
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const int64_t row = row0 + k * half;
+            if (row < rows) {
+                if (lane == 0) { mean[row] = mu[k]; rstd[row] = rs[k]; }
+                T* yr = y + row * C;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) {
+                        float o[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (v[k][i][j] - mu[k]) * rs[k] * ww[i][j] + bb[i][j];
+                        store8(yr + c, o);
+                        if (PE) {
+                            float pv[8];
+                            load8(pe + (row % pe_rows) * C + c, pv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = to_f32(from_f32<T>(o[j])) + pv[j];
+                            store8(y2 + row * C + c, o);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RW; ++k)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) cur[k][i] = nxt[k][i];
     }
-    (void)invC;
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm bwd
-// NCH: 512-column chunks per row (C <= 512*NCH); NW waves per workgroup, one row per wave and trip: 16 rows in
-// flight per CU (one 1024-thread workgroup per CU) instead of 4 -- the kernel is a latency-bound stream of 3 KB rows.
+// NCH: 512-column chunks per row (C <= 512*NCH); NW waves per workgroup.  The kernel is a latency-bound stream of 3-KB rows (x, dy,
+// the residual gradient): a wave walks its rows with the grid stride and requests the next trip's rows before it reduces the
+// current ones.  Round 5: RW rows per wave and TRIP (RW = 2 for C <= 1024) -- one row per trip left a wave with one row set in
+// flight while it stalled on the previous one (4.6 dependent trips per wave at ViT-B bs 12, a memory round trip each: 15 us for
+// 58 MB); two rows per trip halve the trips, double the bytes in flight and give the two cross-lane reduction chains of a trip
+// a partner to overlap with.
 // D2: the gradient of the output is dy + dy2 (the two outputs of the PE form of the forward), summed in fp32.
-template <typename T, int NCH, int NW, bool PF, bool D2>
+template <typename T, int NCH, int NW, bool PF, bool D2, int RW>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                             const T* __restrict__ x,
                                                             const float* __restrict__ w,
@@ -120,103 +152,113 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const T* __restr
         const int c = (lane + i * 64) * 8;
         if (c < C) load8(w + c, ww[i]);
     }
-    // the next row's x / dy / residual gradient / statistics are requested before the current row's two cross-lane
-    // reductions (raw registers, converted only when consumed)
-    const int64_t stride = (int64_t)nblk * NW;
-    int64_t row = (int64_t)blockIdx.x * NW + wave;
-    Raw8<T> cx[NCH], cd[NCH], cr[NCH], nx[NCH], nd[NCH], nres[NCH];
-    Raw8<T> cd2[D2 ? NCH : 1], nd2[D2 ? NCH : 1];
-    float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
-    if (PF && row < rows) {
-        mu = mean[row]; rs = rstd[row];
+    // a trip = rows row0 + k * half, k < RW (half = the number of waves in the grid): the next trip's x / dy / residual gradient /
+    // statistics are requested before the current trip's cross-lane reductions (raw registers, converted only when consumed)
+    const int64_t half = (int64_t)nblk * NW, stride = half * RW;
+    int64_t row0 = (int64_t)blockIdx.x * NW + wave;
+    Raw8<T> cx[RW][NCH], cd[RW][NCH], cr[RW][NCH], nx[RW][NCH], nd[RW][NCH], nres[RW][NCH];
+    Raw8<T> cd2[RW][D2 ? NCH : 1], nd2[RW][D2 ? NCH : 1];
+    float mu[RW], rs[RW], nmu[RW], nrs[RW];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + i * 64) * 8;
-            if (c < C) {
-                cx[i].load(x + row * C + c);
-                cd[i].load(dy + row * C + c);
-                if (D2) cd2[i].load(dy2 + row * C + c);
-                if (dres) cr[i].load(dres + row * C + c);
-            }
-        }
-    }
-    for (; row < rows; row += stride) {
-        const int64_t nr = row + stride;
-        if (PF && nr < rows) {
-            nmu = mean[nr]; nrs = rstd[nr];
+    for (int k = 0; k < RW; ++k) { mu[k] = 0.f; rs[k] = 0.f; nmu[k] = 0.f; nrs[k] = 0.f; }
+    auto request = [&](int64_t r0, Raw8<T> (&ox)[RW][NCH], Raw8<T> (&od)[RW][NCH], Raw8<T> (&orr)[RW][NCH],
+                       Raw8<T> (&od2)[RW][D2 ? NCH : 1], float (&om)[RW], float (&os)[RW]) {
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = (lane + i * 64) * 8;
-                if (c < C) {
-                    nx[i].load(x + nr * C + c);
-                    nd[i].load(dy + nr * C + c);
-                    if (D2) nd2[i].load(dy2 + nr * C + c);
-                    if (dres) nres[i].load(dres + nr * C + c);
+        for (int k = 0; k < RW; ++k) {
+            const int64_t r = r0 + k * half;
+            if (r < rows) {
+                om[k] = mean[r]; os[k] = rstd[r];
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) {
+                        ox[k][i].load(x + r * C + c);
+                        od[k][i].load(dy + r * C + c);
+                        if (D2) od2[k][i].load(dy2 + r * C + c);
+                        if (dres) orr[k][i].load(dres + r * C + c);
+                    }
                 }
             }
         }
-        if (!PF) {   // 4 chunks per lane: no registers for a second row in flight
-            mu = mean[row]; rs = rstd[row];
+    };
+    if (PF && row0 < rows) request(row0, cx, cd, cr, cd2, mu, rs);
+    for (; row0 < rows; row0 += stride) {
+        if (PF && row0 + stride < rows) request(row0 + stride, nx, nd, nres, nd2, nmu, nrs);
+        if (!PF) request(row0, cx, cd, cr, cd2, mu, rs);   // 4 chunks per lane: no registers for a second trip in flight
+        // (x-hat and g = dy * w are recomputed from the raw registers in the output loop instead of being kept: 64 registers)
+        float s1[RW], s2[RW];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = (lane + i * 64) * 8;
-                if (c < C) {
-                    cx[i].load(x + row * C + c);
-                    cd[i].load(dy + row * C + c);
-                    if (D2) cd2[i].load(dy2 + row * C + c);
-                    if (dres) cr[i].load(dres + row * C + c);
+        for (int k = 0; k < RW; ++k) {
+            s1[k] = 0.f; s2[k] = 0.f;
+            if (row0 + k * half < rows) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) {
+                        float xv[8], dv[8];
+                        cx[k][i].get(xv);
+                        cd[k][i].get(dv);
+                        if (D2) {
+                            float d2[8];
+                            cd2[k][i].get(d2);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) dv[j] += d2[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xh = (xv[j] - mu[k]) * rs[k], g = dv[j] * ww[i][j];
+                            s1[k] += g;
+                            s2[k] += g * xh;
+                            dwa[i][j] += dv[j] * xh;
+                            dba[i][j] += dv[j];
+                        }
+                    }
                 }
             }
         }
-        float xh[NCH][8], g[NCH][8];
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + i * 64) * 8;
-            if (c < C) {
-                float xv[8], dv[8];
-                cx[i].get(xv);
-                cd[i].get(dv);
-                if (D2) {
-                    float d2[8];
-                    cd2[i].get(d2);
+        for (int k = 0; k < RW; ++k) { s1[k] = wave_sum(s1[k]) / C; s2[k] = wave_sum(s2[k]) / C; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dv[j] += d2[j];
+        for (int k = 0; k < RW; ++k) {
+            const int64_t row = row0 + k * half;
+            if (row < rows) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + i * 64) * 8;
+                    if (c < C) {
+                        float o[8], xv[8], dv[8];
+                        if (dres) cr[k][i].get(o);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                        }
+                        cx[k][i].get(xv);
+                        cd[k][i].get(dv);
+                        if (D2) {
+                            float d2[8];
+                            cd2[k][i].get(d2);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) dv[j] += d2[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xh = (xv[j] - mu[k]) * rs[k], g = dv[j] * ww[i][j];      // (the same operations as above: same bits)
+                            o[j] += rs[k] * (g - s1[k] - xh * s2[k]);
+                        }
+                        store8(dx + row * C + c, o);
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xh[i][j] = (xv[j] - mu) * rs;
-                    g[i][j] = dv[j] * ww[i][j];
-                    s1 += g[i][j];
-                    s2 += g[i][j] * xh[i][j];
-                    dwa[i][j] += dv[j] * xh[i][j];
-                    dba[i][j] += dv[j];
-                }
-            }
-        }
-        s1 = wave_sum(s1) / C;
-        s2 = wave_sum(s2) / C;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + i * 64) * 8;
-            if (c < C) {
-                float o[8];
-                if (dres) cr[i].get(o);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] += rs * (g[i][j] - s1 - xh[i][j] * s2);
-                store8(dx + row * C + c, o);
             }
         }
         if (PF) {
-            mu = nmu; rs = nrs;
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nres[i];
-                if (D2) cd2[i] = nd2[i];
+            for (int k = 0; k < RW; ++k) {
+                mu[k] = nmu[k]; rs[k] = nrs[k];
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    cx[k][i] = nx[k][i]; cd[k][i] = nd[k][i]; cr[k][i] = nres[k][i];
+                    if (D2) cd2[k][i] = nd2[k][i];
+                }
             }
         }
     }
@@ -725,13 +767,17 @@ extern "C" int vpu_layernorm_fwd_pe(const void* x, const float* w, const float* 
     }
     // balanced persistent grid: at most 2048 workgroups (8 per CU), every wave the same number of rows (+-1)
     static const int64_t capf = [] { const char* e = getenv("VPU_LN_FWD_CAP"); const int v = e ? atoi(e) : 2048; return (int64_t)(v < 256 ? 256 : v); }();
-    const int64_t nb = (rows + 3) / 4, trips = (nb + capf - 1) / capf;
+    static const int rwf = [] { const char* e = getenv("VPU_LN_FWD_RW"); return e ? atoi(e) : 1; }();     // rows per wave and trip (2: measured level with 1 in the step, 12.40 vs 12.40 ms -- unlike the backward)
+    const int rw = (rwf == 2 && C <= 1024 && dtype == VPU_BF16 && !pe && rows >= 4096) ? 2 : 1;
+    const int64_t nb = (rows + 4 * rw - 1) / (4 * rw), trips = (nb + capf - 1) / capf;
     const unsigned grid = (unsigned)((nb + trips - 1) / trips);
-#define VPU_LN_FWD(NCH_)                                                                                              \
-    if (pe) { DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_, true><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)pe, pe_rows, (T*)y2);) } \
-    else { DISPATCH_T(dtype, layernorm_fwd_kernel<T, NCH_, false><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)nullptr, 1, (T*)nullptr);) }
-    if (C <= 512) { VPU_LN_FWD(1) } else if (C <= 1024) { VPU_LN_FWD(2) } else { VPU_LN_FWD(4) }
+#define VPU_LN_FWD_(NCH_, RW_)                                                                                        \
+    if (pe) { DISPATCH_T(dtype, (layernorm_fwd_kernel<T, NCH_, true, RW_><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)pe, pe_rows, (T*)y2));) } \
+    else { DISPATCH_T(dtype, (layernorm_fwd_kernel<T, NCH_, false, RW_><<<grid, 256, 0, ST>>>((const T*)x, w, b, (T*)y, mean, rstd, rows, C, eps, (const T*)nullptr, 1, (T*)nullptr));) }
+#define VPU_LN_FWD(NCH_) if (rw == 2) { VPU_LN_FWD_(NCH_, 2) } else { VPU_LN_FWD_(NCH_, 1) }
+    if (C <= 512) { VPU_LN_FWD(1) } else if (C <= 1024) { VPU_LN_FWD(2) } else { VPU_LN_FWD_(4, 1) }
 #undef VPU_LN_FWD
+#undef VPU_LN_FWD_
     return vpu_check_launch("vpu_layernorm_fwd");
 }
 extern "C" int vpu_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
@@ -751,15 +797,19 @@ extern "C" int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x
     vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
     const int nblk = vpu_layernorm_bwd_nblk(rows);
+    static const int rw2 = [] { const char* e = getenv("VPU_LN_BWD_RW"); return e ? atoi(e) : 2; }();     // rows per wave and trip (A/B: 1)
+#define VPU_LN_BWD_(NCH_, NW_, RW_)                                                                                   \
+    if (dy2) { DISPATCH_T(dtype, (layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), true, RW_><<<nblk, 64 * NW_, 0, ST>>>(   \
+                          (const T*)dy, (const T*)dy2, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk));) } \
+    else { DISPATCH_T(dtype, (layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), false, RW_><<<nblk, 64 * NW_, 0, ST>>>(      \
+                          (const T*)dy, (const T*)nullptr, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk));) }
 #define VPU_LN_BWD(NCH_, NW_)                                                                                         \
-    if (dy2) { DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), true><<<nblk, 64 * NW_, 0, ST>>>(   \
-                          (const T*)dy, (const T*)dy2, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);) } \
-    else { DISPATCH_T(dtype, layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), false><<<nblk, 64 * NW_, 0, ST>>>(      \
-                          (const T*)dy, (const T*)nullptr, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk);) }
+    if (NCH_ <= 2 && rw2 == 2 && dtype == VPU_BF16 && !dy2) { VPU_LN_BWD_(NCH_, NW_, 2) } else { VPU_LN_BWD_(NCH_, NW_, 1) }   /* (two gradients: 271 registers) */
     // (C > 1024 keeps 8 waves: its 4 chunks per lane need the 256-register budget)
     // (<= 2 chunks: 4-wave workgroups, ~170 VGPRs with the prefetched row -> three per CU; 4 chunks: no prefetch)
     if (C <= 512) { VPU_LN_BWD(1, 4) } else if (C <= 1024) { VPU_LN_BWD(2, 4) } else { VPU_LN_BWD(4, 8) }
 #undef VPU_LN_BWD
+#undef VPU_LN_BWD_
     return vpu_check_launch("vpu_layernorm_bwd");
 }
 extern "C" int vpu_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,

@@ -51,6 +51,26 @@ static inline void vpu_clear_stale_error() { (void)hipGetLastError(); }
         }                                                                                                                \
     } while (0)
 
+// -DVPU_DIAG (csrc/build.sh diag -> libvpu_hip_diag.so, for tools/k2_stamps.py and tools/k4_drift.py): the K2 / K4P GEMM kernels
+// take a device buffer and stamp the 100-MHz real-time counter at the phases of their tiles (vpu_debug_gemm_times).  The
+// product library is built without it: no stamp pointer among the kernel arguments, no stamp code in the loops.
+#ifdef VPU_DIAG
+#define VPU_DBG_PARAM_DEF , unsigned long long* __restrict__ dbg = nullptr
+#define VPU_DBG_PARAM , unsigned long long* dbg
+#define VPU_DBG_PASS , dbg
+#define VPU_DBG_LOAD , g_dbg_times.load(std::memory_order_relaxed)
+#define VPU_STAMP(cond, idx)                                                  \
+    do {                                                                      \
+        if (dbg && (cond)) dbg[idx] = __builtin_amdgcn_s_memrealtime();       \
+    } while (0)
+#else
+#define VPU_DBG_PARAM_DEF
+#define VPU_DBG_PARAM
+#define VPU_DBG_PASS
+#define VPU_DBG_LOAD
+#define VPU_STAMP(cond, idx) do { } while (0)
+#endif
+
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);

@@ -154,6 +154,10 @@ class Engine:
         # end of backward with the chip a quarter full (0.47 ms per step).
         self.unify_wgrad = os.environ.get("VPU_WGRAD_UNIFY", "1") != "0"
         self.lazy_zero = os.environ.get("VPU_LAZY_ZERO", "1") != "0"   # zero_grad(lazy=True) honoured (A/B switch)
+        # round 5 launch fusions (the three gates in one launch per pass, the derived operands in one batched cast, the q_out
+        # gradient fan-out in one launch, conv_seg's partial sums through the batched column sums): VPU_R5_FUSED=0 runs the
+        # round-4 launches instead (same-box A/B runs)
+        self.r5_fused = os.environ.get("VPU_R5_FUSED", "1") != "0"
         # fused bias column sums of the packed K4 launches DISTRIBUTED over a problem's column tiles (vpu_hip.h: cs_tn): with
         # the classic form the tiles of the first column block -- a third of a ViT block's -- run 17 % longer than the
         # others, and a packed launch is one round of tiles (tools/k4_drift.py).  VPU_WGRAD_DCS=0: classic form (A/B runs)
@@ -225,6 +229,17 @@ class Engine:
             ops.cast2d(self.flat, self.total, self.shadow, self.total, 1, self.total)
         k3 = 3 * P * P
         po = self.names["backbone.pos_embed"][0]
+        if not self.r5_fused:
+            ops.cast2d(self.Pm("backbone.patch_embed.proj.weight"), k3, (self.w_patch, 0), 2 * self.k3p, D, k3)
+            ops.cast2d(self.Pm("patch_embed_coords.proj.weight"), k3, (self.w_patch, self.k3p), 2 * self.k3p, D, k3)
+            ops.add4(self.Pm("backbone.patch_embed.proj.bias"), self.Pm("patch_embed_coords.proj.bias"), None, None, self.b_patch, D)
+            ops.cast2d(self.Pm("neck.ffn_layer.lin1.weight"), self.E, self.w_lin1p, self.Epad, 2048, self.E, self.Epad)
+            tmp = torch.empty(self.NT, D, device=self.dev, dtype=self.td)
+            ops.cast2d((self.flat, po + D), D, tmp, D, self.NT, D)
+            ops.window_permute(tmp, self.pos_win, 1, self.g, self.wg, D, to_raster=False)
+            self._pos_cache = {self.g: self.pos_win}
+            self.shadow_valid = True
+            return
         # the derived operands in ONE launch (round 5: vpu_cast2d_batched; five launches before): the two patch embeddings side
         # by side in the fused weight, the sum of their biases, the K-padded PuE weight, pos_embed[:, 1:] in window order
         ops.cast2d_batched([
@@ -375,6 +390,14 @@ class Engine:
         else:
             ops.colsum_f32(part.view(nrows, 2 * Cdim)[:, :Cdim].contiguous(), self.G(prefix + ".weight"), nrows, Cdim, beta=1.0)
             ops.colsum_f32(part.view(nrows, 2 * Cdim)[:, Cdim:].contiguous(), self.G(prefix + ".bias"), nrows, Cdim, beta=1.0)
+
+    def _convseg_sums(self, part, part_b, nb, Cc):
+        if self.r5_fused:
+            self._csq.append((part, self.G("head.conv_seg.weight"), nb, Cc))
+            self._csq.append((part_b, self.G("head.conv_seg.bias"), nb, 1))
+        else:
+            ops.colsum_f32(part, self.G("head.conv_seg.weight"), nb, Cc, beta=1.0)
+            ops.colsum_f32(part_b, self.G("head.conv_seg.bias"), nb, 1, beta=1.0)
 
     def _colsum_to(self, dy, ld, gname, rows, N):
         part = self._new(64, N, dtype=torch.float32)
@@ -984,6 +1007,10 @@ class Engine:
                 if q_out.g is None:
                     return
                 vs = (q0, hs[0][0], hs[1][0], hs[2][0])
+                if not self.r5_fused:
+                    for v in vs:
+                        self.acc(v, q_out.g)
+                    return
                 had = [v.g is not None for v in vs]
                 for v, h_ in zip(vs, had):
                     if h_:
@@ -996,12 +1023,39 @@ class Engine:
         # gates in ONE statistics launch and ONE pass over x forward (vpu_gate_fwd_n), one row pass + one column launch backward
         # (vpu_gate_bwd_n: dx summed in fp32 over the three gates, rounded once) instead of nine / six launches
         maps = [xr]
-        ng = len(hs)
+        ng = len(hs) if self.r5_fused else 0
+        for qi, ki in (() if self.r5_fused else hs):       # (VPU_R5_FUSED=0: one gate at a time, three launches each way)
+            cg, sg = self._new(B, D, dtype=torch.float32), self._new(B, NT, dtype=torch.float32)
+            aq, ac = self._new(B, D, dtype=torch.int32), self._new(B, NT, dtype=torch.int32)
+            ops.gate_stats(qi.t, ki.t, cg, aq, sg, ac, B, nq, NT, D)
+            xg = Var(self._new(M, D))
+            ops.gate_apply(xr.t, cg, sg, xg.t, B, NT, D)
+            if training:
+                def bwd_gate(xg=xg, qi=qi, ki=ki, cg=cg, sg=sg, aq=aq, ac=ac):
+                    if xg.g is None:
+                        return
+                    if any(v.g is None for v in (qi, ki)):
+                        pend = [v for pair in hs for v in pair if v.g is None]
+                        pool = ops.zero_(torch.empty(sum(v.t.numel() for v in pend), device=self.dev, dtype=self.td))
+                        o_ = 0
+                        for v in pend:
+                            v.g = pool[o_:o_ + v.t.numel()].view_as(v.t)
+                            o_ += v.t.numel()
+                    accum = xr.g is not None
+                    if not accum:
+                        xr.g = torch.empty_like(xr.t)
+                    for t_ in (xr.g, qi.g, ki.g):
+                        self._writable(t_)
+                    part = self._new(B, 64, D, dtype=torch.float32)
+                    ops.gate_bwd(xg.g, xr.t, cg, aq, sg, ac, xr.g, accum, qi.g, ki.g, part, B, nq, NT, D)
+                self.tape.append(bwd_gate)
+            maps.append(xg)
         cg, sg = self._new(ng, B, D, dtype=torch.float32), self._new(ng, B, NT, dtype=torch.float32)
         aq, ac = self._new(ng, B, D, dtype=torch.int32), self._new(ng, B, NT, dtype=torch.int32)
         xgs = [Var(self._new(M, D)) for _ in range(ng)]
-        ops.gate_fwd_n([qi.t for qi, _ in hs], [ki.t for _, ki in hs], xr.t, [v.t for v in xgs], cg, aq, sg, ac, B, nq, NT, D)
-        if training:
+        if ng:
+            ops.gate_fwd_n([qi.t for qi, _ in hs], [ki.t for _, ki in hs], xr.t, [v.t for v in xgs], cg, aq, sg, ac, B, nq, NT, D)
+        if training and ng:
             def bwd_gates():
                 live = [i for i in range(ng) if xgs[i].g is not None]
                 if not live:
@@ -1168,8 +1222,7 @@ class Engine:
                                             fused.g, part, part_b, B * HW4, HW4, Cc)
                         relu_done[0] = True
                         # (conv_seg's weight / bias partial rows join the batched column sums of the norm layers: flush_colsums)
-                        self._csq.append((part, self.G("head.conv_seg.weight"), nb, Cc))
-                        self._csq.append((part_b, self.G("head.conv_seg.bias"), nb, 1))
+                        self._convseg_sums(part, part_b, nb, Cc)
                         return
                     accum = fused.g is not None
                     if not accum:
@@ -1180,8 +1233,7 @@ class Engine:
                     ops.convseg_bwd(dseg, fused.t, self.Pm("head.conv_seg.weight"), drop_mask, fused.g, int(accum) | 2, part,
                                     part_b, B * HW4, HW4, Cc)
                     relu_done[0] = True
-                    self._csq.append((part, self.G("head.conv_seg.weight"), nb, Cc))
-                    self._csq.append((part_b, self.G("head.conv_seg.bias"), nb, 1))
+                    self._convseg_sums(part, part_b, nb, Cc)
             # must run BEFORE the closures of query / fused: insert at the position just after they were recorded
             self.tape.append(bwd_head)
         self.last_tape = tape if training else None

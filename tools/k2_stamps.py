@@ -3,6 +3,7 @@
 every tile's start, at the end of its main loop and at the end of its epilogue (3 stamps per tile, up to 5 tiles).
 usage: python tools/k2_stamps.py"""
 import os
+os.environ.setdefault("VPU_LIB_DIAG", "1")       # the stamps exist in the -DVPU_DIAG build only (bash pvpuformer_amd/csrc/build.sh diag)
 import sys
 
 import torch

@@ -3,6 +3,7 @@
 vpu_debug_gemm_times stamps the constant 100-MHz real-time counter at the start, the quarters and the end of every workgroup's main loop.
 usage: python tools/k4_drift.py"""
 import os
+os.environ.setdefault("VPU_LIB_DIAG", "1")       # the stamps exist in the -DVPU_DIAG build only (bash pvpuformer_amd/csrc/build.sh diag)
 import sys
 
 import torch

@@ -1,0 +1,25 @@
+# round-5 recording: everything profiles/r05_* is made from, one box (usage: bash tools/r5_record.sh; outputs -> gpurun_out/r05)
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+python3 -c 'import __graft_entry__ as g; g.build()' > /dev/null
+out=gpurun_out/r05; mkdir -p $out
+git_rev=$(cat .git_rev 2>/dev/null); echo "commit: $git_rev" > $out/commit.txt
+# 1. the default bench line (CPU baseline beside it), then the other batch sizes / backbones
+python3 bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; cut -c1-260 $out/bench.json
+python3 bench.py --batch 4 --no-cpu-baseline > $out/bench_b4.json 2>/dev/null; cut -c1-200 $out/bench_b4.json
+python3 bench.py --model vitl --batch 8 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_vitl_b8.json 2>/dev/null; cut -c1-200 $out/bench_vitl_b8.json
+python3 bench.py --model vith --batch 12 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_vith_b12.json 2>/dev/null; cut -c1-200 $out/bench_vith_b12.json
+# 2. kernel statistics of the same command (host-enqueued under the profiler; 20 timed steps so that model construction's copies amortise)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1
+f=$(ls $out/stats_kernel_trace.csv 2>/dev/null | head -1)
+if [ -n "$f" ]; then python3 tools/trace_seq.py $f > $out/seq.txt 2>&1; python3 tools/trace_by_grid.py $f > $out/by_grid.txt 2>&1; wc -l $out/seq.txt; rm -f $f; fi
+# 3. HBM traffic per kernel (two PMC passes)
+VPU_WGRAD_STREAM=0 VPU_BENCH_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1
+VPU_WGRAD_STREAM=0 VPU_BENCH_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
+python3 tools/pmc_traffic.py $out $out/pmc_traffic.json > $out/pmc_traffic.txt 2>&1; head -8 $out/pmc_traffic.txt
+rm -f $out/fetch_kernel_trace.csv $out/write_kernel_trace.csv $out/fetch_counter_collection.csv $out/write_counter_collection.csv
+# 4. the reference-faithful 1-3-iteration training step
+python3 tools/bench_trainstep.py 40 12 > $out/trainstep.txt 2>&1; BENCH_PROMPTS=0,1,2 python3 tools/bench_trainstep.py 40 12 >> $out/trainstep.txt 2>&1; grep -v amdgpu.ids $out/trainstep.txt
+# 5. window attention backward: the three forms against the problem count
+for m in 1 2 0; do echo "== VPU_ATTN_ONEPASS=$m"; VPU_ATTN_ONEPASS=$m python3 tools/attn_bwd_scale.py; done 2>&1 | grep -v amdgpu.ids > $out/attn_bwd_scale.txt
+ls $out
