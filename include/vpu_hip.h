@@ -183,6 +183,26 @@ int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* out, float*
 int vpu_xattn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H, int32_t nq, int32_t nk, int32_t hd,
                   int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq, int32_t ldgk, float scale, void* stream);
+/* Split launches of the attention kernels (round 5; the DMA neck's prompt<->image attentions, transformer.py:499-521: 48 prompt
+ * tokens against 784 image tokens are 96 workgroups walking 25 key chunks each).  Batch entry b of the launch reads its queries
+ * (q, o, d_o; in backward lse / delta) from entry b / qdiv and its keys / values from entry b / kdiv of the operands and writes
+ * its outputs to entry b.  kdiv = S: S consecutive entries are S query ranges of one problem against the same keys -- forward
+ * and dq are complete per entry, dk / dv are S partial sums (vpu_sum_groups).  qdiv = S: S key ranges of one problem for the
+ * same queries -- the forward leaves S partial softmaxes (out, lse per entry: vpu_attn_combine), dq is S partial sums, dk / dv
+ * are complete, lse / delta are the problem's (combined) ones.  One of qdiv / kdiv must be 1; nb counts the launch's entries. */
+int vpu_xattn_fwd_split(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H, int32_t nq,
+                        int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale, int32_t qdiv, int32_t kdiv,
+                        void* stream);
+int vpu_xattn_bwd_split(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                        float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H, int32_t nq, int32_t nk, int32_t hd,
+                        int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq, int32_t ldgk, float scale, int32_t qdiv, int32_t kdiv,
+                        void* stream);
+/* out[b][q][h] = sum_s exp(lse_s - lse) o_s, lse = log sum_s exp(lse_s): the S partial softmaxes of vpu_xattn_fwd_split(qdiv = S)
+ * (o_s bf16 [nb*S*nq][ld_s], entry b*S + s; lse_s fp32 [nb*S*H][nq]) -> out bf16 [nb*nq][ldo], lse fp32 [nb*H][nq]. */
+int vpu_attn_combine(const void* o_s, const float* lse_s, void* out, float* lse, int32_t nb, int32_t H, int32_t nq, int32_t hd,
+                     int32_t S, int32_t ld_s, int32_t ldo, void* stream);
+/* out[g][i] = sum_s in[g][s][i], i < n (n % 8 == 0), summed in fp32 in the order of s. */
+int vpu_sum_groups(const void* in, void* out, int64_t G, int32_t S, int64_t n, int32_t dtype, void* stream);
 
 /* ---- element-wise ---- */
 /* out[i] = a[i] + b[i % period_b]  (with_pos_embed, transformer.py:320, :430) */

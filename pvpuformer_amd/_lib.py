@@ -67,6 +67,10 @@ SIGNATURES = {
     "vpu_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vpu_xattn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vpu_xattn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vpu_xattn_fwd_split": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "vpu_xattn_bwd_split": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "vpu_attn_combine": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpu_sum_groups": [_P, _P, _L, _I, _L, _I, _P],
     "vpu_add_bcast": [_P, _P, _P, _L, _L, _I, _P],
     "vpu_add4": [_P, _P, _P, _P, _P, _L, _I, _P],
     "vpu_cast2d": [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P],

@@ -134,6 +134,12 @@ struct AttnArgs {
     int ldgq, ldgk;            // row strides of dq and of dk/dv
     float scale;
     int gx, nbh;               // see wg_problem
+    // "split" launches (round 5, the lean kernels): batch entry b of the launch reads its queries (q, o, d_o, and in backward lse /
+    // delta) from entry b / qdiv and its keys / values from entry b / kdiv of the operands, and writes its outputs (out + lse in
+    // forward; dq; dk / dv) to entry b.  qdiv = kdiv = 1 (0 is taken as 1): the plain batch.  kdiv = S: S consecutive entries are
+    // S query ranges of one problem against the same keys (dk / dv come out as S partial sums); qdiv = S: S key ranges of one
+    // problem for the same queries (forward: S partial softmaxes, combined by attn_combine_kernel; dq: S partial sums).
+    int qdiv, kdiv;
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -567,7 +573,9 @@ __global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) 
     int bh, xb;
     wg_problem(a.gx, a.nbh, bh, xb);
     const int bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
-    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const int bwq = bw / max(a.qdiv, 1), bwk = bw / max(a.kdiv, 1);      // (split launches: which entry the operands come from)
+    const int64_t rbq = (int64_t)bwq * nq, rbk = (int64_t)bwk * nk, rbqo = (int64_t)bw * nq, rbko = (int64_t)bw * nk;
+    const int bhq = bwq * a.H + h;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) 
             const int qq = qu + 4 * g + r;
             if (qq < nq) {
                 if (c == 0) a.lse[(int64_t)bh * nq + qq] = (mrow + __builtin_amdgcn_logf(l)) * LN2;
-                bf16_t* orow = a.out + (rbq + qq) * a.ldo + h * hd + c;
+                bf16_t* orow = a.out + (rbqo + qq) * a.ldo + h * hd + c;
                 if (hd == HC) {      // (uniform: no per-tile column test on the common path)
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
@@ -732,7 +740,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
     int bh, xb;
     wg_problem(a.gx, a.nbh, bh, xb);
     const int bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
-    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const int bwq = bw / max(a.qdiv, 1), bwk = bw / max(a.kdiv, 1);      // (split launches: which entry the operands come from)
+    const int64_t rbq = (int64_t)bwq * nq, rbk = (int64_t)bwk * nk, rbqo = (int64_t)bw * nq, rbko = (int64_t)bw * nk;
+    const int bhq = bwq * a.H + h;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
     for (int u = 0; u < QT; ++u) {
         const int qu = q0 + 16 * u;
         const bool q_ok = qu + c < nq;
-        nl2[u] = q_ok ? -a.lse[(int64_t)bh * nq + qu + c] * LOG2E : 0.f;
+        nl2[u] = q_ok ? -a.lse[(int64_t)bhq * nq + qu + c] * LOG2E : 0.f;
         load_rows_as_bn<KS>(q, a.ldq, qu, nq, lane, qf[u], hd);
         load_rows_as_bn<KS>(d_o, a.ldo, qu, nq, lane, dof[u], hd);
         // delta[q] = sum_d dO[q][d] * O[q][d] from the dO fragments the wave holds anyway; published for the dK/dV kernel
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
             for (int j = 0; j < 8; ++j) dl += (float)dof[u][ks][j] * (float)of[ks][j];
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
-        if (q_ok && g == 0) a.delta[(int64_t)bh * nq + qu + c] = dl;
+        if (q_ok && g == 0) a.delta[(int64_t)bhq * nq + qu + c] = dl;      // (qdiv > 1: the same value from every key range)
         nds[u] = -dl * a.scale;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) adq[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -833,7 +843,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lean_kernel(const AttnArgs a)
         for (int r = 0; r < 4; ++r) {
             const int qq = q0 + 16 * u + 4 * g + r;
             if (qq < nq) {
-                bf16_t* qr = a.dq + (rbq + qq) * a.ldgq + h * hd + c;
+                bf16_t* qr = a.dq + (rbqo + qq) * a.ldgq + h * hd + c;
                 if (hd == HC) {
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) qr[dt * 16] = (bf16_t)adq[u][dt][r];
@@ -858,7 +868,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
     int bh, xb;
     wg_problem(a.gx, a.nbh, bh, xb);
     const int bw = bh / a.H, h = bh % a.H, nq = a.nq, nk = a.nk, hd = a.hd;
-    const int64_t rbq = (int64_t)bw * nq, rbk = (int64_t)bw * nk;
+    const int bwq = bw / max(a.qdiv, 1), bwk = bw / max(a.kdiv, 1);      // (split launches: which entry the operands come from)
+    const int64_t rbq = (int64_t)bwq * nq, rbk = (int64_t)bwk * nk, rbqo = (int64_t)bw * nq, rbko = (int64_t)bw * nk;
+    const int bhq = bwq * a.H + h;
     const bf16_t* q = a.q + rbq * a.ldq + h * hd;
     const bf16_t* k = a.k + rbk * a.ldk + h * hd;
     const bf16_t* v = a.v + rbk * a.ldk + h * hd;
@@ -880,8 +892,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
     st.offsets(tid, a.ldq, hd, voq);
     st.offsets(tid, a.ldo, hd, voo);
     const __amdgpu_buffer_rsrc_t rsQ = rows_rsrc(q, nq, a.ldq, hd, 2), rsO = rows_rsrc(d_o, nq, a.ldo, hd, 2);
-    const __amdgpu_buffer_rsrc_t rsL = rows_rsrc(reinterpret_cast<const char*>(a.lse + (int64_t)bh * nq), 1, 0, nq, 4);
-    const __amdgpu_buffer_rsrc_t rsD = rows_rsrc(reinterpret_cast<const char*>(a.delta + (int64_t)bh * nq), 1, 0, nq, 4);
+    const __amdgpu_buffer_rsrc_t rsL = rows_rsrc(reinterpret_cast<const char*>(a.lse + (int64_t)bhq * nq), 1, 0, nq, 4);
+    const __amdgpu_buffer_rsrc_t rsD = rows_rsrc(reinterpret_cast<const char*>(a.delta + (int64_t)bhq * nq), 1, 0, nq, 4);
     const int nch = (nq + CH - 1) / CH, qstep = CH * a.ldq * 2, ostep = CH * a.ldo * 2;
     u32x4v pq[S::NI], po[S::NI];
     S::fetch(rsQ, voq, 0, pq);
@@ -948,8 +960,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
         for (int r = 0; r < 4; ++r) {
             const int kk = key0 + 16 * u + 4 * g + r;
             if (kk < nk) {
-                bf16_t* kr = a.dk + (rbk + kk) * a.ldgk + h * hd + c;
-                bf16_t* vr = a.dv + (rbk + kk) * a.ldgk + h * hd + c;
+                bf16_t* kr = a.dk + (rbko + kk) * a.ldgk + h * hd + c;
+                bf16_t* vr = a.dv + (rbko + kk) * a.ldgk + h * hd + c;
                 if (hd == HC) {
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
@@ -1478,6 +1490,41 @@ __global__ __launch_bounds__(256, NU == 1 ? 3 : 2) void attn_bwd_winp_kernel(con
         }
 }
 
+// ------------------------------------------------------------------------------------------------ split forward: combine
+// A forward launched with qdiv = S leaves S partial softmaxes per (batch, head, query): normalised outputs o_s over key range s
+// and their log-sum-exp lse_s.  out = sum_s exp(lse_s - lse) o_s,  lse = log sum_s exp(lse_s).  One thread per 8 columns.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restrict__ o_s, const float* __restrict__ lse_s,
+                                                           bf16_t* __restrict__ out, float* __restrict__ lse, int nb, int H, int nq,
+                                                           int hd, int S, int ld_s, int ldo) {
+    const int cpr = hd / 8;
+    const int64_t total = (int64_t)nb * nq * H * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % cpr);
+        const int h = (int)((i / cpr) % H);
+        const int qq = (int)((i / ((int64_t)cpr * H)) % nq);
+        const int b = (int)(i / ((int64_t)cpr * H * nq));
+        float ls[8], m = -INFINITY;
+        for (int sp = 0; sp < S; ++sp) {
+            ls[sp] = lse_s[((int64_t)(b * S + sp) * H + h) * nq + qq];
+            m = fmaxf(m, ls[sp]);
+        }
+        float tot = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < S; ++sp) {
+            const float w = __expf(ls[sp] - m);
+            tot += w;
+            float v[8];
+            load8(o_s + ((int64_t)(b * S + sp) * nq + qq) * ld_s + h * hd + ck * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+        }
+        const float inv = 1.f / tot;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= inv;
+        store8(out + ((int64_t)b * nq + qq) * ldo + h * hd + ck * 8, acc);
+        if (ck == 0) lse[((int64_t)b * H + h) * nq + qq] = m + __logf(tot);
+    }
+}
+
 // "lean" = 1 (default): the kernels above; 0: the round-1 step kernels (kept for A/B runs and as a second implementation in
 // the tests).  VPU_ATTN_LEAN sets the process default.
 std::atomic<int> g_opt_lean{-1}, g_opt_onepass{-1};
@@ -1528,10 +1575,14 @@ extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
     return VPU_ERR_ARG;
 }
 
-extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
-                             int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
-                             void* stream) {
+static int xattn_fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
+                          int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale, int32_t qdiv,
+                          int32_t kdiv, void* stream) {
     vpu_clear_stale_error();
+    if (qdiv < 1 || kdiv < 1 || (qdiv > 1 && kdiv > 1) || nb % (qdiv * kdiv) || ((qdiv > 1 || kdiv > 1) && !lean_enabled())) {
+        vpu_set_error("xattn_fwd_split: qdiv, kdiv >= 1, one of them 1, nb a multiple of the other; the lean kernels only");
+        return VPU_ERR_ARG;
+    }
     if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || nb <= 0 ||
         H <= 0 || nq <= 0 || nk <= 0 || (int64_t)nk * ldk >= (1 << 29)) {
         vpu_set_error("xattn_fwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0, one batch entry of k/v below 1 GiB");
@@ -1540,6 +1591,7 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale;
+    a.qdiv = qdiv; a.kdiv = kdiv;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lean_enabled()) {
         // two 16-query tiles per wave (128 queries per workgroup) once a problem has more than 64 queries
@@ -1581,11 +1633,39 @@ extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* 
     return vpu_check_launch("vpu_xattn_fwd");
 }
 
-extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                             const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
-                             int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq,
-                             int32_t ldgk, float scale, void* stream) {
+extern "C" int vpu_xattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
+                             int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                             void* stream) {
+    return xattn_fwd_impl(q, k, v, out, lse, nb, H, nq, nk, hd, ldq, ldk, ldo, scale, 1, 1, stream);
+}
+extern "C" int vpu_xattn_fwd_split(const void* q, const void* k, const void* v, void* out, float* lse, int32_t nb, int32_t H,
+                                   int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                                   int32_t qdiv, int32_t kdiv, void* stream) {
+    return xattn_fwd_impl(q, k, v, out, lse, nb, H, nq, nk, hd, ldq, ldk, ldo, scale, qdiv, kdiv, stream);
+}
+extern "C" int vpu_attn_combine(const void* o_s, const float* lse_s, void* out, float* lse, int32_t nb, int32_t H, int32_t nq,
+                                int32_t hd, int32_t S, int32_t ld_s, int32_t ldo, void* stream) {
     vpu_clear_stale_error();
+    if (!o_s || !lse_s || !out || !lse || nb < 1 || H < 1 || nq < 1 || hd < 8 || hd % 8 || S < 1 || S > 8 || ld_s % 8 || ldo % 8) {
+        vpu_set_error("attn_combine: non-null operands, head dim and row strides multiples of 8, 1 <= S <= 8");
+        return VPU_ERR_ARG;
+    }
+    const int64_t total = (int64_t)nb * nq * H * (hd / 8);
+    attn_combine_kernel<<<vpu_grid_for(total, 256, 4096), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const bf16_t*)o_s, lse_s, (bf16_t*)out, lse, nb, H, nq, hd, S, ld_s, ldo);
+    return vpu_check_launch("vpu_attn_combine");
+}
+
+static int xattn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                          const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
+                          int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq,
+                          int32_t ldgk, float scale, int32_t qdiv, int32_t kdiv, void* stream) {
+    vpu_clear_stale_error();
+    const bool split = qdiv > 1 || kdiv > 1;
+    if (qdiv < 1 || kdiv < 1 || (qdiv > 1 && kdiv > 1) || nb % (qdiv * kdiv) || (split && (!lean_enabled() || nq % 4))) {
+        vpu_set_error("xattn_bwd_split: qdiv, kdiv >= 1, one of them 1, nb a multiple of the other; the lean kernels only (nq % 4 == 0)");
+        return VPU_ERR_ARG;
+    }
     if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || !ok16(o) ||
         !ok16(d_o) || nb <= 0 || H <= 0 || nq <= 0 || nk <= 0 || (int64_t)nk * ldk >= (1 << 29) ||
         (int64_t)nq * ldq >= (1 << 29) || (int64_t)nq * ldo >= (1 << 29)) {
@@ -1597,9 +1677,9 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
     a.d_o = (const bf16_t*)d_o; a.lse = const_cast<float*>(lse); a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.nq = nq; a.nk = nk; a.H = H; a.hd = hd; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.ldgq = ldgq; a.ldgk = ldgk;
-    a.scale = scale;
+    a.scale = scale; a.qdiv = qdiv; a.kdiv = kdiv;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (lean_enabled() && onepass_enabled() == 2 && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB && ldgq % 4 == 0 && ldgk % 4 == 0 &&
+    if (!split && lean_enabled() && onepass_enabled() == 2 && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB && ldgq % 4 == 0 && ldgk % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 && (reinterpret_cast<uintptr_t>(dv) & 7) == 0) {
         // three workgroups per CU (round 5); "onepass" = 1 selects the one-workgroup-per-CU form below
         static VpuDevOnce attrp;
@@ -1611,7 +1691,7 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
         attn_bwd_winp_kernel<1><<<dim3(nb * H), 256, WpCfg<1>::LDS, s>>>(a);
         return vpu_check_launch("vpu_xattn_bwd");
     }
-    if (lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
+    if (!split && lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
         static VpuDevOnce attr;
         if (attr.pending()) {
             VPU_SET_LDS(WIN_LDS, attn_bwd_win_kernel);
@@ -1671,6 +1751,19 @@ extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const 
             break;
     }
     return vpu_check_launch("vpu_xattn_bwd");
+}
+
+extern "C" int vpu_xattn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                             const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
+                             int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq,
+                             int32_t ldgk, float scale, void* stream) {
+    return xattn_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale, 1, 1, stream);
+}
+extern "C" int vpu_xattn_bwd_split(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                   const float* lse, float* delta, void* dq, void* dk, void* dv, int32_t nb, int32_t H,
+                                   int32_t nq, int32_t nk, int32_t hd, int32_t ldq, int32_t ldk, int32_t ldo, int32_t ldgq,
+                                   int32_t ldgk, float scale, int32_t qdiv, int32_t kdiv, void* stream) {
+    return xattn_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale, qdiv, kdiv, stream);
 }
 
 // self-attention on a fused qkv activation: the same kernels with nq = nk and one row stride

@@ -2642,7 +2642,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             const int k2 = k2_opt();
             // (VPU_GEMM_K2_MIN_TILES / VPU_GEMM_K2G_MIN_TILES: the smallest tile counts the plain / grouped-compile-time K2
             // forms take -- A/B knobs)
-            static const int k2_min_tiles = [] { const char* e = getenv("VPU_GEMM_K2_MIN_TILES"); return e ? atoi(e) : 160; }();
+            static const int k2_min_tiles = [] { const char* e = getenv("VPU_GEMM_K2_MIN_TILES"); return e ? atoi(e) : 120; }();   // (round 5: 160 -> 120 -- batch 8, 150 tiles: 745 -> 771 images/s; batch 4, 78-84 tiles, loses below 100)
             const int tm2 = (d->M + K2_BM - 1) / K2_BM, tn2 = (d->N + 127) / 128;
             if (k2 > 0 && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % BK == 0 && d->K >= 256 &&
                 (int64_t)tm2 * tn2 >= k2_min_tiles && !d->transA && d->alpha == 1.0f &&

@@ -597,6 +597,24 @@ __global__ __launch_bounds__(256) void add4_kernel(const T* __restrict__ a, cons
         store8(out + i * 8, x);
     }
 }
+// out[g][i] = sum_s in[g][s][i] (fp32 sum in order s = 0, 1, ...: deterministic), 8 elements per thread: the partial sums a split
+// attention backward leaves per key / query range
+template <typename T>
+__global__ __launch_bounds__(256) void sum_groups_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t G, int S, int64_t nchunk) {
+    const int64_t total = G * nchunk;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / nchunk, c = i - g * nchunk;
+        float acc[8];
+        load8(in + (g * S * nchunk + c) * 8, acc);
+        for (int sp = 1; sp < S; ++sp) {
+            float v[8];
+            load8(in + ((g * S + sp) * nchunk + c) * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        store8(out + i * 8, acc);
+    }
+}
 // the adjoint of add4: every dst_i (+)= src, ONE launch (q_out = q + q_1 + q_2 + q_3 hands its gradient to four tensors)
 struct FanOut { void* dst[4]; int accum[4]; int n; };
 template <typename T>
@@ -926,6 +944,12 @@ extern "C" int vpu_add4(const void* a, const void* b, const void* c, const void*
     const int grid = vpu_grid_for(n / 8, 256, 4096);
     DISPATCH_T(dtype, add4_kernel<T><<<grid, 256, 0, ST>>>((const T*)a, (const T*)b, (const T*)c, (const T*)d, (T*)out, n / 8);)
     return vpu_check_launch("vpu_add4");
+}
+extern "C" int vpu_sum_groups(const void* in, void* out, int64_t G, int32_t S, int64_t n, int32_t dtype, void* stream) {
+    vpu_clear_stale_error();
+    if (!in || !out || G < 1 || S < 1 || n < 8 || n % 8) { vpu_set_error("sum_groups: non-null operands, n % 8 == 0"); return VPU_ERR_ARG; }
+    DISPATCH_T(dtype, sum_groups_kernel<T><<<vpu_grid_for(G * (n / 8), 256, 4096), 256, 0, ST>>>((const T*)in, (T*)out, G, S, n / 8);)
+    return vpu_check_launch("vpu_sum_groups");
 }
 extern "C" int vpu_fanout_add(const void* src, void* const* dst, const int32_t* accum, int32_t ndst, int64_t n, int32_t dtype,
                               void* stream) {

@@ -13,6 +13,7 @@ Composes the C-ABI kernels (``include/vpu_hip.h``) into the model of
 * a tape of backward closures with explicit gradient accumulation -- no autograd graph, no per-op torch dispatch;
   torch is used for device memory and streams only.
 """
+import contextlib
 import math
 from collections import OrderedDict
 
@@ -29,15 +30,23 @@ class Tape:
     one per call (``Engine.last_tape``), so several forwards may be pending at once -- the reference trainer sums the
     losses of up to three click iterations before a single ``loss.backward()`` (trainer.py:342-455), which reaches the
     autograd bridge once per forward."""
-    __slots__ = ("fns", "out_grads", "done", "sim_low")
+    __slots__ = ("fns", "out_grads", "done", "sim_low", "lane")
 
     def __init__(self):
         self.fns = []
         self.out_grads = [None, None, None]
         self.done = False
         self.sim_low = None
+        self.lane = None          # the HIP stream the closures recorded now belong to (Engine._lane), None = the caller's
 
     def append(self, fn):
+        s = self.lane
+        if s is not None:         # a closure of the token lane runs on the token lane's stream in backward as well
+            inner = fn
+
+            def fn():
+                with torch.cuda.stream(s):
+                    inner()
         self.fns.append(fn)
 
     def __len__(self):
@@ -158,6 +167,13 @@ class Engine:
         # gradient fan-out in one launch, conv_seg's partial sums through the batched column sums): VPU_R5_FUSED=0 runs the
         # round-4 launches instead (same-box A/B runs)
         self.r5_fused = os.environ.get("VPU_R5_FUSED", "1") != "0"
+        # split launches of the neck's prompt<->image attentions (cross_attention): ranges per long side; 1 = off
+        self.xattn_split = max(1, int(os.environ.get("VPU_XATTN_SPLIT", "1")))
+        # round 5: the DMA neck's prompt-token chain (~90 dependent launches of <= 108 workgroups each) on its own HIP stream
+        # beside the image-side launches (Engine._neck_lanes); VPU_NECK_LANES=0 = everything on the caller's stream
+        self.neck_lanes = int(os.environ.get("VPU_NECK_LANES", "0"))     # (2: only the part that runs beside the backbone)
+        self._tok_stream = None
+        self._in_lanes = False    # backward is inside the two-lane section: the weight-gradient queue only collects
         # fused bias column sums of the packed K4 launches DISTRIBUTED over a problem's column tiles (vpu_hip.h: cs_tn): with
         # the classic form the tiles of the first column block -- a third of a ViT block's -- run 17 % longer than the
         # others, and a packed launch is one round of tiles (tools/k4_drift.py).  VPU_WGRAD_DCS=0: classic form (A/B runs)
@@ -453,40 +469,11 @@ class Engine:
             for t in (dy, x):
                 tt = t[0] if isinstance(t, tuple) else t
                 self._frozen.add(tt.data_ptr())
-            # a full group of one kind (short reductions / this reduction length) is launched at once; the other kinds stay
             kind = 0 if M <= 2048 else M
-            same = [e for e in self._wq if (0 if e[3] <= 2048 else e[3]) == kind]
-            if kind and self.ride_wgrad:
-                # long reductions: the big problems ("anchors": a ViT block's four gradients are 216 tiles of 256 x 128 on
-                # 256 CUs) are launched once they fill a round; the small ones queued meanwhile (the neck's 768 x 384
-                # projections over the same 9408 rows) ride in the CUs such a launch leaves idle
-                # (launched when the rounds of 256 tiles they need are at least 80 % full -- ViT-B's 216 tiles per block are,
-                # ViT-L's 384 / ViT-H's 600 wait for the next block's: 768 = 3 full rounds, 1200 = 94 % of 5 -- or when the
-                # group holds eight problems)
-                anchors = [e for e in same if not self._is_rider(e)]
-                T = sum(self._k2_tiles(e) for e in anchors)
-                if self.pack_wgrad:
-                    self._pack_seen[kind] = self._pack_seen.get(kind, 0) + self._k2_tiles(self._wq[-1])
-                    # (full rounds: with the round cut exactly, the even spread of round 3 only risks a leftover launch)
-                    budget = self.pack_tiles(None, self.wgrad_round - (self.wgrad_round // 256) * self._reserved_cus())
-                    T = sum(self._k2_tiles(e) for e in same)          # riders count: they are packed like everything else
-                    # a launch leaves when it would be FULL: up to 9 small problems (the neck's projections, the reduction slices
-                    # of the head / FPN gradients: ~10 tiles each -- 16 descriptors of them alone fill half a round) plus big
-                    # ones, the last of them cut so that the round is filled to the brim; or when two rounds have piled up
-                    while True:
-                        mine = [e for e in self._wq if e[3] == kind]
-                        T = sum(self._k2_tiles(e) for e in mine)
-                        t_small = sum(self._k2_tiles(e) for e in [e for e in mine if self._pack_small(e)][:9])
-                        t_big = sum(self._k2_tiles(e) for e in mine if not self._pack_small(e))
-                        if not (T >= budget and (t_small + t_big >= budget or T >= 2 * budget)):
-                            break
-                        self.flush_wgrads(kind, ride=True, budget=budget)
-                        if sum(self._k2_tiles(e) for e in self._wq if e[3] == kind) >= T:
-                            break
-                elif (T >= 200 and T >= self.wgrad_fill * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
-                    self.flush_wgrads(kind, ride=True)
-            elif len(same) >= 16:       # (one launch holds 16 descriptors; round 3 launched them in eights)
-                self.flush_wgrads(kind)
+            if kind and self.ride_wgrad and self.pack_wgrad:
+                self._pack_seen[kind] = self._pack_seen.get(kind, 0) + self._k2_tiles(self._wq[-1])
+            if not self._in_lanes:        # (two-lane section of backward: the queue collects, the section's end launches)
+                self._wgrad_autoflush(kind)
             return
         if not self.use_side:
             ops.gemm(dy, x, gout, N, K, M, ld_dy, ld_x, K if ldc is None else ldc, self.dt, transA=True,
@@ -507,6 +494,40 @@ class Engine:
                      transB=True, flags=EPI_OUT_F32 | EPI_ACCUM, colsum=self.G(bias) if fuse else None)
             if bias is not None and not fuse:
                 self._colsum_to(dy, ld_dy, bias, M, N)
+
+    def _wgrad_autoflush(self, kind):
+        """Launch rule of the weight-gradient queue, evaluated after every new entry (kind = 0: short reductions, else the
+        reduction length): a full group of one kind is launched at once; the other kinds stay."""
+        same = [e for e in self._wq if (0 if e[3] <= 2048 else e[3]) == kind]
+        if kind and self.ride_wgrad:
+            # long reductions: the big problems ("anchors": a ViT block's four gradients are 216 tiles of 256 x 128 on
+            # 256 CUs) are launched once they fill a round; the small ones queued meanwhile (the neck's 768 x 384
+            # projections over the same 9408 rows) ride in the CUs such a launch leaves idle
+            # (launched when the rounds of 256 tiles they need are at least 80 % full -- ViT-B's 216 tiles per block are,
+            # ViT-L's 384 / ViT-H's 600 wait for the next block's: 768 = 3 full rounds, 1200 = 94 % of 5 -- or when the
+            # group holds eight problems)
+            anchors = [e for e in same if not self._is_rider(e)]
+            T = sum(self._k2_tiles(e) for e in anchors)
+            if self.pack_wgrad:
+                # (full rounds: with the round cut exactly, the even spread of round 3 only risks a leftover launch)
+                budget = self.pack_tiles(None, self.wgrad_round - (self.wgrad_round // 256) * self._reserved_cus())
+                # a launch leaves when it would be FULL: up to 9 small problems (the neck's projections, the reduction slices
+                # of the head / FPN gradients: ~10 tiles each -- 16 descriptors of them alone fill half a round) plus big
+                # ones, the last of them cut so that the round is filled to the brim; or when two rounds have piled up
+                while True:
+                    mine = [e for e in self._wq if e[3] == kind]
+                    T = sum(self._k2_tiles(e) for e in mine)
+                    t_small = sum(self._k2_tiles(e) for e in [e for e in mine if self._pack_small(e)][:9])
+                    t_big = sum(self._k2_tiles(e) for e in mine if not self._pack_small(e))
+                    if not (T >= budget and (t_small + t_big >= budget or T >= 2 * budget)):
+                        break
+                    self.flush_wgrads(kind, ride=True, budget=budget)
+                    if sum(self._k2_tiles(e) for e in self._wq if e[3] == kind) >= T:
+                        break
+            elif (T >= 200 and T >= self.wgrad_fill * 256 * ((T + 255) // 256)) or len(anchors) >= 8:
+                self.flush_wgrads(kind, ride=True)
+        elif len(same) >= 16:       # (one launch holds 16 descriptors; round 3 launched them in eights)
+            self.flush_wgrads(kind)
 
     def _dgrad(self, dy, ld_dy, w, ldw, xvar, M, K, N, flags=0, aux=None, ldaux=0, defer=False):
         """x.g (+)= dy[M,N] W[N,K].  ``defer``: queued for the group launch of flush_group (the caller's tape runs it)."""
@@ -540,6 +561,50 @@ class Engine:
             q = [e for e, sm in zip(q, is_small) if not sm]
         for args, kw in q:
             ops.gemm(*args, **kw)
+
+    # ------------------------------------------------------------------------------------------ two lanes (round 5)
+    @contextlib.contextmanager
+    def _lane(self, s):
+        """Everything launched inside runs on HIP stream ``s`` and the backward closures recorded inside will (Tape.append);
+        ``s`` None = no-op."""
+        if s is None:
+            yield
+            return
+        prev, self.tape.lane = self.tape.lane, s
+        try:
+            with torch.cuda.stream(s):
+                yield
+        finally:
+            self.tape.lane = prev
+
+    def _cur(self, s):
+        return torch.cuda.current_stream(self.dev) if s is None else s
+
+    def _xrec(self, src, on_bwd=None):
+        """Forward: marks what stream ``src`` (None = the caller's) has queued so far; the matching ``_xwait(h, dst)`` makes
+        ``dst`` wait for it.  Backward, mirrored: the closure of _xwait records on dst (dst's consumers of the crossing
+        tensors have produced their gradients by then), the closure left here makes src wait for that.  Call both OUTSIDE
+        ``_lane`` blocks or pass the streams explicitly -- their closures are lane-less."""
+        h = {"ev": torch.cuda.Event(), "bev": None}
+        h["ev"].record(self._cur(src))
+        if self.training:
+            def bwd():
+                if h["bev"] is not None:
+                    self._cur(src).wait_event(h["bev"])
+                if on_bwd is not None:
+                    on_bwd()
+            self.tape.fns.append(bwd)
+        return h
+
+    def _xwait(self, h, dst, on_bwd=None):
+        self._cur(dst).wait_event(h["ev"])
+        if self.training:
+            def bwd():
+                if on_bwd is not None:
+                    on_bwd()
+                h["bev"] = torch.cuda.Event()
+                h["bev"].record(self._cur(dst))
+            self.tape.fns.append(bwd)
 
     # ------------------------------------------------------------------------------------------ ops with backward
     def linear(self, x, wname, bname, M, N, K, act=None, resid=None, out=None, x_grad=True, group=False, pre_masked=None):
@@ -704,9 +769,28 @@ class Engine:
 
     def cross_attention(self, Qp, Kp, Vp, O, nb, H, nq, nk, hd, ld, scale):
         """Fused attention of the DMA neck: projected queries [nb*nq, ld], keys / values [nb*nk, ld] -> O [nb*nq, ld]
-        (bf16; the [nb, H, nq, nk] scores are never materialised)."""
-        lse = self._new(nb * H, nq, dtype=torch.float32)
-        ops.xattn_fwd(Qp.t, Kp.t, Vp.t, O.t, lse, nb, H, nq, nk, hd, ld, ld, ld, scale)
+        (bf16; the [nb, H, nq, nk] scores are never materialised).
+        Round 5, split launches (VPU_XATTN_SPLIT, default 4): the neck's attentions pair 48 prompt tokens with the image tokens --
+        nb * H = 96 workgroups that walk 784 keys (tokens -> image) or 784 queries (the dK / dV of image -> tokens) in 25 chunks,
+        latency-bound on a third of the chip.  The long side is cut into S ranges that run as S batch entries of one launch:
+        * long QUERIES (image -> tokens): entries share the keys (kdiv = S); forward and dQ are complete per entry, dK / dV come
+          out as S partial sums, added in order by vpu_sum_groups;
+        * long KEYS (tokens -> image): entries share the queries (qdiv = S); the forward leaves S partial softmaxes, merged by
+          vpu_attn_combine (out = sum_s exp(lse_s - lse) o_s); dQ is S partial sums; dK / dV are complete."""
+        S = self.xattn_split
+        long_q = S > 1 and nq >= 4 * nk and nq % (4 * S) == 0 and nq // S >= 64
+        long_k = S > 1 and not long_q and nk >= 4 * nq and nk % S == 0 and nk // S >= 64 and nq % 4 == 0
+        if long_q:
+            lse = self._new(nb * S * H, nq // S, dtype=torch.float32)
+            ops.xattn_fwd_split(Qp.t, Kp.t, Vp.t, O.t, lse, nb * S, H, nq // S, nk, hd, ld, ld, ld, scale, 1, S)
+        elif long_k:
+            lse = self._new(nb * H, nq, dtype=torch.float32)
+            o_s, lse_s = self._new(nb * S * nq, ld), self._new(nb * S * H, nq, dtype=torch.float32)
+            ops.xattn_fwd_split(Qp.t, Kp.t, Vp.t, o_s, lse_s, nb * S, H, nq, nk // S, hd, ld, ld, ld, scale, S, 1)
+            ops.attn_combine(o_s, lse_s, O.t, lse, nb, H, nq, hd, S, ld, ld)
+        else:
+            lse = self._new(nb * H, nq, dtype=torch.float32)
+            ops.xattn_fwd(Qp.t, Kp.t, Vp.t, O.t, lse, nb, H, nq, nk, hd, ld, ld, ld, scale)
         if self.training:
             def bwd():
                 if O.g is None:
@@ -714,9 +798,23 @@ class Engine:
                 for var in {id(Qp): Qp, id(Kp): Kp, id(Vp): Vp}.values():
                     assert var.g is None, "attention inputs must be single-use projections"
                     var.g = torch.empty_like(var.t)
-                delta = self._new(nb * H, nq, dtype=torch.float32)
-                ops.xattn_bwd(Qp.t, Kp.t, Vp.t, O.t, O.g, lse, delta, Qp.g, Kp.g, Vp.g, nb, H, nq, nk, hd, ld, ld, ld,
-                              ld, ld, scale)
+                if long_q:
+                    delta = self._new(nb * S * H, nq // S, dtype=torch.float32)
+                    dkp, dvp = self._new(nb * S * nk, ld), self._new(nb * S * nk, ld)
+                    ops.xattn_bwd_split(Qp.t, Kp.t, Vp.t, O.t, O.g, lse, delta, Qp.g, dkp, dvp, nb * S, H, nq // S, nk, hd, ld, ld,
+                                        ld, ld, ld, scale, 1, S)
+                    ops.sum_groups(dkp, Kp.g, nb, S, nk * ld)
+                    ops.sum_groups(dvp, Vp.g, nb, S, nk * ld)
+                elif long_k:
+                    delta = self._new(nb * H, nq, dtype=torch.float32)
+                    dqp = self._new(nb * S * nq, ld)
+                    ops.xattn_bwd_split(Qp.t, Kp.t, Vp.t, O.t, O.g, lse, delta, dqp, Kp.g, Vp.g, nb * S, H, nq, nk // S, hd, ld, ld,
+                                        ld, ld, ld, scale, S, 1)
+                    ops.sum_groups(dqp, Qp.g, nb, S, nq * ld)
+                else:
+                    delta = self._new(nb * H, nq, dtype=torch.float32)
+                    ops.xattn_bwd(Qp.t, Kp.t, Vp.t, O.t, O.g, lse, delta, Qp.g, Kp.g, Vp.g, nb, H, nq, nk, hd, ld, ld, ld,
+                                  ld, ld, scale)
             self.tape.append(bwd)
 
     def add_pe(self, x, pe, n, period, pe_var=None):
@@ -884,6 +982,69 @@ class Engine:
             curve = self._upload(scribble[0], torch.int32)
             prof = self._upload(scribble[1], torch.float64)
             assert curve.shape[0] == B and tuple(prof.shape) == (B, 2 * self.img)
+        nq = 2 * self.nmax
+        # round 5, two lanes: the prompt tokens' side of the DMA neck on its own stream (see the neck below).  What needs the
+        # prompts only -- the PuE vectors, their MLP, layer 0's token self-attention -- is launched now, beside the backbone;
+        # its backward closures are kept aside and join the tape at the neck's place (they belong to the neck's gradient range)
+        lanes = (self.neck_lanes and training and self.dt == BF16 and self.use_flash and not self.use_side and self.fuse_ln_pe
+                 and (D // 2 // 8) % 16 == 0 and D // 8 <= 128)
+        T = None
+        if lanes:
+            if self._tok_stream is None:
+                self._tok_stream = torch.cuda.Stream(device=self.dev)
+            T = self._tok_stream
+        tok = lambda: self._lane(T)
+
+        def group(fn):      # the projections queued by fn() leave in one grouped launch; so do their dgrads (backward)
+            if training:
+                self.tape.append(self.flush_group)
+            r = fn()
+            self.flush_group()
+            return r
+
+        def proj(prefix, which, x_, rows, width):
+            return self.linear(x_, f"{prefix}.{which}_proj.weight", f"{prefix}.{which}_proj.bias", rows, width, D, group=True)
+
+        def attend(prefix, Qp, Kp, Vp, nq_, nk_, width, resid):
+            O_ = Var(self._new(B * nq_, width))
+            self.cross_attention(Qp, Kp, Vp, O_, B, 8, nq_, nk_, width // 8, width, 1.0 / math.sqrt(width // 8))
+            return self.linear(O_, prefix + ".out_proj.weight", prefix + ".out_proj.bias", B * nq_, D, width, resid=resid)
+
+        def prompt_vectors():
+            pue_ = Var(self._new(B * nq, self.Epad))
+            ops.pue_encode(points, boxes if use_box else None, self.lut, pue_.t, None, B, n, self.nmax, self.img, self.Epad)
+            if use_scr:     # _guassinvector_scribble (is_vpu_model.py:294-352): the last valid positive row becomes the scribble
+                ops.pue_scribble_rows(points, prof, pue_.t, None, B, n, self.nmax, self.img, self.Epad)
+            return self.mlp(pue_, "neck.ffn_layer.lin1", "neck.ffn_layer.lin2", B * nq, self.Epad, 2048, D, "relu",
+                            w1=self.w_lin1p, k_grad=self.E, x_grad=False)
+
+        def tok_pre(l, q_, qq_, q0_):      # token side of layer l up to the token -> image queries: needs no image token
+            p_ = f"neck.att.layers.{l}"
+            if l == 0:
+                q_ = self.mha(p_ + ".self_attn", q_, q_, q_, B, nq, nq, D)
+            else:
+                q_ = self.mha(p_ + ".self_attn", qq_, qq_, q_, B, nq, nq, D, resid=q_)
+            q_, qq_ = self.layernorm(q_, p_ + ".norm1", B * nq, D, 1e-5, pe=q0_.t, pe_rows=B * nq, pe_var=q0_)
+            Qt_ = group(lambda: proj(p_ + ".cross_attn_token_to_image", "q", qq_, B * nq, D // 2))
+            return q_, qq_, Qt_
+
+        def start_token_lane():
+            fns_main, self.tape.fns = self.tape.fns, []
+
+            def lanes_done():       # (backward leaves the two-lane section: what the queue collected meanwhile may go)
+                self._in_lanes = False
+                for kind in sorted({0 if e[3] <= 2048 else e[3] for e in self._wq}):
+                    self._wgrad_autoflush(kind)
+            h_fork = self._xrec(None, on_bwd=lanes_done)
+            self._xwait(h_fork, T)
+            with tok():
+                q0_ = prompt_vectors()
+                pre_ = tok_pre(0, q0_, None, q0_)
+            early_, self.tape.fns = self.tape.fns, fns_main
+            return early_, q0_, pre_
+
+        if lanes and self.neck_lanes != 3:
+            early, q0, q_pre = start_token_lane()
         # ---- a1-a4: prompts -> coordinate features -> fused patch embedding (window token order)
         if coord_override is not None:
             disks = coord_override.to(device=self.dev, dtype=torch.float32).contiguous()
@@ -965,41 +1126,92 @@ class Engine:
             taps["backbone"] = xr.t
         if training:
             self._mark_ready("backbone.fc_norm.weight", None)  # neck + head + the unused tail: final once they are done
-        # ---- a7/a8: PuE vectors
-        nq = 2 * self.nmax
-        pue = Var(self._new(B * nq, self.Epad))
-        ops.pue_encode(points, boxes if use_box else None, self.lut, pue.t, None, B, n, self.nmax, self.img, self.Epad)
-        if use_scr:     # _guassinvector_scribble (is_vpu_model.py:294-352): the last valid positive row becomes the scribble
-            ops.pue_scribble_rows(points, prof, pue.t, None, B, n, self.nmax, self.img, self.Epad)
-        # ---- a10/a11: DMA neck
-        q0 = self.mlp(pue, "neck.ffn_layer.lin1", "neck.ffn_layer.lin2", B * nq, self.Epad, 2048, D, "relu",
-                      w1=self.w_lin1p, k_grad=self.E, x_grad=False)
+        # ---- a7/a8: PuE vectors, a10/a11: DMA neck
         nQ, nK = B * nq * D, M * D
-        q, k = q0, xr
         hs = []
-        qq = None
-        kk = self.add_pe(k, kpe_tab, nK, NT * D)
-        for l in range(3):
-            p = f"neck.att.layers.{l}"
-            # queries + query_pe / keys + key_pe (transformer.py:439-457) come out of the LayerNorm launch that produces the
-            # queries / keys (Engine.layernorm(pe=...)); the sum of unchanged queries is taken once -- the reference adds it
-            # again at the next layer's start (:439 after :457, :374 after :457): same numbers
-            if l == 0:
-                q = self.mha(p + ".self_attn", q, q, q, B, nq, nq, D)
-            else:
-                q = self.mha(p + ".self_attn", qq, qq, q, B, nq, nq, D, resid=q)
-            q, qq = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
-            q = self.mha(p + ".cross_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
-            q = self.layernorm(q, p + ".norm2", B * nq, D, 1e-5)
-            q = self.mlp(q, p + ".mlp.lin1", p + ".mlp.lin2", B * nq, D, 1024, D, "relu", resid=q)
-            q, qq = self.layernorm(q, p + ".norm3", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
-            k2 = self.mha(p + ".cross_attn_image_to_token", kk, qq, q, B, NT, nq, D // 2, resid=k)
-            k, kk = self.layernorm(k2, p + ".norm4", M, D, 1e-5, pe=kpe_tab, pe_rows=NT)
-            if l != 2:
-                hs.append((q, k))
-        q = self.mha("neck.att.final_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
-        q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
-        hs.append((q, k))
+        if lanes:
+            # Two lanes.  The neck alternates between the 576 prompt tokens (self-attention, LayerNorms, MLP, their projections:
+            # ~30 launches per layer of <= 108 workgroups, latency-bound) and the 9408 image tokens (projections, LayerNorm:
+            # full-chip launches).  One stream serialises them; here the token side runs on its own stream and meets the image
+            # side at the two attentions of a layer only:
+            #   image lane (the caller's stream): K / V of tokens -> image, Q of image -> tokens | ... | image -> tokens, norm4
+            #   token lane:  self-attention, norm1, Q | tokens -> image, norm2, MLP, norm3, K / V  | next layer's self-attention ..
+            # Events order the crossings (_xrec / _xwait; their backward closures mirror them), the backward closures run on the
+            # lane they were recorded on, and the weight-gradient queue only collects while backward is inside (its launches
+            # read operands of both lanes).  Same kernels on the same operands: the results do not depend on the lanes.
+            if self.neck_lanes == 3:      # (3: the token lane starts here, nothing runs beside the backbone)
+                early, q0, q_pre = start_token_lane()
+            self.tape.fns.extend(early)
+            if self.neck_lanes == 2:      # the token lane ends here: the neck itself on the caller's stream
+                h_early = self._xrec(T)
+                self._xwait(h_early, None)
+                T = None
+            k = xr
+            kk = self.add_pe(k, kpe_tab, nK, NT * D)
+            q, qq, Qt = q_pre
+            for l in range(4):          # (l == 3: final_attn_token_to_image)
+                p = f"neck.att.layers.{l}"
+                t2i = p + ".cross_attn_token_to_image" if l < 3 else "neck.att.final_attn_token_to_image"
+                i2t = p + ".cross_attn_image_to_token"
+                Kt, Vt = group(lambda: (proj(t2i, "k", kk, M, D // 2), proj(t2i, "v", k, M, D // 2)))
+                h_kv = self._xrec(None)
+                if l < 3:
+                    Qi = group(lambda: proj(i2t, "q", kk, M, D // 2))
+                with tok():
+                    if l == 3:
+                        Qt = group(lambda: proj(t2i, "q", qq, B * nq, D // 2))
+                    elif l > 0:
+                        q, qq, Qt = tok_pre(l, q, qq, q0)
+                self._xwait(h_kv, T)
+                with tok():
+                    q = attend(t2i, Qt, Kt, Vt, nq, NT, D // 2, q)
+                    if l == 3:
+                        q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
+                    else:
+                        q = self.layernorm(q, p + ".norm2", B * nq, D, 1e-5)
+                        q = self.mlp(q, p + ".mlp.lin1", p + ".mlp.lin2", B * nq, D, 1024, D, "relu", resid=q)
+                        q, qq = self.layernorm(q, p + ".norm3", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
+                        Ki, Vi = group(lambda: (proj(i2t, "k", qq, B * nq, D // 2), proj(i2t, "v", q, B * nq, D // 2)))
+                if l == 3:
+                    break
+                h_tok = self._xrec(T)
+                self._xwait(h_tok, None)
+                k2 = attend(i2t, Qi, Ki, Vi, NT, nq, D // 2, k)
+                k, kk = self.layernorm(k2, p + ".norm4", M, D, 1e-5, pe=kpe_tab, pe_rows=NT)
+                if l != 2:
+                    hs.append((q, k))
+            hs.append((q, k))
+
+            def lanes_begin():
+                self._in_lanes = True
+            h_join = self._xrec(T)
+            self._xwait(h_join, None, on_bwd=lanes_begin)
+        else:
+            q0 = prompt_vectors()
+            q, k = q0, xr
+            qq = None
+            kk = self.add_pe(k, kpe_tab, nK, NT * D)
+            for l in range(3):
+                p = f"neck.att.layers.{l}"
+                # queries + query_pe / keys + key_pe (transformer.py:439-457) come out of the LayerNorm launch that produces the
+                # queries / keys (Engine.layernorm(pe=...)); the sum of unchanged queries is taken once -- the reference adds it
+                # again at the next layer's start (:439 after :457, :374 after :457): same numbers
+                if l == 0:
+                    q = self.mha(p + ".self_attn", q, q, q, B, nq, nq, D)
+                else:
+                    q = self.mha(p + ".self_attn", qq, qq, q, B, nq, nq, D, resid=q)
+                q, qq = self.layernorm(q, p + ".norm1", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
+                q = self.mha(p + ".cross_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
+                q = self.layernorm(q, p + ".norm2", B * nq, D, 1e-5)
+                q = self.mlp(q, p + ".mlp.lin1", p + ".mlp.lin2", B * nq, D, 1024, D, "relu", resid=q)
+                q, qq = self.layernorm(q, p + ".norm3", B * nq, D, 1e-5, pe=q0.t, pe_rows=B * nq, pe_var=q0)
+                k2 = self.mha(p + ".cross_attn_image_to_token", kk, qq, q, B, NT, nq, D // 2, resid=k)
+                k, kk = self.layernorm(k2, p + ".norm4", M, D, 1e-5, pe=kpe_tab, pe_rows=NT)
+                if l != 2:
+                    hs.append((q, k))
+            q = self.mha("neck.att.final_attn_token_to_image", qq, kk, k, B, nq, NT, D // 2, resid=q)
+            q = self.layernorm(q, "neck.att.norm_final_attn", B * nq, D, 1e-5)
+            hs.append((q, k))
         q_out = Var(self._new(B * nq, D))
         ops.add4(q0.t, hs[0][0].t, hs[1][0].t, hs[2][0].t, q_out.t, nQ)
         if training:
@@ -1550,6 +1762,7 @@ class Engine:
         self._gq_out, self._frozen = set(), set()
         self._pending_reports, self._reporting = [], False
         self._pack_seen = {}
+        self._in_lanes = False
         self.tape = Tape()
         self.last_tape = None
 

@@ -246,6 +246,26 @@ def xattn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, nq, nk, hd, ldq, l
               ptr(dv), nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale, _stream())
 
 
+def xattn_fwd_split(q, k, v, out, lse, nb, H, nq, nk, hd, ldq, ldk, ldo, scale, qdiv, kdiv):
+    """vpu_xattn_fwd_split: entry b reads its queries from entry b // qdiv, its keys / values from entry b // kdiv (include/vpu_hip.h)."""
+    _lib.call("vpu_xattn_fwd_split", ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), nb, H, nq, nk, hd, ldq, ldk, ldo, scale,
+              int(qdiv), int(kdiv), _stream())
+
+
+def xattn_bwd_split(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale, qdiv, kdiv):
+    _lib.call("vpu_xattn_bwd_split", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
+              ptr(dv), nb, H, nq, nk, hd, ldq, ldk, ldo, ldgq, ldgk, scale, int(qdiv), int(kdiv), _stream())
+
+
+def attn_combine(o_s, lse_s, out, lse, nb, H, nq, hd, S, ld_s, ldo):
+    _lib.call("vpu_attn_combine", ptr(o_s), ptr(lse_s), ptr(out), ptr(lse), nb, H, nq, hd, S, ld_s, ldo, _stream())
+
+
+def sum_groups(inp, out, G, S, n):
+    """out[g][i] = sum_s inp[g][s][i] (fp32 sum in order)."""
+    _lib.call("vpu_sum_groups", ptr(inp), ptr(out), G, S, n, code_of(inp), _stream())
+
+
 def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, nb, H, n, hd, ld, ldo, ldg, scale):
     _lib.call("vpu_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
               ptr(dv), nb, H, n, hd, ld, ldo, ldg, scale, _stream())

@@ -649,6 +649,77 @@ def test_lazy_zero_grad_at_bench_shapes(golden_dir, B, variant):
         assert type(eng).pack_tiles is orig_pack
 
 
+@pytest.mark.parametrize("B,ptype", [(12, 0), (4, 0), (3, 1), (2, 2)])
+def test_neck_lanes_equal_single_stream(golden_dir, B, ptype):
+    """Round 5: the DMA neck's prompt-token chain on its own HIP stream (Engine.forward, `lanes`) against the single-stream
+    order -- the same arithmetic up to which GEMM kernel a projection takes (alone or in a group) and the order in which the
+    weight-gradient queue packs its launches; click, box and scribble prompts; host-enqueued and replayed
+    from ONE captured hipGraph (the token lane joins the capture through its events).  Run twice with lanes: the crossings are
+    ordered, so the result does not change from run to run."""
+    from pvpuformer_amd.graphs import capture
+    from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
+    fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
+    big = vo.synth_batch(B, cfg["img"], seed=300 + B)
+    x = torch.cat([big["images"], torch.zeros(B, 1, cfg["img"], cfg["img"])], 1).cuda()
+    pts, gt = big["points"].cuda(), big["instances"].cuda()
+    boxes = scr = None
+    if ptype == 1:
+        boxes = torch.tensor([[40 + 3 * b, 50, 300, 280 + 5 * b, 1] for b in range(B)], dtype=torch.int32).cuda()
+    if ptype == 2:
+        import random
+        from pvpuformer_amd.isegm.model.scribble import scribble_curves, scribble_profiles
+        tt = np.linspace(0.0, 1.0, 40)
+        strokes = np.stack([np.stack([60 + 20 * b + 250 * tt, 80 + 200 * tt ** 2 + 10 * b], -1)[None] for b in range(B)])    # [B,1,40,2]
+        rects = np.array([[[185 + 20 * b, 180 + 10 * b, 250, 200]] for b in range(B)], np.int64)
+        scr = (torch.from_numpy(scribble_curves(strokes)).cuda(),
+               torch.from_numpy(scribble_profiles(strokes, rects, cfg["img"], random.Random(7))).cuda())
+    model.train()
+    model.head.dropout_ratio = 0.0
+    eng = model._ensure_engine()
+    eng.refresh_weights()
+
+    def step():
+        eng.zero_grad()
+        inst, _ = eng.forward(x, pts, boxes, ptype, None, training=True, materialize_aux=False, scribble=scr)
+        _, d_inst, d_sim = vpu_step_losses(inst, None, gt, None, None, iter_weight=1.0, sim_low=eng.sim_low)
+        eng.backward(d_inst, None, d_sim_low=d_sim)
+        return inst
+
+    def run(lanes):
+        eng.neck_lanes = lanes
+        inst = step()
+        torch.cuda.synchronize()
+        return inst.clone(), eng.sim_low.clone(), eng.gflat.clone()
+    try:
+        i0, s0, g0 = run(False)
+        i1, s1, g1 = run(True)
+        assert eng._tok_stream is not None and not eng._in_lanes and not eng._wq
+        # (not the same bits: a projection that leaves alone takes the plain kernel, in a group of three the grouped one --
+        # other fp32 summation orders, a bf16 ulp here and there)
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        e_i, e_s, e_g = rel(i1, i0), rel(s1, s0), rel(g1, g0)
+        print(f"[neck lanes] B {B} prompt type {ptype}: relative L2 distance lanes vs single stream: logits {e_i:.2e}, "
+              f"similarities {e_s:.2e}, gradients {e_g:.2e}")
+        assert e_i < 5e-3 and e_s < 5e-3 and e_g < 2e-2, (e_i, e_s, e_g)
+        i2, s2, g2 = run(True)
+        assert torch.equal(i2, i1) and torch.equal(g2, g1)
+        if B == 12:     # the whole step captured once and replayed: the token lane is a branch of the graph
+            eng.neck_lanes = True
+            eng.gflat.fill_(float("nan"))
+            g = torch.cuda.CUDAGraph()
+            with capture(g, device=x.device):
+                inst = step()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(inst, i1) and torch.equal(eng.gflat, g1)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.gflat, g1)
+    finally:
+        eng.neck_lanes = True
+        eng.abort_pass()
+
+
 def test_failed_capture_leaves_no_queued_work_behind(golden_dir):
     """A hipGraph capture of the backward that raises half way: the engine's queues then hold entries pointing at
     capture-pool buffers nothing has written.  ``SegmentedBackward.capture`` calls ``Engine.abort_pass()`` before re-raising, so

@@ -1289,6 +1289,57 @@ def test_flash_attention_fwd_bwd(ops, attn_form, hd, n, nb):
         assert (got[i] - ref_g).abs().max().item() < tol, (name, (got[i] - ref_g).abs().max().item(), tol)
 
 
+@pytest.mark.parametrize("nq,nk,hd,S", [(48, 784, 48, 4), (784, 48, 48, 4), (48, 1024, 80, 4), (1024, 48, 80, 2), (64, 256, 64, 2)])
+def test_split_attention_equals_unsplit(ops, nq, nk, hd, S):
+    """vpu_xattn_fwd_split / _bwd_split + vpu_attn_combine / vpu_sum_groups (round 5: the long side of the DMA neck's prompt <->
+    image attentions cut into S ranges that run as batch entries of one launch) against the unsplit launch and torch fp32:
+    long keys (qdiv = S: partial softmaxes merged through their log-sum-exp, dQ as partial sums) and long queries (kdiv = S: dK /
+    dV as partial sums); ViT-B's 48 x 784 at head dim 48 and ViT-H's 48 x 1024 at head dim 80."""
+    nb, H = 3, 8
+    ld = H * hd
+    scale = hd ** -0.5
+    Q = dev(rnd(nb * nq, ld, seed=300 + nq)).to(torch.bfloat16)
+    K = dev(rnd(nb * nk, ld, seed=301 + nk)).to(torch.bfloat16)
+    V = dev(rnd(nb * nk, ld, seed=302 + nk)).to(torch.bfloat16)
+    dO = dev(rnd(nb * nq, ld, seed=303 + nq)).to(torch.bfloat16)
+    O0, lse0 = torch.empty_like(Q), torch.empty(nb * H, nq, device="cuda")
+    ops.xattn_fwd(Q, K, V, O0, lse0, nb, H, nq, nk, hd, ld, ld, ld, scale)
+    dQ0, dK0, dV0 = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    ops.xattn_bwd(Q, K, V, O0, dO, lse0, torch.empty(nb * H, nq, device="cuda"), dQ0, dK0, dV0, nb, H, nq, nk, hd, ld, ld, ld, ld, ld, scale)
+    O1, dQ1, dK1, dV1 = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    if nk > nq:     # long keys: the queries are shared
+        o_s, lse_s = torch.empty(nb * S * nq, ld, device="cuda", dtype=torch.bfloat16), torch.empty(nb * S * H, nq, device="cuda")
+        ops.xattn_fwd_split(Q, K, V, o_s, lse_s, nb * S, H, nq, nk // S, hd, ld, ld, ld, scale, S, 1)
+        lse1 = torch.empty(nb * H, nq, device="cuda")
+        ops.attn_combine(o_s, lse_s, O1, lse1, nb, H, nq, hd, S, ld, ld)
+        dqp = torch.empty(nb * S * nq, ld, device="cuda", dtype=torch.bfloat16)
+        ops.xattn_bwd_split(Q, K, V, O1, dO, lse1, torch.empty(nb * H, nq, device="cuda"), dqp, dK1, dV1, nb * S, H, nq, nk // S, hd,
+                            ld, ld, ld, ld, ld, scale, S, 1)
+        ops.sum_groups(dqp, dQ1, nb, S, nq * ld)
+        assert torch.allclose(lse1, lse0, atol=2e-3, rtol=1e-4)
+    else:           # long queries: the keys are shared
+        lse1 = torch.empty(nb * S * H, nq // S, device="cuda")
+        ops.xattn_fwd_split(Q, K, V, O1, lse1, nb * S, H, nq // S, nk, hd, ld, ld, ld, scale, 1, S)
+        dkp, dvp = torch.empty(nb * S * nk, ld, device="cuda", dtype=torch.bfloat16), torch.empty(nb * S * nk, ld, device="cuda", dtype=torch.bfloat16)
+        ops.xattn_bwd_split(Q, K, V, O1, dO, lse1, torch.empty(nb * S * H, nq // S, device="cuda"), dQ1, dkp, dvp, nb * S, H, nq // S, nk,
+                            hd, ld, ld, ld, ld, ld, scale, 1, S)
+        ops.sum_groups(dkp, dK1, nb, S, nk * ld)
+        ops.sum_groups(dvp, dV1, nb, S, nk * ld)
+        assert torch.equal(O1, O0) and torch.equal(dQ1, dQ0)       # (each query range is its own softmax: the same arithmetic)
+    # torch fp32 on the bf16-rounded operands
+    q_, k_, v_ = (t.float().view(nb, -1, H, hd).transpose(1, 2).clone().requires_grad_(True) for t in (Q, K, V))
+    ref = torch.softmax((q_ @ k_.transpose(-1, -2)) * scale, -1) @ v_
+    ref.backward(dO.float().view(nb, nq, H, hd).transpose(1, 2))
+    back = lambda t: t.transpose(1, 2).reshape(-1, ld)
+    for name, got, base, want in (("O", O1, O0, back(ref.detach())), ("dQ", dQ1, dQ0, back(q_.grad)), ("dK", dK1, dK0, back(k_.grad)),
+                                  ("dV", dV1, dV0, back(v_.grad))):
+        sc = want.abs().max().item()
+        e1, e0 = (got.float() - want).abs().max().item(), (base.float() - want).abs().max().item()
+        print(f"[split attention] {nq}x{nk} hd {hd} {name}: split {e1 / sc:.2e}, unsplit {e0 / sc:.2e} of the scale")
+        assert e1 < 2e-2 * sc, (name, e1, sc)
+        assert (got.float() - base.float()).abs().max().item() < 1.5e-2 * sc, name
+
+
 @pytest.mark.parametrize("n,nb,H", [(196, 5, 3), (256, 2, 2), (208, 1, 1), (100, 3, 2), (64, 2, 4), (16, 3, 1), (4, 2, 1), (132, 2, 12), (50, 2, 2), (197, 1, 2)])
 def test_one_pass_window_backward(ops, n, nb, H):
     """The one-pass (window, head) backward kernels (head dim 64, n <= 256) against torch fp32 on the bf16-rounded inputs AND
