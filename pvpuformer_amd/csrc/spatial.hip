@@ -990,40 +990,77 @@ __global__ __launch_bounds__(256) void gate_apply_n_kernel(const T* __restrict__
             }
     }
 }
+// eight consecutive elements as they sit in memory (bf16: four registers), expanded to fp32 where they are used
+template <typename T> struct Raw8 {
+    float v[8];
+    __device__ __forceinline__ void load(const T* p) { load8(p, v); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[j];
+    }
+};
+template <> struct Raw8<bf16_t> {
+    uint4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(w[j] << 16); o[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+    }
+};
 // one wave per row n: dx, the dsg of every gate (+ scatter into its dK), per-column partials of every dcg
+// (round 5: the column gates of the sample sit in LDS instead of 48 registers per lane and every load of a row -- x, the
+// gates' gradients, dx -- is requested before the first multiply and stays packed until it is used: 170 -> 154 registers =
+// three workgroups per CU, so the 768 workgroups of ViT-B at bs 12 are resident at once instead of a round and a half, and a
+// row costs one memory latency instead of two)
 template <typename T, int NCHK>
 __global__ __launch_bounds__(256) void gate_bwd_rows_n_kernel(const GateSet gs, const T* __restrict__ x, const float* __restrict__ cg,
                                                               const float* __restrict__ sg, const int* __restrict__ argc,
                                                               T* __restrict__ dx, int accum, float* __restrict__ part, int B, int N,
                                                               int C) {
     __shared__ float red[4][8 * 64];
+    __shared__ float gsh[GATE_MAXN][NCHK * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
     const int per = (N + GATE_NBLK - 1) / GATE_NBLK;
     const int n0 = blockIdx.y * per, n1 = n0 + per < N ? n0 + per : N;
     const int64_t rows = (int64_t)B * N;
-    float dcg[GATE_MAXN][NCHK][8], g[GATE_MAXN][NCHK][8];
+    for (int i = threadIdx.x; i < GATE_MAXN * NCHK * 512; i += 256) {
+        const int gi = i / (NCHK * 512), c = i - gi * (NCHK * 512);
+        gsh[gi][c] = (gi < gs.n && c < C) ? cg[((int64_t)gi * B + b) * C + c] : 0.f;
+    }
+    float dcg[GATE_MAXN][NCHK][8];
 #pragma unroll
     for (int gi = 0; gi < GATE_MAXN; ++gi)
 #pragma unroll
-        for (int i = 0; i < NCHK; ++i) {
-            const int c = (lane + i * 64) * 8;
+        for (int i = 0; i < NCHK; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { dcg[gi][i][j] = 0.f; g[gi][i][j] = 0.f; }
-            if (gi < gs.n && c < C) load8(cg + ((int64_t)gi * B + b) * C + c, g[gi][i]);
-        }
+            for (int j = 0; j < 8; ++j) dcg[gi][i][j] = 0.f;
+    __syncthreads();
     for (int n = n0 + wave; n < n1; n += 4) {
         const int64_t row = (int64_t)b * N + n;
         float s[GATE_MAXN], dot[GATE_MAXN];
 #pragma unroll
         for (int gi = 0; gi < GATE_MAXN; ++gi) { s[gi] = gi < gs.n ? sg[(int64_t)gi * rows + row] : 0.f; dot[gi] = 0.f; }
+        Raw8<T> xr[NCHK], orw[NCHK], dr[GATE_MAXN][NCHK];
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {      // every load of the row first
+            const int c = (lane + i * 64) * 8;
+            if (c < C) {
+                xr[i].load(x + row * C + c);
+#pragma unroll
+                for (int gi = 0; gi < GATE_MAXN; ++gi)
+                    if (gi < gs.n) dr[gi][i].load((const T*)gs.out[gi] + row * C + c);
+                if (accum) orw[i].load(dx + row * C + c);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NCHK; ++i) {
             const int c = (lane + i * 64) * 8;
             if (c < C) {
                 float xv[8], o[8];
-                load8(x + row * C + c, xv);
-                if (accum) load8(dx + row * C + c, o);
+                xr[i].get(xv);
+                if (accum) orw[i].get(o);
                 else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = 0.f;
@@ -1031,14 +1068,16 @@ __global__ __launch_bounds__(256) void gate_bwd_rows_n_kernel(const GateSet gs, 
 #pragma unroll
                 for (int gi = 0; gi < GATE_MAXN; ++gi)
                     if (gi < gs.n) {
+                        const float4 ga = *reinterpret_cast<const float4*>(&gsh[gi][c]), gb = *reinterpret_cast<const float4*>(&gsh[gi][c + 4]);
+                        const float g[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
                         float dv[8];
-                        load8((const T*)gs.out[gi] + row * C + c, dv);
+                        dr[gi][i].get(dv);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float t = dv[j] * xv[j];
                             dot[gi] += t;
                             dcg[gi][i][j] += t;
-                            o[j] += dv[j] * (1.f + g[gi][i][j] + s[gi]);
+                            o[j] += dv[j] * (1.f + g[j] + s[gi]);
                         }
                     }
                 store8(dx + row * C + c, o);
