@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-
 # `build.sh diag`: the diagnostic library libvpu_hip_diag.so (-DVPU_DIAG: time-stamp code in the K2 / K4P GEMM kernels, read by
 # tools/k2_stamps.py and tools/k4_drift.py through VPU_LIB_DIAG=1).  The product library has neither the stamp pointer nor the code.
 OUT=libvpu_hip.so; BUILD=build
-if [ "$1" = "diag" ]; then FLAGS="$FLAGS -DVPU_DIAG"; OUT=libvpu_hip_diag.so; BUILD=build_diag; fi
+if [ "$1" = "diag" ]; then FLAGS="$FLAGS -DVPU_DIAG -DVPU_LAB"; OUT=libvpu_hip_diag.so; BUILD=build_diag; fi
 mkdir -p $BUILD
 pids=()
 for f in gemm attention rowops spatial prompt loss optim; do

@@ -2479,7 +2479,20 @@ inline int k3_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_K3"); return e ? atoi(e) : 28; }();   // K3S + K4 + pipelined K4
     return v;
 }
-inline int k3_opt() { const int v = g_opt_k3.load(std::memory_order_relaxed); return v >= 0 ? v : k3_env0(); }
+// The product library (no -DVPU_LAB) carries the kernel families the engine dispatches; the others -- K3 forward / dgrad forms
+// and K3 / K2 grouped weight gradients (k3 bits 0-1), the non-pipelined K4 (bit 3 without bit 4), the three-stage ring forms of
+// the 128 x 128 kernel, the 256 x 128 three-stage kernel (VPU_GEMM_BIG) and the LDS-transposed K2 epilogue
+// (VPU_GEMM_K2_DIRECT=0) -- are compiled into the laboratory library only (`build.sh diag` -> libvpu_hip_diag.so, loaded with
+// VPU_LIB_DIAG=1 by the tools and by the tests marked `lab`); their option bits read as off here.
+inline int k3_opt() {
+    int v = g_opt_k3.load(std::memory_order_relaxed);
+    v = v >= 0 ? v : k3_env0();
+#ifndef VPU_LAB
+    v &= ~3;
+    if (v & 8) v |= 16;
+#endif
+    return v;
+}
 inline int k2_env0() {
     static const int v = [] { const char* e = getenv("VPU_GEMM_K2"); return e ? atoi(e) : 2; }();
     return v;
@@ -2554,7 +2567,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     static const int force_big = [] { const char* e = getenv("VPU_GEMM_BIG"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     // the 256x128 three-stage kernel is kept selectable (VPU_GEMM_BIG=1) but is off by default: at these problem sizes
     // (<= 3.5 rounds of tiles) it measured 5-25 % slower than two co-resident 128x128 blocks per CU (round 1).
+#ifdef VPU_LAB
     const bool big = bf && force_big == 1 && d->M >= 1024 && d->N >= 128 && d->K >= 256;
+#else
+    const bool big = false;
+    (void)force_big;
+#endif
     const int tm = bf ? (big ? BM2 : BM) : FM, tn = bf ? BN : FN;
     const int tiles_m = (d->M + tm - 1) / tm, tiles_n = (d->N + tn - 1) / tn;
     const int key = (d->transA ? 2 : 0) | (d->transB ? 1 : 0);
@@ -2578,7 +2596,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // bytes in flight per CU.  The ring pays at one workgroup per CU with long K; kept for the next tile shapes.
         const int ring_env = g_opt_ring.load(std::memory_order_relaxed) >= 0 ? g_opt_ring.load(std::memory_order_relaxed) : ring_env0();
         static const int ring_min = [] { const char* e = getenv("VPU_GEMM_RING_MIN"); return e ? atoi(e) : 96; }();
+#ifdef VPU_LAB
         const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= ring_min && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
+#else
+        const bool ring = false;
+        (void)ring_env; (void)ring_min;
+#endif
         // (192 ... 256 tiles walking a long K -- the FPN's 2352-row convolution over K = 3072: 228 tiles, 48 K-tiles each on
         // half of the 512 workgroup slots -- are cut in two as well: 55 -> ~35 us with the reduce)
         if (!ring && d->workspace && (tiles < 192 || (tiles <= 256 && d->K >= 32 * BK)) && d->K >= 8 * BK) {
@@ -2595,6 +2618,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
         // K3 (bit 1 of the k3 option): the same problems as K2 below, 256 x 128 tiles in 256-thread workgroups, two per CU
         // (VPU_GEMM_K3_FORMS: a bit mask of single forms -- 1 bias, 2 bias+residual, 4 bias+GELU, 8 plain dgrad, 16 x aux -- for A/B runs)
+#ifdef VPU_LAB
         static const int forms3 = [] { const char* e = getenv("VPU_GEMM_K3_FORMS"); return e ? atoi(e) : 0; }();
         if (((k3_opt() & 2) || forms3) && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % K3_BK == 0 && d->K >= 256 &&
             !d->transA && d->alpha == 1.0f && (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL &&
@@ -2636,6 +2660,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
 #undef VPU_LAUNCH_K3_RB
             if (done3) return vpu_check_launch("vpu_gemm");
         }
+#endif
         // K2: large problems whose 256 x 128 tiles fill the chip and whose epilogue is one of the ViT-block flag sets
         {
             static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
@@ -2686,11 +2711,15 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         NOTE_KERNEL("gemm_bf16_k2_kernel<%d, %d, %d, %d, %d, %d>", TA_, TB_, WN_, FL_, RB_, SW_);                      \
         kern_<<<dim3((unsigned)(tot_ < ncu ? tot_ : ncu)), dim3(512), K2Cfg<WN_>::LDS + K2_BIAS_LDS, s>>>(*d, tm_, tn_, vec2 VPU_DBG_LOAD); \
     } while (0)
+#ifdef VPU_LAB
 #define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_)                                                                     \
     do {                                                                                                             \
         if (direct2 >= 1) VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, 1);                                               \
         else VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, 0);                                                            \
     } while (0)
+#else
+#define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_) do { (void)direct2; VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, 1); } while (0)
+#endif
 #define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_) do { if (short_tile) VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 7); else VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 8); } while (0)
 #define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2(TA_, TB_, 2, FL_); else done = false; } while (0)
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
@@ -2772,6 +2801,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         NOTE_KERNEL("gemm_bf16_kernel<%d, %d, true, %s, %d, 3>", TA_, TB_, CS_ ? "true" : "false", FL_);              \
         kern_<<<pgrid, block, 6 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);       \
     } while (0)
+#ifdef VPU_LAB
         if (ring && use_dma && vec_arg <= 1) {
             launched = true;
             if (d->colsum && key == 3) VPU_LAUNCH_RING(1, 1, true, -1);
@@ -2781,6 +2811,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             else if (key == 2) VPU_LAUNCH_RING(1, 0, false, -1);
             else VPU_LAUNCH_RING(1, 1, false, -1);
         }
+#endif
 #undef VPU_LAUNCH_RING
         // K3S (bit 2 of the k3 option): the same flag sets on the 128 x 128 ring kernel, three workgroups per CU
         // (measured against the two-stage kernel, tools/gemm_bench.py GEMM_BENCH_K2=2,k3s: it wins where K is short -- the FPN /
@@ -2863,6 +2894,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
         if (launched) {
         } else
+#ifdef VPU_LAB
         if (big) {
             static VpuDevOnce attr_done;
             if (attr_done.pending()) {
@@ -2880,7 +2912,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 case 2: gemm_bf16_big_kernel<1, 0><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
                 default: gemm_bf16_big_kernel<1, 1><<<grid, block2, 3 * STAGE2, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg); break;
             }
-        } else {
+        } else
+#endif
+        {
             if (d->colsum) {  // weight-gradient GEMM with the fused bias gradient (always transA = transB = 1 in the engine)
                 NOTE_KERNEL("gemm_bf16_kernel<1, %d, true, true, -1, 0>", key == 3 ? 1 : 0);
                 if (key == 3) gemm_bf16_kernel<1, 1, true, true, -1><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg);
@@ -2920,6 +2954,13 @@ extern "C" const char* vpu_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     vpu_clear_stale_error();
+#ifndef VPU_LAB
+    if (name && ((!strcmp(name, "ring") && value > 0) || (!strcmp(name, "k3") && value > 0 && (value & 3)))) {
+        vpu_set_error("vpu_gemm_set_option: the three-stage ring forms and the K3 forward / grouped forms (k3 bits 0-1) are compiled "
+                      "into the laboratory library only (build.sh diag, VPU_LIB_DIAG=1)");
+        return VPU_ERR_ARG;
+    }
+#endif
     if (name && !strcmp(name, "ring") && value >= -1 && value <= 2) {
         g_opt_ring.store(value, std::memory_order_relaxed);
         return VPU_OK;
@@ -3151,7 +3192,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                           (int64_t)q.M * q.ldc * 4 < 0x7FFFFFF0LL;
             }
             if (attr4_.pending()) {
+#ifdef VPU_LAB
                 VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4_grouped_kernel<1, 1, true>);
+#endif
                 VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4p_grouped_kernel<1, 1, true>);
                 VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4p_grouped_kernel<1, 1, true, true>);
             }
@@ -3159,14 +3202,17 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true%s>", pipe ? "p" : "", direct4 ? ", true" : "");
             if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1 VPU_DBG_LOAD);
-            else if (pipe) gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1 VPU_DBG_LOAD);
-            else gemm_bf16_k4_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+#ifdef VPU_LAB
+            else if (!pipe) gemm_bf16_k4_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1);
+#endif
+            else gemm_bf16_k4p_grouped_kernel<1, 1, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1 VPU_DBG_LOAD);
             return vpu_check_launch("vpu_gemm_grouped");
         }
         if (any_batch && !ok) {
             vpu_set_error("vpu_gemm_grouped: batch > 1 needs K % 64 == 0, K >= 2048, M % 8 == 0, N % 8 == 0 and aligned operands");
             return VPU_ERR_ARG;
         }
+#ifdef VPU_LAB
         // (VPU_GEMM_K3G_MIN_K > 0: short-reduction weight-gradient groups -- the neck's token-side gradients, 576 rows -- with a
         // reduction of at least that many rows on the K3 form: A/B knob)
         static const int k3g_min_k = [] { const char* e = getenv("VPU_GEMM_K3G_MIN_K"); return e ? atoi(e) : 0; }();
@@ -3196,6 +3242,9 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, noepi2 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
         }
+#else
+        (void)very_long; (void)total2;
+#endif
     }
     if (any_batch) { vpu_set_error("vpu_gemm_grouped: batch > 1 is only implemented for 16-byte-addressable weight-gradient groups"); return VPU_ERR_ARG; }
     static const int persist_env = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();

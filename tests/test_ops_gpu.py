@@ -1,6 +1,7 @@
 """GPU parity tests of every C-ABI kernel against plain torch fp32 / the numpy oracle on the same seeded inputs.
 Integer / index work must be bit-exact; floating point tolerances are written at each assert."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -253,6 +254,7 @@ def test_gemm_exact_integers(ops, dtype, tA, tB):
     assert torch.all(out[:, N:] == 7.0), "wrote outside the N range"
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("K", [72, 200, 648])
 def test_gemm_ring_pipeline_exact(ops, tA, tB, K):
@@ -1575,6 +1577,7 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
         assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("tB", [0, 1])
 @pytest.mark.parametrize("shape", [(6001, 1544, 256), (5000, 2304, 640), (9408, 2304, 768)])
 def test_gemm_k3_exact_and_epilogues(ops, tB, shape):
@@ -1753,6 +1756,7 @@ def test_gemm_grouped_skinny_wgrad_form(ops):
             assert torch.equal(cs.cpu(), csref)
 
 
+@pytest.mark.lab
 def test_gemm_k2_grouped_wgrad(ops):
     """Weight-gradient groups over a long reduction in the K2 form (vpu_gemm_grouped: one global tile order cut into a
     contiguous range per XCD): bit-exact accumulation into pre-filled fp32 outputs + the fused bias-gradient column sums,
@@ -1784,7 +1788,7 @@ def test_gemm_k2_grouped_wgrad(ops):
             assert torch.equal(cs.cpu(), csref)
 
 
-@pytest.mark.parametrize("opt", [1, 8, 24])
+@pytest.mark.parametrize("opt", [pytest.param(1, marks=pytest.mark.lab), pytest.param(8, marks=pytest.mark.lab), 24])
 def test_gemm_k3_grouped_wgrad(ops, opt):
     """The round-4 forms of the same groups.  vpu_gemm_set_option("k3", 1): 256 x 128 tiles in 256-thread workgroups, two per
     CU, 32-deep K-steps through a three-stage ring, no K split ("K3"); 8: 256 x 256 tiles, one 512-thread workgroup per CU,
@@ -2044,3 +2048,25 @@ def test_pixel_shuffle2_gn_stats(ops, dtype):
     assert torch.allclose(st1.sum(1), st0.sum(1), rtol=1e-6, atol=1e-4)      # (fp32 partials of 32 values against 8, then float64)
     assert torch.allclose(m1, m0, rtol=1e-6, atol=1e-7) and torch.allclose(r1, r0, rtol=1e-6, atol=1e-7)
     assert torch.allclose(o1.float(), o0.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_lab_library_families():
+    """The kernel families the engine does not dispatch (K3 forward / grouped forms, the non-pipelined K4, the K2 grouped weight
+    gradient, the three-stage ring forms) live in the laboratory library only (`csrc/build.sh diag`: -DVPU_DIAG -DVPU_LAB); the
+    product library rejects their options.  Their exactness tests (marked `lab`) run here in a child process that loads that
+    library (VPU_LIB_DIAG=1), so they stay covered by the same `pytest -m gpu` run."""
+    import subprocess
+    import sys
+    from pvpuformer_amd import ops as pops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("VPU_LIB_DIAG", "0") != "1":
+        for name, v in (("ring", 2), ("k3", 3), ("k3", 1)):
+            with pytest.raises(RuntimeError, match="laboratory library"):
+                pops.gemm_set_option(name, v)
+    assert os.path.exists(os.path.join(root, "pvpuformer_amd", "libvpu_hip_diag.so")), "build it: bash pvpuformer_amd/csrc/build.sh diag"
+    env = dict(os.environ, VPU_LIB_DIAG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-x", "-m", "gpu and lab",
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail

@@ -4,6 +4,9 @@ usage: python tools/gemm_bench.py [reps]"""
 import os
 import sys
 
+if "k3" in os.environ.get("GEMM_BENCH_K2", "").split(","):
+    os.environ.setdefault("VPU_LIB_DIAG", "1")   # the K3 forward forms live in the laboratory library (bash pvpuformer_amd/csrc/build.sh diag)
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

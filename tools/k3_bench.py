@@ -5,6 +5,8 @@ usage: python tools/k3_bench.py [reps]"""
 import os
 import sys
 
+os.environ.setdefault("VPU_LIB_DIAG", "1")       # the K3 / ring families live in the laboratory library (bash pvpuformer_amd/csrc/build.sh diag)
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
