@@ -2739,7 +2739,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // skinny problems (see gemm_bf16_skinny_kernel): few rows, moderate N and K, plain or K-major B
         static const int skinny_env = [] { const char* e = getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
         const int skinny_opt = g_opt_skinny.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny.load(std::memory_order_relaxed) : skinny_env;
-        static const int skinny_m = [] { const char* e = getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 2560; }();
+        static const int skinny_m = [] { const char* e = getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 4096; }();   // (round 5: 2560 -> 4096, batch 4's 3136-row N = 768 GEMMs: 495 -> 502 images/s)
         static const int skinny_n = [] { const char* e = getenv("VPU_GEMM_SKINNY_N"); return e ? atoi(e) : 4096; }();
         static const int skinny_k = [] { const char* e = getenv("VPU_GEMM_SKINNY_K"); return e ? atoi(e) : 4096; }();
         // (under-filled launches only: fewer than 192 tiles of 128x128, the same bound as the split-K rule below)
