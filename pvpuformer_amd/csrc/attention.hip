@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restr
 // the tests).  VPU_ATTN_LEAN sets the process default.
 std::atomic<int> g_opt_lean{-1}, g_opt_onepass{-1};
 inline bool xcd_map_enabled() {   // VPU_ATTN_XCDMAP=0: the plain 2-D grid (A/B runs)
-    static const int e0 = [] { const char* e = getenv("VPU_ATTN_XCDMAP"); return e ? atoi(e) : 1; }();
+    static const int e0 = [] { const char* e = vpu_lab_getenv("VPU_ATTN_XCDMAP"); return e ? atoi(e) : 1; }();
     return e0 != 0;
 }
 inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backward for n <= 256, head dim 64: 2 = key passes, four workgroups per CU (round 5), 1 = one per CU, 0 = two kernels
@@ -1538,7 +1538,7 @@ inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backw
     return v >= 0 ? v : e0;
 }
 inline bool wide_two() {   // two query tiles per wave also in the 128-column instantiation (head dims 80 / 96: ViT-H, the neck)
-    static const int e0 = [] { const char* e = getenv("VPU_ATTN_WIDE2"); return e ? atoi(e) : 1; }();
+    static const int e0 = [] { const char* e = vpu_lab_getenv("VPU_ATTN_WIDE2"); return e ? atoi(e) : 1; }();
     return e0 != 0;
 }
 inline bool lean_enabled() {
@@ -1616,7 +1616,7 @@ static int xattn_fwd_impl(const void* q, const void* k, const void* v, void* out
         }
         return vpu_check_launch("vpu_xattn_fwd");
     }
-    static const int qt2 = [] { const char* e = getenv("VPU_ATTN_QT"); return e ? atoi(e) : 2; }();
+    static const int qt2 = [] { const char* e = vpu_lab_getenv("VPU_ATTN_QT"); return e ? atoi(e) : 2; }();
     const bool two = qt2 == 2 && nq > 64 && nk <= 256 && hd_image(hd) <= 64;
     dim3 grid(two ? (nq + 127) / 128 : (nq + 63) / 64, nb * H);
     snprintf(g_last_attn, sizeof(g_last_attn), "attn_fwd_kernel<%d, 1, %d>", hd_image(hd), two ? 2 : 1);

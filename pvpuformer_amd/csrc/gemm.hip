@@ -2512,12 +2512,12 @@ inline int cu_count() {
     return left >= 64 ? left : v;
 }   // -1 environment default (VPU_GEMM_SKINNY, 1 if unset), 0 off, 1 on
 inline int inlaunch_env0() {
-    static const int v = [] { const char* e = getenv("VPU_GEMM_INLAUNCH"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = vpu_lab_getenv("VPU_GEMM_INLAUNCH"); return e ? atoi(e) : 0; }();
     return v;
 }
 constexpr int64_t CNT_BYTES = 256 << 10;   // tile arrival counters at the end of the split-K workspace
 inline int ring_env0() {
-    static const int v = [] { const char* e = getenv("VPU_GEMM_RING"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = vpu_lab_getenv("VPU_GEMM_RING"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -2564,7 +2564,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         }
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int force_big = [] { const char* e = getenv("VPU_GEMM_BIG"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static const int force_big = [] { const char* e = vpu_lab_getenv("VPU_GEMM_BIG"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     // the 256x128 three-stage kernel is kept selectable (VPU_GEMM_BIG=1) but is off by default: at these problem sizes
     // (<= 3.5 rounds of tiles) it measured 5-25 % slower than two co-resident 128x128 blocks per CU (round 1).
 #ifdef VPU_LAB
@@ -2595,7 +2595,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // specialised epilogue); the 576-row token GEMMs (15-30 tiles) 15.4 us vs 12.4 us for split-K + reduce: too few
         // bytes in flight per CU.  The ring pays at one workgroup per CU with long K; kept for the next tile shapes.
         const int ring_env = g_opt_ring.load(std::memory_order_relaxed) >= 0 ? g_opt_ring.load(std::memory_order_relaxed) : ring_env0();
-        static const int ring_min = [] { const char* e = getenv("VPU_GEMM_RING_MIN"); return e ? atoi(e) : 96; }();
+        static const int ring_min = [] { const char* e = vpu_lab_getenv("VPU_GEMM_RING_MIN"); return e ? atoi(e) : 96; }();
 #ifdef VPU_LAB
         const bool ring = !big && (ring_env == 2 || (ring_env == 1 && tiles >= ring_min && tiles <= 256 && d->K <= 24 * BK && d->K > 2 * BK));
 #else
@@ -2619,12 +2619,12 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         // K3 (bit 1 of the k3 option): the same problems as K2 below, 256 x 128 tiles in 256-thread workgroups, two per CU
         // (VPU_GEMM_K3_FORMS: a bit mask of single forms -- 1 bias, 2 bias+residual, 4 bias+GELU, 8 plain dgrad, 16 x aux -- for A/B runs)
 #ifdef VPU_LAB
-        static const int forms3 = [] { const char* e = getenv("VPU_GEMM_K3_FORMS"); return e ? atoi(e) : 0; }();
+        static const int forms3 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K3_FORMS"); return e ? atoi(e) : 0; }();
         if (((k3_opt() & 2) || forms3) && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % K3_BK == 0 && d->K >= 256 &&
             !d->transA && d->alpha == 1.0f && (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL &&
             (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
-            static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
-            static const int rb3_env = [] { const char* e = getenv("VPU_GEMM_K2_RB"); return e ? atoi(e) : 0; }();
+            static const bool noepi3 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            static const int rb3_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_RB"); return e ? atoi(e) : 0; }();
             constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
                           F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
             const int tn3 = (d->N + 127) / 128;
@@ -2633,7 +2633,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             const int64_t tot3 = short3 ? t224 : t256;
             const int cap3 = 2 * cu_count();
             bool done3 = tot3 > cu_count();      // (one workgroup per CU: K2's ping-pong is the faster form)
-            static const int stag3 = [] { const char* e = getenv("VPU_GEMM_K3_STAGGER"); return e ? atoi(e) : 0; }();
+            static const int stag3 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K3_STAGGER"); return e ? atoi(e) : 0; }();
             const int vec3 = (noepi3 ? 9 : 1) | (stag3 << 8);
 #define VPU_LAUNCH_K3_RB(TA_, TB_, FL_, RB_)                                                                         \
     do {                                                                                                             \
@@ -2663,11 +2663,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
 #endif
         // K2: large problems whose 256 x 128 tiles fill the chip and whose epilogue is one of the ViT-block flag sets
         {
-            static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            static const bool noepi2 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             const int k2 = k2_opt();
             // (VPU_GEMM_K2_MIN_TILES / VPU_GEMM_K2G_MIN_TILES: the smallest tile counts the plain / grouped-compile-time K2
             // forms take -- A/B knobs)
-            static const int k2_min_tiles = [] { const char* e = getenv("VPU_GEMM_K2_MIN_TILES"); return e ? atoi(e) : 120; }();   // (round 5: 160 -> 120 -- batch 8, 150 tiles: 745 -> 771 images/s; batch 4, 78-84 tiles, loses below 100)
+            static const int k2_min_tiles = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_MIN_TILES"); return e ? atoi(e) : 120; }();   // (round 5: 160 -> 120 -- batch 8, 150 tiles: 745 -> 771 images/s; batch 4, 78-84 tiles, loses below 100)
             const int tm2 = (d->M + K2_BM - 1) / K2_BM, tn2 = (d->N + 127) / 128;
             if (k2 > 0 && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % BK == 0 && d->K >= 256 &&
                 (int64_t)tm2 * tn2 >= k2_min_tiles && !d->transA && d->alpha == 1.0f &&
@@ -2679,7 +2679,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 // (fc2 45.1 vs 47.6 us, fc1 dgrad 42.1 vs 46.7, qkv dgrad 33.9 vs 36.7) and for many-tile short-K problems
                 // (qkv 42.3 vs 49.0); one round of 222 tiles over K = 768 stays with the 128 x 128 kernel (proj 21.9 vs 19.8)
                 // (round 4, direct epilogue: the one-round K = 768 problems now win too -- proj 18.1 vs 19.6 us, its dgrad 15.4 vs 16.6)
-                static const bool direct_env = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
+                static const bool direct_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
                 const bool narrow_ok = k2 == 1 || k2 == 3 || d->K >= 1024 || (int64_t)tm2 * tn2 >= 400 ||
                                        (direct_env && d->K >= 512 && (int64_t)tm2 * tn2 >= 200);
                 const int vec2 = noepi2 ? 9 : 1;
@@ -2688,7 +2688,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 // tile height: 256 rows, or 224 when that needs less time per CU (rounds of tiles x rows per tile): M = 9408
                 // is 36.75 x 256 -- 222 / 666 / 444 tiles, 87 % of the CUs busy in the last round -- but 42 x 224 exactly
                 // (252 / 756 / 504 tiles).  VPU_GEMM_K2_RB=8 keeps 256 (A/B runs).
-                static const int rb_env = [] { const char* e = getenv("VPU_GEMM_K2_RB"); return e ? atoi(e) : 0; }();
+                static const int rb_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_RB"); return e ? atoi(e) : 0; }();
                 auto cost = [&](int bm, int bn) {
                     const int64_t tiles = (int64_t)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
                     return ((tiles + ncu - 1) / ncu) * bm;
@@ -2697,7 +2697,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 const bool short_tile = rb_env != 8 && (rb_env == 7 || cost(224, bn_sel) < cost(256, bn_sel));
                 // VPU_GEMM_K2_DIRECT: 0 = LDS-transposed epilogue, 1 (default) = direct epilogue (swapped MFMA operands, stores
                 // from the registers)
-                static const int direct2 = [] { const char* e = getenv("VPU_GEMM_K2_DIRECT"); return e ? atoi(e) : 1; }();
+                static const int direct2 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_DIRECT"); return e ? atoi(e) : 1; }();
 #define VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, SW_)                                                               \
     do {                                                                                                             \
         static VpuDevOnce attr_;                                                                                   \
@@ -2737,11 +2737,11 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             }
         }
         // skinny problems (see gemm_bf16_skinny_kernel): few rows, moderate N and K, plain or K-major B
-        static const int skinny_env = [] { const char* e = getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+        static const int skinny_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
         const int skinny_opt = g_opt_skinny.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny.load(std::memory_order_relaxed) : skinny_env;
-        static const int skinny_m = [] { const char* e = getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 4096; }();   // (round 5: 2560 -> 4096, batch 4's 3136-row N = 768 GEMMs: 495 -> 502 images/s)
-        static const int skinny_n = [] { const char* e = getenv("VPU_GEMM_SKINNY_N"); return e ? atoi(e) : 4096; }();
-        static const int skinny_k = [] { const char* e = getenv("VPU_GEMM_SKINNY_K"); return e ? atoi(e) : 4096; }();
+        static const int skinny_m = [] { const char* e = vpu_lab_getenv("VPU_GEMM_SKINNY_M"); return e ? atoi(e) : 4096; }();   // (round 5: 2560 -> 4096, batch 4's 3136-row N = 768 GEMMs: 495 -> 502 images/s)
+        static const int skinny_n = [] { const char* e = vpu_lab_getenv("VPU_GEMM_SKINNY_N"); return e ? atoi(e) : 4096; }();
+        static const int skinny_k = [] { const char* e = vpu_lab_getenv("VPU_GEMM_SKINNY_K"); return e ? atoi(e) : 4096; }();
         // (under-filled launches only: fewer than 192 tiles of 128x128, the same bound as the split-K rule below)
         if (skinny_opt && !big && !d->transA && d->batch == 1 && !d->colsum && d->M <= skinny_m && d->N <= skinny_n &&
             d->K >= 64 && d->K <= skinny_k && (int64_t)tiles_m * tiles_n < 192) {
@@ -2758,22 +2758,22 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             else gemm_bf16_skinny_kernel<0><<<sgrid, sblock, 4 * TILE_BYTES, s>>>(*d, tn64, kw, vec ? 1 : 0);
             return vpu_check_launch("vpu_gemm");
         }
-        static const bool noepi = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
-        static const bool nostore = [] { const char* e = getenv("VPU_GEMM_NOSTORE"); return e && e[0] == '1'; }();
-        static const int stagger = [] { const char* e = getenv("VPU_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+        static const bool noepi = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+        static const bool nostore = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOSTORE"); return e && e[0] == '1'; }();
+        static const int stagger = [] { const char* e = vpu_lab_getenv("VPU_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
         const int vec_arg = (noepi ? 9 : (nostore ? 8 : (vec ? 1 : 0))) | (stagger << 8);
         float* ws = splitk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splitk, (unsigned)d->batch), block(256);
         // persistent launch of the 128x128 kernel: at most VPU_GEMM_PERSIST (default 2 per CU = 512) workgroups walk the
         // (tile, split-K slice, batch) list
         const int64_t total_work = (int64_t)tiles_m * tiles_n * splitk * d->batch;
-        static const int persist_env = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+        static const int persist_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
         const int persist_cap = persist_env > 0 ? persist_env : 2 * cu_count();
         dim3 pgrid((unsigned)(total_work < persist_cap ? total_work : persist_cap), 1, 1);
         // staging: LDS-DMA + two stages (fragment reads -> DMA of the next tile -> MFMAs) is the default; it beats register
         // staging on every ViT-B shape once the DMA is no longer drained by the compiler's vmcnt(0) (tools/gemm_bench.py:
         // qkv fwd 599 vs 503, fc2 fwd 803 vs 692, wgrad 576 vs 347 TFLOP/s).  VPU_GEMM_DMA=0 selects register staging.
-        static const int force_dma = [] { const char* e = getenv("VPU_GEMM_DMA"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        static const int force_dma = [] { const char* e = vpu_lab_getenv("VPU_GEMM_DMA"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
         const bool use_dma = force_dma != 0;
 #define VPU_LAUNCH(TA_, TB_)                                                                                         \
     do {                                                                                                             \
@@ -2787,7 +2787,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         gemm_bf16_kernel<TA_, TB_, true, false, FL_><<<pgrid, block, 4 * TILE_BYTES, s>>>(*d, tiles_n, splitk, kchunk, ws, vec_arg, tiles_m, d->batch, cnt_arg); \
     } while (0)
         // compile-time epilogues for the flag sets of the ViT blocks (engine.py: linear / mlp / _dgrad)
-        static const bool no_spec = [] { const char* e = getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
+        static const bool no_spec = [] { const char* e = vpu_lab_getenv("VPU_GEMM_GENERIC"); return e && e[0] == '1'; }();
         const bool spec_ok = use_dma && !no_spec && !big && !d->colsum && vec && splitk == 1 && d->N % 8 == 0 && (vec_arg & 255) == 1;
         bool launched = false, inlaunch = false;
         unsigned* cnt_arg = nullptr;
@@ -3059,7 +3059,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     // skinny_group option / VPU_GEMM_SKINNY_GROUP: 0 off, 1 (default) forward / dgrad orientations, 2 also the weight-gradient
     // orientation (measured: 852 / 855 / 848 images/s for 0 / 1 / 2 on one box -- for the 576-row weight gradients eight
     // problems of 128 x 128 tiles in the general grouped kernel beat 64 x 64 tiles with a four-way K split)
-    static const int sk_grp_env0 = [] { const char* e = getenv("VPU_GEMM_SKINNY_GROUP"); return e ? atoi(e) : 1; }();
+    static const int sk_grp_env0 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_SKINNY_GROUP"); return e ? atoi(e) : 1; }();
     const int sk_grp_env = g_opt_skinny_group.load(std::memory_order_relaxed) >= 0 ? g_opt_skinny_group.load(std::memory_order_relaxed) : sk_grp_env0;
     if (!any_batch && sk_grp_env && (key <= 1 || (key == 3 && sk_grp_env >= 2)) && n >= 2) {
         bool ok = true;
@@ -3089,7 +3089,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     }
     // K2 form for forward / dgrad groups whose 256 x 128 tiles fill most of the chip (the DMA neck's image-side K / V
     // projections: two 9408 x 384 x 768 problems = 222 tiles; as 128 x 128 tiles in the general grouped kernel 28 us)
-    static const int k2g_fwd = [] { const char* e = getenv("VPU_GEMM_K2G_FWD"); return e ? atoi(e) : 1; }();
+    static const int k2g_fwd = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2G_FWD"); return e ? atoi(e) : 1; }();
     if (k2g_fwd && key <= 1 && k2_opt() > 0 && vec) {
         bool ok = true;
         int total2 = 0;
@@ -3107,8 +3107,8 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         for (int i = 0; i < n && same_fl; ++i)
             same_fl = descs[i].flags == (key == 0 ? VPU_EPI_BIAS : 0) && (key != 0 || descs[i].bias) && descs[i].dtype == VPU_BF16 &&
                       (int64_t)descs[i].M * descs[i].ldc * 2 < 0x7FFFFFF0LL;
-        static const bool k2g_fl = [] { const char* e = getenv("VPU_GEMM_K2G_FL"); return !e || e[0] != '0'; }();
-        static const int k2g_min_tiles = [] { const char* e = getenv("VPU_GEMM_K2G_MIN_TILES"); return e ? atoi(e) : 100; }();   // (192 -> 100: 12.57 -> 12.53 ms, within noise; the run-time form keeps 192)
+        static const bool k2g_fl = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2G_FL"); return !e || e[0] != '0'; }();
+        static const int k2g_min_tiles = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2G_MIN_TILES"); return e ? atoi(e) : 100; }();   // (192 -> 100: 12.57 -> 12.53 ms, within noise; the run-time form keeps 192)
         if (ok && total2 >= k2g_min_tiles && same_fl && k2g_fl) {
             const int ncu = cu_count();
             static VpuDevOnce attrf0, attrf1;
@@ -3145,7 +3145,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
     // K2 form: weight-gradient groups over a long reduction whose 256 x 128 tiles fill most of the chip
     if (key == 3 && k2_opt() > 0 && vec) {
         // (VPU_GEMM_K4_MIN_K: the shortest reduction the 256 x 256-tile weight-gradient kernels take -- A/B knob)
-        static const int k4_min_k = [] { const char* e = getenv("VPU_GEMM_K4_MIN_K"); return e ? atoi(e) : 2048; }();
+        static const int k4_min_k = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K4_MIN_K"); return e ? atoi(e) : 2048; }();
         bool ok = true;
         int total2 = 0;
         vpu_gemm_group g2 = ga;
@@ -3183,7 +3183,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             const bool pipe = (k3_opt() & 16) != 0;
             // direct fp32 epilogue (swapped MFMA operands): plain weight-gradient descriptors only -- fp32 output with or
             // without accumulation, alpha 1, 16-byte aligned rows; VPU_GEMM_K4_DIRECT=0 keeps the LDS-transposed epilogue
-            static const bool direct4_env = [] { const char* e = getenv("VPU_GEMM_K4_DIRECT"); return !e || e[0] != '0'; }();
+            static const bool direct4_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K4_DIRECT"); return !e || e[0] != '0'; }();
             bool direct4 = pipe && direct4_env;
             for (int i = 0; i < n && direct4; ++i) {
                 const vpu_gemm_desc& q = descs[i];
@@ -3199,7 +3199,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                 VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4p_grouped_kernel<1, 1, true, true>);
             }
             const int ncu = cu_count();
-            static const bool noepi4 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            static const bool noepi4 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k4%s_grouped_kernel<1, 1, true%s>", pipe ? "p" : "", direct4 ? ", true" : "");
             if (direct4) gemm_bf16_k4p_grouped_kernel<1, 1, true, true><<<dim3((unsigned)(total4 < ncu ? total4 : ncu)), dim3(512), K3Cfg<4>::LDS, s>>>(g4, noepi4 ? 9 : 1 VPU_DBG_LOAD);
 #ifdef VPU_LAB
@@ -3215,7 +3215,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
 #ifdef VPU_LAB
         // (VPU_GEMM_K3G_MIN_K > 0: short-reduction weight-gradient groups -- the neck's token-side gradients, 576 rows -- with a
         // reduction of at least that many rows on the K3 form: A/B knob)
-        static const int k3g_min_k = [] { const char* e = getenv("VPU_GEMM_K3G_MIN_K"); return e ? atoi(e) : 0; }();
+        static const int k3g_min_k = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K3G_MIN_K"); return e ? atoi(e) : 0; }();
         bool ok_short = k3g_min_k > 0 && !any_batch && !any_dcs && total2 >= 96;
         for (int i = 0; i < n && ok_short; ++i)
             ok_short = descs[i].K % BK == 0 && descs[i].K >= k3g_min_k && descs[i].K < 2048 && descs[i].N % 8 == 0 && descs[i].M % 8 == 0;
@@ -3225,7 +3225,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                 VPU_SET_LDS(K3_LDS, gemm_bf16_k3_grouped_kernel<1, 1, true>);
             }
             const int cap = 2 * cu_count();
-            static const bool noepi3 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            static const bool noepi3 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k3_grouped_kernel<1, 1, true>");
             gemm_bf16_k3_grouped_kernel<1, 1, true><<<dim3((unsigned)(total2 < cap ? total2 : cap)), dim3(256), K3_LDS, s>>>(g2, noepi3 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
@@ -3237,7 +3237,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                 VPU_SET_LDS(K2Cfg<2>::LDS, kern_);
             }
             const int ncu = cu_count();
-            static const bool noepi2 = [] { const char* e = getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
+            static const bool noepi2 = [] { const char* e = vpu_lab_getenv("VPU_GEMM_NOEPI"); return e && e[0] == '1'; }();
             NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<1, 1, true>");
             kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, noepi2 ? 9 : 1);
             return vpu_check_launch("vpu_gemm_grouped");
@@ -3247,7 +3247,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
 #endif
     }
     if (any_batch) { vpu_set_error("vpu_gemm_grouped: batch > 1 is only implemented for 16-byte-addressable weight-gradient groups"); return VPU_ERR_ARG; }
-    static const int persist_env = [] { const char* e = getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+    static const int persist_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
     const int persist_cap = persist_env > 0 ? persist_env : 2 * cu_count();
     dim3 grid((unsigned)(total < persist_cap ? total : persist_cap)), block(256);
     const int vec_arg = vec ? 1 : 0;

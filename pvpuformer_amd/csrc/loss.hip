@@ -428,7 +428,7 @@ extern "C" int vpu_p2cl_fwd_bwd(const float* prob, const float* gt, const int32_
 
 static inline int p2cl_band(int w) {
     // VPU_P2CL_BAND: anchor rows per workgroup (A/B runs; default below)
-    static const int env = [] { const char* e = getenv("VPU_P2CL_BAND"); return e ? atoi(e) : 0; }();
+    static const int env = [] { const char* e = vpu_lab_getenv("VPU_P2CL_BAND"); return e ? atoi(e) : 0; }();
     int b = 1024 / (w > 0 ? w : 1) - 1;
     const int cap = env > 0 && env <= P2_BAND_MAX ? env : P2_BAND_MAX;
     return b > cap ? cap : b;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // one 16-byte group per thread and no grid-stride loop: 8192 workgroups walking the 123 M parameters took 851 us per launch,
 // 32768 took 731, one group per thread (120 k workgroups) 671 (tools/run_stats.sh, VPU_ADAM_GRID)
 inline int adam_grid_cap() {
-    static const int v = [] { const char* e = getenv("VPU_ADAM_GRID"); return e ? atoi(e) : (1 << 22); }();
+    static const int v = [] { const char* e = vpu_lab_getenv("VPU_ADAM_GRID"); return e ? atoi(e) : (1 << 22); }();
     return v;
 }
 }  // namespace

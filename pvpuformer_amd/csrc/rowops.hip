@@ -784,8 +784,8 @@ extern "C" int vpu_layernorm_fwd_pe(const void* x, const float* w, const float* 
         return VPU_ERR_ARG;
     }
     // balanced persistent grid: at most 2048 workgroups (8 per CU), every wave the same number of rows (+-1)
-    static const int64_t capf = [] { const char* e = getenv("VPU_LN_FWD_CAP"); const int v = e ? atoi(e) : 2048; return (int64_t)(v < 256 ? 256 : v); }();
-    static const int rwf = [] { const char* e = getenv("VPU_LN_FWD_RW"); return e ? atoi(e) : 1; }();     // rows per wave and trip (2: measured level with 1 in the step, 12.40 vs 12.40 ms -- unlike the backward)
+    static const int64_t capf = [] { const char* e = vpu_lab_getenv("VPU_LN_FWD_CAP"); const int v = e ? atoi(e) : 2048; return (int64_t)(v < 256 ? 256 : v); }();
+    static const int rwf = [] { const char* e = vpu_lab_getenv("VPU_LN_FWD_RW"); return e ? atoi(e) : 1; }();     // rows per wave and trip (2: measured level with 1 in the step, 12.40 vs 12.40 ms -- unlike the backward)
     const int rw = (rwf == 2 && C <= 1024 && dtype == VPU_BF16 && !pe && rows >= 4096) ? 2 : 1;
     const int64_t nb = (rows + 4 * rw - 1) / (4 * rw), trips = (nb + capf - 1) / capf;
     const unsigned grid = (unsigned)((nb + trips - 1) / trips);
@@ -806,7 +806,7 @@ extern "C" int vpu_layernorm_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
     int64_t n = rows / (2 * LN_BWD_WAVES);
     // workgroups per CU: 2 (round 1), VPU_LN_BWD_WGS = 3: the 4-wave form's ~170 registers allow three
-    static const int cap = [] { const char* e = getenv("VPU_LN_BWD_WGS"); const int v = e ? atoi(e) : 2; return 256 * (v < 1 ? 1 : (v > 4 ? 4 : v)); }();
+    static const int cap = [] { const char* e = vpu_lab_getenv("VPU_LN_BWD_WGS"); const int v = e ? atoi(e) : 2; return 256 * (v < 1 ? 1 : (v > 4 ? 4 : v)); }();
     return (int)(n < 1 ? 1 : (n > cap ? cap : n));
 }
 extern "C" int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* w, const float* mean,
@@ -815,7 +815,7 @@ extern "C" int vpu_layernorm_bwd2(const void* dy, const void* dy2, const void* x
     vpu_clear_stale_error();
     if (C % 8 || C > LN_MAXCH * 512 || rows <= 0) { vpu_set_error("layernorm_bwd: C"); return VPU_ERR_ARG; }
     const int nblk = vpu_layernorm_bwd_nblk(rows);
-    static const int rw2 = [] { const char* e = getenv("VPU_LN_BWD_RW"); return e ? atoi(e) : 2; }();     // rows per wave and trip (A/B: 1)
+    static const int rw2 = [] { const char* e = vpu_lab_getenv("VPU_LN_BWD_RW"); return e ? atoi(e) : 2; }();     // rows per wave and trip (A/B: 1)
 #define VPU_LN_BWD_(NCH_, NW_, RW_)                                                                                   \
     if (dy2) { DISPATCH_T(dtype, (layernorm_bwd_kernel<T, NCH_, NW_, (NCH_ <= 2), true, RW_><<<nblk, 64 * NW_, 0, ST>>>(   \
                           (const T*)dy, (const T*)dy2, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, part, rows, C, nblk));) } \

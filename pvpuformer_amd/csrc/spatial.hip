@@ -1589,7 +1589,7 @@ extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, 
     if (C % 8 || ld_in % 8 || ld_out % 8) { vpu_set_error("bilinear_cl_bwd: C, ld % 8"); return VPU_ERR_ARG; }
     const int64_t total = (int64_t)B * h * w * (C / 8);
     const int R = (h > 0 && w > 0 && H % h == 0 && W % w == 0 && H / h == W / w) ? H / h : 0;
-    static const int split_min = [] { const char* e = getenv("VPU_BILINEAR_SPLIT_R"); return e ? atoi(e) : 8; }();
+    static const int split_min = [] { const char* e = vpu_lab_getenv("VPU_BILINEAR_SPLIT_R"); return e ? atoi(e) : 8; }();
     if ((R == 4 || R == 8) && R >= split_min && C == 256) {   // few input pixels, long gathers: four slices per window
         const unsigned g2 = (unsigned)(((int64_t)B * h * w + 1) / 2);
         DISPATCH_T(dtype,
@@ -1705,7 +1705,7 @@ extern "C" int vpu_convseg_bwd_nblk(int64_t rows) {
     vpu_clear_stale_error();
     // (workgroups of the conv_seg / fused head backward = rows of their partial-sum output; VPU_CONVSEG_NBLK sets the cap for
     // A/B runs -- measured in the step, round 4: 512 / 1024 / 2048 / 4096 workgroups 12.66-12.68 / 12.61 / 12.68-12.71 / 12.69 ms)
-    static const int cap = [] { const char* e = getenv("VPU_CONVSEG_NBLK"); const int v = e ? atoi(e) : 512; return v < 1 ? 1 : v; }();
+    static const int cap = [] { const char* e = vpu_lab_getenv("VPU_CONVSEG_NBLK"); const int v = e ? atoi(e) : 512; return v < 1 ? 1 : v; }();
     int64_t n = rows / 64;
     return (int)(n < 1 ? 1 : (n > cap ? cap : n));
 }

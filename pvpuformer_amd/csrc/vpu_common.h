@@ -125,6 +125,18 @@ __device__ __forceinline__ float block_max(float v, float* smem) {
     return r;
 }
 
+// Environment knobs.  The product library reads four (VPU_GEMM_K2, VPU_GEMM_K3, VPU_ATTN_LEAN, VPU_ATTN_ONEPASS: which of its tested
+// kernel families a call takes; the same choices as vpu_gemm_set_option / vpu_attn_set_option).  Every other one is an A/B knob of
+// the laboratory build (-DVPU_LAB): in the product library it reads as unset and the code takes its default.
+inline const char* vpu_lab_getenv(const char* name) {
+#ifdef VPU_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
