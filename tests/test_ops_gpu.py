@@ -2070,3 +2070,56 @@ def test_lab_library_families():
     tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+
+
+def test_argument_errors_answer_before_any_launch(ops):
+    """Error behaviour of the C ABI: a call whose arguments the kernels cannot take returns a negative VPU_ERR_* with a message
+    naming the rule (raised as VpuError by the wrappers) BEFORE anything is launched -- the stream stays clean (a following good
+    call works, nothing is pending in hipGetLastError) and output buffers are untouched."""
+    import ctypes as C
+    from pvpuformer_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    z = lambda *shape, dt=torch.bfloat16: torch.zeros(*shape, device="cuda", dtype=dt)
+    sentinel = torch.full((64, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    cases = {
+        "sum_groups: n % 8": lambda: lib.vpu_sum_groups(P(sentinel), P(sentinel), 2, 2, 12, _lib.BF16, st),
+        "sum_groups: S < 1": lambda: lib.vpu_sum_groups(P(sentinel), P(sentinel), 2, 0, 16, _lib.BF16, st),
+        "fanout_add: 5 destinations": lambda: lib.vpu_fanout_add(P(sentinel), (C.c_void_p * 5)(*[sentinel.data_ptr()] * 5), (C.c_int32 * 5)(), 5, 64, _lib.BF16, st),
+        "fanout_add: null destination": lambda: lib.vpu_fanout_add(P(sentinel), (C.c_void_p * 2)(sentinel.data_ptr(), None), (C.c_int32 * 2)(), 2, 64, _lib.BF16, st),
+        "cast2d_batched: no job": lambda: lib.vpu_cast2d_batched((_lib.CastJob * 1)(), 0, st),
+        "cast2d_batched: empty job": lambda: lib.vpu_cast2d_batched((_lib.CastJob * 1)(), 1, st),
+        "attn_combine: S = 9": lambda: lib.vpu_attn_combine(P(sentinel), P(sentinel), P(sentinel), P(sentinel), 1, 1, 8, 8, 9, 8, 8, st),
+        "attn_combine: head dim % 8": lambda: lib.vpu_attn_combine(P(sentinel), P(sentinel), P(sentinel), P(sentinel), 1, 1, 8, 12, 2, 16, 16, st),
+        "gemm_grouped: 0 problems": lambda: lib.vpu_gemm_grouped((_lib.GemmDesc * 1)(), 0, st),
+        "gemm_grouped: 17 problems": lambda: lib.vpu_gemm_grouped((_lib.GemmDesc * 17)(), 17, st),
+        "adam: step 0": lambda: lib.vpu_adam_step(P(sentinel), P(sentinel), P(sentinel), P(sentinel), None, 64, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, st),
+        "p2cl_up: W % 4": lambda: lib.vpu_p2cl_up_fwd_bwd(P(sentinel), P(sentinel), None, None, P(sentinel), P(sentinel), 1.0, 1, 2, 8, 8, 30, 30, st),
+        "bilinear_cl_bwd: C % 8": lambda: lib.vpu_bilinear_cl_bwd(P(sentinel), 12, P(sentinel), 12, 1, 2, 2, 4, 4, 12, _lib.BF16, st),
+        "convseg_bwd: C > 512": lambda: lib.vpu_convseg_bwd(P(sentinel), P(sentinel), P(sentinel), None, P(sentinel), 0, P(sentinel), P(sentinel), 64, 64, 1024, _lib.BF16, st),
+        "head_grad_fused: fp32": lambda: lib.vpu_head_grad_fused(P(sentinel), P(sentinel), P(sentinel), P(sentinel), P(sentinel), P(sentinel), None, P(sentinel), P(sentinel), P(sentinel), 64, 64, 64, _lib.F32, st),
+        "patch_im2col_prenorm: H % P": lambda: lib.vpu_patch_im2col_prenorm(P(sentinel), P(sentinel), P(sentinel), 1, 30, 30, 16, 2, _lib.BF16, st),
+        "gemm_set_option: unknown": lambda: lib.vpu_gemm_set_option(b"no_such_option", 1),
+        "attn_set_option: unknown": lambda: lib.vpu_attn_set_option(b"no_such_option", 1),
+        "gemm_set_option: k2 out of range": lambda: lib.vpu_gemm_set_option(b"k2", 9),
+    }
+    if os.environ.get("VPU_LIB_DIAG", "0") != "1":
+        cases["debug_gemm_times: product library"] = lambda: lib.vpu_debug_gemm_times(P(sentinel))
+    for what, call in cases.items():
+        rc = call()
+        msg = lib.vpu_last_error().decode()
+        assert rc < 0 and msg, (what, rc, msg)
+        print(f"[abi errors] {what:40s} -> {rc}: {msg[:90]}")
+    # a misaligned GEMM operand has its own code
+    A = z(64, 72)
+    with pytest.raises(_lib.VpuError, match="16-byte"):
+        ops.gemm(A.view(-1)[1:64 * 64 + 1].view(64, 64), A[:, :64].contiguous(), z(64, 64), 64, 64, 64, 64, 64, 64, _lib.BF16)
+    torch.cuda.synchronize()
+    assert torch.all(sentinel == 7.0)
+    # ... and the library still works
+    a, b = (torch.randint(-2, 3, (64, 64), device="cuda").to(torch.bfloat16) for _ in range(2))
+    c = z(64, 64)
+    ops.gemm(a, b, c, 64, 64, 64, 64, 64, 64, _lib.BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(c.float(), a.float() @ b.float().t())

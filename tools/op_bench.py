@@ -34,6 +34,8 @@ def main():
     part, dlow = torch.empty(B, S, device=dev), torch.empty_like(low)
     cases["p2cl_up"] = (lambda: ops.p2cl_up_fwd_bwd(low, gt, None, None, part, dlow, 1e-6, B, S, h, h, H, H),
                         low.numel() * 8 + gt.numel() * 4)
+    cases["p2cl_up_loss_only"] = (lambda: ops.p2cl_up_fwd_bwd(low, gt, None, None, part, None, 1e-6, B, S, h, h, H, H),
+                                  low.numel() * 4 + gt.numel() * 4)      # (no gradient output: the pixel pass alone)
     logits = torch.randn(B, 1, H, H, device=dev)
     out, dl = torch.empty(B, 2, device=dev), torch.empty(B, H * H, device=dev)
     cases["nfl_dice"] = (lambda: ops.nfl_dice_fwd_bwd(logits, gt, None, out, dl, 1.0, 1.0, B, H * H), logits.numel() * 20)
