@@ -19,3 +19,4 @@ cp $s/graph_branch_probe.txt $d/r05_graph_branch_probe.txt
 cp $s/neck_lanes_ab.txt $d/r05_neck_lanes_ab.txt
 cp $s/commit.txt $d/r05_commit.txt
 ls -la $d | grep r05
+python3 tools/roofline_table.py profiles/r05 > profiles/r05_roofline_table.txt 2>/dev/null || true
