@@ -655,7 +655,14 @@ __global__ __launch_bounds__(256) void bilinear_cl_bwd_int_kernel(const T* __res
     const int chunks = C / 8;
     const float sh = (float)h / (float)H, sw = (float)w / (float)W;
     const int64_t total = (int64_t)B * h * w * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // round 5: every output value is gathered by four input pixels (2 x 2 overlapping windows); with the workgroups dealt to the
+    // eight XCDs round-robin the four readers sat behind four different L2s and the 77-MB map came from HBM 2.2-3 times (PMC).
+    // Each XCD now walks ONE contiguous eighth of the input pixels (xcd_ranged_block), so the re-reads hit its own L2.
+    const int64_t nblk = (total + 255) / 256, per = (nblk + 7) / 8;
+    for (int64_t vb = blockIdx.x; vb < 8 * per; vb += gridDim.x) {
+        const int64_t bb = (vb & 7) * per + (vb >> 3);
+        const int64_t i = bb * 256 + threadIdx.x;
+        if ((vb >> 3) >= per || bb >= nblk || i >= total) continue;
         const int ck = (int)(i % chunks);
         const int64_t pix = i / chunks;
         const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
@@ -707,8 +714,11 @@ __global__ __launch_bounds__(256) void bilinear_cl_bwd_int4_kernel(const T* __re
     const float sh = (float)h / (float)H, sw = (float)w / (float)W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ck = lane & 31, part = (lane >> 5) | ((wave & 1) << 1);
-    const int64_t pix = (int64_t)blockIdx.x * 2 + (wave >> 1);
-    const bool live = pix < (int64_t)B * h * w;
+    // (XCD-ranged block order, as in bilinear_cl_bwd_int_kernel: the grid is 8 * per blocks)
+    const int64_t nblk = ((int64_t)B * h * w + 1) / 2, per = (nblk + 7) / 8;
+    const int64_t bb = ((int64_t)blockIdx.x & 7) * per + ((int64_t)blockIdx.x >> 3);
+    const int64_t pix = bb * 2 + (wave >> 1);
+    const bool live = bb < nblk && pix < (int64_t)B * h * w;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -1591,19 +1601,21 @@ extern "C" int vpu_bilinear_cl_bwd(const void* dout, int32_t ld_out, void* din, 
     const int R = (h > 0 && w > 0 && H % h == 0 && W % w == 0 && H / h == W / w) ? H / h : 0;
     static const int split_min = [] { const char* e = vpu_lab_getenv("VPU_BILINEAR_SPLIT_R"); return e ? atoi(e) : 8; }();
     if ((R == 4 || R == 8) && R >= split_min && C == 256) {   // few input pixels, long gathers: four slices per window
-        const unsigned g2 = (unsigned)(((int64_t)B * h * w + 1) / 2);
+        const unsigned g2 = (unsigned)(8 * ((((int64_t)B * h * w + 1) / 2 + 7) / 8));     // (a multiple of 8: XCD-ranged block order)
         DISPATCH_T(dtype,
                    if (R == 4) bilinear_cl_bwd_int4_kernel<T, 4><<<g2, 256, 0, ST>>>((const T*)dout, ld_out, (T*)din, ld_in, B, h, w);
                    else bilinear_cl_bwd_int4_kernel<T, 8><<<g2, 256, 0, ST>>>((const T*)dout, ld_out, (T*)din, ld_in, B, h, w);)
         return vpu_check_launch("vpu_bilinear_cl_bwd");
     }
     if (R == 2 || R == 4 || R == 8) {
+        const int64_t nb8 = 8 * (((total + 255) / 256 + 7) / 8);
+        const unsigned gi = (unsigned)(nb8 < 16384 ? nb8 : 16384);      // (a multiple of 8: XCD-ranged block order)
         DISPATCH_T(dtype,
-                   if (R == 2) bilinear_cl_bwd_int_kernel<T, 2><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+                   if (R == 2) bilinear_cl_bwd_int_kernel<T, 2><<<gi, 256, 0, ST>>>(
                        (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, C);
-                   else if (R == 4) bilinear_cl_bwd_int_kernel<T, 4><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+                   else if (R == 4) bilinear_cl_bwd_int_kernel<T, 4><<<gi, 256, 0, ST>>>(
                        (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, C);
-                   else bilinear_cl_bwd_int_kernel<T, 8><<<vpu_grid_for(total, 256, 16384), 256, 0, ST>>>(
+                   else bilinear_cl_bwd_int_kernel<T, 8><<<gi, 256, 0, ST>>>(
                        (const T*)dout, ld_out, (T*)din, ld_in, B, h, w, C);)
         return vpu_check_launch("vpu_bilinear_cl_bwd");
     }
