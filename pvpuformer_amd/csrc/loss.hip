@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     __shared__ double red[16];
     double a = 0.0, b = 0.0, c = 0.0;
     for (int i = threadIdx.x; i < B; i += 256) { a += out[2 * i]; b += out[2 * i + 1]; }
-    for (int i = threadIdx.x; i < npart; i += 256) c += part[i];
+#pragma unroll 8
+    for (int i = threadIdx.x; i < npart; i += 256) c += part[i];      // (eight loads in flight: 8064 band partials at bs 12)
     a = block_sum_d(a, red);
     b = block_sum_d(b, red);
     c = block_sum_d(c, red);

@@ -677,6 +677,7 @@ def test_neck_lanes_equal_single_stream(golden_dir, B, ptype):
     model.head.dropout_ratio = 0.0
     eng = model._ensure_engine()
     eng.refresh_weights()
+    lanes_default = eng.neck_lanes
 
     def step():
         eng.zero_grad()
@@ -716,7 +717,7 @@ def test_neck_lanes_equal_single_stream(golden_dir, B, ptype):
             torch.cuda.synchronize()
             assert torch.equal(eng.gflat, g1)
     finally:
-        eng.neck_lanes = True
+        eng.neck_lanes = lanes_default
         eng.abort_pass()
 
 

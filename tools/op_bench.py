@@ -36,6 +36,8 @@ def main():
                         low.numel() * 8 + gt.numel() * 4)
     cases["p2cl_up_loss_only"] = (lambda: ops.p2cl_up_fwd_bwd(low, gt, None, None, part, None, 1e-6, B, S, h, h, H, H),
                                   low.numel() * 4 + gt.numel() * 4)      # (no gradient output: the pixel pass alone)
+    d_inst, dseg = torch.randn(B, 1, H, H, device=dev), torch.empty(B, h * h, device=dev)
+    cases["upsample_ac_bwd"] = (lambda: ops.upsample_ac_bwd(d_inst, dseg, B, h, h, H, H), d_inst.numel() * 4 + dseg.numel() * 4)
     logits = torch.randn(B, 1, H, H, device=dev)
     out, dl = torch.empty(B, 2, device=dev), torch.empty(B, H * H, device=dev)
     cases["nfl_dice"] = (lambda: ops.nfl_dice_fwd_bwd(logits, gt, None, out, dl, 1.0, 1.0, B, H * H), logits.numel() * 20)
