@@ -2669,8 +2669,31 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             // forms take -- A/B knobs)
             static const int k2_min_tiles = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_MIN_TILES"); return e ? atoi(e) : 120; }();   // (round 5: 160 -> 120 -- batch 8, 150 tiles: 745 -> 771 images/s; batch 4, 78-84 tiles, loses below 100)
             const int tm2 = (d->M + K2_BM - 1) / K2_BM, tn2 = (d->N + 127) / 128;
+            // round 5: the x 128 form picks its tile height among 256 / 224 / 192 rows (RB = 8 / 7 / 6 row blocks per wave) by rounds
+            // of tiles x rows per tile, and 160 rows (RB = 5) where nothing taller reaches the tile count the K2 forms start at
+            // (batch 4: 3136 rows x N = 768 is 78 / 84 / 102 tiles of 256 / 224 / 192 rows, 120 of 160).  Same-box A/B
+            // (VPU_GEMM_K2_RBMIN, laboratory build): 192 rows allowed: ViT-B bs 8 781.7 -> 788.6 images/s, ViT-L bs 8 369.6 -> 370.2,
+            // ViT-H bs 8 161.5 -> 163.1, ViT-H bs 12 level; 160 rows allowed everywhere: ViT-B bs 8 773.8, ViT-L bs 8 364.0 (a
+            // shorter tile reads the B panel once more per row of tiles) -- but batch 4 with it 500 -> 513.  ViT-B bs 12
+            // (9408 = 42 x 224) keeps 224.
+            const int ncu_k2 = cu_count();
+            auto k2_cost = [&](int bm, int bn) {
+                const int64_t t = (int64_t)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
+                return ((t + ncu_k2 - 1) / ncu_k2) * bm;
+            };
+            int rbn = 8;
+            {
+                static const int rb_min = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_RBMIN"); const int v = e ? atoi(e) : 6; return v < 5 ? 5 : (v > 8 ? 8 : v); }();
+                int64_t best = k2_cost(256, 128);
+                for (int rb = 7; rb >= rb_min; --rb) {
+                    const int64_t c = k2_cost(32 * rb, 128);
+                    if (c < best) { best = c; rbn = rb; }
+                }
+                if ((int64_t)((d->M + 32 * rbn - 1) / (32 * rbn)) * tn2 < k2_min_tiles && (int64_t)((d->M + 159) / 160) * tn2 >= k2_min_tiles) rbn = 5;
+            }
+            const int64_t tiles_narrow = (int64_t)((d->M + 32 * rbn - 1) / (32 * rbn)) * tn2;
             if (k2 > 0 && !big && d->batch == 1 && !d->colsum && vec && d->N % 8 == 0 && d->K % BK == 0 && d->K >= 256 &&
-                (int64_t)tm2 * tn2 >= k2_min_tiles && !d->transA && d->alpha == 1.0f &&
+                ((int64_t)tm2 * tn2 >= k2_min_tiles || tiles_narrow >= k2_min_tiles) && !d->transA && d->alpha == 1.0f &&
                 (int64_t)d->M * d->ldc * 2 < 0x7FFFFFF0LL && (int64_t)d->M * (d->ldr > d->ldaux ? d->ldr : d->ldaux) * 2 < 0x7FFFFFF0LL) {
                 constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
                               F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
@@ -2681,7 +2704,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 // (round 4, direct epilogue: the one-round K = 768 problems now win too -- proj 18.1 vs 19.6 us, its dgrad 15.4 vs 16.6)
                 static const bool direct_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
                 const bool narrow_ok = k2 == 1 || k2 == 3 || d->K >= 1024 || (int64_t)tm2 * tn2 >= 400 ||
-                                       (direct_env && d->K >= 512 && (int64_t)tm2 * tn2 >= 200);
+                                       (direct_env && d->K >= 512 && ((int64_t)tm2 * tn2 >= 200 || tiles_narrow >= 200));
                 const int vec2 = noepi2 ? 9 : 1;
                 const int ncu = cu_count();
                 bool done = true;
@@ -2721,7 +2744,15 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
 #define VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, RB_) do { (void)direct2; VPU_LAUNCH_K2_SW(TA_, TB_, WN_, FL_, RB_, 1); } while (0)
 #endif
 #define VPU_LAUNCH_K2(TA_, TB_, WN_, FL_) do { if (short_tile) VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 7); else VPU_LAUNCH_K2_RB(TA_, TB_, WN_, FL_, 8); } while (0)
-#define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2(TA_, TB_, 2, FL_); else done = false; } while (0)
+#define VPU_LAUNCH_K2N(TA_, TB_, FL_)                                                                                   \
+    do {                                                                                                             \
+        const int rb_ = rb_env == 7 || rb_env == 8 ? rb_env : rbn;                                                    \
+        if (rb_ == 5) VPU_LAUNCH_K2_RB(TA_, TB_, 2, FL_, 5);                                                          \
+        else if (rb_ == 6) VPU_LAUNCH_K2_RB(TA_, TB_, 2, FL_, 6);                                                     \
+        else if (rb_ == 7) VPU_LAUNCH_K2_RB(TA_, TB_, 2, FL_, 7);                                                     \
+        else VPU_LAUNCH_K2_RB(TA_, TB_, 2, FL_, 8);                                                                   \
+    } while (0)
+#define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2N(TA_, TB_, FL_); else done = false; } while (0)
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
                 else if (key == 0 && f == F_BR) VPU_K2_BOTH(0, 0, F_BR);
                 else if (key == 0 && f == F_G) VPU_K2_BOTH(0, 0, F_G);
@@ -2730,6 +2761,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 else if (key == 1 && f == F_M) VPU_K2_BOTH(0, 1, F_M);
                 else done = false;
 #undef VPU_K2_BOTH
+#undef VPU_LAUNCH_K2N
 #undef VPU_LAUNCH_K2
 #undef VPU_LAUNCH_K2_RB
 #undef VPU_LAUNCH_K2_SW

@@ -1577,6 +1577,38 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
         assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("shape,rb", [((6272, 768, 768), 6), ((6235, 768, 1024), 6), ((9408, 1280, 1280), 6), ((3136, 768, 1024), 5),
+                                      ((9408, 768, 768), 7), ((2300, 1288, 256), 6), ((5120, 1536, 256), 8)])
+def test_gemm_k2_tile_height_by_rounds(ops, shape, rb):
+    """Round 5: the 256 x 128 K2 form picks 256 / 224 / 192-row tiles (8 / 7 / 6 row blocks per wave) by rounds of tiles x rows per
+    tile, and 160 rows where nothing taller reaches the K2 forms' tile count -- batch 8's 6272 rows and ViT-H's N = 1280 take 192,
+    batch 4's 3136 rows 160, ViT-B's 9408 x 768 keeps 224.  The
+    instantiation the call took is checked by name; exact-integer operands give the fp32 product bit for bit in every form the
+    ViT blocks use (plain, + bias, + bias + residual, dgrad, dgrad x aux), ragged last tiles included."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(41)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = A @ Bm.t()
+    Ad, Bd, Bt = dev(A).to(torch.bfloat16), dev(Bm).to(torch.bfloat16), dev(Bm.t().contiguous()).to(torch.bfloat16)
+    bias = dev(torch.randint(-4, 5, (N,), generator=g).float())
+    R = dev(torch.randint(-4, 5, (M, N), generator=g).float()).to(torch.bfloat16)
+    aux = dev(torch.randint(-2, 3, (M, N), generator=g).float()).to(torch.bfloat16)
+    ops.gemm_set_option("k2", 1)
+    try:
+        for tB, flags, kw, want in ((0, 0, {}, ref), (0, ops.EPI_BIAS, dict(bias=bias), ref + bias.cpu()),
+                                    (0, ops.EPI_BIAS | ops.EPI_RESID, dict(bias=bias, resid=R, ldr=N), ref + bias.cpu() + R.float().cpu()),
+                                    (1, 0, {}, ref), (1, ops.EPI_MULAUX, dict(aux=aux, ldaux=N), ref * aux.float().cpu())):
+            Cd = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+            ops.gemm(Ad, Bt if tB else Bd, Cd, M, N, K, K, N if tB else K, N, 0, transB=bool(tB), flags=flags, **kw)
+            name = ops.gemm_last_kernel()
+            assert name.startswith("gemm_bf16_k2_kernel<0, %d, 2, " % tB) and name.endswith(", %d, 1>" % rb), name
+            torch.cuda.synchronize()
+            assert torch.equal(Cd.float().cpu(), want.to(torch.bfloat16).float()), (tB, flags)
+    finally:
+        ops.gemm_set_option("k2", -1)
+
+
 @pytest.mark.lab
 @pytest.mark.parametrize("tB", [0, 1])
 @pytest.mark.parametrize("shape", [(6001, 1544, 256), (5000, 2304, 640), (9408, 2304, 768)])
