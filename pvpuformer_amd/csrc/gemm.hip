@@ -2703,8 +2703,10 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                 // (qkv 42.3 vs 49.0); one round of 222 tiles over K = 768 stays with the 128 x 128 kernel (proj 21.9 vs 19.8)
                 // (round 4, direct epilogue: the one-round K = 768 problems now win too -- proj 18.1 vs 19.6 us, its dgrad 15.4 vs 16.6)
                 static const bool direct_env = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_DIRECT"); return !e || e[0] != '0'; }();
+                // (round 5: the short-K forms from 120 tiles of the chosen height on -- batch 4 / 6 / 8: +0.8-1.0 %; was 200)
+                static const int narrow_min = [] { const char* e = vpu_lab_getenv("VPU_GEMM_K2_NARROW_MIN"); return e ? atoi(e) : 120; }();
                 const bool narrow_ok = k2 == 1 || k2 == 3 || d->K >= 1024 || (int64_t)tm2 * tn2 >= 400 ||
-                                       (direct_env && d->K >= 512 && ((int64_t)tm2 * tn2 >= 200 || tiles_narrow >= 200));
+                                       (direct_env && d->K >= 512 && ((int64_t)tm2 * tn2 >= 200 || tiles_narrow >= narrow_min));
                 const int vec2 = noepi2 ? 9 : 1;
                 const int ncu = cu_count();
                 bool done = true;
