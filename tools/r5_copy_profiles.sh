@@ -20,3 +20,4 @@ cp $s/neck_lanes_ab.txt $d/r05_neck_lanes_ab.txt
 cp $s/commit.txt $d/r05_commit.txt
 ls -la $d | grep r05
 python3 tools/roofline_table.py profiles/r05 > profiles/r05_roofline_table.txt 2>/dev/null || true
+cp $s/nobrs.txt $d/r05_nobrs.txt 2>/dev/null || true

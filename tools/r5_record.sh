@@ -44,3 +44,4 @@ python3 tools/graph_branch_probe.py 2>&1 | grep -v amdgpu.ids > $out/graph_branc
 python3 bench.py --batch 8 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_b8.json 2>/dev/null; cut -c1-200 $out/bench_b8.json
 for m in 0 1; do echo "VPU_NECK_LANES=$m"; VPU_NECK_LANES=$m python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c1-200; done > $out/neck_lanes_ab.txt
 ls $out
+    python3 tools/bench_nobrs.py 2>&1 | grep -v amdgpu.ids > $out/nobrs.txt
