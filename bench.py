@@ -57,7 +57,7 @@ def spawn_ranks(args):
     import subprocess
     if not args.rehearse_launch:
         import __graft_entry__ as ge
-        ge.build()                     # hipcc only (no GPU): the ranks find a fresh library instead of racing to build it
+        ge.build(lab=False)            # hipcc only (no GPU): the ranks find a fresh library instead of racing to build it
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -313,7 +313,7 @@ def main():
         if os.path.exists(failed):
             os.remove(failed)
         try:
-            ge.build()
+            ge.build(lab=False)      # (the laboratory library is test infrastructure: never built on the way to a measurement)
         except BaseException as e:
             with open(failed, "w") as f:
                 f.write(f"{type(e).__name__}: {e}\n")

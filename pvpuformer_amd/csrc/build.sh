@@ -10,7 +10,7 @@ OUT=libvpu_hip.so; BUILD=build
 if [ "$1" = "diag" ]; then FLAGS="$FLAGS -DVPU_DIAG -DVPU_LAB"; OUT=libvpu_hip_diag.so; BUILD=build_diag; fi
 mkdir -p $BUILD
 pids=()
-for f in gemm attention rowops spatial prompt loss optim; do
+for f in gemm gemm_k5 attention rowops spatial prompt loss optim; do
   # attention.hip: MFMA results straight into VGPRs (the softmax consumes every score tile with VALU instructions; with the
   # accumulator-register form hipcc copies each tile through v_accvgpr_read and the kernels drop to one wave per SIMD)
   EXTRA=""; [ $f = attention ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"

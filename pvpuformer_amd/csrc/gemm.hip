@@ -17,6 +17,15 @@
 #include <atomic>
 #include "vpu_common.h"
 #include "../../include/vpu_hip.h"
+#include "gemm_tiles.h"
+
+// K5 (gemm_k5.hip): the two-tile ping-pong form of the many-tile forward / dgrad launches
+int vpu_k5_option();
+void vpu_k5_set_option(int v);
+void vpu_k5_set_grid(int v);
+void vpu_k5_set_split(int v);
+void vpu_k5_set_noepi(int v);
+int vpu_k5_launch(const vpu_gemm_desc* d, int rb, int ncu, int vec, void* stream, char* name, size_t name_len);
 
 namespace {
 
@@ -61,17 +70,6 @@ __device__ __forceinline__ void epilogue_store(const vpu_gemm_desc& p, int64_t c
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
-
-typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
-
-// LDS image of a K-contiguous tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk index XOR ((row>>1)&7)
-__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// LDS image of a K-major tile: [64 k][128 cols] bf16, 256-B rows, 8-B unit index XOR f(k)
-__device__ __forceinline__ int km_off(int k, int unit) {
-    return k * 256 + ((unit ^ ((k & 3) << 2) ^ (((k >> 3) & 1) << 4)) << 3);
-}
 
 // Register staging of one tile: 4 x 16 B per thread, global -> VGPR -> ds_write_b128 into the swizzled image.
 template <int TRANS>
@@ -104,9 +102,6 @@ struct TileLoader {
     }
 };
 
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-constexpr int OOB_OFFSET = (int)0x80000000;  // >= num_records of the descriptors below: the load returns zeros
 
 // LDS-DMA staging of one 128x64 (K-contiguous) or 64x128 (K-major) bf16 tile: 16 pieces of 1 KiB, each one
 // `buffer_load_dwordx4 ... lds` wave-instruction (64 lanes x 16 B, landing at piece_base + 16*lane, no VGPRs).  The LDS
@@ -152,46 +147,6 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, 
     }
 }
 
-// fragment for 16 rows (or cols) starting at x16 within the tile, k-substep ks (0/1)
-template <int TRANS>
-__device__ __forceinline__ bf16x8_t read_frag(const char* lds, int x16, int ks, int lane) {
-    if (TRANS == 0) {
-        const int row = x16 + (lane & 15);
-        const int chunk = ks * 4 + (lane >> 4);
-        // (an ext-vector load: through HIP's uint4 struct the load carries TBAA info, and SIInsertWaitcnts then puts
-        // s_waitcnt vmcnt(0) in front of every such ds_read while an LDS-DMA is pending -- the ring would never overlap)
-        return *reinterpret_cast<const bf16x8_t*>(lds + kc_off(row, chunk));
-    } else {
-        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-        const int k = ks * 32 + 8 * g + q;
-        const int unit = (x16 >> 2) + pp;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + km_off(k, unit)));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + km_off(k + 4, unit)));
-        s16x8_t v;
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        return __builtin_bit_cast(bf16x8_t, v);
-    }
-}
-
-// Workgroup -> output tile.  Hardware deals consecutive workgroups round-robin over the 8 XCDs (private 4-MiB L2 each):
-// (1) give XCD x a CONTIGUOUS range of a linear tile order (guide T1, bijective for any grid size);
-// (2) make that order "M-chunks of tiles_m/8 row-panels, inside a chunk M-fastest": the A row-panels of a chunk
-//     (~1.8 MB for fc1 at bs 12) stay resident in the XCD's L2 while each B (weight) tile is fetched once per chunk.
-//     With the N-fastest order every row-panel re-streamed the whole weight (4.7 MB > L2): L2 hit rate 65 %,
-//     fabric fetch 160 MB for 19 MB of unique inputs (rocprofv3 TCC_HIT/MISS, FETCH_SIZE, round 1).
-// (chunking along the longer tile dimension instead -- column chunks for a weight gradient with few row-panels, e.g. fc2's
-//  6 x 24 tiles -- was tried in round 1: no measurable change at ViT-B (706 vs 706 images/s), so the one rule is kept.)
-__device__ __forceinline__ void tile_coords(int bid, int nwg, int tiles_n, int& tile_m, int& tile_n) {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tiles_m = nwg / tiles_n;
-    const int cm = (tiles_m + 7) >> 3;
-    const int chunk = v / (cm * tiles_n), rem = v - chunk * (cm * tiles_n);
-    const int mcount = (tiles_m - chunk * cm) < cm ? (tiles_m - chunk * cm) : cm;
-    tile_n = rem / mcount;
-    tile_m = chunk * cm + (rem - tile_n * mcount);
-}
 
 // 8 consecutive output columns of one row through the full epilogue with 16-byte accesses.
 // Preconditions (checked on the host, flag `vec`): n % 8 == 0, n + 8 <= N, every leading dimension / batch offset /
@@ -224,11 +179,6 @@ __device__ __forceinline__ void prefetch_epi(const vpu_gemm_desc& p, const int f
 // `pre` (optional): the 8 bf16 of the residual (VPU_EPI_RESID) or of aux (DGELU/DRELU/MULAUX) for this position, fetched
 // before the main loop so that their HBM latency is hidden behind the MFMA work.
 // (everything by value / whole-array reference: a pointer to one element of a local array forces it into scratch)
-// v <- gelu(v), d <- gelu'(v) for 8 values (see the derivation at its use in epilogue_store8)
-__device__ __forceinline__ void gelu_dgelu8(float (&v)[8], float (&d)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gelu_pair_fast(v[j], v[j], d[j]);
-}
 struct EpiPre {
     bool has_pre, has_bias;
     uint4 pre;        // 8 bf16 of resid or aux for this position
@@ -930,12 +880,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const vpu_gemm_desc 
 //     through its L2 instead of every XCD streaming every panel (round 1: 700 MB read for 231 MB of operands).
 // ------------------------------------------------------------------------------------------------
 constexpr int K2_BM = 256;
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ const void* rfl_ptr(const void* q) {
-    const uint64_t u = reinterpret_cast<uint64_t>(q);
-    const uint32_t lo = (uint32_t)rfl((int)(uint32_t)u), hi = (uint32_t)rfl((int)(uint32_t)(u >> 32));
-    return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
-}
 template <int WN> struct K2Cfg {
     static constexpr int KG = WN == 2 ? 2 : 1;
     static constexpr int NSUB = 2 + WN / 2;   // 16-KiB sub-tiles of a stage: A rows 0-127 | A rows 128-255 | B cols 0-127 [| 128-255]
@@ -1112,12 +1056,6 @@ __device__ __forceinline__ void k2_prefetch(const vpu_gemm_desc& p, const int mr
         if (n + 8 <= p.N) load8(p.bias + n, q.bias);
     }
 }
-__device__ __forceinline__ u32x4v pack_bf16x8(const float (&v)[8]) {
-    bf16x8_t a;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
-    return __builtin_bit_cast(u32x4v, a);
-}
 template <int FL>
 __device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)[4][4], const int mrow0, const int ncol0,
                                             float* wl, const int lane, const K2Pre<FL>& q, const int npass) {
@@ -1175,7 +1113,6 @@ __device__ __forceinline__ void k2_epi_fast(const vpu_gemm_desc& p, f32x4_t (&a)
 // column blocks 2t / 2t+1 (odd 16-lane rows of the first operand <-> even rows of the second), after which every lane owns
 // 8 consecutive columns of its row -- 16-byte stores straight from the registers: no LDS transposition, no lgkmcnt waits,
 // and the ring stages are free for the next tile's DMA while the stores go out.  Same store count as k2_epi_fast.
-typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 template <int FL> struct K2PreD {
     u32x4v x[4][2];    // residual or aux: [row block][column-block pair]
 };
@@ -1188,7 +1125,6 @@ __device__ __forceinline__ void k2_bias_issue(const vpu_gemm_desc& p, const int 
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(p.bias)), 0, p.N * 4, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)slot, 4, (ncol0 + lane) * 4, 0, 0, 0);   // columns >= N: zeros
 }
-__device__ __forceinline__ int k2_direct_col(const int lane) { const int fq = lane >> 4; return (fq & 1) * 16 + (fq >> 1) * 8; }
 template <int FL>
 __device__ __forceinline__ void k2_prefetch_direct(const vpu_gemm_desc& p, const int mrow0, const int ncol0, const int lane,
                                                    K2PreD<FL>& q, const int npass) {
@@ -2755,6 +2691,29 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         else VPU_LAUNCH_K2_RB(TA_, TB_, 2, FL_, 8);                                                                   \
     } while (0)
 #define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2N(TA_, TB_, FL_); else done = false; } while (0)
+                // K5 (round 6, gemm_k5.hip): launches with more than one 128-column tile per workgroup -- the two 4-wave groups own
+                // alternate tiles, one group's direct epilogue + all LDS-DMA run beside the other group's main loop.  Default
+                // rule of the k2 option only (an explicit k2 = 1 / 3 keeps the K2 forms: tests, A/B runs); k5 = 2: wherever legal.
+                {
+                    const int k5 = vpu_k5_option();
+                    if (k5 > 0 && (k2 == 2 || k5 == 2) && d->K >= 9 * BK && !((f & VPU_EPI_RESID) && d->resid_period > 0)) {
+                        int rb5 = 8;
+                        int64_t best5 = cost(256, 128);
+                        for (int rb = 7; rb >= 6; --rb) {
+                            const int64_t c5 = cost(32 * rb, 128);
+                            if (c5 < best5) { best5 = c5; rb5 = rb; }
+                        }
+                        const int64_t tiles5 = (int64_t)((d->M + 32 * rb5 - 1) / (32 * rb5)) * tn2;
+                        // (fc1's bias + GELU + GELU' stays on the 256-column K2 form: 4.2 vector instructions per MFMA make K5's
+                        // producer the slower role -- 62.1 against 58.4 us; k5 = 2 takes it for the tests)
+                        const bool gelu5 = (f & VPU_EPI_GELU) != 0;
+                        if (k5 == 2 || (tiles5 > ncu && !gelu5)) {
+                            const int r5 = vpu_k5_launch(d, rb5, ncu, vec2, stream, g_last_kernel, sizeof(g_last_kernel));
+                            if (r5 < 0) return r5;
+                            if (r5 == 1) return vpu_check_launch("vpu_gemm");
+                        }
+                    }
+                }
                 if (key == 0 && f == F_B) VPU_K2_BOTH(0, 0, F_B);
                 else if (key == 0 && f == F_BR) VPU_K2_BOTH(0, 0, F_BR);
                 else if (key == 0 && f == F_G) VPU_K2_BOTH(0, 0, F_G);
@@ -3011,6 +2970,22 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
         g_opt_k3.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
+    if (name && !strcmp(name, "k5") && value >= -1 && value <= 2) {
+        vpu_k5_set_option(value);
+        return VPU_OK;
+    }
+    if (name && !strcmp(name, "k5_split") && value >= -1 && value <= 1) {   // LDS-DMA issue of K5 shared by both wave groups: -1 by flag set
+        vpu_k5_set_split(value);
+        return VPU_OK;
+    }
+    if (name && !strcmp(name, "k5_noepi") && value >= 0 && value <= 1) {   // diagnostic: K5 main loops only, nothing stored
+        vpu_k5_set_noepi(value);
+        return VPU_OK;
+    }
+    if (name && !strcmp(name, "k5_grid") && value >= 0 && value <= 1024) {   // cap on the K5 grid (tests: many tiles per workgroup)
+        vpu_k5_set_grid(value);
+        return VPU_OK;
+    }
     if (name && !strcmp(name, "skinny_group") && value >= -1 && value <= 2) {
         g_opt_skinny_group.store(value, std::memory_order_relaxed);
         return VPU_OK;
@@ -3028,6 +3003,7 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
                   "skinny (-1 environment default, 0 off, 1 on), "
                   "k2 (-1 environment default, 0 off, 1 256x128 tiles, 2 + 256x256 where it fills the chip, 3 256x256 wherever legal), "
                   "k3 (-1 environment default, bit 0 grouped weight gradients, bit 1 forward / dgrad, bit 2 grouped forward / dgrad), "
+                  "k5 (-1 environment default, 0 off, 1 launches of more than one tile per workgroup, 2 wherever legal), k5_grid (0 = none), "
                   "reserve_cus (0..128 CUs the persistent launches leave unclaimed)");
     return VPU_ERR_ARG;
 }

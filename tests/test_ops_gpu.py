@@ -1577,6 +1577,70 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
         assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("tB", [0, 1])
+@pytest.mark.parametrize("shape,grid", [((6001, 1544, 640), 0), ((6001, 1544, 640), 24), ((9408, 2304, 768), 0), ((5000, 1288, 1024), 7),
+                                        ((2300, 1288, 576), 3), ((9408, 768, 3072), 40)])
+def test_gemm_k5_exact_and_epilogues(ops, tB, shape, grid):
+    """Round 6, K5 (gemm_k5.hip): the two 4-wave groups of a workgroup own alternate 128-column tiles; one group's LDS-DMA +
+    direct epilogue run beside the other group's main loop, the K-steps of consecutive tiles form one stream through a three-stage
+    ring.  Exact-integer operands must give the fp32 matmul bit for bit in every flag set of the ViT blocks -- ragged M and N,
+    K of 9 .. 48 K-steps, one to dozens of tiles per workgroup (`k5_grid` caps the grid so that every workgroup walks many tiles:
+    odd and even counts, both groups ending a launch), tile heights 256 / 224 / 192 by the rounds rule -- and GELU + GELU' equal
+    the 128 x 128 kernel's output."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(61)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[0, 1] = 3; A[1, 0] = -2; Bm[0, 1] = 1; Bm[1, 0] = -3
+    ref = A @ Bm.t()
+    Ad = dev(A).to(torch.bfloat16)
+    Bd = dev(Bm.t().contiguous() if tB else Bm).to(torch.bfloat16)
+    ldb = N if tB else K
+    bias = dev(torch.randint(-4, 5, (N,), generator=g).float())
+    R = dev(torch.randint(-4, 5, (M, N), generator=g).float()).to(torch.bfloat16)
+    aux = dev(torch.randint(-2, 3, (M, N), generator=g).float()).to(torch.bfloat16)
+
+    def run(k5, flags, A_=None, split=-1, **kw):
+        Cd = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        pre = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_set_option("k5", 2 if k5 else 0)
+        ops.gemm_set_option("k5_grid", grid if k5 else 0)
+        ops.gemm_set_option("k5_split", split)
+        if not k5:
+            ops.gemm_set_option("k2", 0)
+        try:
+            ops.gemm(Ad if A_ is None else A_, Bd, Cd, M, N, K, K, ldb, N, 0, transB=bool(tB), flags=flags, preact=pre, **kw)
+            name = ops.gemm_last_kernel()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_set_option("k5", -1)
+            ops.gemm_set_option("k5_grid", 0)
+            ops.gemm_set_option("k5_split", -1)
+            ops.gemm_set_option("k2", -1)
+        assert name.startswith("gemm_bf16_k5_kernel<%d, " % tB) == bool(k5), name
+        return Cd.float().cpu(), pre.float().cpu()
+
+    # k5_split: the LDS-DMA pieces issued by the producer waves alone (0) or half by each wave group (1; the default for GELU)
+    for split in (0, 1):
+        if tB == 0:
+            out, _ = run(1, 0, split=split)
+            assert torch.equal(out, ref.to(torch.bfloat16).float())
+            out, _ = run(1, ops.EPI_BIAS, split=split, bias=bias)
+            assert torch.equal(out, (ref + bias.cpu()).to(torch.bfloat16).float())
+            out, _ = run(1, ops.EPI_BIAS | ops.EPI_RESID, split=split, bias=bias, resid=R, ldr=N)
+            assert torch.equal(out, (ref + bias.cpu() + R.float().cpu()).to(torch.bfloat16).float())
+            fl = ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU
+            As = (Ad.float() * 0.125).to(torch.bfloat16)   # small magnitudes: the activation away from saturation
+            o_new, p_new = run(1, fl, A_=As, split=split, bias=bias * 0.25)
+            o_old, p_old = run(0, fl, A_=As, bias=bias * 0.25)
+            assert torch.equal(o_new, o_old) and torch.equal(p_new, p_old)
+        else:
+            out, _ = run(1, 0, split=split)
+            assert torch.equal(out, ref.to(torch.bfloat16).float())
+            out, _ = run(1, ops.EPI_MULAUX, split=split, aux=aux, ldaux=N)
+            assert torch.equal(out, (ref * aux.float().cpu()).to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("shape,rb", [((6272, 768, 768), 6), ((6235, 768, 1024), 6), ((9408, 1280, 1280), 6), ((3136, 768, 1024), 5),
                                       ((9408, 768, 768), 7), ((2300, 1288, 256), 6), ((5120, 1536, 256), 8)])
 def test_gemm_k2_tile_height_by_rounds(ops, shape, rb):

@@ -55,6 +55,21 @@ NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
 def set_k2(opt):
     """k2 option value: 0 the 128 x 128 kernel, 1 the 256 x 128 form, 2 the default rule, 3 the 256 x 256 form wherever legal;
     "k3": the round-4 form (two 256-thread workgroups per CU) where it is legal, the default rule elsewhere"""
+    ops.gemm_set_option("k5", 0)
+    ops.gemm_set_option("k5_noepi", 0)
+    if opt == "k5x":            # K5 main loops only (diagnostic: nothing is stored)
+        ops.gemm_set_option("k5_noepi", 1)
+        opt = "k5n"
+    if opt in ("k5s", "k5n"):   # K5 with the LDS-DMA issue always / never shared by both wave groups
+        ops.gemm_set_option("k5_split", 1 if opt == "k5s" else 0)
+        opt = "k5"
+    else:
+        ops.gemm_set_option("k5_split", -1)
+    if opt == "k5":        # round 6: the two-tile ping-pong form wherever more than one tile per workgroup (default rule otherwise)
+        ops.gemm_set_option("k3", -1)
+        ops.gemm_set_option("k2", -1)
+        ops.gemm_set_option("k5", 1)
+        return
     if opt == "k3":
         ops.gemm_set_option("k2", -1)
         ops.gemm_set_option("k3", 3)
@@ -131,6 +146,9 @@ def main():
                     torch.cuda.synchronize()
                     res.setdefault(opt, []).append(e0.elapsed_time(e1) * 1e-3 / reps)
             set_k2("-1")
+            ops.gemm_set_option("k5", -1)
+            ops.gemm_set_option("k5_noepi", 0)
+            ops.gemm_set_option("k5_split", -1)
             fl = 2.0 * m * n * k
             txt = "  ".join(f"k2={o}: {sorted(v)[2] * 1e6:7.1f} us {fl / sorted(v)[2] / 1e12:6.0f} TF" for o, v in res.items())
             print(f"{name:16s} M={m:6d} N={n:5d} K={k:5d}  {txt}")
