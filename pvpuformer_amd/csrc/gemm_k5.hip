@@ -414,7 +414,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
                 c.wst = q + 2 >= 3 ? q - 1 : q + 2;
                 int kt = 0;
                 if (has_e) {
+                    // (a vector-ALU-heavy epilogue is the slower role: it takes the issue priority its partner's MFMAs leave alone)
+                    if constexpr (!MPRIO) __builtin_amdgcn_s_setprio(2);
                     k5_producer_intervals<TB, FL, RB, PWP, 0>(c, acc);
+                    if constexpr (!MPRIO) __builtin_amdgcn_s_setprio(0);
                     kt = K5_NI;
                 }
                 for (; kt < c.nk; ++kt) {
