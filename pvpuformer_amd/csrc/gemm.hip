@@ -2691,9 +2691,14 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
         else VPU_LAUNCH_K2_RB(TA_, TB_, 2, FL_, 8);                                                                   \
     } while (0)
 #define VPU_K2_BOTH(TA_, TB_, FL_) do { if (wide) VPU_LAUNCH_K2(TA_, TB_, 4, FL_); else if (narrow_ok) VPU_LAUNCH_K2N(TA_, TB_, FL_); else done = false; } while (0)
-                // K5 (round 6, gemm_k5.hip): launches with more than one 128-column tile per workgroup -- the two 4-wave groups own
-                // alternate tiles, one group's direct epilogue + all LDS-DMA run beside the other group's main loop.  Default
-                // rule of the k2 option only (an explicit k2 = 1 / 3 keeps the K2 forms: tests, A/B runs); k5 = 2: wherever legal.
+                // K5 (round 6, gemm_k5.hip): the two 4-wave groups of a workgroup own alternate 128-column tiles, one group's direct
+                // epilogue + all LDS-DMA run beside the other group's main loop (no K-half exchange either).  Same-box A/B
+                // (tools/gemm_bench.py GEMM_BENCH_K2=2,k5a, M = 9408): qkv 45.6 -> 39.6 us, fc2-dgrad x aux 54.9 -> 51.9, fc2 45.0 ->
+                // 43.8, fc1-dgrad 42.8 -> 41.9, proj-dgrad 16.7 -> 16.1, the FPN's 37632 x 384 x 768 35.8 -> 32.2; level or better
+                // on every ViT-B / -L / -H shape down to batch 4 -- one tile per workgroup included, so the same family (one
+                // accumulation order) serves a batch and its micro-batches.  fc1's bias + GELU + GELU' stays on the 256-column K2
+                // form (4.2 vector instructions per MFMA make K5's producer the slower role: 62.1 against 58.4-62.5 us).
+                // Default rule of the k2 option only (an explicit k2 = 1 / 3 keeps the K2 forms: tests, A/B runs); k5 = 2: GELU too.
                 {
                     const int k5 = vpu_k5_option();
                     if (k5 > 0 && (k2 == 2 || k5 == 2) && d->K >= 9 * BK && !((f & VPU_EPI_RESID) && d->resid_period > 0)) {
@@ -2703,11 +2708,8 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                             const int64_t c5 = cost(32 * rb, 128);
                             if (c5 < best5) { best5 = c5; rb5 = rb; }
                         }
-                        const int64_t tiles5 = (int64_t)((d->M + 32 * rb5 - 1) / (32 * rb5)) * tn2;
-                        // (fc1's bias + GELU + GELU' stays on the 256-column K2 form: 4.2 vector instructions per MFMA make K5's
-                        // producer the slower role -- 62.1 against 58.4 us; k5 = 2 takes it for the tests)
                         const bool gelu5 = (f & VPU_EPI_GELU) != 0;
-                        if (k5 == 2 || (tiles5 > ncu && !gelu5)) {
+                        if (k5 == 2 || !gelu5) {
                             const int r5 = vpu_k5_launch(d, rb5, ncu, vec2, stream, g_last_kernel, sizeof(g_last_kernel));
                             if (r5 < 0) return r5;
                             if (r5 == 1) return vpu_check_launch("vpu_gemm");
@@ -3003,7 +3005,7 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
                   "skinny (-1 environment default, 0 off, 1 on), "
                   "k2 (-1 environment default, 0 off, 1 256x128 tiles, 2 + 256x256 where it fills the chip, 3 256x256 wherever legal), "
                   "k3 (-1 environment default, bit 0 grouped weight gradients, bit 1 forward / dgrad, bit 2 grouped forward / dgrad), "
-                  "k5 (-1 environment default, 0 off, 1 launches of more than one tile per workgroup, 2 wherever legal), k5_grid (0 = none), "
+                  "k5 (-1 environment default, 0 off, 1 wherever legal except bias + GELU, 2 that too), k5_grid (0 = none), "
                   "reserve_cus (0..128 CUs the persistent launches leave unclaimed)");
     return VPU_ERR_ARG;
 }

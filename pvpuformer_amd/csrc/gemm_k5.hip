@@ -481,8 +481,8 @@ int k5_launch_rb(const vpu_gemm_desc* d, const int rb, const int ncu, const int 
 
 }  // namespace
 
-// option value of the K5 family: -1 environment default (VPU_GEMM_K5, 1 if unset), 0 off, 1 launches of more than one tile per
-// workgroup, 2 wherever the form is legal (tests)
+// option value of the K5 family: -1 environment default (VPU_GEMM_K5, 1 if unset), 0 off, 1 wherever the form is legal except
+// the GELU flag set, 2 that one too (tests)
 int vpu_k5_option() { const int v = g_opt_k5.load(std::memory_order_relaxed); return v >= 0 ? v : k5_env0(); }
 void vpu_k5_set_option(int v) { g_opt_k5.store(v, std::memory_order_relaxed); }
 void vpu_k5_set_grid(int v) { g_opt_k5_grid.store(v, std::memory_order_relaxed); }

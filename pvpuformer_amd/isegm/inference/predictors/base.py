@@ -11,7 +11,16 @@ from ..transforms import AddHorizontalFlip, LimitLongestSide, SigmoidForPred, cr
 
 class BasePredictor:
     def __init__(self, model, device, net_clicks_limit=None, with_flip=False, with_sigmoid=True, zoom_in=None,
-                 max_size=None, **kwargs):
+                 max_size=None, cascade_step=0, cascade_adaptive=False, cascade_clicks=1, **kwargs):
+        # base.py:109-125 -- the cascade re-prediction of the first clicks and the per-click model list (`model` given as a
+        # (net, click_models) tuple) are side branches the shipped evaluation never takes (scripts/evaluate_vpumodel.py:187-192
+        # passes neither): not mirrored, and refused here rather than silently ignored
+        if cascade_step:
+            raise NotImplementedError("BasePredictor(cascade_step > 0): the cascade branch of base.py:109-119 is not mirrored")
+        if isinstance(model, tuple):
+            raise NotImplementedError("BasePredictor(model=(net, click_models)): the per-click model list of base.py:121-125 is not mirrored")
+        self.cascade_step, self.cascade_adaptive, self.cascade_clicks = 0, bool(cascade_adaptive), cascade_clicks
+        self.click_models, self.model_indx = None, 0
         self.net, self.device = model, device
         self.net_clicks_limit, self.with_flip, self.with_sigmoid = net_clicks_limit, with_flip, with_sigmoid
         self.original_image = None
@@ -91,12 +100,17 @@ class BasePredictor:
                            click_indx=0, as_multi_prompts=True):
         """base.py:106-151,166-177: the model also receives the box prompt derived from (prev_mask, gt), both cropped to
         the ZoomIn region of interest."""
+        if not as_multi_prompts:
+            raise NotImplementedError("get_vqu_prediction(as_multi_prompts=False): the get_next_promts_inference branch of "
+                                      "base.py:154-164 is not mirrored (the shipped evaluation passes True, vpu_evaluation.py:43)")
         image_nd, clicks_lists, prev = self._net_input(clicker, prev_mask)
         points_nd = self.get_points_nd(clicks_lists).float()
         boxes = None
         if as_prompt_type != 0 or self.always_simulate_prompts:
             # the reference derives the box prompt on EVERY click (base.py:176), also for click prompts, where the network
-            # never reads it: here it is simulated only when it is consumed (~3 ms of a 7.5-ms click otherwise)
+            # never reads it: here it is simulated only when it is consumed (~3 ms of a 7.5-ms click otherwise) -- by the
+            # network (as_prompt_type != 0) or by a caller that reads ``prompts[1]``: ``always_simulate_prompts=True`` (a
+            # get_predictor keyword / attribute; evaluate_sample sets it while a visualisation callback is attached)
             gt = torch.from_numpy(np.asarray(gt_mask, dtype=np.float32))[None, None].to(self.device)
             if self.with_flip:
                 gt = torch.cat([gt, torch.flip(gt, dims=[3])], dim=0)

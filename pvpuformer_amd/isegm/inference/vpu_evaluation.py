@@ -30,6 +30,21 @@ def click_series(image, gt_mask, predictor, pred_thr=0.49, max_clicks=20, as_pro
 def evaluate_sample(image, gt_mask, predictor, max_iou_thr, pred_thr=0.49, min_clicks=1, max_clicks=20, sample_id=None,
                     callback=None, as_prompt_type=0):
     ious, probs, clicker = [], None, None
+    # the callback (the reference's visualisation hook, vpu_evaluation.py:84-97) is the one consumer of ``prompts`` in this
+    # protocol: with one attached the predictor derives the box prompt on every click as the reference does (base.py:176)
+    keep = getattr(predictor, "always_simulate_prompts", None)
+    if callback is not None and keep is not None:
+        predictor.always_simulate_prompts = True
+    try:
+        return _evaluate_sample(image, gt_mask, predictor, max_iou_thr, pred_thr, min_clicks, max_clicks, sample_id, callback,
+                                as_prompt_type)
+    finally:
+        if keep is not None:
+            predictor.always_simulate_prompts = keep
+
+
+def _evaluate_sample(image, gt_mask, predictor, max_iou_thr, pred_thr, min_clicks, max_clicks, sample_id, callback, as_prompt_type):
+    ious, probs, clicker = [], None, None
     with torch.no_grad():
         for k, probs, iou, clicker, prompts in click_series(image, gt_mask, predictor, pred_thr, max_clicks, as_prompt_type):
             ious.append(iou)

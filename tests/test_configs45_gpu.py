@@ -130,7 +130,10 @@ def test_bench_batch_bf16_step(golden_dir, fixture, B, logit_tol):
     # ---- the instantiations this configuration is meant to select really ran
     used = set(gemms)
     assert any(k.startswith("gemm_bf16_k4p_grouped_kernel<1, 1, true") for k in used) or "gemm_bf16_k2_grouped_kernel<1, 1, true>" in used, sorted(used)
-    assert any(k.startswith("gemm_bf16_k2_kernel<0, 0,") for k in used) and any(k.startswith("gemm_bf16_k2_kernel<0, 1,") for k in used)
+    # (round 6: the forward / dgrad forms of the blocks run on K5, the two-tile ping-pong family -- all but fc1's bias + GELU + GELU',
+    # which keeps the 256-column K2 form)
+    assert any(k.startswith("gemm_bf16_k2_kernel<0, 0,") for k in used), sorted(used)
+    assert any(k.startswith("gemm_bf16_k5_kernel<0, ") for k in used) and any(k.startswith("gemm_bf16_k5_kernel<1, ") for k in used), sorted(used)
     # the long-reduction weight gradients (M = 6272 / 12288 token rows: 98+ K-steps per output tile) leave in PACKED launches
     # (round 4, Engine._wgrad: every geometry packs under the K4 form): one round of 256 tiles of 256 x 256 = 512 of the
     # 256 x 128 units counted here, big problems cut at 256-row / 256-column blocks so that the round is full, up to nine small

@@ -1579,14 +1579,14 @@ def test_gemm_k2_exact_and_epilogues(ops, tB, k2, shape):
 
 @pytest.mark.parametrize("tB", [0, 1])
 @pytest.mark.parametrize("shape,grid", [((6001, 1544, 640), 0), ((6001, 1544, 640), 24), ((9408, 2304, 768), 0), ((5000, 1288, 1024), 7),
-                                        ((2300, 1288, 576), 3), ((9408, 768, 3072), 40)])
+                                        ((2300, 1288, 576), 3), ((9408, 768, 3072), 40), ((6144, 2688, 640), 0), ((6100, 2680, 1280), 50)])
 def test_gemm_k5_exact_and_epilogues(ops, tB, shape, grid):
     """Round 6, K5 (gemm_k5.hip): the two 4-wave groups of a workgroup own alternate 128-column tiles; one group's LDS-DMA +
     direct epilogue run beside the other group's main loop, the K-steps of consecutive tiles form one stream through a three-stage
     ring.  Exact-integer operands must give the fp32 matmul bit for bit in every flag set of the ViT blocks -- ragged M and N,
     K of 9 .. 48 K-steps, one to dozens of tiles per workgroup (`k5_grid` caps the grid so that every workgroup walks many tiles:
-    odd and even counts, both groups ending a launch), tile heights 256 / 224 / 192 by the rounds rule -- and GELU + GELU' equal
-    the 128 x 128 kernel's output."""
+    odd and even counts, both groups ending a launch), tile heights 256 / 224 / 192 by the rounds rule (256 rows: the form with one
+    fragment set, ViT-H's 12288 rows; (6144 | 6100) x (2688 | 2680) take it) -- and GELU + GELU' equal the 128 x 128 kernel's output."""
     M, N, K = shape
     g = torch.Generator().manual_seed(61)
     A = torch.randint(-3, 4, (M, K), generator=g).float()

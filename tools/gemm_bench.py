@@ -12,20 +12,21 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pvpuformer_amd import ops  # noqa: E402
 
-M = 9408
+M = int(os.environ.get("GEMM_BENCH_M", "9408"))      # token rows: 9408 (ViT-B bs 12), 6272 (ViT-L bs 8), 12288 (ViT-H bs 12)
+D = int(os.environ.get("GEMM_BENCH_D", "768"))       # width: 768 / 1024 / 1280
 SHAPES = [  # name, tA, tB, M, N, K, flags
-    ("qkv fwd", 0, 0, M, 2304, 768, ops.EPI_BIAS),
-    ("proj fwd+res", 0, 0, M, 768, 768, ops.EPI_BIAS | ops.EPI_RESID),
-    ("fc1 fwd gelu", 0, 0, M, 3072, 768, ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU),
-    ("fc2 fwd+res", 0, 0, M, 768, 3072, ops.EPI_BIAS | ops.EPI_RESID),
-    ("fc2 dgrad*aux", 0, 1, M, 3072, 768, ops.EPI_MULAUX),
-    ("fc1 dgrad", 0, 1, M, 768, 3072, 0),
-    ("qkv dgrad", 0, 1, M, 768, 2304, 0),
-    ("proj dgrad", 0, 1, M, 768, 768, 0),
-    ("fc1 wgrad", 1, 1, 3072, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
-    ("fc2 wgrad", 1, 1, 768, 3072, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
-    ("qkv wgrad", 1, 1, 2304, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
-    ("proj wgrad", 1, 1, 768, 768, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("qkv fwd", 0, 0, M, 3 * D, D, ops.EPI_BIAS),
+    ("proj fwd+res", 0, 0, M, D, D, ops.EPI_BIAS | ops.EPI_RESID),
+    ("fc1 fwd gelu", 0, 0, M, 4 * D, D, ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_SAVE_DGELU),
+    ("fc2 fwd+res", 0, 0, M, D, 4 * D, ops.EPI_BIAS | ops.EPI_RESID),
+    ("fc2 dgrad*aux", 0, 1, M, 4 * D, D, ops.EPI_MULAUX),
+    ("fc1 dgrad", 0, 1, M, D, 4 * D, 0),
+    ("qkv dgrad", 0, 1, M, D, 3 * D, 0),
+    ("proj dgrad", 0, 1, M, D, D, 0),
+    ("fc1 wgrad", 1, 1, 4 * D, D, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("fc2 wgrad", 1, 1, D, 4 * D, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("qkv wgrad", 1, 1, 3 * D, D, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
+    ("proj wgrad", 1, 1, D, D, M, ops.EPI_OUT_F32 | ops.EPI_ACCUM),
     ("square 4096", 0, 0, 4096, 4096, 4096, 0),
 ]
 NECK = [  # the DMA neck's prompt-token (576-row) and 384-wide GEMMs
@@ -60,6 +61,12 @@ def set_k2(opt):
     if opt == "k5x":            # K5 main loops only (diagnostic: nothing is stored)
         ops.gemm_set_option("k5_noepi", 1)
         opt = "k5n"
+    if opt == "k5a":            # K5 wherever it is legal (also one tile per workgroup)
+        ops.gemm_set_option("k3", -1)
+        ops.gemm_set_option("k2", -1)
+        ops.gemm_set_option("k5_split", 0)
+        ops.gemm_set_option("k5", 2)
+        return
     if opt in ("k5s", "k5n"):   # K5 with the LDS-DMA issue always / never shared by both wave groups
         ops.gemm_set_option("k5_split", 1 if opt == "k5s" else 0)
         opt = "k5"
