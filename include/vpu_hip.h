@@ -99,6 +99,16 @@ int vpu_gemm(const vpu_gemm_desc* d, void* stream);
  * in slice order, by the slice that arrives last at the tile's counter, inside the GEMM launch; n > 1: that, but only
  * when the slabs of the launch total at most n MiB.  Same results bit for bit; the default is the measured-faster one. */
 int vpu_gemm_set_option(const char* name, int32_t value);
+/* "k5" (round 6, csrc/gemm_k5.hip): the two-tile ping-pong family for the forward / dgrad forms of the blocks (the two 4-wave
+ * groups of a workgroup own alternate 128-column tiles; one group's LDS-DMA + direct epilogue run beside the other group's main
+ * loop): -1 environment default (VPU_GEMM_K5, 1 if unset), 0 off, 1 wherever legal except bias + GELU + GELU', 2 that too.
+ * "k5_split" (-1 by flag set, 0 / 1: the LDS-DMA pieces issued by the producer waves alone / half by each wave group),
+ * "k5_grid" (cap on its grid, 0 = none) and "k5_noepi" (main loops only) are test / diagnostic knobs.
+ *
+ * vpu_gemm_get_option: the EFFECTIVE value of "k2" / "k3" / "k5" as the dispatch of THIS library reads it -- environment default
+ * resolved, laboratory-only bits masked in the product library -- so that a host that sizes its launches by the kernel family
+ * (pvpuformer_amd/engine.py: the packed weight-gradient rounds) cannot disagree with the library about it. */
+int vpu_gemm_get_option(const char* name, int32_t* value);
 /* Name (as rocprofv3 prints it) of the kernel instantiation the calling host thread's last vpu_gemm / vpu_gemm_grouped call
  * launched -- lets a measurement harness label launches without mirroring the dispatch rules.  "" before the first call. */
 const char* vpu_gemm_last_kernel(void);

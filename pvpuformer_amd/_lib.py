@@ -130,6 +130,7 @@ SIGNATURES = {
     "vpu_adam_step_groups": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _F, _F, _F, _I, _I, _F, _P],
     "vpu_adam_step_hyper": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P],
     "vpu_gemm_set_option": [C.c_char_p, _I],
+    "vpu_gemm_get_option": [C.c_char_p, C.POINTER(C.c_int32)],
     "vpu_gemm_last_kernel": [],
     "vpu_attn_last_kernel": [],
     "vpu_attn_set_option": [C.c_char_p, _I],

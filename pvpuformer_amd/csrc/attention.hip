@@ -1213,8 +1213,8 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
 // Round 5.  The kernel above holds a whole (window, head) problem in 132 KB of LDS and 210 registers: ONE workgroup per CU,
 // two waves per SIMD, and 576 problems on 256 CUs are 2.25 rounds -- the third one a quarter full; inside a round nothing
 // overlaps a workgroup's 6.4-us prologue or the latencies of its loop (LDS read -> MFMA -> exp -> LDS write -> barrier ->
-// LDS read -> MFMA).  This form trades LDS traffic for occupancy: a 256-thread workgroup that needs 37 KB of LDS and < 128
-// registers, FOUR per CU, so that all 576 problems of a ViT-B window block are resident at once (1024 slots) and a SIMD
+// LDS read -> MFMA).  This form trades LDS traffic for occupancy: a 256-thread workgroup that needs 52 KB of LDS (WpCfg<1>::LDS = 53248: three per CU) and < 128
+// registers, THREE per CU, so that all 576 problems of a ViT-B window block are resident at once (768 slots) and a SIMD
 // always has another problem's wave to issue from:
 //   * the keys are walked in PASSES of 4 NU tiles of 16 (NU per wave: K / V fragments and the dK / dV accumulators of one
 //     tile are 48 registers); a pass streams every 32-query block of Q and dO through a three-stage ring of 8-KB stages
@@ -1532,7 +1532,7 @@ inline bool xcd_map_enabled() {   // VPU_ATTN_XCDMAP=0: the plain 2-D grid (A/B 
     static const int e0 = [] { const char* e = vpu_lab_getenv("VPU_ATTN_XCDMAP"); return e ? atoi(e) : 1; }();
     return e0 != 0;
 }
-inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backward for n <= 256, head dim 64: 2 = key passes, four workgroups per CU (round 5), 1 = one per CU, 0 = two kernels
+inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backward for n <= 256, head dim 64: 2 = key passes, three workgroups per CU (round 5), 1 = one per CU, 0 = two kernels
     static const int e0 = [] { const char* e = getenv("VPU_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
     const int v = g_opt_onepass.load(std::memory_order_relaxed);
     return v >= 0 ? v : e0;
@@ -1683,9 +1683,8 @@ static int xattn_bwd_impl(const void* q, const void* k, const void* v, const voi
         (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 && (reinterpret_cast<uintptr_t>(dv) & 7) == 0) {
         // three workgroups per CU (round 5); "onepass" = 1 selects the one-workgroup-per-CU form below
         static VpuDevOnce attrp;
-        if (attrp.pending() && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_winp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WpCfg<1>::LDS) != hipSuccess) {
-            vpu_set_error("xattn_bwd: hipFuncSetAttribute(attn_bwd_winp_kernel<1>, dynamic LDS) failed");
-            return VPU_ERR_LAUNCH;
+        if (auto todo_ = attrp.pending()) {
+            VPU_SET_LDS(WpCfg<1>::LDS, attn_bwd_winp_kernel<1>);
         }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_winp_kernel<1>");
         attn_bwd_winp_kernel<1><<<dim3(nb * H), 256, WpCfg<1>::LDS, s>>>(a);
@@ -1693,7 +1692,7 @@ static int xattn_bwd_impl(const void* q, const void* k, const void* v, const voi
     }
     if (!split && lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
         static VpuDevOnce attr;
-        if (attr.pending()) {
+        if (auto todo_ = attr.pending()) {
             VPU_SET_LDS(WIN_LDS, attn_bwd_win_kernel);
         }
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_win_kernel");

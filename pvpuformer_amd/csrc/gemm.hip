@@ -2575,7 +2575,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     do {                                                                                                             \
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k3_kernel<TA_, TB_, FL_, RB_>;                                                         \
-        if (attr_.pending()) {                                                                                                \
+        if (auto todo_ = attr_.pending()) {                                                                                                \
             VPU_SET_LDS(K3_LDS, kern_); \
         }                                                                                                            \
         const int tm_ = (d->M + 32 * RB_ - 1) / (32 * RB_);                                                           \
@@ -2663,7 +2663,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     do {                                                                                                             \
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k2_kernel<TA_, TB_, WN_, FL_, RB_, SW_>;                                               \
-        if (attr_.pending()) {                                                                                                \
+        if (auto todo_ = attr_.pending()) {                                                                                                \
             VPU_SET_LDS(K2Cfg<WN_>::LDS + K2_BIAS_LDS, kern_); \
         }                                                                                                            \
         const int tn_ = (d->N + K2Cfg<WN_>::BN_ - 1) / K2Cfg<WN_>::BN_;                                               \
@@ -2743,7 +2743,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
             const int tn64 = (d->N + SK_T - 1) / SK_T, tm64 = (d->M + SK_T - 1) / SK_T;
             const int kw = (int)(((d->K + 3) / 4 + 63) / 64 * 64);
             static VpuDevOnce attr_sk;
-            if (attr_sk.pending()) {
+            if (auto todo_ = attr_sk.pending()) {
                 VPU_SET_LDS(4 * TILE_BYTES, gemm_bf16_skinny_kernel<0>);
                 VPU_SET_LDS(8 * TILE_BYTES, gemm_bf16_skinny_kernel<1>);
             }
@@ -2790,7 +2790,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     do {                                                                                                             \
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_kernel<TA_, TB_, true, CS_, FL_, 3>;                                                   \
-        if (attr_.pending()) {                                                                                                \
+        if (auto todo_ = attr_.pending()) {                                                                                                \
             VPU_SET_LDS(6 * TILE_BYTES, kern_); \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_kernel<%d, %d, true, %s, %d, 3>", TA_, TB_, CS_ ? "true" : "false", FL_);              \
@@ -2835,7 +2835,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
     do {                                                                                                             \
         static VpuDevOnce attr_;                                                                                   \
         auto kern_ = gemm_bf16_k3s_kernel<TA_, TB_, FL_>;                                                             \
-        if (attr_.pending()) {                                                                                                \
+        if (auto todo_ = attr_.pending()) {                                                                                                \
             VPU_SET_LDS((K3Cfg<2, 128>::LDS), kern_); \
         }                                                                                                            \
         NOTE_KERNEL("gemm_bf16_k3s_kernel<%d, %d, %d>", TA_, TB_, FL_);                                                \
@@ -2892,7 +2892,7 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
 #ifdef VPU_LAB
         if (big) {
             static VpuDevOnce attr_done;
-            if (attr_done.pending()) {
+            if (auto todo_ = attr_done.pending()) {
                 const int sz = 3 * STAGE2;
                 VPU_SET_LDS(sz, gemm_bf16_big_kernel<0, 0>);
                 VPU_SET_LDS(sz, gemm_bf16_big_kernel<0, 1>);
@@ -3010,6 +3010,16 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     return VPU_ERR_ARG;
 }
 
+extern "C" int vpu_gemm_get_option(const char* name, int32_t* value) {
+    vpu_clear_stale_error();
+    if (!name || !value) { vpu_set_error("vpu_gemm_get_option: null argument"); return VPU_ERR_ARG; }
+    if (!strcmp(name, "k2")) { *value = k2_opt(); return VPU_OK; }
+    if (!strcmp(name, "k3")) { *value = k3_opt(); return VPU_OK; }
+    if (!strcmp(name, "k5")) { *value = vpu_k5_option(); return VPU_OK; }
+    vpu_set_error("vpu_gemm_get_option: known options: k2, k3, k5");
+    return VPU_ERR_ARG;
+}
+
 extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* stream) {
     vpu_clear_stale_error();
     if (!descs || n < 1 || n > VPU_GEMM_GROUP_MAX) { vpu_set_error("vpu_gemm_grouped: 1 <= n <= VPU_GEMM_GROUP_MAX"); return VPU_ERR_ARG; }
@@ -3087,7 +3097,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         for (int i = n; i <= VPU_GEMM_GROUP_MAX; ++i) g3.start[i] = total64;
         if (ok && total64 <= 2048) {
             static VpuDevOnce attr_skg;
-            if (attr_skg.pending()) {
+            if (auto todo_ = attr_skg.pending()) {
                 VPU_SET_LDS(4 * TILE_BYTES, gemm_bf16_skinny_grouped_kernel<0, 0>);
                 VPU_SET_LDS(8 * TILE_BYTES, gemm_bf16_skinny_grouped_kernel<0, 1>);
                 VPU_SET_LDS(8 * TILE_BYTES, gemm_bf16_skinny_grouped_kernel<1, 1>);
@@ -3126,12 +3136,12 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             static VpuDevOnce attrf0, attrf1;
             if (key == 0) {
                 auto kern_ = gemm_bf16_k2_grouped_fl_kernel<0, 0, VPU_EPI_BIAS>;
-                if (attrf0.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS + K2_BIAS_LDS, kern_); }
+                if (auto todo_ = attrf0.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS + K2_BIAS_LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_fl_kernel<0, 0, 1>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS + K2_BIAS_LDS, s>>>(g2, 1);
             } else {
                 auto kern_ = gemm_bf16_k2_grouped_fl_kernel<0, 1, 0>;
-                if (attrf1.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS + K2_BIAS_LDS, kern_); }
+                if (auto todo_ = attrf1.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS + K2_BIAS_LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_fl_kernel<0, 1, 0>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS + K2_BIAS_LDS, s>>>(g2, 1);
             }
@@ -3142,12 +3152,12 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             static VpuDevOnce attr0, attr1;
             if (key == 0) {
                 auto kern_ = gemm_bf16_k2_grouped_kernel<0, 0, false>;
-                if (attr0.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS, kern_); }
+                if (auto todo_ = attr0.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 0, false>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
             } else {
                 auto kern_ = gemm_bf16_k2_grouped_kernel<0, 1, false>;
-                if (attr1.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS, kern_); }
+                if (auto todo_ = attr1.pending()) { VPU_SET_LDS(K2Cfg<2>::LDS, kern_); }
                 NOTE_KERNEL("gemm_bf16_k2_grouped_kernel<0, 1, false>");
                 kern_<<<dim3((unsigned)(total2 < ncu ? total2 : ncu)), dim3(512), K2Cfg<2>::LDS, s>>>(g2, 1);
             }
@@ -3203,7 +3213,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
                           q.ldc % 4 == 0 && q.N % 4 == 0 && q.sCo % 4 == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 &&
                           (int64_t)q.M * q.ldc * 4 < 0x7FFFFFF0LL;
             }
-            if (attr4_.pending()) {
+            if (auto todo_ = attr4_.pending()) {
 #ifdef VPU_LAB
                 VPU_SET_LDS(K3Cfg<4>::LDS, gemm_bf16_k4_grouped_kernel<1, 1, true>);
 #endif
@@ -3233,7 +3243,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
             ok_short = descs[i].K % BK == 0 && descs[i].K >= k3g_min_k && descs[i].K < 2048 && descs[i].N % 8 == 0 && descs[i].M % 8 == 0;
         if ((ok && (any_batch || ((k3_opt() & 1) && total2 > cu_count()))) || ok_short) {
             static VpuDevOnce attr3_;
-            if (attr3_.pending()) {
+            if (auto todo_ = attr3_.pending()) {
                 VPU_SET_LDS(K3_LDS, gemm_bf16_k3_grouped_kernel<1, 1, true>);
             }
             const int cap = 2 * cu_count();
@@ -3245,7 +3255,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
         if (ok && (total2 >= 192 || (very_long && total2 >= 96))) {
             static VpuDevOnce attr_;
             auto kern_ = gemm_bf16_k2_grouped_kernel<1, 1, true>;
-            if (attr_.pending()) {
+            if (auto todo_ = attr_.pending()) {
                 VPU_SET_LDS(K2Cfg<2>::LDS, kern_);
             }
             const int ncu = cu_count();

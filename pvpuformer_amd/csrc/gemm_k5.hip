@@ -454,7 +454,7 @@ template <int TB, int FL, int RB, int PWP>
 int k5_launch_pw(const vpu_gemm_desc* d, const int ncu, const int vec, hipStream_t s, char* name, size_t name_len) {
     static VpuDevOnce attr_;
     auto kern_ = gemm_bf16_k5_kernel<TB, FL, RB, PWP>;
-    if (attr_.pending()) VPU_SET_LDS(K5_LDS, kern_);
+    if (auto todo_ = attr_.pending()) { VPU_SET_LDS(K5_LDS, kern_); }
     const int tn_ = (d->N + 127) / 128, tm_ = (d->M + 32 * RB - 1) / (32 * RB);
     const int tot_ = tm_ * tn_;
     int grid = tot_ < ncu ? tot_ : ncu;

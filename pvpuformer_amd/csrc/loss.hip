@@ -458,9 +458,8 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
         return VPU_ERR_ARG;
     }
     static VpuDevOnce attr_set;
-    if (attr_set.pending()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2cl_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 4096);   // (static: reduction scratch + the anchor tables)
+    if (auto todo_ = attr_set.pending()) {
+        VPU_SET_LDS(160 * 1024 - 4096, p2cl_up_kernel);   // (static: reduction scratch + the anchor tables)
     }
     // (as many threads as the pixel / cell passes use: (band + 1) * W / 4, a multiple of 64)
     const int nthr = (int)((((int64_t)(band + 1) * (W / 4 > w ? W / 4 : w)) + 63) / 64 * 64);

@@ -6,16 +6,28 @@
 
 
 // "done once per DEVICE" flag of a call site (hipFuncSetAttribute is a per-device setting; a process that moves from one
-// device to another must repeat it there): one bit per device id.
+// device to another must repeat it there): one bit per device id.  Use:
+//     static VpuDevOnce once;  if (auto todo = once.pending()) { VPU_SET_LDS(bytes, kernel); ... }
+// The bit is committed when `todo` goes out of scope -- i.e. AFTER the attribute calls -- and only if none of them failed (a
+// failing VPU_SET_LDS returns from the C-ABI call with VPU_ERR_LAUNCH: the next call tries again instead of launching with a
+// dynamic-LDS request the kernel was never granted).  A thread that races the first one repeats the (idempotent)
+// calls rather than launching before they have completed.
+inline thread_local bool g_vpu_attr_failed = false;
 struct VpuDevOnce {
     std::atomic<unsigned long long> done{0};
-    bool pending() {
+    struct Todo {
+        VpuDevOnce* o;
+        unsigned long long bit;
+        explicit operator bool() const { return o != nullptr; }
+        ~Todo() { if (o && !g_vpu_attr_failed) o->done.fetch_or(bit, std::memory_order_release); }
+    };
+    Todo pending() {
         int dev = 0;
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
-        if (done.load(std::memory_order_relaxed) & bit) return false;
-        done.fetch_or(bit, std::memory_order_relaxed);
-        return true;
+        if (done.load(std::memory_order_acquire) & bit) return Todo{nullptr, 0};
+        g_vpu_attr_failed = false;
+        return Todo{this, bit};
     }
 };
 
@@ -46,6 +58,7 @@ static inline void vpu_clear_stale_error() { (void)hipGetLastError(); }
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (bytes)) != hipSuccess) {                                                                \
             (void)hipGetLastError();                                                                                     \
+            g_vpu_attr_failed = true;                                                                                    \
             vpu_set_error("hipFuncSetAttribute(" #__VA_ARGS__ ", hipFuncAttributeMaxDynamicSharedMemorySize) failed");   \
             return VPU_ERR_LAUNCH;                                                                                       \
         }                                                                                                                \

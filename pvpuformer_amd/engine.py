@@ -146,11 +146,14 @@ class Engine:
         blk = sum(((n + 255) // 256) * ((k + 127) // 128) for n, k in ((3 * self.D, self.D), (self.D, self.D), (hid, self.D), (self.D, hid)))
         pk = os.environ.get("VPU_WGRAD_PACK", "")
         # (round 4: with the K4 launches -- 256 x 256 tiles, rounds cut exactly, small problems riding -- every geometry packs)
-        k4_default = (int(os.environ.get("VPU_GEMM_K3", "28")) & 8) != 0
+        # (the EFFECTIVE k3 option of the loaded library -- environment default resolved, laboratory-only bits masked in the
+        # product build -- not the raw environment variable: ADVICE r5, the engine must size its rounds for the kernels the
+        # library really dispatches)
+        k3 = ops.gemm_get_option("k3")
+        k4_default = (k3 & 8) != 0
         self.pack_wgrad = pk == "1" or (pk != "0" and (blk < 0.95 * 256 or k4_default))
         # K3 weight-gradient launches (round 4: 256 x 128 tiles in 256-thread workgroups, TWO per CU, free-running): a full
         # round is 512 tiles.  VPU_GEMM_K3 (bit 0) selects them in the library; the engine sizes its packed launches for it.
-        k3 = int(os.environ.get("VPU_GEMM_K3", "28"))
         self.k3_wgrad = (k3 & 1) != 0
         self.k4_wgrad = (k3 & 8) != 0          # 256 x 256 tiles, one workgroup per CU
         self.wgrad_round = 256 if (self.k4_wgrad or not self.k3_wgrad) else 512
@@ -566,7 +569,12 @@ class Engine:
     @contextlib.contextmanager
     def _lane(self, s):
         """Everything launched inside runs on HIP stream ``s`` and the backward closures recorded inside will (Tape.append);
-        ``s`` None = no-op."""
+        ``s`` None = no-op.
+        Allocator lifetime: tensors created inside (torch.empty on stream ``s``) are handed to kernels of the OTHER
+        stream at the crossings without ``record_stream``.  That is safe only because (a) every such tensor is kept alive by
+        the tape / the engine's buffers until the pass has ended -- the caching allocator cannot hand its block to another
+        stream while a reference exists -- and (b) every crossing is fenced by the ``_xrec`` / ``_xwait`` event pair.  A
+        tensor that is created in a lane, crosses, and is DROPPED before the pass ends would need ``record_stream``."""
         if s is None:
             yield
             return
@@ -770,7 +778,7 @@ class Engine:
     def cross_attention(self, Qp, Kp, Vp, O, nb, H, nq, nk, hd, ld, scale):
         """Fused attention of the DMA neck: projected queries [nb*nq, ld], keys / values [nb*nk, ld] -> O [nb*nq, ld]
         (bf16; the [nb, H, nq, nk] scores are never materialised).
-        Round 5, split launches (VPU_XATTN_SPLIT, default 4): the neck's attentions pair 48 prompt tokens with the image tokens --
+        Round 5, split launches (VPU_XATTN_SPLIT, default 1 = off; opt-in, measured level): the neck's attentions pair 48 prompt tokens with the image tokens --
         nb * H = 96 workgroups that walk 784 keys (tokens -> image) or 784 queries (the dK / dV of image -> tokens) in 25 chunks,
         latency-bound on a third of the chip.  The long side is cut into S ranges that run as S batch entries of one launch:
         * long QUERIES (image -> tokens): entries share the keys (kdiv = S); forward and dQ are complete per entry, dK / dV come

@@ -25,7 +25,9 @@ class ISModel(nn.Module):
     def prepare_input(self, image):
         """is_model.py:59-66: (normalised rgb, previous mask) -- ``(x - mean) / std`` as BatchImageNormalize does it
         (ops.py:398-407: a clone, sub_, div_).  The model's own ``forward`` does not come through here (the normalisation is
-        fused into the patch im2col); this serves callers of the public pieces: ``backbone_forward`` takes what it returns."""
+        fused into the patch im2col); this serves callers of the public pieces: ``backbone_forward`` takes what it returns.
+        NOTE: ``forward()`` expects the UN-normalised [B,4,H,W] input, as the reference's does -- do not chain
+        ``prepare_input`` -> ``forward`` (the image would be normalised twice)."""
         prev_mask = None
         if self.with_prev_mask:
             prev_mask = image[:, 3:, :, :]

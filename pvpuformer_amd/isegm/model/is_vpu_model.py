@@ -237,7 +237,12 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         click maps, exactly as given: nothing is drawn here) -> {'instances': [B,1,H/4,W/4] logits, 'instances_aux':
         [B,2n,H/4,W/4] similarities}.  The stages stay fused inside the engine: the caller's planes go into the patch
         embedding's operand through ``vpu_patch_im2col_prenorm``, the low-resolution maps come out through the engine's taps.
-        Inference only (the outputs carry no autograd graph: training goes through ``forward``)."""
+        Inference only (the outputs carry no autograd graph: training goes through ``forward``): where the reference's method is
+        the differentiable body of its ``forward`` (is_vpu_model.py:383-419), a caller that tries to train through this one gets
+        a RuntimeError here instead of silent zero gradients.  ``pclout`` is accepted for signature parity only."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("backbone_forward is inference-only in this build (no autograd graph behind its outputs): call it under "
+                               "model.eval() / torch.no_grad(), and train through forward()")
         eng = self._ensure_engine()
         points, boxes, scribble = self._unpack_prompts(points, prompts, as_prompt_type, edloss)
         if coord_features is None or coord_features.shape[1] != 3:
@@ -246,11 +251,8 @@ class VitMultiGaussianVector_ed_Model(ISModel):
         image4 = torch.cat([image.float(), coord[:, :1]], dim=1).contiguous()
         if not self.weights_frozen or not eng.shadow_valid:
             eng.refresh_weights()
-        drop_mask = None
-        if self.training and self.head.dropout_ratio > 0:
-            drop_mask = ops.dropout_mask(image.shape[0], self.head.channels, 1.0 - self.head.dropout_ratio, image.device)
         taps = {}
         with torch.no_grad():
-            eng.forward(image4, points, boxes, as_prompt_type, drop_mask, training=False, taps=taps, materialize_aux=False,
+            eng.forward(image4, points, boxes, as_prompt_type, None, training=False, taps=taps, materialize_aux=False,
                         scribble=scribble, coord_override=coord[:, 1:3], prenorm=True)
         return {'instances': taps["seg_lowres"].float(), 'instances_aux': taps["sim_lowres"].float() if self.with_aux_output else None}

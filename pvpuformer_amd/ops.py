@@ -127,6 +127,14 @@ def gemm_set_option(name, value):
     _lib.call("vpu_gemm_set_option", name.encode(), int(value))
 
 
+def gemm_get_option(name):
+    """Effective value of a kernel-family option ("k2" / "k3" / "k5") as the loaded library's dispatch reads it."""
+    import ctypes
+    v = ctypes.c_int32(0)
+    _lib.call("vpu_gemm_get_option", name.encode(), ctypes.byref(v))
+    return int(v.value)
+
+
 def layernorm_fwd(x, w, b, y, mean, rstd, rows, Cdim, eps):
     _lib.call("vpu_layernorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, Cdim, eps, code_of(x),
               _stream())

@@ -552,6 +552,13 @@ def test_backbone_forward_public_method(golden_dir, ptype):
     assert float((other["instances"] - low["instances"]).abs().max()) > 1e-4
     with pytest.raises(ValueError):
         model.backbone_forward(image, coord[:, :2], pts, prompts, ptype)
+    # inference-only: training through it raises instead of returning graph-less tensors (the reference's is differentiable)
+    model.train()
+    try:
+        with pytest.raises(RuntimeError, match="inference-only"):
+            model.backbone_forward(image, coord, pts, prompts, ptype)
+    finally:
+        model.eval()
 
 
 @pytest.mark.parametrize("fixture", ["tiny.npz", "vitb.npz"])
