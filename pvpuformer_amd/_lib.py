@@ -9,7 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPU_LIB_DIAG=1: the diagnostic build (csrc/build.sh diag: -DVPU_DIAG, time stamps in the K2 / K4P kernels) for tools/k2_stamps.py and
 # tools/k4_drift.py; the product library carries no stamp code
-LIB_PATH = os.path.join(_HERE, "libvpu_hip_diag.so" if os.environ.get("VPU_LIB_DIAG", "0") == "1" else "libvpu_hip.so")
+# (VPU_LIB_FILE: an experiment library built by `csrc/build.sh x` for a same-box A/B; never set by the product or the tests)
+LIB_PATH = os.path.join(_HERE, os.environ.get("VPU_LIB_FILE") or
+                        ("libvpu_hip_diag.so" if os.environ.get("VPU_LIB_DIAG", "0") == "1" else "libvpu_hip.so"))
 
 BF16, F32 = 0, 1
 

@@ -32,7 +32,15 @@ constexpr int K5_STAGE = 3 * TILE_BYTES;          // A rows 0-127 | A rows 128-2
 constexpr int K5_PW = 12;                         // DMA pieces (1 KiB) per producer wave per stage: 48 / 4 waves
 constexpr int K5_BIAS_LDS = 2 * 8 * 256;          // [tile parity of a group][wave]: 64 fp32 bias values per wave
 constexpr int K5_LDS = 3 * K5_STAGE + K5_BIAS_LDS;
-constexpr int K5_NI = 9;                          // epilogue intervals: 0 = operand loads, 1..8 = two units each
+// epilogue intervals of a phase: the operand loads first, then eight intervals of two units each.  A form with a residual / aux
+// operand takes one interval more: its operand (cold in the step: the saved GELU' of a block was written a forward pass ago)
+// is requested TWO intervals before the first unit that consumes it -- the producer's vector-memory queue is in order, so a
+// unit that waits for its operand also holds back the DMA pieces behind it, i.e. the consumer's next K-steps (measured in the
+// step: fc2-dgrad x aux 60.6 us with one interval of lead against 50-54 us on warm operands)
+template <int FL> constexpr int k5_ni() { return (FL & (VPU_EPI_RESID | VPU_EPI_MULAUX)) ? 10 : 9; }
+template <int FL> constexpr int k5_u0() { return (FL & (VPU_EPI_RESID | VPU_EPI_MULAUX)) ? 2 : 1; }     // interval of units 0 and 1
+template <int FL, int RB> constexpr int k5_xl1() { return (FL & (VPU_EPI_RESID | VPU_EPI_MULAUX)) ? (RB < 8 ? 1 : 5) : 4; }   // interval that requests the second half's operand
+constexpr int K5_NI_MAX = 10;
 
 template <int N> __device__ __forceinline__ void k5_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void k5_barrier() {
@@ -161,13 +169,15 @@ __device__ __forceinline__ void k5_unit(const __amdgpu_buffer_rsrc_t rC, const _
 // compile-time bookkeeping of the epilogue schedule: unit u = (half, row block, column half) = (u / 8, (u % 8) / 2, u % 2);
 // interval I >= 1 runs units 2 (I - 1) and 2 (I - 1) + 1; interval 0 requests the first half's operand, interval 4 the second's
 template <int RB> constexpr bool k5_unit_valid(int u) { return u >= 0 && u < 16 && (u / 8) * 4 + (u % 8) / 2 < RB; }
-template <int FL, int RB> constexpr int k5_eops(int I) {       // vector-memory operations of interval I behind its DMA pieces
+template <int FL, int RB> constexpr int k5_eops(int I) {       // vector-memory operations of interval I beside its DMA pieces
     constexpr bool HAS_X = (FL & (VPU_EPI_RESID | VPU_EPI_MULAUX)) != 0;
     constexpr int ST_U = (FL & VPU_EPI_SAVE_DGELU) ? 2 : 1;
-    if (I == 0) return HAS_X ? 8 : 0;
     int n = 0;
-    for (int u = 2 * (I - 1); u < 2 * I; ++u) n += k5_unit_valid<RB>(u) ? ST_U : 0;
-    if (I == 4 && HAS_X && RB > 4) n += 8;
+    if (I == 0 && HAS_X) n += 8;
+    if (I == k5_xl1<FL, RB>() && HAS_X && RB > 4) n += 8;
+    const int i = I - k5_u0<FL>();
+    if (i >= 0)
+        for (int u = 2 * i; u < 2 * i + 2; ++u) n += k5_unit_valid<RB>(u) ? ST_U : 0;
     return n;
 }
 
@@ -255,16 +265,16 @@ __device__ __forceinline__ void k5_do_unit(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[
 // role by that blocked time -- see DESIGN section 5)
 template <int TB, int FL, int RB, int I, int PART>
 __device__ __forceinline__ void k5_epi_part(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[RB][4]) {
-    if constexpr (I == 0) {
-        if constexpr (PART == 0) k5_epi_begin(c);
-    } else if constexpr (PART == 0) {
-        if constexpr (I == 4 && RB > 4) k5_xload<FL>(c.p, c.mq + 64, c.nq, c.lane, c.x1, RB - 4);
-        k5_do_unit<TB, FL, RB, 2 * (I - 1)>(c, acc);
+    constexpr int i = I - k5_u0<FL>();
+    if constexpr (PART == 0) {
+        if constexpr (I == 0) k5_epi_begin(c);
+        if constexpr (I == k5_xl1<FL, RB>() && RB > 4) k5_xload<FL>(c.p, c.mq + 64, c.nq, c.lane, c.x1, RB - 4);
+        if constexpr (i >= 0) k5_do_unit<TB, FL, RB, 2 * i>(c, acc);
     } else {
-        k5_do_unit<TB, FL, RB, 2 * (I - 1) + 1>(c, acc);
+        if constexpr (i >= 0) k5_do_unit<TB, FL, RB, 2 * i + 1>(c, acc);
     }
 }
-// producer intervals 0 .. K5_NI - 1 of a phase with an epilogue: DMA in three bursts with the epilogue work between them, then
+// producer intervals 0 .. k5_ni<FL>() - 1 of a phase with an epilogue: DMA in three bursts with the epilogue work between them, then
 // the counted wait for everything this wave requested BEFORE this interval (the pieces of the next K-step among it: behind them
 // the wave has issued this interval's PWP pieces and E(I) epilogue operations), barrier
 template <int TB, int FL, int RB, int PWP, int I>
@@ -282,7 +292,7 @@ __device__ __forceinline__ void k5_producer_intervals(K5Ctx<TB, FL, RB>& c, f32x
     // (interval 0 with all pieces from the producer: nothing of this wave is older than this interval)
     if constexpr (I > 0 || PWP < K5_PW) k5_wait_vm<PWP + k5_eops<FL, RB>(I)>();
     k5_barrier();
-    if constexpr (I + 1 < K5_NI) k5_producer_intervals<TB, FL, RB, PWP, I + 1>(c, acc);
+    if constexpr (I + 1 < k5_ni<FL>()) k5_producer_intervals<TB, FL, RB, PWP, I + 1>(c, acc);
 }
 template <int TB, int FL, int RB, int I>
 __device__ __forceinline__ void k5_epi_interval(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[RB][4]) {
@@ -292,7 +302,7 @@ __device__ __forceinline__ void k5_epi_interval(K5Ctx<TB, FL, RB>& c, f32x4_t (&
 template <int TB, int FL, int RB, int I>
 __device__ __forceinline__ void k5_epi_all(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[RB][4]) {
     k5_epi_interval<TB, FL, RB, I>(c, acc);
-    if constexpr (I + 1 < K5_NI) k5_epi_all<TB, FL, RB, I + 1>(c, acc);
+    if constexpr (I + 1 < k5_ni<FL>()) k5_epi_all<TB, FL, RB, I + 1>(c, acc);
 }
 
 // PWP: LDS-DMA pieces per K-step a PRODUCER wave issues -- 12 (all of them) or 6 (the consumer waves issue the other half:
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
                     if constexpr (!MPRIO) __builtin_amdgcn_s_setprio(2);
                     k5_producer_intervals<TB, FL, RB, PWP, 0>(c, acc);
                     if constexpr (!MPRIO) __builtin_amdgcn_s_setprio(0);
-                    kt = K5_NI;
+                    kt = k5_ni<FL>();
                 }
                 for (; kt < c.nk; ++kt) {
                     k5_dma<0, PWP, true>(c, kt);
@@ -449,7 +459,7 @@ inline int k5_env0() {
 }
 
 std::atomic<int> g_opt_k5_noepi{0};      // diagnostic: main loops only (the outputs are not written)
-std::atomic<int> g_opt_k5_split{-1};     // -1: by flag set (GELU forms split), 0 / 1: never / always (A/B runs)
+std::atomic<int> g_opt_k5_split{-1};     // -1 / 0: the producer waves issue every LDS-DMA piece; 1: half of them by the consumer waves (A/B runs, tests)
 template <int TB, int FL, int RB, int PWP>
 int k5_launch_pw(const vpu_gemm_desc* d, const int ncu, const int vec, hipStream_t s, char* name, size_t name_len) {
     static VpuDevOnce attr_;
@@ -467,8 +477,13 @@ int k5_launch_pw(const vpu_gemm_desc* d, const int ncu, const int vec, hipStream
 template <int TB, int FL, int RB>
 int k5_launch_one(const vpu_gemm_desc* d, const int ncu, const int vec, hipStream_t s, char* name, size_t name_len) {
     const int sp = g_opt_k5_split.load(std::memory_order_relaxed);
-    const bool split = sp >= 0 ? sp != 0 : (FL & VPU_EPI_GELU) != 0;
-    if constexpr (RB < 8) if (split) return k5_launch_pw<TB, FL, RB, 6>(d, ncu, vec, s, name, name_len);
+    // (measured, tools/gemm_bench.py GEMM_BENCH_K2=k5n,k5s: ANY LDS-DMA piece in the consumer's instruction stream costs more
+    // than it takes off the producer -- half of them: qkv 38.3 -> 44.6 us, fc2-dgrad x aux 49.8 -> 56.0; a quarter (nine by the
+    // producer, three by the consumer): 43.1 / 55.1.  The split form stays selectable for the tests and for A/B runs only.)
+    const int split = sp >= 0 ? sp : 0;
+    if constexpr (RB < 8) {
+        if (split == 1) return k5_launch_pw<TB, FL, RB, 6>(d, ncu, vec, s, name, name_len);
+    }
     return k5_launch_pw<TB, FL, RB, 12>(d, ncu, vec, s, name, name_len);
 }
 template <int TB, int FL>
@@ -498,7 +513,8 @@ int vpu_k5_launch(const vpu_gemm_desc* d, int rb, int ncu, int vec, void* stream
     constexpr int F_B = VPU_EPI_BIAS, F_BR = VPU_EPI_BIAS | VPU_EPI_RESID,
                   F_G = VPU_EPI_BIAS | VPU_EPI_GELU | VPU_EPI_SAVE_DGELU, F_M = VPU_EPI_MULAUX;
     const int f = d->flags;
-    if (d->transA || d->K < K5_NI * BK || d->K % BK) return 0;
+    if (d->transA || d->K < 9 * BK || d->K % BK) return 0;
+    if ((f & (VPU_EPI_RESID | VPU_EPI_MULAUX)) && d->K < K5_NI_MAX * BK) return 0;      // (these forms: ten epilogue intervals)
     if (!d->transB) {
         if (f == F_B) return k5_launch_rb<0, F_B>(d, rb, ncu, vec, s, name, name_len);
         if (f == F_BR) return k5_launch_rb<0, F_BR>(d, rb, ncu, vec, s, name, name_len);

@@ -37,9 +37,11 @@ def main():
     eng = model._ensure_engine()
     eng.refresh_weights()
     opt = FusedAdam(model, lr=5e-5)
-    B = 12
+    B = int(os.environ.get("DP_BATCH", "12"))      # 12: bench.py's per-GPU batch; 4: the reference recipe's 32 images on 8 GPUs
     b = synth_batch(B, 448, seed=100, device=dev)
     x = torch.cat([b["images"], torch.zeros(B, 1, 448, 448, device=dev)], 1).contiguous()
+
+    host_ms = [0.0]
 
     def run(red):
         eng.grad_ready_hook = red.ready if red is not None else None
@@ -57,6 +59,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             one()
+        host_ms[0] = (time.perf_counter() - t0) / steps * 1e3      # the host's enqueue time per step (it does not block)
         torch.cuda.synchronize()
         eng.grad_ready_hook = None
         return (time.perf_counter() - t0) / steps * 1e3
@@ -95,11 +98,12 @@ def main():
         dt = time.perf_counter() - t0
         return dt / steps * 1e3, t_host / steps * 1e3, sum(1 for g, _ in seg.segments if g is not None)
 
-    res = {"what": "ViT-B 448 bs=12 bf16 training step on ONE MI355X, eager launch, RCCL world size 1", "steps": steps,
-           "NCCL_MAX_NCHANNELS": channels}
+    res = {"what": f"ViT-B 448 bs={B} bf16 training step on ONE MI355X, eager launch, RCCL world size 1", "steps": steps,
+           "NCCL_MAX_NCHANNELS": channels, "host_threads_allowed": len(os.sched_getaffinity(0))}
     res["ms_no_reducer"] = round(run(None), 3)
     red = GradReducer(eng.gflat, force=True, reserve_cus=16)
     res["ms_reducer_fp32_wire_reserve16"] = round(run(red), 3)
+    res["eager_host_ms_per_step_reserve16"] = round(host_ms[0], 3)
     res["collectives_per_step"] = len(red.launched)          # (reset by begin(): the last step's)
     res["rccl_kernels_at_world_size_1"] = "none: RCCL returns from an in-place all-reduce over one rank without launching (kernel trace: 0 nccl kernels)"
     res["ms_reducer_bf16_wire_reserve16"] = round(run(GradReducer(eng.gflat, force=True, wire="bf16", reserve_cus=16)), 3)
