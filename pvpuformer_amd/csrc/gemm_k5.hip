@@ -134,9 +134,10 @@ __device__ __forceinline__ void k5_xload(const vpu_gemm_desc& p, const int mrow0
 }
 // one epilogue unit: 16 rows x 32 columns of the wave's block = two accumulator tiles = 8 consecutive columns of one row
 // per lane = ONE 16-byte store (two with the saved GELU')
-template <int FL>
+struct K5NoGap { template <int G> __device__ __forceinline__ void at() const {} };
+template <int FL, typename GAP = K5NoGap>
 __device__ __forceinline__ void k5_unit(const __amdgpu_buffer_rsrc_t rC, const __amdgpu_buffer_rsrc_t rP, const f32x4_t a0, const f32x4_t a1,
-                                        const int off, const f32x4_t b0, const f32x4_t b1, const u32x4v xv) {
+                                        const int off, const f32x4_t b0, const f32x4_t b1, const u32x4v xv, const GAP& gap = GAP()) {
     float v[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -150,8 +151,18 @@ __device__ __forceinline__ void k5_unit(const __amdgpu_buffer_rsrc_t rC, const _
         for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
     }
     if constexpr ((FL & VPU_EPI_GELU) != 0) {
+        // the GELU / GELU' pairs two elements at a time, a gap behind each pair: the producer puts its LDS-DMA pieces there, one
+        // or two per ~45 vector instructions -- the rate the memory pipe drains them at, so that the issue never finds the
+        // queue full (twelve pieces in one burst wait ~130 cycles each at the issue, and the wave's arithmetic waits with them)
         float d[8];
-        gelu_dgelu8(v, d);
+        gelu_pair_fast(v[0], v[0], d[0]); gelu_pair_fast(v[1], v[1], d[1]);
+        __builtin_amdgcn_sched_barrier(0); gap.template at<0>(); __builtin_amdgcn_sched_barrier(0);
+        gelu_pair_fast(v[2], v[2], d[2]); gelu_pair_fast(v[3], v[3], d[3]);
+        __builtin_amdgcn_sched_barrier(0); gap.template at<1>(); __builtin_amdgcn_sched_barrier(0);
+        gelu_pair_fast(v[4], v[4], d[4]); gelu_pair_fast(v[5], v[5], d[5]);
+        __builtin_amdgcn_sched_barrier(0); gap.template at<2>(); __builtin_amdgcn_sched_barrier(0);
+        gelu_pair_fast(v[6], v[6], d[6]); gelu_pair_fast(v[7], v[7], d[7]);
+        __builtin_amdgcn_sched_barrier(0); gap.template at<3>(); __builtin_amdgcn_sched_barrier(0);
         if constexpr ((FL & VPU_EPI_SAVE_DGELU) != 0) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rP, off, 0, 0);
     }
     if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX)) != 0) {
@@ -248,17 +259,30 @@ __device__ __forceinline__ void k5_epi_begin(K5Ctx<TB, FL, RB>& c) {
     }
     k5_xload<FL>(c.p, c.mq, c.nq, c.lane, c.x0, 4);
 }
-template <int TB, int FL, int RB, int U>
-__device__ __forceinline__ void k5_do_unit(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[RB][4]) {
+template <int TB, int FL, int RB, int U, typename GAP = K5NoGap>
+__device__ __forceinline__ void k5_do_unit(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[RB][4], const GAP& gap = GAP()) {
     if constexpr (k5_unit_valid<RB>(U)) {
         constexpr int h = U / 8, pass = (U % 8) / 2, t = U % 2;
         const int fr = c.lane & 15, cl = k2_direct_col(c.lane);
         const int m = c.mq + h * 64 + pass * 16 + fr, n = c.nq + 32 * t + cl;
         const int off = (m < c.p.M && n < c.p.N) ? (m * c.p.ldc + n) * 2 : OOB_OFFSET;
-        k5_unit<FL>(c.rC, c.rP, acc[h * 4 + pass][2 * t], acc[h * 4 + pass][2 * t + 1], off, c.bq[t][0], c.bq[t][1],
-                    h == 0 ? c.x0.x[pass][t] : c.x1.x[pass][t]);
+        k5_unit<FL, GAP>(c.rC, c.rP, acc[h * 4 + pass][2 * t], acc[h * 4 + pass][2 * t + 1], off, c.bq[t][0], c.bq[t][1],
+                         h == 0 ? c.x0.x[pass][t] : c.x1.x[pass][t], gap);
     }
 }
+// the producer's pieces of one K-step spread over the four gaps of a GELU unit: unit slot S (0 / 1 of its interval) carries
+// pieces [S * PWP / 2, (S + 1) * PWP / 2) as 2 + 1 + 2 + 1 (PWP = 12) or 1 + 1 + 1 + 0 (PWP = 6)
+template <int TB, int FL, int RB, int PWP, int S>
+struct K5PieceGaps {
+    K5Ctx<TB, FL, RB>& c;
+    const K5Dma& d;
+    template <int G> __device__ __forceinline__ void at() const {
+        constexpr int H = PWP / 2, B0 = S * H;
+        constexpr int lo = PWP == 12 ? (G == 0 ? 0 : G == 1 ? 2 : G == 2 ? 3 : 5) : (G < 3 ? G : 3);
+        constexpr int hi = PWP == 12 ? (G == 0 ? 2 : G == 1 ? 3 : G == 2 ? 5 : 6) : (G < 3 ? G + 1 : 3);
+        k5_dma_issue<B0 + lo, B0 + hi>(c, d);
+    }
+};
 // epilogue work of interval I in two parts, so that the producer's DMA pieces can go out between them: a wave that issues
 // twelve pieces in one burst into a full vector-memory queue waits ~130 cycles per piece at the issue (in order: its vector ALU
 // work waits with it); a third of them every ~half unit keeps the queue short of full (fc1 + GELU: the producer was the slower
@@ -280,15 +304,22 @@ __device__ __forceinline__ void k5_epi_part(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)
 template <int TB, int FL, int RB, int PWP, int I>
 __device__ __forceinline__ void k5_producer_intervals(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[RB][4]) {
     const K5Dma d = k5_dma_prepare<true>(c, I);
-    k5_dma_issue<0, PWP / 3>(c, d);
-    __builtin_amdgcn_sched_barrier(0);
-    k5_epi_part<TB, FL, RB, I, 0>(c, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    k5_dma_issue<PWP / 3, 2 * PWP / 3>(c, d);
-    __builtin_amdgcn_sched_barrier(0);
-    k5_epi_part<TB, FL, RB, I, 1>(c, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    k5_dma_issue<2 * PWP / 3, PWP>(c, d);
+    constexpr int iu = I - k5_u0<FL>();
+    if constexpr ((FL & VPU_EPI_GELU) != 0 && iu >= 0 && k5_unit_valid<RB>(2 * iu) && k5_unit_valid<RB>(2 * iu + 1)) {
+        // vector-ALU-heavy units: the pieces inside them, at the rate the memory pipe takes them
+        k5_do_unit<TB, FL, RB, 2 * iu>(c, acc, K5PieceGaps<TB, FL, RB, PWP, 0>{c, d});
+        k5_do_unit<TB, FL, RB, 2 * iu + 1>(c, acc, K5PieceGaps<TB, FL, RB, PWP, 1>{c, d});
+    } else {
+        k5_dma_issue<0, PWP / 3>(c, d);
+        __builtin_amdgcn_sched_barrier(0);
+        k5_epi_part<TB, FL, RB, I, 0>(c, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        k5_dma_issue<PWP / 3, 2 * PWP / 3>(c, d);
+        __builtin_amdgcn_sched_barrier(0);
+        k5_epi_part<TB, FL, RB, I, 1>(c, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        k5_dma_issue<2 * PWP / 3, PWP>(c, d);
+    }
     // (interval 0 with all pieces from the producer: nothing of this wave is older than this interval)
     if constexpr (I > 0 || PWP < K5_PW) k5_wait_vm<PWP + k5_eops<FL, RB>(I)>();
     k5_barrier();
