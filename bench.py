@@ -368,11 +368,14 @@ def main():
     # the backward tape: there the step is replayed as a CHAIN of graphs -- zero-grad + forward + losses, then the backward
     # cut wherever the engine reports a finished gradient range (pvpuformer_amd/graphs.py), the reducer's collectives
     # launched by the host between two segments, Adam host-enqueued -- ~25 launches per step instead of ~530.
-    # (N > 1 default: host-enqueued.  The chain has run under RCCL at world size 1 and over two gloo ranks only, and on a
-    # host that keeps up it is not faster -- 14.23 vs 14.08 ms per step under the forced reducer, HISTORY.md section 6 --:
-    # VPU_BENCH_DP_GRAPH=1 selects it once it has been seen on a multi-GPU node.)
+    # (N > 1 default, round 6: the CHAIN.  Decided on what one GPU can show -- the forced reducer at world size 1 with the
+    # process pinned to 32 host threads, what one of 8 ranks gets (tools/dp_mode_job.sh): eager 15.8 ms per
+    # step with 13.9 ms of it host enqueue time -- host-bound before any collective -- against 14.3 ms and 0.63 ms of host time for
+    # the chain at B = 12; level at B = 4 (8.66 / 8.68 ms) with 7.6 against 0.64 ms of host time.  The chain has run under RCCL at
+    # world size 1 and over two gloo ranks; a rank whose capture fails stays host-enqueued (same kernels, same collectives, same
+    # order).  VPU_BENCH_DP_GRAPH=0 selects the eager loop.)
     use_graph = world == 1 and os.environ.get("VPU_BENCH_GRAPH", "1") != "0"
-    use_chain = world > 1 and os.environ.get("VPU_BENCH_DP_GRAPH", "0") == "1"
+    use_chain = world > 1 and os.environ.get("VPU_BENCH_DP_GRAPH", "1") != "0"
     opt = FusedAdam(model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, capturable=use_graph)
     red = GradReducer(eng.gflat, wire=os.environ.get("VPU_DIST_WIRE", "fp32"))   # VPU_DIST_WIRE=bf16: half the bytes per link
     eng.grad_ready_hook = red.ready if red.enabled else None

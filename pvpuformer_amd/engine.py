@@ -192,6 +192,7 @@ class Engine:
         self._frozen = set()   # data_ptr of buffers a queued / side-stream GEMM still reads: no in-place writes
         self._token_rows = 0
         self.grad_ready_hook = None   # callable(lo, hi): gflat[lo:hi] is final for this backward (data-parallel reducer)
+        self.report_lag = max(1, int(os.environ.get("VPU_DIST_REPORT_LAG", "2")))   # blocks a finished range may wait for its launches to fill
 
     # ------------------------------------------------------------------------------------------ parameters
     def bind(self, named_params):
@@ -1478,10 +1479,16 @@ class Engine:
                         self.flush_wgrads(k)
                     self._pending_reports.append((lo, hi))
                     self._report_ready()
-                    if len(self._pending_reports) >= 2:
-                        # the oldest range has waited a whole block: what still writes into it goes now -- the neck's small
-                        # long-reduction gradients wait to ride in a block's launch, and where the blocks' launches are whole
-                        # rounds already (D = 1024: 768 tiles) there is never room for them before the end of backward
+                    if len(self._pending_reports) > self.report_lag:
+                        # the oldest range has waited ``report_lag`` whole blocks: what still writes into it goes now -- the
+                        # neck's small long-reduction gradients wait to ride in a block's launch, and where the blocks'
+                        # launches are whole rounds already (D = 1024: 768 tiles) there is never room for them before the end
+                        # of backward.  (Round 6: two blocks, not one.  A ViT-B block's four gradients are 108 tiles of
+                        # 256 x 256; flushed block by block they left in 15 launches of 42 % of a round per step -- 42.6 ms of
+                        # K4P kernels per 13 steps against 22.5 without a reducer, +1.55 ms per step, the whole cost of
+                        # running under the reducer at world size 1 (tools/dp_stats_ab.sh).  With two blocks of slack the
+                        # full-round rule launches 240 tiles before the flush is due; a range reaches its collective one
+                        # block later.)
                         lo0, hi0 = self._pending_reports[0]
                         off_of = lambda t: t[1] if isinstance(t, tuple) else None
                         late = [e for e in self._wq

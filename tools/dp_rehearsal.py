@@ -98,6 +98,13 @@ def main():
         dt = time.perf_counter() - t0
         return dt / steps * 1e3, t_host / steps * 1e3, sum(1 for g, _ in seg.segments if g is not None)
 
+    only = os.environ.get("DP_ONLY")        # "none" / "reducer": ONE configuration, eager, for a kernel-trace A/B (tools/dp_stats_ab.sh)
+    if only:
+        red1 = GradReducer(eng.gflat, force=True, reserve_cus=int(os.environ.get("DP_RESERVE", "16"))) if only == "reducer" else None
+        print(only, round(run(red1), 3), "ms per step")
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     res = {"what": f"ViT-B 448 bs={B} bf16 training step on ONE MI355X, eager launch, RCCL world size 1", "steps": steps,
            "NCCL_MAX_NCHANNELS": channels, "host_threads_allowed": len(os.sched_getaffinity(0))}
     res["ms_no_reducer"] = round(run(None), 3)

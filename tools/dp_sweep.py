@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """One-shot sweep for the FIRST multi-GPU node this build sees: the two knobs of the data-parallel step that could only be
 guessed on one GPU -- the CUs the persistent GEMM grids leave to RCCL (VPU_DIST_RESERVE_CUS) and RCCL's channel cap
-(NCCL_MAX_NCHANNELS) -- plus the wire format, the split optimizer step and the graph chain.  Every cell is one
+(NCCL_MAX_NCHANNELS) -- plus the wire format, the split optimizer step, the eager loop against the graph chain and the
+report lag of the gradient ranges.  Every cell is one
 ``python bench.py --gpus N`` (bench.py starts its own ranks); the table shows images/s, exposed communication and the
 single-GPU-relative efficiency.
 
@@ -44,8 +45,12 @@ def main():
     print(f"1 GPU: {one} images/s")
     rows = []
     grid = list(itertools.product((0, 8, 16, 32), (None, 8, 16, 32)))       # (reserved CUs, channel cap; None = RCCL's default)
+    # (round 6: the graph chain is bench.py's default at N > 1 and a finished gradient range may wait two blocks for its weight-
+    # gradient launches to fill, VPU_DIST_REPORT_LAG = 2: both decided on one GPU -- the eager loop and the other lags are cells here)
     extra = [] if a.quick else [({"VPU_DIST_WIRE": "bf16"}, "bf16 wire"), ({"VPU_DIST_SPLIT_ADAM": 2}, "split Adam"),
-                                ({"VPU_BENCH_DP_GRAPH": 1}, "graph chain")]
+                                ({"VPU_BENCH_DP_GRAPH": 0}, "eager loop"), ({"VPU_DIST_REPORT_LAG": 1}, "report lag 1"),
+                                ({"VPU_DIST_REPORT_LAG": 3}, "report lag 3"),
+                                ({"VPU_DIST_REPORT_LAG": 3, "VPU_DIST_WIRE": "bf16"}, "report lag 3 + bf16 wire")]
     for res, ch in grid:
         # (no cap given: bench.py's configure_rccl_env() caps the channels at the reserve; reserve 0 leaves RCCL's default)
         env = {"VPU_DIST_RESERVE_CUS": res, "NCCL_MAX_NCHANNELS": ch}
