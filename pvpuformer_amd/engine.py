@@ -119,18 +119,18 @@ class Engine:
         self.shadow_valid = False
         self._const_ready = False
         import os
-        self.use_flash = os.environ.get("VPU_FLASH_ATTN", "1") != "0"   # 0: unfused S/P path (also used for fp32 / other head dims)
+        self.use_flash = True    # False: the unfused S / P path (what fp32 and other head dimensions take anyway); an attribute, no environment knob
         # weight gradients are only consumed by the optimizer: VPU_WGRAD_STREAM=1 runs them on a second HIP stream.  Off by
         # default: since the GEMM launches became persistent (every launch fills the chip) the two streams only share the
         # CUs, and the fork/join events cost host time (measured: 19.45 ms/step on one stream, 19.9 ms on two)
         self.use_side = os.environ.get("VPU_WGRAD_STREAM", "0") == "1"
         self.side = None
-        self.fuse_ln_pe = os.environ.get("VPU_LN_PE", "1") != "0"   # LayerNorm + position-embedding add in one launch (neck)
+        self.fuse_ln_pe = True   # LayerNorm + position-embedding add in one launch (neck); attribute for the tests
         # weight-gradient GEMMs are queued and launched in groups (ops.gemm_grouped): the four of a ViT block are 432
         # full-K tiles -- one round of the persistent grid, no split-K slabs, no reduce launches --, the neck's 576-row
-        # ones (9 K-tiles each) go eight to a launch.  VPU_WGRAD_GROUP=0 launches each one on its own.
-        self.group_wgrad = os.environ.get("VPU_WGRAD_GROUP", "1") != "0"
-        self.ride_wgrad = os.environ.get("VPU_WGRAD_RIDE", "1") != "0"      # small long-reduction gradients ride with the big groups
+        # ones (9 K-tiles each) go eight to a launch.  ``group_wgrad`` = False launches each one on its own.
+        self.group_wgrad = True    # (the settled A/B switches of rounds 2-5 are attributes: the tests flip them, no environment knob)
+        self.ride_wgrad = True      # small long-reduction gradients ride with the big groups
         self.wgrad_fill = 0.8     # a big group is launched once its rounds of 256 tiles are this full
         # VPU_WGRAD_PACK (default 1): the queued long-reduction gradients leave in launches of ONE FULL ROUND of 256-row x
         # 128-column tiles: every tile of a reduction length costs the same (147 K-tiles at 9408 rows), so a launch takes as
@@ -158,18 +158,18 @@ class Engine:
         self.k4_wgrad = (k3 & 8) != 0          # 256 x 256 tiles, one workgroup per CU
         self.wgrad_round = 256 if (self.k4_wgrad or not self.k3_wgrad) else 512
         self.wgrad_tn = 256 if self.k4_wgrad else 128      # tile width of the long-reduction weight-gradient launches
-        # VPU_WGRAD_UNIFY (default 1, with the packed queue): every weight gradient over a multiple of the token rows -- the
+        # ``unify_wgrad`` (with the packed queue): every weight gradient over a multiple of the token rows -- the
         # FPN's and the head's maps: 4 x / 16 x the 9408 rows of a ViT block -- is cut into reduction slices of exactly the
         # token rows, given to the launch as BATCH ENTRIES of one problem (one descriptor), each writing its own fp32 slab; the
         # slices are tiles of the same cost as a ViT block's, so they pack into the same launches, and one batched column
         # sum adds the slabs to the gradients.  Before: a split-K launch + a reduce launch per problem, most of them at the
         # end of backward with the chip a quarter full (0.47 ms per step).
-        self.unify_wgrad = os.environ.get("VPU_WGRAD_UNIFY", "1") != "0"
-        self.lazy_zero = os.environ.get("VPU_LAZY_ZERO", "1") != "0"   # zero_grad(lazy=True) honoured (A/B switch)
+        self.unify_wgrad = True
+        self.lazy_zero = True      # zero_grad(lazy=True) honoured
         # round 5 launch fusions (the three gates in one launch per pass, the derived operands in one batched cast, the q_out
-        # gradient fan-out in one launch, conv_seg's partial sums through the batched column sums): VPU_R5_FUSED=0 runs the
+        # gradient fan-out in one launch, conv_seg's partial sums through the batched column sums): ``r5_fused`` = False runs the
         # round-4 launches instead (same-box A/B runs)
-        self.r5_fused = os.environ.get("VPU_R5_FUSED", "1") != "0"
+        self.r5_fused = True
         # split launches of the neck's prompt<->image attentions (cross_attention): ranges per long side; 1 = off
         self.xattn_split = max(1, int(os.environ.get("VPU_XATTN_SPLIT", "1")))
         # round 5: the DMA neck's prompt-token chain (~90 dependent launches of <= 108 workgroups each) on its own HIP stream
@@ -179,12 +179,12 @@ class Engine:
         self._in_lanes = False    # backward is inside the two-lane section: the weight-gradient queue only collects
         # fused bias column sums of the packed K4 launches DISTRIBUTED over a problem's column tiles (vpu_hip.h: cs_tn): with
         # the classic form the tiles of the first column block -- a third of a ViT block's -- run 17 % longer than the
-        # others, and a packed launch is one round of tiles (tools/k4_drift.py).  VPU_WGRAD_DCS=0: classic form (A/B runs)
-        self.dist_colsum = os.environ.get("VPU_WGRAD_DCS", "1") != "0"
+        # others, and a packed launch is one round of tiles (tools/k4_drift.py).  ``dist_colsum`` = False: classic form
+        self.dist_colsum = True
         self._pack_seen, self._pack_total = {}, {}     # reduction length -> tiles queued in this / the previous backward pass
         self._pending_reports, self._reporting = [], False    # gradient ranges whose marker has been passed but not reported yet
-        self.group_tiles = int(os.environ.get("VPU_GROUP_TILES", "256"))     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
-        self.split_wgrad = os.environ.get("VPU_WGRAD_SLICED", "1") != "0"   # _wgrad_sliced for few-tile long reductions
+        self.group_tiles = 256     # flush_group: largest problem (output tiles) grouped (256: the 9408-row K / V projections of the neck share one launch, +0.7 % step rate)
+        self.split_wgrad = True   # _wgrad_sliced for few-tile long reductions
         self._wq = []          # queued weight gradients: (gemm args, gemm kwargs, output tiles, reduction length)
         self._csq = []         # queued column sums of norm-layer gradient partials: (part, out, rows, cols)
         self._gq = []          # deferred small GEMMs of one group (an attention's q / k / v projections or their dgrads)
@@ -694,7 +694,7 @@ class Engine:
         """y = LN(x).  ``pe`` [pe_rows, C]: also yy = y + pe[row % pe_rows] from the same launch -- the position-embedding
         add of the DMA neck (transformer.py:439-457) -- and (y, yy) is returned; ``pe_var``: the Var behind ``pe`` when it
         takes a gradient (the prompt tokens).  The backward takes the two outputs' gradients in one launch."""
-        if pe is not None and not self.fuse_ln_pe:       # VPU_LN_PE=0: the separate add launch (A/B runs)
+        if pe is not None and not self.fuse_ln_pe:       # ``fuse_ln_pe`` = False: the separate add launch
             y = self.layernorm(x, prefix, rows, Cdim, eps)
             return y, self.add_pe(y, pe, rows * Cdim, pe_rows * Cdim, pe_var=pe_var)
         y = Var(self._new(rows, Cdim))
@@ -1245,7 +1245,7 @@ class Engine:
         # (vpu_gate_bwd_n: dx summed in fp32 over the three gates, rounded once) instead of nine / six launches
         maps = [xr]
         ng = len(hs) if self.r5_fused else 0
-        for qi, ki in (() if self.r5_fused else hs):       # (VPU_R5_FUSED=0: one gate at a time, three launches each way)
+        for qi, ki in (() if self.r5_fused else hs):       # (``r5_fused`` = False: one gate at a time, three launches each way)
             cg, sg = self._new(B, D, dtype=torch.float32), self._new(B, NT, dtype=torch.float32)
             aq, ac = self._new(B, D, dtype=torch.int32), self._new(B, NT, dtype=torch.int32)
             ops.gate_stats(qi.t, ki.t, cg, aq, sg, ac, B, nq, NT, D)

@@ -20,9 +20,9 @@ from scipy import ndimage
 _EIGHT = np.ones((3, 3), dtype=bool)
 # The connected components of cal_box on the GPU too (ops.cc_roots + ops.cc_table: union-find labels, then one reduction
 # pass to a per-component size / bounding-box table), so that no mask crosses to the host.  Identical results (tests).
-# VPU_SIM_GPU_CC=0: one uint8 mask per sample goes to the host and is labelled there (scipy) inside its bounding box.
+# GPU_CC = False: one uint8 mask per sample goes to the host and is labelled there (scipy) inside its bounding box.
 import os as _os
-GPU_CC = _os.environ.get("VPU_SIM_GPU_CC", "1") == "1"
+GPU_CC = True      # connected components on the device (module attribute: tests compare against the host path)
 
 
 def distance_transform(mask_u8):
@@ -354,7 +354,7 @@ def _get_next_promts_gpu(pred, gt, points, state, pred_thresh, as_allmask, jitte
         chosen = torch.where(sel[:, None, None], fn, fp).to(torch.uint8)
         if GPU_CC:
             bbox = _kept_region_boxes(chosen)
-        else:   # VPU_SIM_GPU_CC=0: one uint8 mask per sample to the host, labelled there inside its bounding box
+        else:   # GPU_CC = False: one uint8 mask per sample to the host, labelled there inside its bounding box
             bbox = []
             for m in chosen.cpu().numpy():
                 region = max_connected_regions(m > 0) == 1

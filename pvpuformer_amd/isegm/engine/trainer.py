@@ -57,12 +57,12 @@ class VPUTrainStep:
         self.as_allmask, self.lw = as_allmask, loss_weights
         # The prompt simulators read results back (component sizes, distance maxima, the chosen pixel): on the training
         # stream every such read waits for everything queued before it -- the previous step's backward, or this
-        # iteration's.  They run on a stream of their own instead (VPU_SIM_STREAM=0: on the training stream): the
+        # iteration's.  They run on a stream of their own instead (``use_sim_stream`` = False: on the training stream): the
         # iteration-0 box simulation depends on the batch only, the later ones on the forward output only, so the host
         # waits for the few small simulator kernels and keeps the training stream fed meanwhile.
         import os
         self.sim_stream = None
-        self.use_sim_stream = os.environ.get("VPU_SIM_STREAM", "1") != "0"
+        self.use_sim_stream = True      # (attribute: the simulators on their own stream; settled A/B, no environment knob)
         # One click iteration = ~530 kernel launches the host needs 7-9 ms to enqueue -- beside the simulators' host work
         # that is more than the 13-14 ms the GPU needs for them.  The iteration is therefore captured once per (prompt type,
         # iteration number, batch geometry) as hipGraphs over static input buffers -- forward + losses, and backward, so that

@@ -610,7 +610,7 @@ def test_lazy_zero_grad_at_bench_shapes(golden_dir, B, variant):
     (`_split_entry` cuts entries that carry distributed column sums), with a reducer hook attached (the `late` flushes) -- and
     on the ones odd batches take: B = 6 / 3 (M = 4704 / 2352 rows: M % 64 != 0, no distributed column sums, the entries
     eligible for `_wgrad_sliced`, whose slab add ACCUMULATES and once added the new gradient to the previous step's) and
-    VPU_WGRAD_DCS=0.  NaN in every gradient word beforehand; the lazily zeroed step must equal the eagerly zeroed one (bit
+    ``dist_colsum`` off.  NaN in every gradient word beforehand; the lazily zeroed step must equal the eagerly zeroed one (bit
     for bit where both take the same launches)."""
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
     fx, cfg, sd, model, batch, img4 = _setup(golden_dir, "vitb.npz", "bf16")
