@@ -1571,7 +1571,7 @@ extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
         return VPU_OK;
     }
     vpu_set_error("vpu_attn_set_option: known options: lean (-1 environment default VPU_ATTN_LEAN, 0 round-1 step kernels, 1 lean kernels), "
-                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems with one workgroup per CU, 2 in key passes with four)");
+                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems with one workgroup per CU, 2 in key passes with three)");
     return VPU_ERR_ARG;
 }
 

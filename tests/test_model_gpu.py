@@ -1458,15 +1458,19 @@ def test_vitl_width_bf16_close_to_reference(golden_dir):
     _within("vitl8 grad norms " + max(rel, key=rel.get), max(rel.values()), 0.1)      # measured 6.0e-2
 
 
-@pytest.mark.parametrize("fixture,B", [("vitb.npz", 12), ("vitl.npz", 8)])
-def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir, fixture, B):
+@pytest.mark.parametrize("fixture,B,lag", [("vitb.npz", 12, 1), ("vitl.npz", 8, 1), ("vitb.npz", 12, 2), ("vitl.npz", 8, 2)])
+def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir, fixture, B, lag):
     """Data parallel at the benchmark's shapes (ViT-B, B = 12 and ViT-L, B = 8 -- config 4's per-GPU batch, where the blocks'
     launches are whole rounds and the neck's small gradients never find room to ride: they once held every range back to the
     end --, bf16, a reducer attached): the exchange can only overlap the
     backward if the ranges are reported WHILE it runs -- one per ViT block, each at most two blocks after its marker,
     although the blocks' weight gradients are packed into full rounds across blocks and the head's long reductions would
     otherwise sit in the queue until the end (every range was once reported after the last kernel).  Counted in launches
-    of the library.  The same backward captured as a chain of hipGraphs cut at those reports gives the same gradients."""
+    of the library.  The same backward captured as a chain of hipGraphs cut at those reports gives the same gradients.
+    ``lag`` = Engine.report_lag, the blocks a finished range may wait for the launches that write into it to FILL: 1 (rounds 3-5:
+    a range leaves at the next block's marker, and a ViT-B block's 108 tiles of 256 x 256 leave alone, 42 % of a round: +1.55 ms
+    of K4P kernels per step under a reducer) or 2 (round 6's default: two blocks share a launch; the ranges leave in pairs, the
+    last two blocks' with the end of backward)."""
     from pvpuformer_amd import _lib
     from pvpuformer_amd.graphs import SegmentedBackward
     from pvpuformer_amd.isegm.engine.trainer import vpu_step_losses
@@ -1478,6 +1482,7 @@ def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir, fixture,
     model.head.dropout_ratio = 0.0
     eng = model._ensure_engine()
     eng.refresh_weights()
+    lag_was, eng.report_lag = eng.report_lag, lag
 
     class Red:
         reserve_cus = 16
@@ -1516,21 +1521,24 @@ def test_bench_shape_gradient_ranges_go_out_during_backward(golden_dir, fixture,
     assert len(seen) == cfg["depth"] + 2 and seen[0][1] == eng.total and seen[-1][0] == 0
     at = [c for _, _, c in seen]
     # head + neck (30 % of the bytes) once block 11's packed launch has taken the neck's riders along; then a block each
+    # (lag 2: two blocks each)
     assert at[0] < 0.7 * total, (at, total)
-    assert at[len(at) // 2] < 0.9 * total and len(set(at)) >= cfg["depth"] - 1, (at, total)
+    points = cfg["depth"] - 1 if lag == 1 else cfg["depth"] // 2
+    assert at[len(at) // 2] < 0.9 * total and len(set(at)) >= points, (at, total)
     late = sum(hi - lo for lo, hi, c in seen if c >= total - 1)
-    assert late < 0.1 * eng.total, f"{late} of {eng.total} gradient elements were reported only when backward had ended"
+    assert late < (0.1 if lag == 1 else 0.2) * eng.total, f"{late} of {eng.total} gradient elements were reported only when backward had ended"
     # the chain of graphs cut at those reports: same ranges at the same places, same gradients
     d_inst, d_sim = head_part()
     seg = SegmentedBackward.capture(eng, lambda: eng.backward(d_inst, None, d_sim_low=d_sim), hook_owner=red)
     assert eng.grad_ready_hook is None and _lib.call is orig
     assert [r for _, rs in seg.segments for r in rs] == [(lo, hi) for lo, hi, _ in seen]
-    assert sum(1 for g, _ in seg.segments if g is not None) >= cfg["depth"] - 2
+    assert sum(1 for g, _ in seg.segments if g is not None) >= (cfg["depth"] - 2 if lag == 1 else cfg["depth"] // 2 - 1)
     got = []
     seg.replay(lambda lo, hi: got.append((lo, hi)))
     torch.cuda.synchronize()
     assert got == [(lo, hi) for lo, hi, _ in seen]
     assert torch.equal(eng.gflat, eager)
+    eng.report_lag = lag_was
 
 
 @pytest.mark.parametrize("B", [12, 4])
