@@ -28,6 +28,11 @@
 
 namespace {
 
+// cache policy of the epilogue's streamed traffic (the residual / aux operand is read once, the output written once): 0 = default,
+// 2 = non-temporal -- -DVPU_K5_NT=2 in an experiment build (csrc/build.sh x) for a same-box A/B
+#ifndef VPU_K5_NT
+#define VPU_K5_NT 0
+#endif
 constexpr int K5_STAGE = 3 * TILE_BYTES;          // A rows 0-127 | A rows 128-255 (of 16 RB each) | B 128 columns
 constexpr int K5_PW = 12;                         // DMA pieces (1 KiB) per producer wave per stage: 48 / 4 waves
 constexpr int K5_BIAS_LDS = 2 * 8 * 256;          // [tile parity of a group][wave]: 64 fp32 bias values per wave
@@ -128,7 +133,7 @@ __device__ __forceinline__ void k5_xload(const vpu_gemm_desc& p, const int mrow0
             for (int t = 0; t < 2; ++t) {
                 const int m = mrow0 + pass * 16 + fr, n = ncol0 + 32 * t + cl;
                 const int off = (pass < npass && m < p.M && n < p.N) ? (m * ld + n) * 2 : OOB_OFFSET;
-                q.x[pass][t] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+                q.x[pass][t] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, VPU_K5_NT);
             }
     }
 }
@@ -163,7 +168,7 @@ __device__ __forceinline__ void k5_unit(const __amdgpu_buffer_rsrc_t rC, const _
         __builtin_amdgcn_sched_barrier(0); gap.template at<2>(); __builtin_amdgcn_sched_barrier(0);
         gelu_pair_fast(v[6], v[6], d[6]); gelu_pair_fast(v[7], v[7], d[7]);
         __builtin_amdgcn_sched_barrier(0); gap.template at<3>(); __builtin_amdgcn_sched_barrier(0);
-        if constexpr ((FL & VPU_EPI_SAVE_DGELU) != 0) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rP, off, 0, 0);
+        if constexpr ((FL & VPU_EPI_SAVE_DGELU) != 0) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rP, off, 0, VPU_K5_NT);
     }
     if constexpr ((FL & (VPU_EPI_RESID | VPU_EPI_MULAUX)) != 0) {
         const bf16x8_t e = __builtin_bit_cast(bf16x8_t, xv);
@@ -174,7 +179,7 @@ __device__ __forceinline__ void k5_unit(const __amdgpu_buffer_rsrc_t rC, const _
             else v[j] += x;
         }
     }
-    __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rC, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rC, off, 0, VPU_K5_NT);
 }
 
 // compile-time bookkeeping of the epilogue schedule: unit u = (half, row block, column half) = (u / 8, (u % 8) / 2, u % 2);
