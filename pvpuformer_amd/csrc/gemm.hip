@@ -2708,7 +2708,9 @@ extern "C" int vpu_gemm(const vpu_gemm_desc* d, void* stream) {
                             const int64_t c5 = cost(32 * rb, 128);
                             if (c5 < best5) { best5 = c5; rb5 = rb; }
                         }
-                        const bool gelu5 = (f & VPU_EPI_GELU) != 0;
+                        // (GELU: up to 6272 rows K5 wins -- 3136 rows 34.3 -> 30.0 us, ViT-L's 6272 x 4096 x 1024 74.9 -> 71.1 --, at 9408 rows
+                        // it is level with the 256-column K2 form, at ViT-H's 12288 rows 3.6 % behind)
+                        const bool gelu5 = (f & VPU_EPI_GELU) != 0 && d->M > 6272;
                         if (k5 == 2 || !gelu5) {
                             const int r5 = vpu_k5_launch(d, rb5, ncu, vec2, stream, g_last_kernel, sizeof(g_last_kernel));
                             if (r5 < 0) return r5;
