@@ -179,7 +179,11 @@ int vpu_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  int32_t ldo, int32_t ldg, float scale, void* stream);
 /* Kernel-selection knob of the attention entry points: "lean" = 1 (default) runs the round-2 kernels (buffer-load staging
  * with hardware zero fill, thresholded running maximum, two tiles per wave), 0 the round-1 32-key-step kernels,
- * -1 = environment default (VPU_ATTN_LEAN).  Same results within bf16 rounding; both are covered by the tests. */
+ * -1 = environment default (VPU_ATTN_LEAN).  Same results within bf16 rounding; both are covered by the tests.
+ * "onepass": the backward of window-sized self-attention (head dim 64, n <= 256 keys = queries): 0 the dQ and dK / dV kernels,
+ * 1 one workgroup per (window, head) problem, 2 key passes with three workgroups per CU, 3 (default) persistent workgroups that
+ * fetch the next problem by LDS-DMA while they compute the current one (65 <= n <= 224; form 1 elsewhere; forms 1 and 3 give the
+ * same bits), -1 = environment default (VPU_ATTN_ONEPASS). */
 int vpu_attn_set_option(const char* name, int32_t value);
 /* Name(s), as rocprofv3 prints them and separated by one space, of the kernel instantiation(s) the calling host thread's
  * last vpu_(x)attn_fwd / vpu_(x)attn_bwd call launched (the backward launches a dQ and a dK/dV kernel).  "" before the

@@ -1003,9 +1003,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_lean_kernel(const AttnAr
 // too (two-way bank conflicts there instead of none: the LDS is not what bounds this kernel).
 constexpr int WIN_MAX_KB = 8;                                   // 32-row blocks: n <= 256
 constexpr int WIN_ROWS = WIN_MAX_KB * 32;
-constexpr int WIN_LDS_M = WIN_ROWS * 64 * 2;                    // one [256][64] bf16 image
-constexpr int WIN_LDS_S = 2 * (WIN_ROWS + 16) * 32 * 2;         // two [256 keys + 16 spare rows][32 queries] dS images
-constexpr int WIN_LDS = 3 * WIN_LDS_M + WIN_LDS_S + 2 * WIN_ROWS * 4;
+// LDS of a problem of NKB 32-row blocks: Q, dO, K images [32 NKB][64] bf16, two dS images [32 NKB keys + 16 spare rows][32 queries],
+// -delta * scale and -lse * log2 e per query
+constexpr int win_lds(int nkb) { return 3 * (32 * nkb * 64 * 2) + 2 * ((32 * nkb + 16) * 64) + 2 * (32 * nkb) * 4; }
 
 // dS image [key][32 queries]: 64-byte rows of eight 8-byte units.  unit ^= {bit 2: row bit 2, bit 1: row bit 3, bit 0: row bit
 // 1}: the 16 consecutive rows of a ds_write_b64 lane group fill 16 distinct 8-byte slots of the 128-byte bank row, the 8
@@ -1027,16 +1027,40 @@ template <int HD> __device__ __forceinline__ bf16x8_t frag_rc_tr(const char* lds
     const uint4 v = *reinterpret_cast<const uint4*>(lds + tr_off<HD>(row16 + (lane & 15), 2 * (ks * 4 + (lane >> 4))));
     return __builtin_bit_cast(bf16x8_t, v);
 }
+// frag_rc_tr as an ext-vector load (through HIP's uint4 struct the load carries TBAA info, and hipcc then puts s_waitcnt
+// vmcnt(0) in front of it while an LDS-DMA is pending)
+__device__ __forceinline__ bf16x8_t frag_rc_trv(const char* lds, int row16, int ks, int lane) {
+    const u32x4v v = *reinterpret_cast<const u32x4v*>(lds + tr_off<64>(row16 + (lane & 15), 2 * (ks * 4 + (lane >> 4))));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+typedef __attribute__((address_space(3))) void* lds_vptr3;
+typedef __bf16 bf16x4w_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x4w_t pack4(const f32x4_t& a) {
+    bf16x4w_t w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = (bf16_t)a[r];
+    return w;
+}
 
+// Round 6.  The loop of the round-3 form was a chain: per 32-query block, fragment reads -> S / dP -> exp -> dS image -> barrier ->
+// transposing reads -> dV / dK -> NKB x (two transposing reads, wait, ONE dQ MFMA) behind runtime branches, 1.63 us per block for
+// 0.6 us of MFMA work (`tools/win_dbg_job.sh`: the loop 11.4 of a problem's 21.4 us).  Now NKB is a template parameter (no branch in
+// the dQ sum: all its reads are issued with the dV / dK operands right after the barrier), the scores of block i + 1 share the basic
+// block with the gradients of block i (independent MFMA chains and the exp / conversion arithmetic for the scheduler to interleave),
+// and all three gradients leave through SWAPPED MFMA operands: a lane then holds four consecutive head-dim columns of one row, one
+// 8-byte store instead of four 2-byte ones (64 -> 16 store instructions per wave for dK / dV, 4 -> 1 per block for dQ).
+template <int NKB>
 __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
-    constexpr int HD = 64, KS = 2, DT = 4, NP = WIN_ROWS * 8 / 512;   // 16-byte pieces per thread and matrix
+    constexpr int HD = 64, KS = 2, DT = 4, ROWS = 32 * NKB, NP = (NKB + 1) / 2;   // NP: 16-byte pieces per thread and matrix
+    constexpr int LDS_M = ROWS * HD * 2, LDS_S1 = (ROWS + 16) * 64;
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     char* const ldsQ = wlds;
-    char* const ldsO = wlds + WIN_LDS_M;      // dO
-    char* const ldsK = wlds + 2 * WIN_LDS_M;
-    char* const ldsS = wlds + 3 * WIN_LDS_M;  // [2][keys][32 queries] bf16, transposing-read layout (HD = 32 image)
-    float* const ldsD = reinterpret_cast<float*>(ldsS + WIN_LDS_S);   // -delta * scale per query
-    float* const ldsL = ldsD + WIN_ROWS;                              // -lse * log2 e per query
+    char* const ldsO = wlds + LDS_M;          // dO
+    char* const ldsK = wlds + 2 * LDS_M;
+    char* const ldsS = wlds + 3 * LDS_M;      // [2][keys][32 queries] bf16, transposing-read layout
+    float* const ldsD = reinterpret_cast<float*>(ldsS + 2 * LDS_S1);  // -delta * scale per query
+    float* const ldsL = ldsD + ROWS;                                  // -lse * log2 e per query
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.x, bw = bh / a.H, h = bh % a.H, n = a.nq;
     const int64_t rb = (int64_t)bw * n;
@@ -1046,11 +1070,14 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
     const bf16_t* o = a.o + rb * a.ldo + h * HD;
     const bf16_t* d_o = a.d_o + rb * a.ldo + h * HD;
     const float sc2 = a.scale * LOG2E;
-    const int NT = (n + 15) >> 4, NKB = (NT + 1) >> 1, nch = (n + CH - 1) / CH, rows = 32 * nch;
+    const int NT = (n + 15) >> 4;             // (the launcher guarantees (NT + 1) >> 1 == NKB)
     // key tiles of this wave: NT = 8 base + rem, the first rem waves take one more
     const int base = NT >> 3, rem = NT & 7;
     const int nu = base + (wave < rem ? 1 : 0), tile0 = wave * base + (wave < rem ? wave : rem);
     const int my_t = wave >> 2, my_dt = wave & 3;     // this wave's tile of a block's dQ: queries 16 my_t.., columns 16 my_dt..
+#ifdef VPU_WIN_STAMPS
+    const unsigned t_start = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     // ---- prologue: every global load of the problem is requested before the first wait
     bf16x8_t kf[2][KS], vf[2][KS];
 #pragma unroll
@@ -1068,21 +1095,21 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = row0 + 64 * i;
-            const bool live = row < rows;
+            const bool live = row < ROWS;
             pq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, live ? (row * a.ldq + ch * 8) * 2 : 0x40000000, 0, 0);
             pk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, live ? (row * a.ldk + ch * 8) * 2 : 0x40000000, 0, 0);
             pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsG, live ? (row * a.ldo + ch * 8) * 2 : 0x40000000, 0, 0);
             po[i] = __builtin_amdgcn_raw_buffer_load_b128(rsO, live ? (row * a.ldo + ch * 8) * 2 : 0x40000000, 0, 0);
         }
-        const float pl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, tid < WIN_ROWS ? tid * 4 : 0x40000000, 0, 0));
-#pragma unroll
-        for (int i = 0; i < (WIN_LDS_S / 16 + 511) / 512; ++i)
-            if (tid + i * 512 < WIN_LDS_S / 16) *reinterpret_cast<u32x4v*>(ldsS + (tid + i * 512) * 16) = (u32x4v){0u, 0u, 0u, 0u};
-        if (tid < WIN_ROWS) ldsL[tid] = -pl * LOG2E;
+        const float pl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, tid < ROWS ? tid * 4 : 0x40000000, 0, 0));
+        // the dS rows nobody writes: the odd sixteenth tile of the last 32-key block, in both images (the dQ sum reads whole blocks)
+        if ((NT & 1) && tid < 128)
+            *reinterpret_cast<u32x4v*>(ldsS + (tid >> 6) * LDS_S1 + NT * 16 * 64 + (tid & 63) * 16) = (u32x4v){0u, 0u, 0u, 0u};
+        if (tid < ROWS) ldsL[tid] = -pl * LOG2E;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = row0 + 64 * i;
-            if (row < rows) {      // (wave-uniform for whole waves: a wave covers 8 consecutive rows)
+            if (row < ROWS) {      // (wave-uniform for whole waves: a wave covers 8 consecutive rows)
                 const int off = tr_off<HD>(row, ch * 2);
                 *reinterpret_cast<u32x4v*>(ldsQ + off) = pq[i];
                 *reinterpret_cast<u32x4v*>(ldsK + off) = pk[i];
@@ -1100,115 +1127,493 @@ __global__ __launch_bounds__(512) void attn_bwd_win_kernel(const AttnArgs a) {
         }
     }
     // where this lane's dS of slot u goes: key row 16 (tile0 + u) + c of the [key][32 queries] image -- an unowned slot (the
-    // loop has no divergent branches: every wave computes two tiles, an unowned one on zero K / V) writes to spare rows
+    // loop has no divergent branches: every wave computes two tiles, an unowned one on zero K / V) writes to the spare rows
     int srow[2], smask[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int krow = (u < nu ? (tile0 + u) * 16 : WIN_ROWS) + c;
+        const int krow = (u < nu ? (tile0 + u) * 16 : ROWS) + c;
         srow[u] = krow * 64;
-        smask[u] = ds_swz(krow);          // (round 5: the conflict-free image of the pass form below; was tr_off<32>'s swizzle: 2.45 M conflict cycles per launch)
+        smask[u] = ds_swz(krow);
     }
+    // dK^T, dV^T of this wave's key tiles: [16 head-dim columns of dt][16 keys], i.e. lane (g, c): key c, columns 16 dt + 4 g + r
     f32x4_t adk[2][DT], adv[2][DT];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
     __syncthreads();                 // the images are complete
-    bf16x8_t ktf[WIN_MAX_KB];        // K[32 keys of block kb][16 columns of my_dt] as the B operand of the dQ product
+    bf16x8_t ktf[NKB];               // K[32 keys of block kb][16 columns of my_dt]: the transposed operand of the dQ product
 #pragma unroll
-    for (int kb = 0; kb < WIN_MAX_KB; ++kb)
-        if (kb < NKB) ktf[kb] = frag_tr_perm<HD>(ldsK + kb * 32 * HD * 2, my_dt, lane);
-    // dQ tile of block j from the dS image of that block
-    auto dq_block = [&](int j) {
-        const char* sS = ldsS + (j & 1) * (WIN_LDS_S / 2);
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < WIN_MAX_KB; ++kb)
-            if (kb < NKB) {
-                const bf16x8_t af = frag_ds(sS + kb * 32 * 64, my_t, lane);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ktf[kb], acc, 0, 0, 0);
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = j * CH + 16 * my_t + 4 * g + r;
-            if (qq < n) a.dq[(rb + qq) * a.ldgq + h * HD + 16 * my_dt + c] = (bf16_t)acc[r];
-        }
-    };
-    for (int i = 0; i < nch; ++i) {
-        const int b = i & 1, qc = i * CH;
+    for (int kb = 0; kb < NKB; ++kb) ktf[kb] = frag_tr_perm<HD>(ldsK + kb * 32 * HD * 2, my_dt, lane);
+    // scores of query block i: P and dS as MFMA operands for this wave's key tiles, dS also into the block's image
+    auto scores = [&](int i, bf16x8_t (&pf)[2], bf16x8_t (&dsf)[2]) {
+        const int qc = i * CH;
         const char* sQ = ldsQ + qc * HD * 2;
         const char* sO = ldsO + qc * HD * 2;
-        char* const sS = ldsS + b * (WIN_LDS_S / 2);
-        bf16x8_t pf[2], dsf[2];
-        {
-            f32x4_t P[2][2], dS[2][2];
+        char* const sS = ldsS + (i & 1) * LDS_S1;
+        f32x4_t P[2][2], dS[2][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const f32x4_t nl2 = *reinterpret_cast<const f32x4_t*>(ldsL + qc + 16 * t + 4 * g);
-                const f32x4_t nds = *reinterpret_cast<const f32x4_t*>(ldsD + qc + 16 * t + 4 * g);
-                f32x4_t s[2], dp[2];
+        for (int t = 0; t < 2; ++t) {
+            const f32x4_t nl2 = *reinterpret_cast<const f32x4_t*>(ldsL + qc + 16 * t + 4 * g);
+            const f32x4_t nds = *reinterpret_cast<const f32x4_t*>(ldsD + qc + 16 * t + 4 * g);
+            f32x4_t s[2], dp[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
+            for (int u = 0; u < 2; ++u) { s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8_t qfr = frag_rc_tr<HD>(sQ, 16 * t, ks, lane), ofr = frag_rc_tr<HD>(sO, 16 * t, ks, lane);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], s[u], 0, 0, 0);
-                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[u][ks], dp[u], 0, 0, 0);
-                    }
-                }
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t qfr = frag_rc_tr<HD>(sQ, 16 * t, ks, lane), ofr = frag_rc_tr<HD>(sO, 16 * t, ks, lane);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {   // element [query = qc + 16 t + 4 g + r][key = 16 (tile0 + u) + c]
-                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sc2, nl2[r]));
-                            P[u][t][r] = p;
-                            dS[u][t][r] = p * __builtin_fmaf(dp[u][r], a.scale, nds[r]);
-                        }
-                        // this lane's four queries of key row 16 (tile0 + u) + c: one 8-byte unit of the [key][query] image
-                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                        bf16x4_t w4;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) w4[r] = (bf16_t)dS[u][t][r];
-                        *reinterpret_cast<bf16x4_t*>(sS + srow[u] + ((4 * t + g) ^ smask[u]) * 8) = w4;
-                    }
+                    s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], s[u], 0, 0, 0);
+                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[u][ks], dp[u], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { pf[u] = pack_pair(P[u][0], P[u][1]); dsf[u] = pack_pair(dS[u][0], dS[u][1]); }
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // element [query = qc + 16 t + 4 g + r][key = 16 (tile0 + u) + c]
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], sc2, nl2[r]));
+                    P[u][t][r] = p;
+                    dS[u][t][r] = p * __builtin_fmaf(dp[u][r], a.scale, nds[r]);
+                }
+                // this lane's four queries of key row 16 (tile0 + u) + c: one 8-byte unit of the [key][query] image
+                *reinterpret_cast<bf16x4w_t*>(sS + srow[u] + ((4 * t + g) ^ smask[u]) * 8) = pack4(dS[u][t]);
+            }
         }
-        __syncthreads();     // the dS image of block i is complete (and everybody has finished reading the image of block i - 1)
-        // everything that does not feed the barrier comes after it: the waves reach it sooner and then have 23 independent
-        // MFMAs (dV, dK and the dQ tile) to issue while the next block's fragment reads are in flight
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { pf[u] = pack_pair(P[u][0], P[u][1]); dsf[u] = pack_pair(dS[u][0], dS[u][1]); }
+    };
+    const __amdgpu_buffer_rsrc_t rsDQ = rows_rsrc(a.dq + rb * a.ldgq + h * HD, n, a.ldgq, HD, 2);
+    const int dq_ld2 = a.ldgq * 2, dq_col2 = (16 * my_dt + 4 * g) * 2;
+    // gradients of query block i: dV^T += dO^T P, dK^T += Q^T dS for this wave's key tiles (operands in registers / the Q, dO images),
+    // and this wave's 16 x 16 tile of the block's dQ^T = K^T dS^T, summed over ALL keys from the block's dS image
+    auto grads = [&](int i, const bf16x8_t (&pf)[2], const bf16x8_t (&dsf)[2]) {
+        const int qc = i * CH;
+        const char* sQ = ldsQ + qc * HD * 2;
+        const char* sO = ldsO + qc * HD * 2;
+        const char* sS = ldsS + (i & 1) * LDS_S1;
+        bf16x8_t otf[DT], qtf[DT], af[NKB];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { otf[dt] = frag_tr_perm<HD>(sO, dt, lane); qtf[dt] = frag_tr_perm<HD>(sQ, dt, lane); }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) af[kb] = frag_ds(sS + kb * 32 * 64, my_t, lane);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8_t otf = frag_tr_perm<HD>(sO, dt, lane), qtf = frag_tr_perm<HD>(sQ, dt, lane);
-                adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], otf, adv[u][dt], 0, 0, 0);
-                adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[u], qtf, adk[u][dt], 0, 0, 0);
+                adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[dt], pf[u], adv[u][dt], 0, 0, 0);
+                adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[dt], dsf[u], adk[u][dt], 0, 0, 0);
             }
-        dq_block(i);
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kb], af[kb], acc, 0, 0, 0);
+        // lane (g, c): query c of the tile, columns 16 my_dt + 4 g ..; a buffer store (rows >= n fall outside the resource and are
+        // dropped): no branch, so that the scores of the next block share this basic block
+        const int qq = qc + 16 * my_t + c;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2w, pack4(acc)), rsDQ, qq < n ? qq * dq_ld2 + dq_col2 : 0x40000000, 0, 0);
+    };
+#ifdef VPU_WIN_STAMPS
+    const __amdgpu_buffer_rsrc_t rsDbg = rows_rsrc(a.delta + (int64_t)bh * n, 1, 0, n, 4);
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)__builtin_amdgcn_s_memtime(), rsDbg, lane == 0 ? (wave * 16 + 14) * 4 : 0x40000000, 0, 0);
+#endif
+    bf16x8_t pf[2], dsf[2];
+    scores(0, pf, dsf);
+#pragma nounroll
+    for (int i = 0; i + 1 < NKB; ++i) {
+        __syncthreads();     // the dS image of block i is complete (and everybody has finished reading the image of block i - 1)
+#ifdef VPU_WIN_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)__builtin_amdgcn_s_memtime(), rsDbg, lane == 0 ? (wave * 16 + i * 2) * 4 : 0x40000000, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        bf16x8_t pn[2], dn[2];
+        grads(i, pf, dsf);
+        scores(i + 1, pn, dn);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { pf[u] = pn[u]; dsf[u] = dn[u]; }
+#ifdef VPU_WIN_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the iteration's LDS traffic is complete
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)__builtin_amdgcn_s_memtime(), rsDbg, lane == 0 ? (wave * 16 + i * 2 + 1) * 4 : 0x40000000, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+    __syncthreads();
+    grads(NKB - 1, pf, dsf);
+#ifdef VPU_WIN_STAMPS
+    __builtin_amdgcn_raw_buffer_store_b32(t_start, rsDbg, lane == 0 ? (wave * 16 + 15) * 4 : 0x40000000, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)__builtin_amdgcn_s_memtime(), rsDbg, lane == 0 ? (wave * 16 + 13) * 4 : 0x40000000, 0, 0);
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u)
         if (u < nu) {
+            const int kk = (tile0 + u) * 16 + c;      // lane (g, c): key c of the tile, columns 16 dt + 4 g ..
+            if (kk < n) {
+                bf16_t* kr = a.dk + (rb + kk) * a.ldgk + h * HD + 4 * g;
+                bf16_t* vr = a.dv + (rb + kk) * a.ldgk + h * HD + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = (tile0 + u) * 16 + 4 * g + r;
-                if (kk < n) {
-                    bf16_t* kr = a.dk + (rb + kk) * a.ldgk + h * HD + c;
-                    bf16_t* vr = a.dv + (rb + kk) * a.ldgk + h * HD + c;
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        kr[dt * 16] = (bf16_t)adk[u][dt][r];
-                        vr[dt * 16] = (bf16_t)adv[u][dt][r];
-                    }
+                for (int dt = 0; dt < DT; ++dt) {
+                    *reinterpret_cast<bf16x4w_t*>(kr + dt * 16) = pack4(adk[u][dt]);
+                    *reinterpret_cast<bf16x4w_t*>(vr + dt * 16) = pack4(adv[u][dt]);
                 }
             }
         }
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass backward, persistent
+// Round 6 ("onepass" = 3, the default where it applies: 65 <= n <= 224).  Time stamps in the kernel above (`tools/win_stamps.py`)
+// split a problem's 19 us into 5.9 us until the first score (every CU requests its 128 KB in the same microsecond: the chip's
+// memory system, not the CU, sets that wait), 1.2 us for the first block's scores, 6 x 1.4 us for the loop (the SIMD's vector issue
+// port: MFMA 8, exp 8, fma 4, cvt 4-5 cycles each, both waves of a SIMD) and 2-3 us of gradient stores -- and a launch of 576
+// problems is three such rounds in lock step.  Here a workgroup walks problems p, p + grid, ... and fetches the NEXT problem while it
+// computes the current one:
+//   * Q / dO images are rings of NKB + 1 32-row slots: the next problem's block j goes, by LDS-DMA, into the slot the current block
+//     j - 1 left (block 0 into the spare one) during iteration j; K and V of the next problem go into their images during the first
+//     iterations (the current problem's K / V fragments are in registers by then: they are read from the images at the switch);
+//   * delta = rowsum(dO * O) of the next problem: waves 0-3 fetch the 4 KB of O that match their dO pieces into a scratch slot and
+//     reduce them one iteration later (one 16-byte LDS read each of O and dO per lane, as the prologue above does from registers);
+//   * -lse arrives raw (4-byte LDS-DMA) and is scaled in place in the final phase;
+//   * counted waits only: before every barrier each wave leaves at most 6 vector-memory operations in flight (so whatever was issued
+//     two phases ago is in LDS for everybody), waves 0-3 wait for exactly their two O / dO pieces before the delta step, and the
+//     switch leaves the final phase's own operations (1-2 pieces, the dQ store, 8 dK / dV stores) in flight.
+// Gradient values: the same instruction sequence per element as the kernel above (bit-identical results).
+template <int NKB> struct WxCfg {
+    static constexpr int ROWS = 32 * NKB, BLK = 32 * 64 * 2, NSLOT = NKB + 1, S1 = (ROWS + 16) * 64;
+    static constexpr int OFF_Q = 0, OFF_O = OFF_Q + NSLOT * BLK, OFF_K = OFF_O + NSLOT * BLK, OFF_V = OFF_K + NKB * BLK;
+    static constexpr int OFF_S = OFF_V + NKB * BLK, OFF_X = OFF_S + 2 * S1, OFF_D = OFF_X + BLK, OFF_L = OFF_D + 2 * 1024;
+    static constexpr int LDS = OFF_L + 2 * 1024;      // NKB = 7: 161,792 bytes
+};
+template <int N> __device__ __forceinline__ void wx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// The LDS-DMA instructions of this kernel are inline assembly: behind the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS
+// read that MAY touch the bytes in flight -- here every read of the Q / dO rings, i.e. the whole prefetch would be waited for in the
+// phase that issues it.  (An operation the compiler does not count can only make ITS counted waits longer, never shorter: the queue
+// retires in order.)  rs: the descriptor as four scalars; lds: byte address of the instruction's 1 KB (or 256 bytes) in LDS.
+__device__ __forceinline__ void wx_dma16(u32x4v rs, unsigned lds, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void wx_dma4(u32x4v rs, unsigned lds, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4v wx_rsrc(const void* base, int bytes) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    return (u32x4v){(unsigned)b, (unsigned)(b >> 32), (unsigned)bytes, 0x00020000u};
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)reinterpret_cast<uintptr_t>((lds_vptr3)const_cast<char*>(p)); }
+__device__ __forceinline__ void wx_barrier() { asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+struct WxOff { int q, k, o, l, dq, dk; };     // byte offsets of a problem inside the operands (soffset of every access)
+
+template <int NKB>
+__global__ __launch_bounds__(512) void attn_bwd_winx_kernel(const AttnArgs a) {
+    using C = WxCfg<NKB>;
+    constexpr int HD = 64, KS = 2, DT = 4, ROWS = C::ROWS, BLK = C::BLK, NSLOT = C::NSLOT, NP = (NKB + 1) / 2;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    char* const ldsQ = wlds + C::OFF_Q;
+    char* const ldsO = wlds + C::OFF_O;       // dO
+    char* const ldsK = wlds + C::OFF_K;
+    char* const ldsV = wlds + C::OFF_V;
+    char* const ldsS = wlds + C::OFF_S;       // [2][keys][32 queries] bf16
+    char* const ldsX = wlds + C::OFF_X;       // the O pieces of the block whose delta is pending
+    char* const ldsDb = wlds + C::OFF_D;      // [2][256] -delta * scale per query
+    char* const ldsLb = wlds + C::OFF_L;      // [2][256] -lse * log2 e per query
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c = lane & 15;
+    const int n = a.nq, H = a.H, nprob = a.nbh, stride = gridDim.x;
+    const float sc2 = a.scale * LOG2E;
+    const int NT = (n + 15) >> 4;
+    const int base = NT >> 3, rem = NT & 7;
+    const int nu = base + (wave < rem ? 1 : 0), tile0 = wave * base + (wave < rem ? wave : rem);
+    const int my_t = wave >> 2, my_dt = wave & 3;
+    // the operands whole (a problem is a soffset): rows of all windows, this launch's head columns
+    const int trows = (nprob / H) * n;
+    const u32x4v rsQ = wx_rsrc(a.q, ((trows - 1) * a.ldq + H * HD) * 2), rsK = wx_rsrc(a.k, ((trows - 1) * a.ldk + H * HD) * 2);
+    const u32x4v rsV = wx_rsrc(a.v, ((trows - 1) * a.ldk + H * HD) * 2), rsG = wx_rsrc(a.d_o, ((trows - 1) * a.ldo + H * HD) * 2);
+    const u32x4v rsO = wx_rsrc(a.o, ((trows - 1) * a.ldo + H * HD) * 2), rsL = wx_rsrc(a.lse, nprob * n * 4);
+    const __amdgpu_buffer_rsrc_t rsDQ = rows_rsrc(a.dq, trows, a.ldgq, H * HD, 2), rsDK = rows_rsrc(a.dk, trows, a.ldgk, H * HD, 2);
+    const __amdgpu_buffer_rsrc_t rsDV = rows_rsrc(a.dv, trows, a.ldgk, H * HD, 2);
+    auto offsets = [&](int p) {
+        const int bw = p / H, h = p - bw * H, rb = bw * n;
+        WxOff o;
+        o.q = (rb * a.ldq + h * HD) * 2; o.k = (rb * a.ldk + h * HD) * 2; o.o = (rb * a.ldo + h * HD) * 2; o.l = p * n * 4;
+        o.dq = (rb * a.ldgq + h * HD) * 2; o.dk = (rb * a.ldgk + h * HD) * 2;
+        return o;
+    };
+    // one LDS-DMA instruction = rows [row0, row0 + 8) x 64 columns -> 1 KB of a transposing-read image: lane -> row row0 + lane / 8,
+    // LDS chunk lane % 8 <- the source chunk the image's swizzle puts there (row0 a multiple of 8: the swizzle reads row bits 1, 2)
+    // (the lane's row and chunk are recomputed behind an opaque copy of the lane index at every use: hoisted out of the problem loop
+    // they would be two more of the 256 registers the loop already fills)
+    auto dma8 = [&](const u32x4v& rs, int soff, int ld, int row0, const char* dst) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int row = row0 + (l >> 3), lch16 = ((l & 7) ^ (((l >> 4) & 3) << 1)) * 16;
+        wx_dma16(rs, lds_addr(dst), row < n ? row * ld * 2 + lch16 : OOB, soff);
+    };
+    int srow[2], smask[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int krow = (u < nu ? (tile0 + u) * 16 : ROWS) + c;
+        srow[u] = krow * 64;
+        smask[u] = ds_swz(krow);
+    }
+    // ---- the first problem: images by LDS-DMA, -lse and delta through registers
+    int p = blockIdx.x;
+    WxOff off = offsets(p);
+    {
+#pragma unroll
+        for (int j = 0; j < (4 * NKB + 7) / 8; ++j) {
+            const int q8 = wave + 8 * j;          // piece: rows 8 q8 .. 8 q8 + 7 (slot q8 / 4 of a ring with base 0)
+            if (q8 < 4 * NKB) {
+                dma8(rsQ, off.q, a.ldq, q8 * 8, ldsQ + q8 * 1024);
+                dma8(rsG, off.o, a.ldo, q8 * 8, ldsO + q8 * 1024);
+                dma8(rsK, off.k, a.ldk, q8 * 8, ldsK + q8 * 1024);
+                dma8(rsV, off.k, a.ldk, q8 * 8, ldsV + q8 * 1024);
+            }
+        }
+        u32x4v pg[NP], po[NP];
+        const int ch = tid & 7, row0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = row0 + 64 * i;
+            const int vo = row < n ? (row * a.ldo + ch * 8) * 2 : OOB;
+            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(a.d_o, trows, a.ldo, H * HD, 2), vo, off.o, 0);
+            po[i] = __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(a.o, trows, a.ldo, H * HD, 2), vo, off.o, 0);
+        }
+        const float pl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(a.lse, 1, 0, nprob * n, 4), tid < n ? tid * 4 : OOB, off.l, 0));
+        if ((NT & 1) && tid < 128)
+            *reinterpret_cast<u32x4v*>(ldsS + (tid >> 6) * C::S1 + NT * 16 * 64 + (tid & 63) * 16) = (u32x4v){0u, 0u, 0u, 0u};
+        if (tid < 256) reinterpret_cast<float*>(ldsLb)[tid] = -pl * LOG2E;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = row0 + 64 * i;
+            if (row < ROWS) {
+                const bf16x8_t x = __builtin_bit_cast(bf16x8_t, pg[i]), y = __builtin_bit_cast(bf16x8_t, po[i]);
+                float dl = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)x[j] * (float)y[j];
+                dl += __shfl_xor(dl, 1, 64);
+                dl += __shfl_xor(dl, 2, 64);
+                dl += __shfl_xor(dl, 4, 64);
+                if (ch == 0) reinterpret_cast<float*>(ldsDb)[row] = -dl * a.scale;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    f32x4_t adk[2][DT], adv[2][DT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
+#ifdef VPU_WIN_STAMPS
+    int mloc = 0;
+    const __amdgpu_buffer_rsrc_t rsDbg = rows_rsrc(a.delta + (int64_t)blockIdx.x * n, 1, 0, n, 4);
+#define WX_STAMP(slot_) do { __builtin_amdgcn_sched_barrier(0); if (mloc == 1) __builtin_amdgcn_raw_buffer_store_b32((unsigned)__builtin_amdgcn_s_memtime(), rsDbg, lane == 0 ? (wave * 16 + (slot_)) * 4 : OOB, 0, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WX_STAMP(slot_) do { } while (0)
+#endif
+    int cur = 0, par = 0;                      // ring slot of the current problem's block 0; buffer of its -lse / delta
+    bool pend = false;                         // waves 0-3: a block of the next problem whose O / dO pieces are on their way
+    int pend_row = 0, pend_slot = 0, pend_par = 0;
+    const int dq_col2 = (16 * my_dt + 4 * g) * 2;
+    for (;;) {
+        const bool has_next = p + stride < nprob;
+        const WxOff offn = offsets(has_next ? p + stride : p);
+        const int nbase = cur == 0 ? NSLOT - 1 : cur - 1;             // the next problem's block j: slot (nbase + j) % NSLOT
+        auto slot = [&](int b0, int j) { const int s = b0 + j; return s >= NSLOT ? s - NSLOT : s; };
+        const float* const ldsL = reinterpret_cast<const float*>(ldsLb + par * 1024);
+        const float* const ldsD = reinterpret_cast<const float*>(ldsDb + par * 1024);
+        // ---- the problem's K / V operands out of the images
+        bf16x8_t ktf[NKB], kf[2][KS], vf[2][KS];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) ktf[kb] = frag_tr_perm<HD>(ldsK + kb * BLK, my_dt, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kf[u][ks] = frag_rc_trv(ldsK, (tile0 + u) * 16, ks, lane);
+                vf[u][ks] = frag_rc_trv(ldsV, (tile0 + u) * 16, ks, lane);
+                if (u >= nu) { kf[u][ks] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; vf[u][ks] = kf[u][ks]; }     // (an unowned slot computes on zeros)
+            }
+        // what the phase after barrier i adds to the stream: the pending delta, the next problem's pieces
+        auto fetch = [&](int i) {
+            if (wave < 4) {
+                if (pend) {
+                    if (i == 0) wx_wait_vm<9>(); else wx_wait_vm<1>();       // (behind the two pieces: the dQ store; after a switch also 8 dK / dV stores)
+                    const u32x4v xo = *reinterpret_cast<const u32x4v*>(ldsX + wave * 1024 + lane * 16);
+                    const u32x4v xg = *reinterpret_cast<const u32x4v*>(ldsO + pend_slot * BLK + wave * 1024 + lane * 16);
+                    const bf16x8_t x = __builtin_bit_cast(bf16x8_t, xg), y = __builtin_bit_cast(bf16x8_t, xo);
+                    float dl = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dl += (float)x[j] * (float)y[j];
+                    dl += __shfl_xor(dl, 1, 64);
+                    dl += __shfl_xor(dl, 2, 64);
+                    dl += __shfl_xor(dl, 4, 64);
+                    if ((lane & 7) == 0) reinterpret_cast<float*>(ldsDb + pend_par * 1024)[pend_row + wave * 8 + (lane >> 3)] = -dl * a.scale;
+                    pend = false;
+                }
+            }
+            if (has_next) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int q8 = i * 16 + 2 * wave + e;
+                    if (q8 < 4 * NKB) dma8(rsK, offn.k, a.ldk, q8 * 8, ldsK + q8 * 1024);
+                    else if (q8 < 8 * NKB) dma8(rsV, offn.k, a.ldk, (q8 - 4 * NKB) * 8, ldsV + (q8 - 4 * NKB) * 1024);
+                }
+                const int sl = slot(nbase, i);
+                if (wave < 4) {
+                    dma8(rsG, offn.o, a.ldo, i * 32 + wave * 8, ldsO + sl * BLK + wave * 1024);
+                    dma8(rsO, offn.o, a.ldo, i * 32 + wave * 8, ldsX + wave * 1024);
+                    pend = true; pend_row = i * 32; pend_slot = sl; pend_par = par ^ 1;
+                } else {
+                    dma8(rsQ, offn.q, a.ldq, i * 32 + (wave - 4) * 8, ldsQ + sl * BLK + (wave - 4) * 1024);
+                    if (i == 0) {
+                        const int f = (wave - 4) * 64 + lane;
+                        wx_dma4(rsL, lds_addr(ldsLb + (par ^ 1) * 1024 + (wave - 4) * 256), f < n ? f * 4 : OOB, offn.l);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto scores = [&](int i, bf16x8_t (&pf)[2], bf16x8_t (&dsf)[2]) {
+            const int qc = i * CH, sl = slot(cur, i);
+            const char* sQ = ldsQ + sl * BLK;
+            const char* sO = ldsO + sl * BLK;
+            char* const sS = ldsS + (i & 1) * C::S1;
+            bf16x4w_t p4[2][2], d4[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4_t nl2 = *reinterpret_cast<const f32x4_t*>(ldsL + qc + 16 * t + 4 * g);
+                const f32x4_t nds = *reinterpret_cast<const f32x4_t*>(ldsD + qc + 16 * t + 4 * g);
+                f32x4_t sv[2], dp[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { sv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[u] = sv[u]; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8_t qfr = frag_rc_trv(sQ, 16 * t, ks, lane), ofr = frag_rc_trv(sO, 16 * t, ks, lane);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        sv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], sv[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[u][ks], dp[u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4_t pv, dv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[u][r], sc2, nl2[r]));
+                        dv[r] = pv[r] * __builtin_fmaf(dp[u][r], a.scale, nds[r]);
+                    }
+                    p4[u][t] = pack4(pv);
+                    d4[u][t] = pack4(dv);
+                    *reinterpret_cast<bf16x4w_t*>(sS + srow[u] + ((4 * t + g) ^ smask[u]) * 8) = d4[u][t];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pf[u] = __builtin_shufflevector(p4[u][0], p4[u][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                dsf[u] = __builtin_shufflevector(d4[u][0], d4[u][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        // gradients of query block i: dV^T += dO^T P, dK^T += Q^T dS for this wave's key tiles, this wave's tile of the block's dQ^T
+        auto grads = [&](int i, const bf16x8_t (&pf)[2], const bf16x8_t (&dsf)[2]) {
+            const int qc = i * CH, sl = slot(cur, i);
+            const char* sQ = ldsQ + sl * BLK;
+            const char* sO = ldsO + sl * BLK;
+            const char* sS = ldsS + (i & 1) * C::S1;
+            // (the second half of the dS fragments is read behind the dV / dK products, into the registers their operands leave:
+            // 256 registers per lane hold the accumulators, the K / V operands and ONE set of fragments)
+            constexpr int NA = NKB > 4 ? NKB / 2 : NKB;
+            bf16x8_t otf[DT], qtf[DT], af[NKB];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { otf[dt] = frag_tr_perm<HD>(sO, dt, lane); qtf[dt] = frag_tr_perm<HD>(sQ, dt, lane); }
+#pragma unroll
+            for (int kb = 0; kb < NA; ++kb) af[kb] = frag_ds(sS + kb * 32 * 64, my_t, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    adv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[dt], pf[u], adv[u][dt], 0, 0, 0);
+                    adk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[dt], dsf[u], adk[u][dt], 0, 0, 0);
+                }
+            if (NA < NKB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = NA; kb < NKB; ++kb) af[kb] = frag_ds(sS + kb * 32 * 64, my_t, lane);
+            f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kb], af[kb], acc, 0, 0, 0);
+            const int qq = qc + 16 * my_t + c;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2w, pack4(acc)), rsDQ, qq < n ? qq * a.ldgq * 2 + dq_col2 : OOB, off.dq, 0);
+        };
+        bf16x8_t pf[2], dsf[2];
+        WX_STAMP(1);
+        scores(0, pf, dsf);
+        WX_STAMP(2);
+#pragma nounroll
+        for (int i = 0; i + 1 < NKB; ++i) {
+            wx_barrier();        // the dS image of block i is complete (and everybody has finished with block i - 1 and its dS image)
+            WX_STAMP(3 + i);
+            fetch(i);
+            bf16x8_t pn[2], dn[2];
+            grads(i, pf, dsf);
+            scores(i + 1, pn, dn);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { pf[u] = pn[u]; dsf[u] = dn[u]; }
+        }
+        // ---- the final phase: gradients of the last block, the problem's dK / dV
+        wx_barrier();
+        WX_STAMP(3 + NKB - 1);
+        fetch(NKB - 1);
+        grads(NKB - 1, pf, dsf);
+        WX_STAMP(11);
+        // dK / dV leave in whole 64-byte lines: a lane holds 8 bytes of a row (key c, columns 16 dt + 4 g ..), four lanes 32 contiguous
+        // bytes -- stored like that every wave instruction was sixteen half-line writes and took 260-460 cycles to issue.  Two column
+        // tiles at a time go through 1 KB of the dS image this phase does not read (16 keys x 32 columns), come back as 16 bytes per
+        // lane (row lane / 4, 8 columns) and are stored as sixteen full 64-byte segments per instruction.
+        // (the 1 KB: the rows of the wave's own key tile in that image -- nobody else's, never the zero rows; an unowned slot
+        // stores nothing but issues its instructions: the counted waits below assume eight per wave)
+        {
+            const int srow16 = lane >> 2, sch = lane & 3;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                char* const stg = ldsS + (NKB & 1) * C::S1 + (u < nu ? (tile0 + u) * 16 : ROWS) * 64;
+                const int kk = (tile0 + u) * 16 + srow16;
+                const bool live = u < nu && kk < n;
+                const int vo = (kk * a.ldgk + 8 * sch) * 2;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int kv = 0; kv < 2; ++kv) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int dt = 2 * hf + e;
+                            *reinterpret_cast<bf16x4w_t*>(stg + c * 64 + e * 32 + g * 8) = pack4(kv ? adv[u][dt] : adk[u][dt]);
+                        }
+                        const u32x4v row = *reinterpret_cast<const u32x4v*>(stg + srow16 * 64 + sch * 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(row, kv ? rsDV : rsDK, live ? vo + hf * 64 : OOB, off.dk, 0);
+                    }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { adk[u][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[u][dt] = adk[u][dt]; }
+            }
+        }
+        WX_STAMP(12);
+        if (!has_next) break;
+        // ---- switch: everything the next problem starts from is in LDS once the operations older than this phase's own are done
+        if (wave < 4) wx_wait_vm<11>();
+        else {
+            wx_wait_vm<10>();
+            // the next problem's -lse arrived raw (phase 0, this wave's own 64 values): scale it in place
+            float* const ln = reinterpret_cast<float*>(ldsLb + (par ^ 1) * 1024) + (wave - 4) * 64 + lane;
+            *ln = -*ln * LOG2E;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        p += stride; off = offn; cur = nbase; par ^= 1;
+#ifdef VPU_WIN_STAMPS
+        ++mloc;
+#endif
+        WX_STAMP(0);
+    }
+}
+
+#undef WX_STAMP
 // ------------------------------------------------------------------------------------------------ one-pass backward, several per CU
 // Round 5.  The kernel above holds a whole (window, head) problem in 132 KB of LDS and 210 registers: ONE workgroup per CU,
 // two waves per SIMD, and 576 problems on 256 CUs are 2.25 rounds -- the third one a quarter full; inside a round nothing
@@ -1237,13 +1642,6 @@ template <int NU> struct WpCfg {
     static constexpr int LDS = WP_NST * WP_STAGE + 2 * SBUF + 2 * WIN_ROWS * 4;      // NU = 1: 40960 + 10240 + 2048 = 53248: three per CU
 };
 
-// frag_rc_tr as an ext-vector load (through HIP's uint4 struct the load carries TBAA info, and hipcc then puts s_waitcnt
-// vmcnt(0) in front of it while an LDS-DMA is pending)
-__device__ __forceinline__ bf16x8_t frag_rc_trv(const char* lds, int row16, int ks, int lane) {
-    const u32x4v v = *reinterpret_cast<const u32x4v*>(lds + tr_off<64>(row16 + (lane & 15), 2 * (ks * 4 + (lane >> 4))));
-    return __builtin_bit_cast(bf16x8_t, v);
-}
-typedef __attribute__((address_space(3))) void* lds_vptr3;
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
 // rows [r0 + 8 piece, + 8) x 64 columns of a [*, ld] matrix -> 1 KB of a transposing-read image by ONE LDS-DMA instruction of
@@ -1532,8 +1930,8 @@ inline bool xcd_map_enabled() {   // VPU_ATTN_XCDMAP=0: the plain 2-D grid (A/B 
     static const int e0 = [] { const char* e = vpu_lab_getenv("VPU_ATTN_XCDMAP"); return e ? atoi(e) : 1; }();
     return e0 != 0;
 }
-inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backward for n <= 256, head dim 64: 2 = key passes, three workgroups per CU (round 5), 1 = one per CU, 0 = two kernels
-    static const int e0 = [] { const char* e = getenv("VPU_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
+inline int onepass_enabled() {   // "onepass": the one-pass (window, head) backward for n <= 256, head dim 64: 3 = persistent workgroups that fetch the next problem (round 6; 65 <= n <= 224, 1 elsewhere), 2 = key passes, three workgroups per CU (round 5), 1 = one workgroup per problem, 0 = two kernels
+    static const int e0 = [] { const char* e = getenv("VPU_ATTN_ONEPASS"); return e ? atoi(e) : 3; }();
     const int v = g_opt_onepass.load(std::memory_order_relaxed);
     return v >= 0 ? v : e0;
 }
@@ -1566,12 +1964,12 @@ extern "C" int vpu_attn_set_option(const char* name, int32_t value) {
         g_opt_lean.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
-    if (name && !strcmp(name, "onepass") && value >= -1 && value <= 2) {
+    if (name && !strcmp(name, "onepass") && value >= -1 && value <= 3) {
         g_opt_onepass.store(value, std::memory_order_relaxed);
         return VPU_OK;
     }
     vpu_set_error("vpu_attn_set_option: known options: lean (-1 environment default VPU_ATTN_LEAN, 0 round-1 step kernels, 1 lean kernels), "
-                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems with one workgroup per CU, 2 in key passes with three)");
+                  "onepass (-1 environment default VPU_ATTN_ONEPASS, 0 two-kernel backward, 1 one-pass backward for window-sized problems with one workgroup per problem, 2 in key passes with three workgroups per CU, 3 persistent workgroups that fetch the next problem while they compute (65 <= n <= 224; 1 elsewhere))");
     return VPU_ERR_ARG;
 }
 
@@ -1690,13 +2088,42 @@ static int xattn_bwd_impl(const void* q, const void* k, const void* v, const voi
         attn_bwd_winp_kernel<1><<<dim3(nb * H), 256, WpCfg<1>::LDS, s>>>(a);
         return vpu_check_launch("vpu_xattn_bwd");
     }
-    if (!split && lean_enabled() && onepass_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB) {
-        static VpuDevOnce attr;
-        if (auto todo_ = attr.pending()) {
-            VPU_SET_LDS(WIN_LDS, attn_bwd_win_kernel);
+    const bool win_ok = !split && lean_enabled() && hd == 64 && nq == nk && nq <= 32 * WIN_MAX_KB && ldgq % 4 == 0 && ldgk % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 && (reinterpret_cast<uintptr_t>(dv) & 7) == 0;
+    {
+        // the persistent form addresses the operands whole (a problem is an soffset): every operand below 2 GiB
+        const int64_t trows = (int64_t)nb * nq, lim = (int64_t)1 << 30;
+        const int nkb = (nq + 31) / 32;
+        if (win_ok && onepass_enabled() == 3 && nkb >= 3 && nkb <= 7 && trows * ldq < lim && trows * ldk < lim && trows * ldo < lim &&
+            trows * ldgq < lim && trows * ldgk < lim && (int64_t)nb * H * nq < lim / 2) {
+            static const int ncu = [] { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c > 0 ? c : 256; }();
+            a.nbh = nb * H;
+            const int grid = a.nbh < ncu ? a.nbh : ncu;
+            snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_winx_kernel");
+#define WINX_CASE(NKB_)                                                                               \
+            case NKB_: {                                                                              \
+                static VpuDevOnce attr;                                                               \
+                if (auto todo_ = attr.pending()) { VPU_SET_LDS(WxCfg<NKB_>::LDS, attn_bwd_winx_kernel<NKB_>); } \
+                attn_bwd_winx_kernel<NKB_><<<dim3(grid), 512, WxCfg<NKB_>::LDS, s>>>(a);              \
+            } break;
+            switch (nkb) { WINX_CASE(3) WINX_CASE(4) WINX_CASE(5) WINX_CASE(6) WINX_CASE(7) }
+#undef WINX_CASE
+            return vpu_check_launch("vpu_xattn_bwd");
         }
+    }
+    if (win_ok && onepass_enabled()) {
+        // (8-byte gradient stores: rows and slices 8-byte aligned; anything else takes the two kernels below)
         snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_win_kernel");
-        attn_bwd_win_kernel<<<dim3(nb * H), 512, WIN_LDS, s>>>(a);
+#define WIN_CASE(NKB_)                                                                           \
+        case NKB_: {                                                                             \
+            static VpuDevOnce attr;                                                              \
+            if (auto todo_ = attr.pending()) { VPU_SET_LDS(win_lds(NKB_), attn_bwd_win_kernel<NKB_>); } \
+            attn_bwd_win_kernel<NKB_><<<dim3(nb * H), 512, win_lds(NKB_), s>>>(a);               \
+        } break;
+        switch ((nq + 31) / 32) {
+            WIN_CASE(1) WIN_CASE(2) WIN_CASE(3) WIN_CASE(4) WIN_CASE(5) WIN_CASE(6) WIN_CASE(7) WIN_CASE(8)
+        }
+#undef WIN_CASE
         return vpu_check_launch("vpu_xattn_bwd");
     }
     if (lean_enabled() && nq % 4 == 0) {

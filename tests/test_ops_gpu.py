@@ -1361,10 +1361,10 @@ def test_one_pass_window_backward(ops, n, nb, H):
     ref = torch.softmax((x[0] @ x[1].transpose(-1, -2)) * scale, -1) @ x[2]
     dO = dev(rnd(nb * n, D, seed=161 + n)).to(torch.bfloat16)
     ref.backward(dO.float().view(nb, n, H, hd).transpose(1, 2))
-    names = {2: "attn_bwd_winp_kernel<1>", 1: "attn_bwd_win_kernel"}
+    names = {3: "attn_bwd_winx_kernel" if 65 <= n <= 224 else "attn_bwd_win_kernel", 2: "attn_bwd_winp_kernel<1>", 1: "attn_bwd_win_kernel"}
     res = {}
     try:
-        for onepass in (2, 1, 0):
+        for onepass in (3, 2, 1, 0):
             ops.attn_set_option("onepass", onepass)
             dqkv = torch.full_like(qkv, float("nan"))
             delta = torch.zeros(nb * H, n, device="cuda")
@@ -1381,6 +1381,7 @@ def test_one_pass_window_backward(ops, n, nb, H):
                 assert torch.equal(again.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4), res[onepass])
     finally:
         ops.attn_set_option("onepass", -1)
+    assert torch.equal(res[3], res[1])       # the persistent form runs the per-problem form's arithmetic: same bits
     for mode in (2, 1):
         for i, name in enumerate("qkv"):
             ref_g = x.grad[i]
@@ -1390,6 +1391,49 @@ def test_one_pass_window_backward(ops, n, nb, H):
             print(f"[one-pass {mode}] n={n} d{name}: vs torch {err / sc:.2e}, vs two kernels {dif / sc:.2e} of the scale")
             assert err < 2e-2 * sc, (mode, name, err, sc)
             assert dif < (1.5e-2 if mode == 2 and name == "q" else 1e-2) * sc, (mode, name, dif, sc)
+
+
+@pytest.mark.parametrize("n,nb,H", [(196, 48, 12), (100, 130, 4), (160, 90, 6), (70, 300, 2), (200, 45, 12), (176, 100, 3), (224, 33, 8)])
+def test_persistent_window_backward_walks_several_problems_per_workgroup(ops, n, nb, H):
+    """The persistent window backward (attn_bwd_winx_kernel: "onepass" = 3, the default) with MORE problems than the chip has CUs,
+    so that every workgroup goes through the switch -- the next problem's Q / dO ring slots, K / V images, -lse and delta all come
+    from the prefetch -- two or three times (576, 520, 540, 600, 540, 300, 264 problems; 7, 4, 5, 3, 7, 6, 7 blocks of 32 keys;
+    odd and even tile counts, a ragged last tile): bit-identical to the per-problem kernel ("onepass" = 1) on the same inputs,
+    twice in a row (no stale ring slot from the previous launch), and -- first case, the ViT-B bs-12 launch -- within 2e-2 of torch
+    fp32 on the bf16-rounded inputs."""
+    hd = 64
+    D = H * hd
+    qkv = dev(rnd(nb * n, 3 * D, seed=260 + n, scale=1.5)).to(torch.bfloat16)
+    O = torch.zeros(nb * n, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(nb * H, n, device="cuda")
+    scale = hd ** -0.5
+    ops.attn_fwd(qkv, (qkv, D), (qkv, 2 * D), O, lse, nb, H, n, hd, 3 * D, D, scale)
+    dO = dev(rnd(nb * n, D, seed=261 + n)).to(torch.bfloat16)
+    res = {}
+    try:
+        for onepass in (1, 3, 3):
+            ops.attn_set_option("onepass", onepass)
+            dqkv = torch.full_like(qkv, float("nan"))
+            delta = torch.zeros(nb * H, n, device="cuda")
+            ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, delta, dqkv, (dqkv, D), (dqkv, 2 * D), nb, H, n, hd, 3 * D, D,
+                         3 * D, scale)
+            assert ops.attn_last_kernel() == ("attn_bwd_winx_kernel" if onepass == 3 else "attn_bwd_win_kernel"), ops.attn_last_kernel()
+            assert torch.isfinite(dqkv.float()).all()
+            if onepass == 3:
+                assert torch.equal(dqkv, res[1]), (n, nb, H, (dqkv.float() - res[1].float()).abs().max().item())
+            res[onepass] = dqkv
+    finally:
+        ops.attn_set_option("onepass", -1)
+    if n == 196:
+        x = qkv.float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+        ref = torch.softmax((x[0] @ x[1].transpose(-1, -2)) * scale, -1) @ x[2]
+        ref.backward(dO.float().view(nb, n, H, hd).transpose(1, 2))
+        got = res[3].float().view(nb, n, 3, H, hd).permute(2, 0, 3, 1, 4)
+        for i, name in enumerate("qkv"):
+            sc = x.grad[i].abs().max().item()
+            err = (got[i] - x.grad[i]).abs().max().item()
+            print(f"[persistent window backward] d{name}: {err / sc:.2e} of the scale")
+            assert err < 2e-2 * sc, (name, err, sc)
 
 
 def test_attention_large_scores_raise_the_reference(ops, attn_form):
