@@ -557,12 +557,11 @@ __device__ __forceinline__ void wg_problem(int gx, int nbh, int& bh, int& xb) {
 constexpr float RESCALE_TH = 8.0f;   // log2 units: probabilities relative to the reference maximum stay below 2^8
 
 template <int HD, int QT, int HC>
-// (HD = 64, two tiles per wave: five workgroups per CU -- the window forward is 1152 workgroups, 1.125 rounds of the 1024 slots
-// that 126 registers give, i.e. two rounds; VPU_ATTN_FWD_OCC picks the variant for A/B runs)
-// Measured, round 4: occupancy 5 = 96 registers + 120 bytes of scratch in the loop: 51.5 us (window) / 106 us (global) against
-// 22.9 / 37 -- the default stays 1 (no bound).
+// (HD = 64, two tiles per wave: FOUR workgroups per CU -- 126 registers through round 5 without asking; the round-6 epilogue takes
+// 134 unless the bound is stated, and three workgroups per CU are 1.5 rounds of the window forward's 1152 instead of 1.125.
+// Round 4: occupancy 5 = 96 registers + 120 bytes of scratch in the loop: 51.5 us (window) / 106 us (global) against 22.9 / 37.)
 #ifndef VPU_ATTN_FWD_OCC
-#define VPU_ATTN_FWD_OCC 1
+#define VPU_ATTN_FWD_OCC 4
 #endif
 __global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) void attn_fwd_lean_kernel(const AttnArgs a) {
     constexpr int KS = HC / 32, DT = HC / 16;   // computed width HC <= image width HD (head dim 80 / 96: 96 of the 128 columns)
@@ -661,14 +660,13 @@ __global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) 
             xm = fmaxf(xm, __shfl_xor(xm, 16, 64));
             xm = fmaxf(xm, __shfl_xor(xm, 32, 64));
             const float mnew = (xm > mref[u] + RESCALE_TH) ? xm : mref[u];
-            const float alpha = __builtin_amdgcn_exp2f(mref[u] - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(mref[u] - mnew);     // (of query c: the lane's own, see probs_pv)
             mref[u] = mnew;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ar = __shfl(alpha, 4 * g + r, 64);
-                accl[u][r] *= ar;
+                accl[u][r] *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) acc[u][dt][r] *= ar;
+                for (int dt = 0; dt < DT; ++dt) acc[u][dt][r] *= alpha;
             }
         }
     };
@@ -682,14 +680,17 @@ __global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) 
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sc2, nm));
+            // round 6: the products are taken TRANSPOSED (O^T = V^T P^T, l^T = 1 P^T: the same operand registers, swapped) -- a lane
+            // then holds four consecutive columns of ONE query (c), its running maximum and row sum are that query's own (no
+            // broadcast in raise() or at the end) and the output leaves in 8-byte pieces instead of 2-byte ones
             pf[u] = pack_pair(s[u][0], s[u][1]);
-            accl[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], ones, accl[u], 0, 0, 0);
+            accl[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[u], accl[u], 0, 0, 0);
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const bf16x8_t vfr = frag_tr_perm<HD>(sV, dt, lane);
 #pragma unroll
-            for (int u = 0; u < QT; ++u) acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[u], vfr, acc[u][dt], 0, 0, 0);
+            for (int u = 0; u < QT; ++u) acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, pf[u], acc[u][dt], 0, 0, 0);
         }
     };
     stage(0); scores(0); raise();      // the first step sets the reference (alpha = 0 on all-zero tiles)
@@ -706,26 +707,36 @@ __global__ __launch_bounds__(256, (HD == 64 && QT == 2) ? VPU_ATTN_FWD_OCC : 1) 
         ++i;
         if (i < nch) { stage(i); scores(i); }
     }
+    // the wave's [16 QT queries][HD] output tile goes through the K / V buffers (nobody reads them any more) and leaves in whole
+    // rows, 16 bytes per lane: the 2-byte stores of rounds 2-5 were 32 half-line write instructions per wave at the end of a
+    // workgroup's life.  16-byte chunk ch of row r sits at chunk ch ^ (r & 7) of its row (bank spread; r & 3 in the 4-chunk rows of HD = 32).
+    __syncthreads();
+    {
+        typedef __bf16 bf16x4o_t __attribute__((ext_vector_type(4)));
+        constexpr int RB = HD * 2, NCHK = HD / 8, SW = NCHK >= 8 ? 7 : NCHK - 1;
+        char* const stg = (wave < 2 ? &ldsK[0][0] : &ldsV[0][0]) + (wave & 1) * (CH * HD * 2);
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-        const int qu = q0 + 16 * u;
+        for (int u = 0; u < QT; ++u) {
+            const float l = accl[u][0], il = __builtin_amdgcn_rcpf(l);   // (the quotient is rounded to bf16 anyway)
+            const int qq = q0 + 16 * u + c;
+            if (g == 0 && qq < nq) a.lse[(int64_t)bh * nq + qq] = (mref[u] + __builtin_amdgcn_logf(l)) * LN2;
+            const int row = 16 * u + c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float mrow = __shfl(mref[u], 4 * g + r, 64);
-            const float l = accl[u][r], il = __builtin_amdgcn_rcpf(l);   // (the quotient is rounded to bf16 anyway)
-            const int qq = qu + 4 * g + r;
-            if (qq < nq) {
-                if (c == 0) a.lse[(int64_t)bh * nq + qq] = (mrow + __builtin_amdgcn_logf(l)) * LN2;
-                bf16_t* orow = a.out + (rbqo + qq) * a.ldo + h * hd + c;
-                if (hd == HC) {      // (uniform: no per-tile column test on the common path)
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4o_t w4;
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
-                } else {
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-                        if (dt * 16 < hd) orow[dt * 16] = (bf16_t)(acc[u][dt][r] * il);
-                }
+                for (int r = 0; r < 4; ++r) w4[r] = (bf16_t)(acc[u][dt][r] * il);
+                const int chk = (2 * dt + (g >> 1)) ^ (row & SW);
+                *reinterpret_cast<bf16x4o_t*>(stg + row * RB + chk * 16 + (g & 1) * 8) = w4;
             }
+        }
+        // (same wave: the LDS writes above are ordered before these reads)
+#pragma unroll
+        for (int i = 0; i < 16 * QT * NCHK / 64; ++i) {
+            const int idx = i * 64 + lane, row = idx / NCHK, ch = idx % NCHK;
+            const u32x4v v16 = *reinterpret_cast<const u32x4v*>(stg + row * RB + ((ch ^ (row & SW)) * 16));
+            const int qq = q0 + row;
+            if (qq < nq && ch * 8 < hd) *reinterpret_cast<u32x4v*>(a.out + (rbqo + qq) * a.ldo + h * hd + ch * 8) = v16;
         }
     }
 }
@@ -1981,9 +1992,9 @@ static int xattn_fwd_impl(const void* q, const void* k, const void* v, void* out
         vpu_set_error("xattn_fwd_split: qdiv, kdiv >= 1, one of them 1, nb a multiple of the other; the lean kernels only");
         return VPU_ERR_ARG;
     }
-    if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || nb <= 0 ||
+    if (hd <= 0 || hd > 128 || hd % 16 || ldq % 8 || ldk % 8 || ldo % 8 || !ok16(q) || !ok16(k) || !ok16(v) || !ok16(out) || nb <= 0 ||
         H <= 0 || nq <= 0 || nk <= 0 || (int64_t)nk * ldk >= (1 << 29)) {
-        vpu_set_error("xattn_fwd: head dim a multiple of 16 up to 128, 16-byte aligned slices, row strides % 8 == 0, one batch entry of k/v below 1 GiB");
+        vpu_set_error("xattn_fwd: head dim a multiple of 16 up to 128, 16-byte aligned slices (q, k, v, out), row strides % 8 == 0, one batch entry of k/v below 1 GiB");
         return VPU_ERR_ARG;
     }
     AttnArgs a{};
