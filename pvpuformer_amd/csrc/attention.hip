@@ -1299,11 +1299,13 @@ template <int N> __device__ __forceinline__ void wx_wait_vm() { asm volatile("s_
 // read that MAY touch the bytes in flight -- here every read of the Q / dO rings, i.e. the whole prefetch would be waited for in the
 // phase that issues it.  (An operation the compiler does not count can only make ITS counted waits longer, never shorter: the queue
 // retires in order.)  rs: the descriptor as four scalars; lds: byte address of the instruction's 1 KB (or 256 bytes) in LDS.
+// m0 is written without being declared (hipcc refuses a reserved register on the clobber list): nothing else in the kernel that
+// uses these helpers reads m0 -- no builtin LDS-DMA, no s_movrel; gfx950's ds_* instructions do not use it.
 __device__ __forceinline__ void wx_dma16(u32x4v rs, unsigned lds, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void wx_dma4(u32x4v rs, unsigned lds, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ u32x4v wx_rsrc(const void* base, int bytes) {
     const uint64_t b = reinterpret_cast<uint64_t>(base);
@@ -2107,7 +2109,9 @@ static int xattn_bwd_impl(const void* q, const void* k, const void* v, const voi
         const int nkb = (nq + 31) / 32;
         if (win_ok && onepass_enabled() == 3 && nkb >= 3 && nkb <= 7 && trows * ldq < lim && trows * ldk < lim && trows * ldo < lim &&
             trows * ldgq < lim && trows * ldgk < lim && (int64_t)nb * H * nq < lim / 2) {
-            static const int ncu = [] { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c > 0 ? c : 256; }();
+            // one workgroup per CU the step may claim: a workgroup that finds its CU taken (a collective's kernel in a data-parallel
+            // step) would start when another one has finished ALL its problems
+            const int ncu = vpu_cu_budget();
             a.nbh = nb * H;
             const int grid = a.nbh < ncu ? a.nbh : ncu;
             snprintf(g_last_attn, sizeof(g_last_attn), "attn_bwd_winx_kernel");

@@ -3012,6 +3012,10 @@ extern "C" int vpu_gemm_set_option(const char* name, int32_t value) {
     return VPU_ERR_ARG;
 }
 
+// the CUs a persistent grid may claim right now (all of them, minus the "reserve_cus" a data-parallel step keeps for its collectives):
+// the attention launcher sizes its persistent window backward with it (vpu_common.h)
+int vpu_cu_budget() { return cu_count(); }
+
 extern "C" int vpu_gemm_get_option(const char* name, int32_t* value) {
     vpu_clear_stale_error();
     if (!name || !value) { vpu_set_error("vpu_gemm_get_option: null argument"); return VPU_ERR_ARG; }

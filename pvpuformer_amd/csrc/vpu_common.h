@@ -141,6 +141,8 @@ __device__ __forceinline__ float block_max(float v, float* smem) {
 // Environment knobs.  The product library reads four (VPU_GEMM_K2, VPU_GEMM_K3, VPU_ATTN_LEAN, VPU_ATTN_ONEPASS: which of its tested
 // kernel families a call takes; the same choices as vpu_gemm_set_option / vpu_attn_set_option).  Every other one is an A/B knob of
 // the laboratory build (-DVPU_LAB): in the product library it reads as unset and the code takes its default.
+int vpu_cu_budget();     // gemm.hip: CUs a persistent grid may claim (the "reserve_cus" option of vpu_gemm_set_option taken off)
+
 inline const char* vpu_lab_getenv(const char* name) {
 #ifdef VPU_LAB
     return getenv(name);

@@ -1422,6 +1422,16 @@ def test_persistent_window_backward_walks_several_problems_per_workgroup(ops, n,
             if onepass == 3:
                 assert torch.equal(dqkv, res[1]), (n, nb, H, (dqkv.float() - res[1].float()).abs().max().item())
             res[onepass] = dqkv
+        if n == 196:
+            # a data-parallel step keeps CUs out of the persistent grids ("reserve_cus"): the walk over the problems changes, not the bits
+            ops.gemm_set_option("reserve_cus", 16)
+            try:
+                dqkv = torch.full_like(qkv, float("nan"))
+                ops.attn_bwd(qkv, (qkv, D), (qkv, 2 * D), O, dO, lse, torch.zeros(nb * H, n, device="cuda"), dqkv, (dqkv, D), (dqkv, 2 * D),
+                             nb, H, n, hd, 3 * D, D, 3 * D, scale)
+                assert ops.attn_last_kernel() == "attn_bwd_winx_kernel" and torch.equal(dqkv, res[1])
+            finally:
+                ops.gemm_set_option("reserve_cus", 0)
     finally:
         ops.attn_set_option("onepass", -1)
     if n == 196:
