@@ -26,6 +26,9 @@ void vpu_k5_set_grid(int v);
 void vpu_k5_set_split(int v);
 void vpu_k5_set_noepi(int v);
 int vpu_k5_launch(const vpu_gemm_desc* d, int rb, int ncu, int vec, void* stream, char* name, size_t name_len);
+#ifdef VPU_DIAG
+void vpu_k5_set_dbg(unsigned long long* p);
+#endif
 
 namespace {
 
@@ -3292,6 +3295,7 @@ extern "C" int vpu_gemm_grouped(const vpu_gemm_desc* descs, int32_t n, void* str
 extern "C" int vpu_debug_gemm_times(void* dev_buf) {
 #ifdef VPU_DIAG
     g_dbg_times.store(reinterpret_cast<unsigned long long*>(dev_buf), std::memory_order_relaxed);
+    vpu_k5_set_dbg(reinterpret_cast<unsigned long long*>(dev_buf));
     return VPU_OK;
 #else
     (void)dev_buf;

@@ -344,7 +344,8 @@ __device__ __forceinline__ void k5_epi_all(K5Ctx<TB, FL, RB>& c, f32x4_t (&acc)[
 // PWP: LDS-DMA pieces per K-step a PRODUCER wave issues -- 12 (all of them) or 6 (the consumer waves issue the other half:
 // for the epilogue-heavy flag sets, whose producer is the slower of the two roles)
 template <int TB, int FL, int RB, int PWP>
-__global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n, const int vec) {
+__global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p, const int tiles_m, const int tiles_n, const int vec
+                                                           VPU_DBG_PARAM_DEF) {   // (-DVPU_DIAG, vpu_debug_gemm_times: per tile start / main loop end / epilogue end)
     constexpr int PWC = K5_PW - PWP;
     // the consumer's MFMA clusters at raised priority -- except beside a vector-ALU-heavy epilogue (GELU + GELU': 4.2 vector
     // instructions per MFMA of the partner wave), which the priority starves: the producer then is the slower role
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
     c.rP = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, 0x7FFFFFFF, 0x00020000);
     c.mq = 0; c.nq = 0; c.bl = nullptr; c.wst = 0; c.ph = 0;
     const bool noepi = vec == 9;       // diagnostic (VPU_GEMM_NOEPI=1): main loops only
+    VPU_STAMP(tid == 0, blockIdx.x * 16 + 15);
 
     f32x4_t acc[RB][4];
 #pragma unroll
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                VPU_STAMP((tid & 255) == 0 && ph < 5, blockIdx.x * 16 + 3 * ph);
                 int rst = q;
                 if constexpr (RB < 8) {
                     bf16x8_t a0[RB], b0[4], a1[RB], b1[4];
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
                         rst = rst == 2 ? 0 : rst + 1;
                     }
                 }
+                VPU_STAMP((tid & 255) == 0 && ph < 5, blockIdx.x * 16 + 3 * ph + 1);
             } else {
                 // ---- producer for tile ph (+ the epilogue of tile ph - 1)
                 const bool has_e = ph >= 1 && !noepi;
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
                     k5_producer_intervals<TB, FL, RB, PWP, 0>(c, acc);
                     if constexpr (!MPRIO) __builtin_amdgcn_s_setprio(0);
                     kt = k5_ni<FL>();
+                    VPU_STAMP((tid & 255) == 0 && ph - 1 < 5, blockIdx.x * 16 + 3 * (ph - 1) + 2);
                 }
                 for (; kt < c.nk; ++kt) {
                     k5_dma<0, PWP, true>(c, kt);
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_k5_kernel(const vpu_gemm_desc p
             }
         } else if (g != (ph & 1) && !noepi && ph >= 1) {
             k5_epi_all<TB, FL, RB, 0>(c, acc);
+            VPU_STAMP((tid & 255) == 0 && ph - 1 < 5, blockIdx.x * 16 + 3 * (ph - 1) + 2);
         }
         q = (q + c.nk) % 3;
     }
@@ -495,6 +501,9 @@ inline int k5_env0() {
 }
 
 std::atomic<int> g_opt_k5_noepi{0};      // diagnostic: main loops only (the outputs are not written)
+#ifdef VPU_DIAG
+std::atomic<unsigned long long*> g_dbg_times{nullptr};     // (VPU_DBG_LOAD)
+#endif
 std::atomic<int> g_opt_k5_split{-1};     // -1 / 0: the producer waves issue every LDS-DMA piece; 1: half of them by the consumer waves (A/B runs, tests)
 template <int TB, int FL, int RB, int PWP>
 int k5_launch_pw(const vpu_gemm_desc* d, const int ncu, const int vec, hipStream_t s, char* name, size_t name_len) {
@@ -507,7 +516,7 @@ int k5_launch_pw(const vpu_gemm_desc* d, const int ncu, const int vec, hipStream
     const int cap = g_opt_k5_grid.load(std::memory_order_relaxed);
     if (cap > 0 && grid > cap) grid = cap;
     snprintf(name, name_len, "gemm_bf16_k5_kernel<%d, %d, %d, %d>", TB, FL, RB, PWP);
-    kern_<<<dim3((unsigned)grid), dim3(512), K5_LDS, s>>>(*d, tm_, tn_, g_opt_k5_noepi.load(std::memory_order_relaxed) ? 9 : vec);
+    kern_<<<dim3((unsigned)grid), dim3(512), K5_LDS, s>>>(*d, tm_, tn_, g_opt_k5_noepi.load(std::memory_order_relaxed) ? 9 : vec VPU_DBG_LOAD);
     return 1;
 }
 template <int TB, int FL, int RB>
@@ -540,6 +549,9 @@ void vpu_k5_set_grid(int v) { g_opt_k5_grid.store(v, std::memory_order_relaxed);
 int vpu_k5_grid() { return g_opt_k5_grid.load(std::memory_order_relaxed); }
 void vpu_k5_set_split(int v) { g_opt_k5_split.store(v, std::memory_order_relaxed); }
 void vpu_k5_set_noepi(int v) { g_opt_k5_noepi.store(v, std::memory_order_relaxed); }
+#ifdef VPU_DIAG
+void vpu_k5_set_dbg(unsigned long long* p) { g_dbg_times.store(p, std::memory_order_relaxed); }
+#endif
 
 // Launches the K5 instantiation for (transB, flag set, tile height); returns 1 when a kernel was enqueued, 0 when the form has no
 // instantiation (the caller falls through to K2), a negative error code otherwise.  Preconditions (checked by vpu_gemm): bf16,
