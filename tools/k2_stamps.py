@@ -20,7 +20,10 @@ SHAPES = [
     ("fc2 dgrad*aux", 1, M, 3072, 768, ops.EPI_MULAUX),
     ("fc1 dgrad", 1, M, 768, 3072, 0),
     ("qkv dgrad", 1, M, 768, 2304, 0),
+    ("fc1 bias only", 0, M, 3072, 768, ops.EPI_BIAS),
 ]
+if os.environ.get("K2_STAMPS_ONLY"):
+    SHAPES = [s_ for s_ in SHAPES if any(k_ in s_[0] for k_ in os.environ["K2_STAMPS_ONLY"].split(","))]
 dev = "cuda"
 for name, tB, m, n, k, flags in SHAPES:
     A = (torch.rand(m, k, device=dev) - 0.5).to(torch.bfloat16)
