@@ -74,51 +74,55 @@ constexpr int P2_BAND_MAX = 8;   // anchor rows per block: min(8, 1024 / w - 1) 
 constexpr int P2_SPAN = 5;   // most full-resolution pixels per low-resolution cell and axis
 constexpr int P2_W_MAX = 512;   // widest low-resolution map (host-side check)
 
+// workgroup barrier that waits for this wave's LDS operations only: `__syncthreads()` also waits for every global load in flight --
+// the next item's labels, requested on purpose long before they are needed
+__device__ __forceinline__ void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Round 6: PERSISTENT.  The kernel is bound by instruction issue (16 waves on 4 SIMDs: whatever a wave executes costs the SIMD four
+// times its cycles), and a block per (plane, band) paid its setup 8064 times: time stamps (`tools/p2_stamps.py`, experiment build)
+// split such a block's 23,600 cycles into 7,250 until its operands were in LDS (anchor-row searches, 64-bit address arithmetic, the
+// loads), 3,070 for the horizontal interpolation (an integer division and an anchor computation per element), 8,290 for the pixel pass
+// with the loss reduction (every thread summed the sixteen wave partials in double precision), 3,740 for the cell pass and 1,270 for
+// the folds and the store.  Now a workgroup walks a contiguous range of (plane, band) items: the row-anchor table of the WHOLE map and
+// every per-thread constant are computed once per workgroup; the labels of the next item go into the label registers as soon as the
+// pixel pass has consumed the current ones, its low-resolution rows into two registers (in flight under the cell pass, the folds and
+// the store: the barriers behind the request wait for LDS only); the interpolation pass gives a thread one column and every second row;
+// thread 0 alone adds the wave partials (same order, same bits).  16,600 cycles per item, of which the pixel pass is 7,200 (the last
+// wave's; the first one's 3,500); 344 -> 249 us per launch, bit-identical.
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
                                                        const int* __restrict__ slot_idx,
                                                        const float* __restrict__ override_masks,
                                                        float* __restrict__ loss_part, float* __restrict__ dlow,
                                                        float grad_scale, int S, int h, int w, int H, int W, int nband,
-                                                       int max_rows, int BAND) {
+                                                       int max_rows, int BAND, int nitems) {
     extern __shared__ float sm[];   // [(BAND+2)*w] values (rows r0-1..r1) | [BAND*w] gradients | [(BAND+2)*W] hr | [max_rows*W] d loss / d prob
     __shared__ double red[16];
     // first full-resolution column / row whose bilinear anchor is >= a given low-resolution column / anchor row of the block
     // (the anchor index is monotone, so cell x0 owns columns [tXa[x0], tXa[x0 + 1])).  Built once per block: the search loops
     // used to run in every thread of both passes (PMC: 1969 VALU instructions per wave, the kernel is VALU-bound).
-    __shared__ int tXa[P2_W_MAX + 2], tYa[P2_BAND_MAX + 3];
-    const int plane = blockIdx.x / nband, band = blockIdx.x % nband;
-    const int b = plane / S, s = plane % S;
-    const int r0 = band * BAND, r1 = (r0 + BAND < h) ? r0 + BAND : h;
-    float* sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
-    float* sg = sm + (BAND + 2) * w;    // sg[(y - r0) * w + x]
-    float* hr = sg + BAND * w;          // hr[(y - (r0 - 1)) * W + X]: rows of sv interpolated along x
+    __shared__ int tXa[P2_W_MAX + 2], tYall[P2_W_MAX + 4];      // tYall[1 + y]: first full-resolution row anchored at or below row y, y = -1 .. h + 1
+    float* const sv = sm;                        // sv[(y - (r0 - 1)) * w + x]
+    float* const sg = sm + (BAND + 2) * w;    // sg[(y - r0) * w + x]
+    float* const hr = sg + BAND * w;          // hr[(y - (r0 - 1)) * W + X]: rows of sv interpolated along x
     // (gp in raster order: the cell pass's stride-4 gathers are 4-way bank conflicts -- 27 % of the kernel's LDS cycles, PMC --
     // but a column-permuted layout that makes them conflict-free costs four 4-byte stores per pixel quad in the pixel pass
     // and measured slower, 570 vs 547 us: the kernel is issue-bound, not LDS-bound)
-    float* gp = hr + (BAND + 2) * W;    // gp[(Y - Y0) * W + X]
-    const int ov = slot_idx ? slot_idx[plane] : -1;
-    const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)b * H * W;
-    const bool invert = ov < 0 && s >= S / 2;
+    float* const gp = hr + (BAND + 2) * W;    // gp[(Y - Y0) * W + X]
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const float fh = sh > 0.f ? 1.f / sh : 0.f;
-    // pixel rows of the block: the first row anchored at max(r0-1, 0) .. the last row anchored at r1-1
-    const int ya = r0 > 0 ? r0 - 1 : 0;
-    int Y0 = (int)(fh * (float)ya) - 1; Y0 = Y0 < 0 ? 0 : Y0;
-    while (Y0 < H && ac_i0(Y0, sh, h) < ya) ++Y0;
-    int Y1 = (int)(fh * (float)r1) - 1; Y1 = Y1 < Y0 ? Y0 : (Y1 > H ? H : Y1);
-    while (Y1 < H && ac_i0(Y1, sh, h) < r1) ++Y1;          // one past the last row anchored below r1
-    if (Y1 - Y0 > max_rows) Y1 = Y0 + max_rows;            // (cannot happen: host-side bound)
-    for (int i = threadIdx.x; i <= w; i += blockDim.x) tXa[i] = W;
-    if (threadIdx.x < BAND + 3) {      // anchor rows r0 - 1 .. r1 + 1
-        const int arow = r0 - 1 + (int)threadIdx.x;
+    // first full-resolution row anchored at or below low-resolution row `arow`
+    auto first_row = [&](int arow) {
         int Yf = 0;
         if (arow > 0) {
             Yf = (int)(fh * (float)arow) - 1; Yf = Yf < 0 ? 0 : (Yf > H ? H : Yf);
             while (Yf < H && ac_i0(Yf, sh, h) < arow) ++Yf;
         }
-        tYa[threadIdx.x] = Yf;
-    }
+        return Yf;
+    };
+    // the column table and the row table are the same for every item
+    for (int i = threadIdx.x; i <= w; i += blockDim.x) tXa[i] = W;
+    for (int i = threadIdx.x; i < h + 3; i += blockDim.x) tYall[i] = first_row(i - 1);
     __syncthreads();
     for (int X = threadIdx.x; X < W; X += blockDim.x) {
         const int cur = ac_i0(X, sw, w), prev = X > 0 ? ac_i0(X - 1, sw, w) : -1;
@@ -126,167 +130,238 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     }
     const int W4 = W >> 2;
     // pixel-pass mapping: thread -> (anchor row yq = r0-1+g, 4-pixel column group X4); it walks the <= P2_SPAN pixel
-    // rows anchored at yq.  Every label vector it needs is requested before anything else (independent 16-byte loads
-    // in flight together with the low-resolution rows below).
+    // rows anchored at yq
     const int pg = threadIdx.x / W4, X4 = (threadIdx.x - pg * W4) * 4;
-    const int yq = r0 - 1 + pg;
-    const bool plive = pg <= (r1 - r0) && yq >= 0 && yq < h;
-    int Ya = 0, Yb = 0;
-    if (plive) { Ya = tYa[pg]; Yb = tYa[pg + 1]; }
+    const int nsv = (BAND + 2) * w;
+    // this workgroup's items: a contiguous range (consecutive bands of a plane, then the next plane)
+    const int it0 = (int)(((int64_t)blockIdx.x * nitems) / gridDim.x), it1 = (int)(((int64_t)(blockIdx.x + 1) * nitems) / gridDim.x);
+    // per-thread operands of an item's pixel pass and its share of the low-resolution rows: requested one item ahead
     float4 lv[P2_SPAN];
+    float svn[2];
+    int Ya = 0, Yb = 0;
+    int svy[2], svx[2];          // this thread's two elements of the (BAND + 2) x w rows: row (or -1: none) and column
 #pragma unroll
-    for (int k = 0; k < P2_SPAN; ++k) {
-        lv[k] = make_float4(-1.f, -1.f, -1.f, -1.f);
-        if (Ya + k < Yb) lv[k] = *reinterpret_cast<const float4*>(lab + (int64_t)(Ya + k) * W + X4);
+    for (int j = 0; j < 2; ++j) {
+        const int i = threadIdx.x + j * (int)blockDim.x;
+        svy[j] = i < nsv ? i / w : -1;
+        svx[j] = i < nsv ? i % w : 0;
     }
-    for (int i = threadIdx.x; i < (BAND + 2) * w; i += blockDim.x) {
-        const int y = r0 - 1 + i / w;
-        sv[i] = (y >= 0 && y < h) ? low[(int64_t)plane * h * w + (int64_t)y * w + (i % w)] : 0.f;
-    }
-    for (int i = threadIdx.x; i < BAND * w; i += blockDim.x) sg[i] = 0.f;
-    __syncthreads();
-    // ---- pass 0: horizontal interpolation of the band's low-resolution rows, hr[row][X] = hx*v[x0] + lx*v[x1]
-    // (the inner sums of the align_corners=True formula  hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11), same rounding)
-    for (int i = threadIdx.x; i < (BAND + 2) * W; i += blockDim.x) {
-        const int rr = i / W, X = i - rr * W;
-        const int x0 = ac_i0(X, sw, w);
-        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-        const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
-        hr[i] = hx * sv[rr * w + x0] + lx * sv[rr * w + x1];
-    }
-    __syncthreads();
-    // ---- pass 1: pixels
-    float part = 0.f;
-    if (plive) {
-        const bool own = yq >= r0;
-        const int yq1 = yq + (yq < h - 1 ? 1 : 0);
-        const float4 t0 = *reinterpret_cast<const float4*>(hr + (yq - r0 + 1) * W + X4);
-        const float4 t1 = *reinterpret_cast<const float4*>(hr + (yq1 - r0 + 1) * W + X4);
-        const float top[4] = {t0.x, t0.y, t0.z, t0.w}, bot[4] = {t1.x, t1.y, t1.z, t1.w};
-        // one test per THREAD for what almost never occurs -- a soft label (neither 0 nor 1) or the ignore label among its
-        // <= 20 values -- instead of three compares per pixel: the common loop below knows every label is 0 or 1
-        bool plain = true;
+    auto request = [&](int itn) {
+        const int plane = itn / nband, band = itn - plane * nband;
+        const int r0 = band * BAND, r1 = (r0 + BAND < h) ? r0 + BAND : h;
+        const int ov = slot_idx ? slot_idx[plane] : -1;
+        const float* lab = ov >= 0 ? override_masks + (int64_t)ov * H * W : gt + (int64_t)(plane / S) * H * W;
+        const int yq = r0 - 1 + pg;
+        Ya = 0; Yb = 0;
+        if (pg <= (r1 - r0) && yq >= 0 && yq < h) { Ya = tYall[1 + yq]; Yb = tYall[2 + yq]; }
 #pragma unroll
         for (int k = 0; k < P2_SPAN; ++k) {
-            const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) plain = plain && (ls[q4] == 0.f || ls[q4] == 1.f || Ya + k >= Yb);
+            lv[k] = make_float4(-1.f, -1.f, -1.f, -1.f);
+            if (Ya + k < Yb) lv[k] = *reinterpret_cast<const float4*>(lab + ((Ya + k) * W + X4));
         }
-        if (plain) {
+        const float* lowp = low + (int64_t)plane * h * w;
 #pragma unroll
-            for (int k = 0; k < P2_SPAN; ++k) {
-                const int Y = Ya + k;
-                if (Y < Yb) {
-                    const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
-                    const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
-                    float gout[4];
+        for (int j = 0; j < 2; ++j) {
+            const int y = r0 - 1 + svy[j];
+            svn[j] = (svy[j] >= 0 && y >= 0 && y < h) ? lowp[y * w + svx[j]] : 0.f;
+        }
+    };
+    if (it0 < it1) request(it0);
+#pragma nounroll
+    for (int it = it0; it < it1; ++it) {
+        const int plane = it / nband, band = it - plane * nband;
+        const int s = plane % S;
+        const int r0 = band * BAND, r1 = (r0 + BAND < h) ? r0 + BAND : h;
+        const int ov = slot_idx ? slot_idx[plane] : -1;
+        const bool invert = ov < 0 && s >= S / 2;
+        // pixel rows of the block: the first row anchored at max(r0-1, 0) .. the last row anchored at r1-1
+        const int ya = r0 > 0 ? r0 - 1 : 0;
+        const int Y0 = tYall[1 + ya];
+        int Y1 = tYall[1 + r1];                                // one past the last row anchored below r1
+        if (Y1 - Y0 > max_rows) Y1 = Y0 + max_rows;            // (cannot happen: host-side bound)
+        const int* const tYa = tYall + r0;                     // tYa[k]: anchor row r0 - 1 + k
+        const int yq = r0 - 1 + pg;
+        const bool plive = pg <= (r1 - r0) && yq >= 0 && yq < h;
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const float pr = hy * top[q4] + ly * bot[q4];
-                        const bool yb = (ls[q4] != 0.f) != invert;     // the label after logical_not (trainer.py:330)
-                        const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-                        // one raw v_log_f32 (log2; the arguments are >= 1e-12, far from the denormals that logf's
-                        // ~14-instruction wrapper guards) and one reciprocal, no branch
-                        const float q = yb ? a : c;
-                        part += -0.69314718056f * __builtin_amdgcn_logf(q);
-                        const float rq = __builtin_amdgcn_rcpf(q) * grad_scale;
-                        gout[q4] = yb ? -rq : rq;
-                    }
-                    *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * (int)blockDim.x;
+            if (i < nsv) sv[i] = svn[j];
+        }
+        for (int i = threadIdx.x; i < BAND * w; i += blockDim.x) sg[i] = 0.f;
+        __syncthreads();
+        // ---- pass 0: horizontal interpolation of the band's low-resolution rows, hr[row][X] = hx*v[x0] + lx*v[x1]
+        // (the inner sums of the align_corners=True formula  hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11), same rounding):
+        // a thread keeps one column (anchor and weights once) and walks every (blockDim / W)-th row
+        {
+            const int nrp = (int)blockDim.x / W;
+            if (nrp > 0) {
+                if ((int)threadIdx.x < nrp * W) {
+                    const int rr0 = threadIdx.x / W, X = threadIdx.x - rr0 * W;
+                    const int x0 = ac_i0(X, sw, w);
+                    const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                    const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
+                    for (int rr = rr0; rr < BAND + 2; rr += nrp) hr[rr * W + X] = hx * sv[rr * w + x0] + lx * sv[rr * w + x1];
+                }
+            } else {
+                for (int i = threadIdx.x; i < (BAND + 2) * W; i += blockDim.x) {
+                    const int rr = i / W, X = i - rr * W;
+                    const int x0 = ac_i0(X, sw, w);
+                    const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                    const float lx = sw * (float)X - (float)x0, hx = 1.f - lx;
+                    hr[i] = hx * sv[rr * w + x0] + lx * sv[rr * w + x1];
                 }
             }
-        } else {
+        }
+        __syncthreads();
+        // ---- pass 1: pixels
+        float part = 0.f;
+        if (plive) {
+            const bool own = yq >= r0;
+            const int yq1 = yq + (yq < h - 1 ? 1 : 0);
+            const float4 t0 = *reinterpret_cast<const float4*>(hr + (yq - r0 + 1) * W + X4);
+            const float4 t1 = *reinterpret_cast<const float4*>(hr + (yq1 - r0 + 1) * W + X4);
+            const float top[4] = {t0.x, t0.y, t0.z, t0.w}, bot[4] = {t1.x, t1.y, t1.z, t1.w};
+            // one test per THREAD for what almost never occurs -- a soft label (neither 0 nor 1) or the ignore label among its
+            // <= 20 values -- instead of three compares per pixel: the common loop below knows every label is 0 or 1
+            bool plain = true;
 #pragma unroll
             for (int k = 0; k < P2_SPAN; ++k) {
-                const int Y = Ya + k;
-                if (Y < Yb) {
-                    const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
-                    const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
-                    float gout[4];
+                const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const float pr = hy * top[q4] + ly * bot[q4];
-                        float y = ls[q4];
-                        const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
-                        if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
-                        const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
-                        const bool yb = y != 0.f;
-                        const float q = yb ? a : c;
-                        float l = -0.69314718056f * __builtin_amdgcn_logf(q);
-                        const float rq = __builtin_amdgcn_rcpf(q);
-                        float g = yb ? -rq : rq;
-                        if (valid && yb && y != 1.f) {   // soft label: the general form
-                            l = -0.69314718056f * (__builtin_amdgcn_logf(a) * y + __builtin_amdgcn_logf(c) * (1.f - y));
-                            g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+                for (int q4 = 0; q4 < 4; ++q4) plain = plain && (ls[q4] == 0.f || ls[q4] == 1.f || Ya + k >= Yb);
+            }
+            if (plain) {
+#pragma unroll
+                for (int k = 0; k < P2_SPAN; ++k) {
+                    const int Y = Ya + k;
+                    if (Y < Yb) {
+                        const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
+                        const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
+                        float gout[4];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const float pr = hy * top[q4] + ly * bot[q4];
+                            const bool yb = (ls[q4] != 0.f) != invert;     // the label after logical_not (trainer.py:330)
+                            const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                            // one raw v_log_f32 (log2; the arguments are >= 1e-12, far from the denormals that logf's
+                            // ~14-instruction wrapper guards) and one reciprocal, no branch
+                            const float q = yb ? a : c;
+                            part += -0.69314718056f * __builtin_amdgcn_logf(q);
+                            const float rq = __builtin_amdgcn_rcpf(q) * grad_scale;
+                            gout[q4] = yb ? -rq : rq;
                         }
-                        part += valid ? l : 0.f;
-                        gout[q4] = valid ? g * grad_scale : 0.f;
+                        *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
                     }
-                    *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < P2_SPAN; ++k) {
+                    const int Y = Ya + k;
+                    if (Y < Yb) {
+                        const float ly = sh * (float)Y - (float)yq, hy = 1.f - ly;
+                        const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
+                        float gout[4];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const float pr = hy * top[q4] + ly * bot[q4];
+                            float y = ls[q4];
+                            const bool valid = y != -1.0f;   // ignore_label (never set by ed_mask_label, kept for fidelity)
+                            if (invert) y = (y != 0.f) ? 0.f : 1.f;   // logical_not (trainer.py:330)
+                            const float a = pr + 1e-12f, c = 1.f - pr + 1e-12f;
+                            const bool yb = y != 0.f;
+                            const float q = yb ? a : c;
+                            float l = -0.69314718056f * __builtin_amdgcn_logf(q);
+                            const float rq = __builtin_amdgcn_rcpf(q);
+                            float g = yb ? -rq : rq;
+                            if (valid && yb && y != 1.f) {   // soft label: the general form
+                                l = -0.69314718056f * (__builtin_amdgcn_logf(a) * y + __builtin_amdgcn_logf(c) * (1.f - y));
+                                g = -(y * __builtin_amdgcn_rcpf(a)) + (1.f - y) * __builtin_amdgcn_rcpf(c);
+                            }
+                            part += valid ? l : 0.f;
+                            gout[q4] = valid ? g * grad_scale : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(gp + (Y - Y0) * W + X4) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+                    }
                 }
             }
+            if (!own) part = 0.f;      // (the halo row's pixels belong to the band above)
         }
-        if (!own) part = 0.f;      // (the halo row's pixels belong to the band above)
-    }
-    const double t = block_sum_d((double)part, red);   // (its barriers also publish gp)
-    if (threadIdx.x == 0) loss_part[(int64_t)plane * nband + band] = (float)t;
-    if (!dlow) return;
-    // ---- pass 2: thread -> cell (y0, x0) with y0 in [r0-1, r1)
-    const int ly_ = threadIdx.x / w, x0 = threadIdx.x % w;
-    const int y0 = r0 - 1 + ly_;
-    const bool live = ly_ <= (r1 - r0) && y0 >= 0 && y0 < h;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
-    if (live) {
-        // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone): <= P2_SPAN
-        // columns x <= P2_SPAN rows.  Column weights once per cell; a tap outside the range reads the cell's first pixel
-        // with weight zero (every gradient in gp is finite: |g| <= 1e12 * grad_scale), so the 25 taps are one LDS read with
-        // an immediate offset and two FMAs each, no compare
-        const int Ya = tYa[ly_], Yb = tYa[ly_ + 1], Xa = tXa[x0], Xb = tXa[x0 + 1];
-        float wl0[P2_SPAN], wl1[P2_SPAN];
-        int xo[P2_SPAN];
-#pragma unroll
-        for (int ix = 0; ix < P2_SPAN; ++ix) {
-            const int X = Xa + ix;
-            const bool in = X < Xb;
-            const float lx = sw * (float)X - (float)x0;
-            wl0[ix] = in ? 1.f - lx : 0.f;
-            wl1[ix] = in ? lx : 0.f;
-            xo[ix] = in ? ix : 0;
+        // the next item's labels take the registers the pixel pass has just consumed; with its low-resolution rows they are in flight
+        // under the reduction, the cell pass, the folds and the store
+        if (it + 1 < it1) request(it + 1);
+        // the block's loss: wave partials in double precision, added by ONE thread in wave order (the barriers also publish gp)
+        {
+            const double wv = wave_sum_d((double)part);
+            const int wi = threadIdx.x >> 6, nw = blockDim.x >> 6;
+            p2_barrier();
+            if ((threadIdx.x & 63) == 0) red[wi] = wv;
+            p2_barrier();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+                for (int i = 0; i < nw; ++i) t += red[i];
+                loss_part[(int64_t)plane * nband + band] = (float)t;
+            }
         }
-#pragma unroll
-        for (int iy = 0; iy < P2_SPAN; ++iy) {
-            const int Y = Ya + iy;
-            if (Y < Yb && Xa < Xb) {     // (a cell that owns no column reads nothing: grow[0] would be the NEXT row's first pixel)
-                const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
-                const float* grow = gp + (Y - Y0) * W + Xa;
-                float rx0 = 0.f, rx1 = 0.f;   // this row's gradient split over the left / right corner columns
+        if (dlow) {
+            // ---- pass 2: thread -> cell (y0, x0) with y0 in [r0-1, r1)
+            const int ly_ = threadIdx.x / w, x0 = threadIdx.x % w;
+            const int y0 = r0 - 1 + ly_;
+            const bool live = ly_ <= (r1 - r0) && y0 >= 0 && y0 < h;
+            const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
+            if (live) {
+                // the pixels anchored at this cell form a contiguous range in each axis (the anchor index is monotone): <= P2_SPAN
+                // columns x <= P2_SPAN rows.  Column weights once per cell; a tap outside the range reads the cell's first pixel
+                // with weight zero (every gradient in gp is finite: |g| <= 1e12 * grad_scale), so the 25 taps are one LDS read with
+                // an immediate offset and two FMAs each, no compare
+                const int Ya = tYa[ly_], Yb = tYa[ly_ + 1], Xa = tXa[x0], Xb = tXa[x0 + 1];
+                float wl0[P2_SPAN], wl1[P2_SPAN];
+                int xo[P2_SPAN];
 #pragma unroll
                 for (int ix = 0; ix < P2_SPAN; ++ix) {
-                    const float g = grow[xo[ix]];
-                    rx0 += g * wl0[ix]; rx1 += g * wl1[ix];
+                    const int X = Xa + ix;
+                    const bool in = X < Xb;
+                    const float lx = sw * (float)X - (float)x0;
+                    wl0[ix] = in ? 1.f - lx : 0.f;
+                    wl1[ix] = in ? lx : 0.f;
+                    xo[ix] = in ? ix : 0;
                 }
-                g00 += hy * rx0; g01 += hy * rx1; g10 += ly * rx0; g11 += ly * rx1;
+#pragma unroll
+                for (int iy = 0; iy < P2_SPAN; ++iy) {
+                    const int Y = Ya + iy;
+                    if (Y < Yb && Xa < Xb) {     // (a cell that owns no column reads nothing: grow[0] would be the NEXT row's first pixel)
+                        const float ly = sh * (float)Y - (float)y0, hy = 1.f - ly;
+                        const float* grow = gp + (Y - Y0) * W + Xa;
+                        float rx0 = 0.f, rx1 = 0.f;   // this row's gradient split over the left / right corner columns
+#pragma unroll
+                        for (int ix = 0; ix < P2_SPAN; ++ix) {
+                            const float g = grow[xo[ix]];
+                            rx0 += g * wl0[ix]; rx1 += g * wl1[ix];
+                        }
+                        g00 += hy * rx0; g01 += hy * rx1; g10 += ly * rx0; g11 += ly * rx1;
+                    }
+                }
             }
+            // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
+            // corner terms into the cell's own word and skip the write
+            const bool bx = x1 != x0, by = y1 != y0;
+            if (!bx) { g00 += g01; g10 += g11; }
+            if (!by) { g00 += g10; if (bx) g01 += g11; }
+            const bool up = live && y0 >= r0;              // upper corners land on row y0 (inside the band unless halo)
+            const bool dn = live && by && y1 < r1;         // lower corners land on row y1 (dropped for the last anchor row)
+            if (up) sg[(y0 - r0) * w + x0] += g00;
+            p2_barrier();
+            if (up && bx) sg[(y0 - r0) * w + x1] += g01;
+            p2_barrier();
+            if (dn) sg[(y1 - r0) * w + x0] += g10;
+            p2_barrier();
+            if (dn && bx) sg[(y1 - r0) * w + x1] += g11;
+            p2_barrier();
+            for (int i = threadIdx.x; i < (r1 - r0) * w; i += blockDim.x)
+                dlow[(int64_t)plane * h * w + (int64_t)r0 * w + i] = sg[i];
         }
+        p2_barrier();      // the item's LDS is free
     }
-    // clamped edge cells (x1 == x0 or y1 == y0) would alias a neighbour's target word: fold their (zero-weight)
-    // corner terms into the cell's own word and skip the write
-    const bool bx = x1 != x0, by = y1 != y0;
-    if (!bx) { g00 += g01; g10 += g11; }
-    if (!by) { g00 += g10; if (bx) g01 += g11; }
-    const bool up = live && y0 >= r0;              // upper corners land on row y0 (inside the band unless halo)
-    const bool dn = live && by && y1 < r1;         // lower corners land on row y1 (dropped for the last anchor row)
-    if (up) sg[(y0 - r0) * w + x0] += g00;
-    __syncthreads();
-    if (up && bx) sg[(y0 - r0) * w + x1] += g01;
-    __syncthreads();
-    if (dn) sg[(y1 - r0) * w + x0] += g10;
-    __syncthreads();
-    if (dn && bx) sg[(y1 - r0) * w + x1] += g11;
-    __syncthreads();
-    for (int i = threadIdx.x; i < (r1 - r0) * w; i += blockDim.x)
-        dlow[(int64_t)plane * h * w + (int64_t)r0 * w + i] = sg[i];
 }
 
 // NFL + Dice in three launches over (sample, chunk) blocks: per-chunk partial sums -> gradients + per-chunk loss partials
@@ -444,27 +519,31 @@ extern "C" int vpu_p2cl_up_fwd_bwd(const float* sim_low, const float* gt, const 
                                    int32_t B, int32_t S, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
     vpu_clear_stale_error();
     const int band = p2cl_band(w);
-    if (S % 2 || band < 1 || h < 2 || w < 2 || W % 4 || (int64_t)(H - 1) >= (int64_t)P2_SPAN * (h - 1) ||
+    if (S % 2 || band < 1 || h < 2 || h > P2_W_MAX || w < 2 || W % 4 || (int64_t)(H - 1) >= (int64_t)P2_SPAN * (h - 1) ||
         (int64_t)(W - 1) >= (int64_t)P2_SPAN * (w - 1)) {
-        vpu_set_error("p2cl_up: S % 2, W % 4, 2 <= w <= 512, upsampling factor (H-1)/(h-1) < 5");
+        vpu_set_error("p2cl_up: S % 2, W % 4, 2 <= h, w <= 512, upsampling factor (H-1)/(h-1) < 5");
         return VPU_ERR_ARG;
     }
     const int nband = (h + band - 1) / band;
     // pixel rows one block can own: (band + 1) anchor rows x (H-1)/(h-1) rows per anchor row, + 2 for rounding
     const int max_rows = (int)(((int64_t)(band + 1) * (H - 1)) / (h - 1)) + 2;
     const size_t shmem = ((size_t)(2 * band + 2) * w + (size_t)(band + 2 + max_rows) * W) * sizeof(float);
-    if (shmem > 160 * 1024 - 4096 || (int64_t)(band + 1) * (W / 4) > 1024) {
+    if (shmem > 160 * 1024 - 6144 || (int64_t)(band + 1) * (W / 4) > 1024) {
         vpu_set_error("p2cl_up: band does not fit LDS / one block ((band + 1) * W/4 <= 1024)");
         return VPU_ERR_ARG;
     }
     static VpuDevOnce attr_set;
     if (auto todo_ = attr_set.pending()) {
-        VPU_SET_LDS(160 * 1024 - 4096, p2cl_up_kernel);   // (static: reduction scratch + the anchor tables)
+        VPU_SET_LDS(160 * 1024 - 6144, p2cl_up_kernel);   // (static: reduction scratch + the anchor tables)
     }
     // (as many threads as the pixel / cell passes use: (band + 1) * W / 4, a multiple of 64)
     const int nthr = (int)((((int64_t)(band + 1) * (W / 4 > w ? W / 4 : w)) + 63) / 64 * 64);
-    p2cl_up_kernel<<<(unsigned)(B * S * nband), nthr < 1024 ? nthr : 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
-                                                                  dsim_low, grad_scale, S, h, w, H, W, nband, max_rows, band);
+    // persistent: one workgroup per CU walks nitems / CUs consecutive (plane, band) items
+    const int nitems = B * S * nband;
+    const int ncu = vpu_cu_budget();
+    const int grid = nitems < ncu ? nitems : ncu;
+    p2cl_up_kernel<<<(unsigned)grid, nthr < 1024 ? nthr : 1024, shmem, ST>>>(sim_low, gt, slot_mask_idx, override_masks, loss_part,
+                                                                  dsim_low, grad_scale, S, h, w, H, W, nband, max_rows, band, nitems);
     return vpu_check_launch("vpu_p2cl_up_fwd_bwd");
 }
 
