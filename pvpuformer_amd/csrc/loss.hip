@@ -87,8 +87,9 @@ __device__ __forceinline__ void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // every per-thread constant are computed once per workgroup; the labels of the next item go into the label registers as soon as the
 // pixel pass has consumed the current ones, its low-resolution rows into two registers (in flight under the cell pass, the folds and
 // the store: the barriers behind the request wait for LDS only); the interpolation pass gives a thread one column and every second row;
-// thread 0 alone adds the wave partials (same order, same bits).  16,600 cycles per item, of which the pixel pass is 7,200 (the last
-// wave's; the first one's 3,500); 344 -> 249 us per launch, bit-identical.
+// thread 0 alone adds the wave partials (same order, same bits) behind ONE barrier; the test for a label that is neither 0 nor 1 is
+// one fma and one OR per label; no SLP packing (build.sh).  16,600 -> ~14,500 cycles per item, of which the pixel pass is 7,200 (the
+// last wave's; the first one's 3,500); 344 -> 216 us per launch, bit-identical (tools/p2_compare.py: soft and ignore labels included).
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
                                                        const int* __restrict__ slot_idx,
                                                        const float* __restrict__ override_masks,
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         if (pg <= (r1 - r0) && yq >= 0 && yq < h) { Ya = tYall[1 + yq]; Yb = tYall[2 + yq]; }
 #pragma unroll
         for (int k = 0; k < P2_SPAN; ++k) {
-            lv[k] = make_float4(-1.f, -1.f, -1.f, -1.f);
+            lv[k] = make_float4(0.f, 0.f, 0.f, 0.f);      // (a row this thread does not own: never used, and "plain" below)
             if (Ya + k < Yb) lv[k] = *reinterpret_cast<const float4*>(lab + ((Ya + k) * W + X4));
         }
         const float* lowp = low + (int64_t)plane * h * w;
@@ -223,13 +224,16 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
             const float top[4] = {t0.x, t0.y, t0.z, t0.w}, bot[4] = {t1.x, t1.y, t1.z, t1.w};
             // one test per THREAD for what almost never occurs -- a soft label (neither 0 nor 1) or the ignore label among its
             // <= 20 values -- instead of three compares per pixel: the common loop below knows every label is 0 or 1
-            bool plain = true;
+            // (l * l - l is +0 exactly for l = 0, -0, 1 and for nothing else -- a NaN stays a NaN: the bit patterns OR-ed, one fma and one
+            // OR per label instead of two compares, two mask operations and the row test)
+            unsigned nz = 0u;
 #pragma unroll
             for (int k = 0; k < P2_SPAN; ++k) {
                 const float ls[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) plain = plain && (ls[q4] == 0.f || ls[q4] == 1.f || Ya + k >= Yb);
+                for (int q4 = 0; q4 < 4; ++q4) nz |= __float_as_uint(__builtin_fmaf(ls[q4], ls[q4], -ls[q4]));
             }
+            const bool plain = nz == 0u;
             if (plain) {
 #pragma unroll
                 for (int k = 0; k < P2_SPAN; ++k) {
@@ -293,8 +297,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         {
             const double wv = wave_sum_d((double)part);
             const int wi = threadIdx.x >> 6, nw = blockDim.x >> 6;
-            p2_barrier();
-            if ((threadIdx.x & 63) == 0) red[wi] = wv;
+            if ((threadIdx.x & 63) == 0) red[wi] = wv;      // (thread 0 read the previous item's partials six barriers ago)
             p2_barrier();
             if (threadIdx.x == 0) {
                 double t = 0.0;
