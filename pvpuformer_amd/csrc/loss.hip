@@ -90,6 +90,14 @@ __device__ __forceinline__ void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // thread 0 alone adds the wave partials (same order, same bits) behind ONE barrier; the test for a label that is neither 0 nor 1 is
 // one fma and one OR per label; no SLP packing (build.sh).  16,600 -> ~14,500 cycles per item, of which the pixel pass is 7,200 (the
 // last wave's; the first one's 3,500); 344 -> 216 us per launch, bit-identical (tools/p2_compare.py: soft and ignore labels included).
+// (experiment builds only -- VPU_X_loss="-DVPU_P2_STAMPS -DP2_STAMP_THREAD=0" bash build.sh x, tools/p2_stamps.py: one thread's
+// s_memtime at the phases of every item)
+#ifdef VPU_P2_STAMPS
+__device__ unsigned g_p2_dbg[8192 * 8];
+#define P2_STAMP(k) do { if (threadIdx.x == P2_STAMP_THREAD && it < 8192) g_p2_dbg[it * 8 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P2_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__ low, const float* __restrict__ gt,
                                                        const int* __restrict__ slot_idx,
                                                        const float* __restrict__ override_masks,
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
     for (int it = it0; it < it1; ++it) {
         const int plane = it / nband, band = it - plane * nband;
         const int s = plane % S;
+        P2_STAMP(0);
         const int r0 = band * BAND, r1 = (r0 + BAND < h) ? r0 + BAND : h;
         const int ov = slot_idx ? slot_idx[plane] : -1;
         const bool invert = ov < 0 && s >= S / 2;
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         }
         for (int i = threadIdx.x; i < BAND * w; i += blockDim.x) sg[i] = 0.f;
         __syncthreads();
+        P2_STAMP(1);
         // ---- pass 0: horizontal interpolation of the band's low-resolution rows, hr[row][X] = hx*v[x0] + lx*v[x1]
         // (the inner sums of the align_corners=True formula  hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11), same rounding):
         // a thread keeps one column (anchor and weights once) and walks every (blockDim / W)-th row
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
             }
         }
         __syncthreads();
+        P2_STAMP(2);
         // ---- pass 1: pixels
         float part = 0.f;
         if (plive) {
@@ -292,7 +303,9 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
         }
         // the next item's labels take the registers the pixel pass has just consumed; with its low-resolution rows they are in flight
         // under the reduction, the cell pass, the folds and the store
+        P2_STAMP(7);
         if (it + 1 < it1) request(it + 1);
+        P2_STAMP(3);
         // the block's loss: wave partials in double precision, added by ONE thread in wave order (the barriers also publish gp)
         {
             const double wv = wave_sum_d((double)part);
@@ -305,6 +318,7 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
                 loss_part[(int64_t)plane * nband + band] = (float)t;
             }
         }
+        P2_STAMP(4);
         if (dlow) {
             // ---- pass 2: thread -> cell (y0, x0) with y0 in [r0-1, r1)
             const int ly_ = threadIdx.x / w, x0 = threadIdx.x % w;
@@ -360,10 +374,12 @@ __global__ __launch_bounds__(1024) void p2cl_up_kernel(const float* __restrict__
             p2_barrier();
             if (dn && bx) sg[(y1 - r0) * w + x1] += g11;
             p2_barrier();
+            P2_STAMP(5);
             for (int i = threadIdx.x; i < (r1 - r0) * w; i += blockDim.x)
                 dlow[(int64_t)plane * h * w + (int64_t)r0 * w + i] = sg[i];
         }
         p2_barrier();      // the item's LDS is free
+        P2_STAMP(6);
     }
 }
 
@@ -512,6 +528,9 @@ static inline int p2cl_band(int w) {
     const int cap = env > 0 && env <= P2_BAND_MAX ? env : P2_BAND_MAX;
     return b > cap ? cap : b;
 }
+#ifdef VPU_P2_STAMPS
+extern "C" int vpu_dbg_p2(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_p2_dbg), sizeof(unsigned) * 8192 * 8, 0, hipMemcpyDeviceToHost); }
+#endif
 extern "C" int vpu_p2cl_up_nband(int32_t h, int32_t w) {
     const int band = p2cl_band(w);
     return band < 1 ? 0 : (h + band - 1) / band;
